@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/sec of the SRPS hot path on synthetic data (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): synthetic full-mask HR grid 2048x2048, sf 4, 20 images per GPU, 3 channels,
+seed 1234+3.  One "step" = one pass of the alternating loop of SRPS.cu:276-315:
+lighting -> albedo -> depth (tensor assembly + 101 truncated CG steps + energy) -> normals, inputs
+resident in HBM.  value = CG iterations of the whole job per second = 101*K / T (the CG is replicated
+on every rank when the images are sharded, so it is counted once -- see DESIGN.md section 7).
+Also reported: the isolated inner loop (cg_only_*), the full solve to the reference's stop rule
+(total_solve_s), the roofline of the dominant kernel and the CPU baseline.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(sc, pkg, budget_s=20.0):
+    """The oracle's C restatement of the depth CG (assembled CSR, exactly dc.cu:229-279) timed on the
+    host cores on a bounded number of iterations of the SAME 2048^2 system.  Falls back to the numpy
+    restatement when the C oracle is not built.  Checker code, imported here only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import c_oracle
+        return c_oracle.bench_cpu_baseline(sc, budget_s)
+    except ImportError:
+        pass
+    import srps_oracle as O
+    geo = O.build_geometry(sc.h, sc.w, sc.sf, sc.mask)
+    P = geo.npix
+    rng = np.random.default_rng(0)
+    M = np.abs(rng.normal(size=(6, P))).astype(np.float32)
+    M[[1, 2, 4]] *= 0.1
+    x = rng.normal(size=P).astype(np.float32)
+    b = rng.normal(size=P).astype(np.float32)
+    Dx = geo.Dx; Dy = geo.Dy; KT = geo.KT
+    DxT = Dx.T.tocsr(); DyT = Dy.T.tocsr(); KTT = KT.T.tocsr()
+
+    def mv(v):
+        gx = Dx @ v; gy = Dy @ v
+        u = M[0] * gx + M[1] * gy + M[2] * v
+        w = M[1] * gx + M[3] * gy + M[4] * v
+        t = M[2] * gx + M[4] * gy + M[5] * v
+        return DxT @ u + DyT @ w + t + KTT @ (KT @ v)
+
+    iters = 0
+    t0 = time.perf_counter()
+    p = b.copy(); r = b.copy(); r1 = float(r @ r)
+    while time.perf_counter() - t0 < budget_s and iters < 101:
+        w = mv(p); a = r1 / float(p @ w); x += a * p; r -= a * w
+        r0 = r1; r1 = float(r @ r); p = (r1 / r0) * p + r
+        iters += 1
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "cg_iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} CG steps of the matrix-free 2048^2 system (numpy/scipy restatement, 1 thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--sf", type=int, default=4)
+    ap.add_argument("--images", type=int, default=20, help="images per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-total-solve", action="store_true")
+    ap.add_argument("--apply-mode", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    pkg.load()                                       # no fallback: raises when the extension is missing
+    H = W = args.size
+    n_total = args.images * world
+    lo, hi = pkg.shard_range(n_total, world, rank)
+    sc = pkg.synth.make_scene(H, W, args.sf, n_total, seed=1234 + 3, mask_kind="full", img_begin=lo, img_end=hi)
+    dh = pkg.DataHandler.from_scene(sc)
+    ctx = pkg.Context(device_id=local_rank)
+    ctx.use_torch_stream()
+    if args.apply_mode:
+        ctx.set_option("apply_mode", args.apply_mode)
+    ctx.setup(dh)
+    dims = ctx.dims()
+
+    def all_reduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    ar = all_reduce if world > 1 else None
+
+    def step():
+        return pkg.alternating_loop(ctx, ar, max_outer=1)[0]
+
+    for _ in range(args.warmup):
+        step()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    energies = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    cg_iters = 101 * args.steps
+    out = {
+        "metric": "cg_iterations_per_sec", "value": cg_iters / dt, "unit": "cg_iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic full-mask HR grid {H}x{W}, sf {args.sf}, {args.images} images/GPU x {world} GPU, 3 channels",
+                   "hr_grid": [H, W], "sf": args.sf, "images_per_gpu": args.images, "images_total": n_total,
+                   "unknowns": dims["npix"], "cg_steps_per_solve": 101,
+                   "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, replicated CG"},
+        "energies": energies,
+    }
+    if rank == 0:
+        # isolated inner loop + per-kernel HIP-event timings (same stream as the launches)
+        b = ctx.bench_cg(solves=10, iters=101)
+        out["cg_only_it_per_s"] = b["iterations"] / b["seconds"]
+        out["cg_only_us_per_iteration"] = 1e6 * b["seconds"] / b["iterations"]
+        loop_bytes = b["apply_bytes"] + b["update_bytes"]
+        out["cg_loop_roofline"] = {"bound": "hbm", "achieved": loop_bytes / (1e3 * out["cg_only_us_per_iteration"]),
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": loop_bytes / (1e3 * out["cg_only_us_per_iteration"]) / HBM_PEAK_GBS}
+        ach = b["apply_bytes"] / (1e3 * b["apply_us"])
+        out["roofline"] = {"bound": "hbm", "kernel": "depth operator (p-update + A_ p + p.Ap partial)",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "avg_launch_us": b["apply_us"], "algorithmic_bytes_per_launch": b["apply_bytes"],
+                           "update_kernel_us": b["update_us"],
+                           "update_kernel_GBs": b["update_bytes"] / (1e3 * b["update_us"])}
+    if not args.no_total_solve:
+        # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up
+        ctx.setup(dh)
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        en = pkg.alternating_loop(ctx, ar)
+        torch.cuda.synchronize()
+        ts = time.perf_counter() - t0
+        if rank == 0:
+            out["total_solve_s"] = ts
+            out["total_solve_outer_iterations"] = len(en)
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sc, pkg)
+        print(json.dumps(out))
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+/*
+ * srps.h -- C ABI of libsrps_hip.so: the MI355X (gfx950) implementation of the SRPS
+ * alternating-optimisation hot path of nihalsid/SRmeetsPS-CUDA.
+ *
+ * This header is the drop-in boundary.  The reference has no FFI layer; its seam is the C++
+ * header devicecalls.cuh:26-37 (free functions cuda_based_*) plus SRPS::execute (SRPS.cu:84-370).
+ * Every entry point below names the reference interface it replaces ("replaces: file:line").
+ * Paths are relative to /root/reference/SRmeetsPS-GPU/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; float = fp32, int = int32, all device pointers are HIP
+ *     device memory on the context's device;
+ *   - layouts are the reference's: flat column-major images (linear index i + j*h), masked
+ *     ("compact") vectors in ascending linear index, I[n][c][p], s[n][c][4], rho[c][p], N[k][p];
+ *   - every function returns an int status (SRPS_OK == 0); srps_last_error() gives the text of
+ *     the calling thread's last failure.  The library never calls exit() and never throws
+ *     across the boundary (the reference prints + exit(1) on CUDA errors, Utilities.cpp:8-19,
+ *     and throws std::runtime_error on library errors, Utilities.cpp:21-31; the C++ facade in
+ *     srmeetsps-cuda_amd/host/ re-creates the throwing behaviour on top of these codes);
+ *   - ownership: the caller allocates every output buffer (the reference's functions
+ *     cudaMalloc their results and make the caller cudaFree them, e.g. devicecalls.cu:24-29,
+ *     197-199); the context owns all workspace;
+ *   - one context per device, one host thread per context; kernels are enqueued on the
+ *     context's stream (srps_set_stream) and calls return without synchronising unless they
+ *     hand a host scalar back (energy, iteration counts, srps_get_*).
+ */
+#ifndef SRPS_H
+#define SRPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srps_ctx srps_ctx;
+
+enum {
+    SRPS_OK = 0,
+    SRPS_ERR_INVALID = 1,      /* bad argument (null pointer, non {0,1} mask, size mismatch) */
+    SRPS_ERR_HIP = 2,          /* HIP runtime error (text in srps_last_error)               */
+    SRPS_ERR_STATE = 3,        /* call order violated (e.g. depth before srps_bind_grid)    */
+    SRPS_ERR_NOMEM = 4,
+    SRPS_ERR_UNSUPPORTED = 5
+};
+
+/* albedo solver: the reference solves the per-pixel diagonal system with its global CG
+ * (devicecalls.cu:513-548); CLOSED_FORM is the fixed point of that CG (num/den per pixel). */
+enum { SRPS_ALBEDO_CG = 0, SRPS_ALBEDO_CLOSED_FORM = 1 };
+/* operator used by the depth CG: AUTO picks the register-marching kernel when sf is 1, 2 or 4 */
+enum { SRPS_APPLY_AUTO = 0, SRPS_APPLY_SIMPLE = 1, SRPS_APPLY_MARCH = 2 };
+
+const char* srps_last_error(void);
+const char* srps_version(void);
+
+/* ---- context ------------------------------------------------------------------------------
+ * replaces: cudaSetDevice + cusparseCreate + cublasCreate (SRPS.cu:88-98) and their destroy
+ * calls (SRPS.cu:340-345).  block_x / block_y are the reference's --blockx/--blocky
+ * (Main.cpp:27-28, Preferences Utilities.h:224-230); they are accepted and advisory. */
+int srps_create(int device_id, int block_x, int block_y, srps_ctx** out);
+int srps_destroy(srps_ctx* ctx);
+int srps_set_stream(srps_ctx* ctx, void* hip_stream);      /* NULL = the context's own stream */
+int srps_synchronize(srps_ctx* ctx);
+int srps_set_option(srps_ctx* ctx, const char* name, int value); /* "albedo_mode", "apply_mode", "cg_max_iter" */
+
+/* ---- generic sparse operators (device pointers) -------------------------------------------*/
+/* replaces: cuda_based_host_COO_to_device_CSR (devicecalls.cuh:37, devicecalls.cu:51-67) incl.
+ * sort_COO (devicecalls.cu:4-21).  Host COO in, device CSR out (d_row_ptr[n_row+1],
+ * d_col_ind[nnz], d_val[nnz], caller-allocated).  Entries of a row keep their COO order. */
+int srps_host_COO_to_device_CSR(srps_ctx* ctx, const int* row, const int* col, const float* val,
+                                int n_row, int n_col, int nnz,
+                                int* d_row_ptr, int* d_col_ind, float* d_val);
+/* replaces: cuda_based_sparsemat_densevec_mul (devicecalls.cuh:26, devicecalls.cu:23-49).
+ * y = A x (transpose == 0, y has n_rows) or y = A^T x (transpose != 0, y has n_cols). */
+int srps_sparsemat_densevec_mul(srps_ctx* ctx, const int* d_row_ptr, const int* d_col_ind,
+                                const float* d_val, int n_rows, int n_cols, int nnz,
+                                const float* d_x, int transpose, float* d_y);
+/* replaces: cuda_based_conjugate_gradient (devicecalls.cu:229-279): un-preconditioned CG,
+ * tol 1e-9 (squared), at most 101 steps, x = warm start (in/out), b = residual (destroyed). */
+int srps_conjugate_gradient(srps_ctx* ctx, const int* d_row_ptr, const int* d_col_ind,
+                            const float* d_val, int n, int nnz, float* d_x, float* d_b, int* iters);
+
+/* ---- init kernels -------------------------------------------------------------------------*/
+/* replaces: cuda_based_mean_across_channels (devicecalls.cuh:28, devicecalls.cu:95-125).
+ * h_data is HOST memory [nc][h*w]; d_mean [h*w] and d_inpaint_locations [h*w] are device. */
+int srps_mean_across_channels(srps_ctx* ctx, const float* h_data, int h, int w, int nc,
+                              float* d_mean, uint8_t* d_inpaint_locations);
+/* replaces: cuda_based_rho_init (devicecalls.cuh:31, devicecalls.cu:133-149): rho = 0.5 */
+int srps_rho_init(srps_ctx* ctx, float* d_rho, int npix, int nc);
+/* replaces: cuda_based_meshgrid_create (devicecalls.cuh:32, devicecalls.cu:151-169):
+ * xx[j*h+i] = j - K02, yy[j*h+i] = i - K12 on the full h x w grid (every pixel is written;
+ * the reference kernel's landscape indexing bug is not reproduced). */
+int srps_meshgrid_create(srps_ctx* ctx, int w, int h, float K02, float K12, float* d_xx, float* d_yy);
+
+/* ---- the four phase operators (device pointers, reference layouts) ------------------------*/
+/* replaces: cuda_based_normal_init (devicecalls.cuh:33, devicecalls.cu:171-223).
+ * d_N [4][npix] and d_dz [npix] are caller-allocated outputs. */
+int srps_normal_init(srps_ctx* ctx, const float* d_z, const float* d_zx, const float* d_zy,
+                     const float* d_xx, const float* d_yy, int npix, float K00, float K11,
+                     float* d_N, float* d_dz);
+/* replaces: cuda_based_lightning_estimation (devicecalls.cuh:34, devicecalls.cu:376-444).
+ * d_s [nimages][nchannels][4] is updated in place. */
+int srps_lightning_estimation(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N,
+                              const float* d_I, int npix, int nimages, int nchannels);
+/* replaces: cuda_based_albedo_estimation (devicecalls.cuh:35, devicecalls.cu:447-548).
+ * d_rho [nchannels][npix] is updated in place. */
+int srps_albedo_estimation(srps_ctx* ctx, const float* d_s, float* d_rho, const float* d_N,
+                           const float* d_I, int npix, int nimages, int nchannels);
+/* Grid geometry for the matrix-free depth operator.  The reference hands Dx, Dy, KT to
+ * cuda_based_depth_estimation as CSR matrices it built on the host (make_gradient SRPS.cu:23-71,
+ * KT SRPS.cu:170-193); this library rebuilds the same operators from the mask itself and applies
+ * them matrix-free, so the mask is bound once instead.  mask is HOST memory, h*w floats in {0,1}. */
+int srps_bind_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask);
+/* replaces: cuda_based_depth_estimation (devicecalls.cuh:36, devicecalls.cu:550-786).
+ * The nine CSR arguments of the reference (Dx, Dy, KT) are implied by srps_bind_grid.
+ * d_z [npix] is updated in place (101 CG steps from the warm start); *energy receives
+ * ||KT z - z0s||^2 + lambda * ||A z - B||^2 (devicecalls.cu:762-785). Synchronises. */
+int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_N,
+                          const float* d_I, const float* d_xx, const float* d_yy, const float* d_dz,
+                          const float* d_z0s, float* d_z, float K00, float K11,
+                          int npix, int nimages, int nchannels, float* energy);
+/* zx = Dx z, zy = Dy z on the bound grid.
+ * replaces: the two cuda_based_sparsemat_densevec_mul calls at SRPS.cu:264-265 / 310-311. */
+int srps_gradient(srps_ctx* ctx, const float* d_z, int npix, float* d_zx, float* d_zy);
+/* y = (KT^T KT + lambda A^T A) x for the tensor assembled by the last depth call (tests). */
+int srps_depth_operator_apply(srps_ctx* ctx, const float* d_x, int npix, float* d_y);
+
+/* ---- whole pipeline = SRPS::execute (SRPS.cu:84-370) ----------------------------------------
+ * srps_problem mirrors DataHandler (Utilities.h:166-181) after the CPU pre-processing of
+ * SRPS.cu:117-149 (zs_lr = smoothed LR depth, z_full = up-sampled HR depth).  All pointers
+ * are HOST memory.  Image sharding (new): a rank passes only its images
+ * [image_offset, image_offset + n_images) of n_images_total. */
+typedef struct srps_problem {
+    int h, w;               /* I_h, I_w */
+    int n_channels;         /* I_c */
+    int n_images;           /* images in I (this rank's shard) */
+    int n_images_total;     /* I_n of the whole job (== n_images on one GPU) */
+    int image_offset;       /* index of this shard's first image */
+    int sf;
+    const float* mask;      /* [h*w], {0,1} */
+    const float* K;         /* [9] column-major: K[0]=fx K[4]=fy K[6]=cx K[7]=cy */
+    const float* I;         /* [n_images][n_channels][h*w] or NULL (then srps_upload_image) */
+    const float* zs_lr;     /* [(h/sf)*(w/sf)] */
+    const float* z_full;    /* [h*w] */
+} srps_problem;
+
+/* replaces: SRPS.cu:100-270 (mask indices, KT/Dx/Dy structure, compaction, s/rho init,
+ * meshgrid, first normals). */
+int srps_setup(srps_ctx* ctx, const srps_problem* prob);
+int srps_upload_image(srps_ctx* ctx, int local_index, const float* host_image /* [c][h*w] */);
+int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, int* n_images, int* n_channels);
+
+/* one-GPU phases on the context's own state; each replaces the call at the cited line */
+int srps_lighting(srps_ctx* ctx);                    /* SRPS.cu:281 */
+int srps_albedo(srps_ctx* ctx);                      /* SRPS.cu:287 */
+int srps_depth(srps_ctx* ctx, float* energy);        /* SRPS.cu:293 */
+int srps_normals(srps_ctx* ctx);                     /* SRPS.cu:310-315 */
+
+/* Sharded phases.  *_partial computes this rank's contribution into an exchange
+ * buffer; the host sums the buffer over ranks (RCCL all-reduce on the context's stream) and
+ * calls the matching *_finish.  srps_exchange returns the device pointer and length of the
+ * buffer the last *_partial filled. */
+int srps_lighting_local(srps_ctx* ctx);              /* s of the local images; other rows zeroed */
+int srps_albedo_partial(srps_ctx* ctx);              /* [2][C][P] num, den                        */
+int srps_albedo_finish(srps_ctx* ctx);
+int srps_depth_partial(srps_ctx* ctx);               /* q planes on the grid [3][Hs*Ws]           */
+int srps_depth_solve(srps_ctx* ctx);                 /* rhs, residual, 101 CG steps               */
+int srps_energy_partial(srps_ctx* ctx);              /* [2] floats: t1 (replicated), t2 (partial) */
+int srps_energy_finish(srps_ctx* ctx, float* energy);
+int srps_exchange(srps_ctx* ctx, const char* which /* "s","albedo","depth","energy" */,
+                  void** d_ptr, size_t* n_floats);
+
+/* stop rule + loop of SRPS.cu:272-335 on one GPU.  energies (may be NULL) receives up to
+ * max_outer values; *n_outer the number of passes executed. */
+int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer);
+
+/* state read-back: name in {"z","rho","s","N","dz","zx","zy","xx","yy","z0s","I"}; host buffer
+ * of n floats (must equal the array length). */
+int srps_get(srps_ctx* ctx, const char* name, float* host, size_t n);
+int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n);
+int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats);
+int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters /*[C]*/, int* lighting_iters_max);
+
+/* ---- measurement --------------------------------------------------------------------------
+ * Runs `solves` depth-CG solves of exactly `iters_per_solve` steps on the current system
+ * (state is restored afterwards) and reports wall seconds of the whole loop plus the average
+ * HIP-event duration (microseconds) of the operator kernel and of the update kernel. */
+int srps_bench_cg(srps_ctx* ctx, int solves, int iters_per_solve, double* seconds,
+                  double* apply_kernel_us, double* update_kernel_us);
+/* algorithmic bytes per launch of the operator / update kernel */
+int srps_cg_bytes(srps_ctx* ctx, double* apply_bytes, double* update_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRPS_H */

@@ -1,0 +1,9 @@
+"""srmeetsps-cuda_amd -- MI355X (gfx950) implementation of the SRPS alternating-optimisation hot
+path of nihalsid/SRmeetsPS-CUDA behind the reference's SRPS / DataHandler surface.
+
+The directory name contains a hyphen (it is fixed by the project layout); import it with
+``importlib.import_module("srmeetsps-cuda_amd")``.
+"""
+from ._lib import SRPSError, build, load, declared_symbols, LIB_PATH  # noqa: F401
+from .api import (Context, DataHandler, Preferences, SRPS, alternating_loop, shard_range)  # noqa: F401
+from . import synth  # noqa: F401

@@ -1,0 +1,82 @@
+// device_utils.h -- wave-64 reductions and small vector helpers (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace srps {
+
+// ---- wave-64 shuffle reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {          // total in every lane (butterfly)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block sum for blockDim.x*blockDim.y*blockDim.z = NT threads (multiple of 64, <= 1024).
+// sm must hold 16 floats. Result valid in every thread. Fixed order => deterministic.
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    const int nw = (blockDim.x * blockDim.y * blockDim.z) >> 6;
+    v = wave_sum(v);
+    if (nw == 1) return v;
+    __syncthreads();                      // protect sm from a previous call
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sm[i];
+    return t;
+}
+
+// Sum of a partial-sum array written by a PREVIOUS kernel. Done by wave 0 of the block in a
+// fixed pattern (lane l adds elements l, l+64, ... in double, then a butterfly), so every block
+// of every kernel obtains the bit-identical value irrespective of its block size; broadcast
+// through one double of LDS.
+__device__ __forceinline__ double sum_partials(const float* __restrict__ part, int n, double* sm_d) {
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    const int nt = blockDim.x * blockDim.y * blockDim.z;
+    double acc = 0.0;
+    if (tid < 64) {
+        for (int i = tid; i < n; i += 64) acc += (double)part[i];
+        acc = wave_sum(acc);
+    }
+    if (nt == 64) return acc;
+    __syncthreads();
+    if (tid == 0) *sm_d = acc;
+    __syncthreads();
+    return *sm_d;
+}
+
+// ---- V-wide loads of consecutive floats (V = 1 or 4) ---------------------------------------
+template <int V>
+struct Vec {
+    float v[V];
+};
+template <int V>
+__device__ __forceinline__ Vec<V> ldv(const float* __restrict__ p);
+template <>
+__device__ __forceinline__ Vec<1> ldv<1>(const float* __restrict__ p) {
+    Vec<1> r;
+    r.v[0] = *p;
+    return r;
+}
+template <>
+__device__ __forceinline__ Vec<4> ldv<4>(const float* __restrict__ p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    Vec<4> r;
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    return r;
+}
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ p, const Vec<V>& a);
+template <>
+__device__ __forceinline__ void stv<1>(float* __restrict__ p, const Vec<1>& a) { *p = a.v[0]; }
+template <>
+__device__ __forceinline__ void stv<4>(float* __restrict__ p, const Vec<4>& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+}  // namespace srps

@@ -1,0 +1,379 @@
+// kernels_cg.hip -- the depth solve on the bounding-box grid: scatter/gather between the compact
+// (reference) layout and the grid, masked gradients, right-hand side, the matrix-free operator
+//      A_ x = KT'(KT x) + lambda * ( Dx' u + Dy' v + w ),   (u,v,w) = M (Dx x, Dy x, x)
+// (matrix-free form of devicecalls.cu:668-736) and the reference's CG recurrence
+// (devicecalls.cu:229-279) with device-resident scalars.
+//
+// Grid layout: plane[(j - j_lo + PAD) * Hs + (i - i_lo + PAD)], zero outside the mask; a
+// structure byte per pixel (F_* in srps_internal.h) encodes the rows of Dx, Dy and KT.
+#include "srps_internal.h"
+#include "device_utils.h"
+
+namespace srps {
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion
+// ---------------------------------------------------------------------------------------------
+__global__ void k_scatter(const float* __restrict__ compact, const int* __restrict__ gofp, int P, float* __restrict__ plane) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) plane[gofp[p]] = compact[p];
+}
+__global__ void k_gather(const float* __restrict__ plane, const int* __restrict__ gofp, int P, float* __restrict__ compact) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) compact[p] = plane[gofp[p]];
+}
+int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane) {
+    Grid& G = ctx->grid;
+    hipLaunchKernelGGL(k_scatter, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_compact, G.d_gofp, G.P, d_plane);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact) {
+    Grid& G = ctx->grid;
+    hipLaunchKernelGGL(k_gather, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_plane, G.d_gofp, G.P, d_compact);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// zx = Dx z, zy = Dy z  (rows of make_gradient, SRPS.cu:29-47) -> compact outputs
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gradient(const float* __restrict__ zg, const uint8_t* __restrict__ flags, const int* __restrict__ gofp,
+                           int P, int Hs, float* __restrict__ zx, float* __restrict__ zy) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int g = gofp[p];
+        const uint8_t fl = flags[g];
+        const float xc = zg[g];
+        float gx = 0.f, gy = 0.f;
+        if (fl & F_FX) gx = zg[g + Hs] - xc; else if (fl & F_BX) gx = xc - zg[g - Hs];
+        if (fl & F_FY) gy = zg[g + 1] - xc; else if (fl & F_BY) gy = xc - zg[g - 1];
+        zx[p] = gx;
+        zy[p] = gy;
+    }
+}
+int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy) {
+    Grid& G = ctx->grid;
+    hipLaunchKernelGGL(k_gradient, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_plane, G.d_flags, G.d_gofp, G.P, G.Hs, d_zx, d_zy);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rhs = KT' z0s + lambda (Dx' q0 + Dy' q1 + q2)        (devicecalls.cu:743-745, matrix-free)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rhs(const float* __restrict__ Q, const uint8_t* __restrict__ flags, const int* __restrict__ lr_index,
+                      const float* __restrict__ z0s, int Hg, int Wg, int Hs, size_t plane, int sf, int Hl, float lambda,
+                      float* __restrict__ rhs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= Hg || j >= Wg) return;
+    const int g = (j + PAD) * Hs + i + PAD;
+    const uint8_t fl = flags[g];
+    if (!(fl & F_MASK)) return;
+    const float* q0 = Q;
+    const float* q1 = Q + plane;
+    const float* q2 = Q + 2 * plane;
+    float acc = q2[g];
+    if (fl & F_FX) acc -= q0[g]; else if (fl & F_BX) acc += q0[g];
+    if (flags[g - Hs] & F_FX) acc += q0[g - Hs];
+    if (flags[g + Hs] & F_BX) acc -= q0[g + Hs];
+    if (fl & F_FY) acc -= q1[g]; else if (fl & F_BY) acc += q1[g];
+    if (flags[g - 1] & F_FY) acc += q1[g - 1];
+    if (flags[g + 1] & F_BY) acc -= q1[g + 1];
+    acc *= lambda;
+    if (fl & F_KB) {
+        const int lr = lr_index[(j / sf) * Hl + (i / sf)];
+        acc += z0s[lr] / (float)(sf * sf);                       // KT value 1/sf^2, SRPS.cu:188
+    }
+    rhs[g] = acc;
+}
+int grid_rhs(srps_ctx* ctx, const float* d_z0s) {
+    Grid& G = ctx->grid;
+    dim3 blk(64, 4), grd(cdiv(G.Hg, 64), cdiv(G.Wg, 4));
+    hipLaunchKernelGGL(k_rhs, grd, blk, 0, ctx->stream, G.d_q, G.d_flags, G.d_lr_index, d_z0s, G.Hg, G.Wg, G.Hs, G.plane, G.sf, G.Hl, ctx->lambda, G.d_r);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operator, simple form: one thread per grid pixel, neighbours gathered from global memory.
+// Works for every sf; it is the cross-check of (and the fall-back for) the marching kernel.
+// MODE 0: out = A_ x                       (x = xin)
+// MODE 1: r = r - A_ x ; partial r.r       (residual before CG, devicecalls.cu:758)
+// MODE 2: CG step k: x := p_new = beta p + r (p_new = r when k == 1), out = A_ p_new,
+//         p_out = p_new, partial p_new.out (devicecalls.cu:256-268)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float scal_then_axpy(float beta, float p, float r) {
+#pragma clang fp contract(off)
+    const float t = beta * p;                 // Sscal  dc.cu:263
+    return t + r;                             // Saxpy  dc.cu:264 (two roundings, as in the reference)
+}
+
+template <int MODE>
+struct XRead {
+    const float* x;
+    const float* p;
+    const float* r;
+    float beta;
+    int first;
+    __device__ __forceinline__ float operator()(int g) const {
+        if (MODE != 2) return x[g];
+        if (first) return r[g];
+        return scal_then_axpy(beta, p[g], r[g]);
+    }
+};
+
+struct ApplyArgs {
+    const float* M;
+    const uint8_t* flags;
+    const float* xin;      // MODE 0/1
+    const float* p_in;     // MODE 2
+    float* p_out;          // MODE 2
+    float* r;              // MODE 1 (in/out), MODE 2 (in)
+    float* out;            // MODE 0/2
+    const float* rr_part;  // MODE 2: partials of r.r from the previous update kernel
+    int n_rr;
+    float* part_out;       // one partial per block
+    CgScalars* scal;
+    int Hg, Wg, Hs, sf;
+    size_t plane;
+    float lambda, inv_sf4, tol2;
+    int k;
+};
+
+template <int MODE, typename XR>
+__device__ __forceinline__ void grad_at(const XR& X, int g, uint8_t fl, int Hs, float& gx, float& gy, float& xc) {
+    xc = X(g);
+    gx = 0.f; gy = 0.f;
+    if (fl & F_FX) gx = X(g + Hs) - xc; else if (fl & F_BX) gx = xc - X(g - Hs);
+    if (fl & F_FY) gy = X(g + 1) - xc; else if (fl & F_BY) gy = xc - X(g - 1);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_apply_simple(ApplyArgs a) {
+    __shared__ float sm[16];
+    __shared__ double smd;
+    XRead<MODE> X;
+    X.x = a.xin; X.p = a.p_in; X.r = a.r; X.beta = 0.f; X.first = 1;
+    if (MODE == 2) {
+        const float r1 = (float)sum_partials(a.rr_part, a.n_rr, &smd);
+        if (!(r1 > a.tol2)) return;                         // converged: dc.cu:252
+        X.first = (a.k == 1);
+        if (!X.first) X.beta = r1 / a.scal->r0;             // dc.cu:262
+    }
+    const int Hs = a.Hs;
+    const size_t pl = a.plane;
+    const int nti = (a.Hg + 63) >> 6, ntj = (a.Wg + 3) >> 2;
+    float acc_red = 0.f;
+    for (int tile = blockIdx.x; tile < nti * ntj; tile += gridDim.x) {
+        const int tj = tile / nti, ti = tile - tj * nti;
+        const int i = ti * 64 + threadIdx.x, j = tj * 4 + threadIdx.y;
+        if (i >= a.Hg || j >= a.Wg) continue;
+        const int g = (j + PAD) * Hs + i + PAD;
+        const uint8_t fl = a.flags[g];
+        if (!(fl & F_MASK)) continue;
+        float gx, gy, xc;
+        grad_at<MODE>(X, g, fl, Hs, gx, gy, xc);
+        const float m0 = a.M[g], m1 = a.M[pl + g], m2 = a.M[2 * pl + g], m3 = a.M[3 * pl + g], m4 = a.M[4 * pl + g], m5 = a.M[5 * pl + g];
+        const float u = m0 * gx + m1 * gy + m2 * xc;
+        const float v = m1 * gx + m3 * gy + m4 * xc;
+        float acc = m2 * gx + m4 * gy + m5 * xc;                     // w
+        if (fl & F_FX) acc -= u; else if (fl & F_BX) acc += u;       // own row of Dx'
+        if (fl & F_FY) acc -= v; else if (fl & F_BY) acc += v;       // own row of Dy'
+        {   // left neighbour's forward row references this pixel with +1
+            const int gl = g - Hs; const uint8_t f2 = a.flags[gl];
+            if (f2 & F_FX) { float ax, ay, xx; grad_at<MODE>(X, gl, f2, Hs, ax, ay, xx); acc += a.M[gl] * ax + a.M[pl + gl] * ay + a.M[2 * pl + gl] * xx; }
+        }
+        {   // right neighbour's backward row references this pixel with -1
+            const int gr = g + Hs; const uint8_t f2 = a.flags[gr];
+            if (f2 & F_BX) { float ax, ay, xx; grad_at<MODE>(X, gr, f2, Hs, ax, ay, xx); acc -= a.M[gr] * ax + a.M[pl + gr] * ay + a.M[2 * pl + gr] * xx; }
+        }
+        {   // upper neighbour (i-1), forward in y
+            const int gu = g - 1; const uint8_t f2 = a.flags[gu];
+            if (f2 & F_FY) { float ax, ay, xx; grad_at<MODE>(X, gu, f2, Hs, ax, ay, xx); acc += a.M[pl + gu] * ax + a.M[3 * pl + gu] * ay + a.M[4 * pl + gu] * xx; }
+        }
+        {   // lower neighbour (i+1), backward in y
+            const int gd = g + 1; const uint8_t f2 = a.flags[gd];
+            if (f2 & F_BY) { float ax, ay, xx; grad_at<MODE>(X, gd, f2, Hs, ax, ay, xx); acc -= a.M[pl + gd] * ax + a.M[3 * pl + gd] * ay + a.M[4 * pl + gd] * xx; }
+        }
+        acc *= a.lambda;
+        if (fl & F_KB) {                                              // KT'KT: block sum / sf^4
+            const int bi = (i / a.sf) * a.sf, bj = (j / a.sf) * a.sf;
+            float S = 0.f;
+            for (int dj = 0; dj < a.sf; ++dj)
+                for (int di = 0; di < a.sf; ++di) S += X((bj + dj + PAD) * Hs + bi + di + PAD);
+            acc += S * a.inv_sf4;
+        }
+        if (MODE == 0) {
+            a.out[g] = acc;
+        } else if (MODE == 1) {
+            const float rv = a.r[g] - acc;
+            a.r[g] = rv;
+            acc_red = fmaf(rv, rv, acc_red);
+        } else {
+            a.p_out[g] = xc;
+            a.out[g] = acc;
+            acc_red = fmaf(xc, acc, acc_red);
+        }
+    }
+    if (MODE != 0) {
+        const float t = block_sum(acc_red, sm);
+        if (threadIdx.x == 0 && threadIdx.y == 0) a.part_out[blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CG vector update:  alpha = r1 / (p.w);  x += alpha p;  r -= alpha w;  partial r.r
+// (devicecalls.cu:269-274 fused into one pass)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cg_update(int k, float* __restrict__ x, float* __restrict__ r,
+                                                   const float* __restrict__ p, const float* __restrict__ w, size_t n4,
+                                                   const float* __restrict__ rr_old, float* __restrict__ rr_new, int n_rr,
+                                                   const float* __restrict__ pw_part, int n_pw, CgScalars* __restrict__ scal,
+                                                   float tol2) {
+    __shared__ float sm[16];
+    __shared__ double smd;
+    const float r1 = (float)sum_partials(rr_old, n_rr, &smd);
+    if (!(r1 > tol2)) {
+        if (threadIdx.x == 0) {
+            rr_new[blockIdx.x] = rr_old[blockIdx.x];
+            if (blockIdx.x == 0) scal->active = 0;
+        }
+        return;
+    }
+    const float dot = (float)sum_partials(pw_part, n_pw, &smd);
+    const float alpha = r1 / dot;                                   // dc.cu:269
+    float acc = 0.f;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    float4* r4 = reinterpret_cast<float4*>(r);
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < n4; t += (size_t)gridDim.x * 256) {
+        const float4 pv = p4[t], wv = w4[t];
+        float4 xv = x4[t], rv = r4[t];
+        xv.x = fmaf(alpha, pv.x, xv.x); xv.y = fmaf(alpha, pv.y, xv.y); xv.z = fmaf(alpha, pv.z, xv.z); xv.w = fmaf(alpha, pv.w, xv.w);
+        rv.x = fmaf(-alpha, wv.x, rv.x); rv.y = fmaf(-alpha, wv.y, rv.y); rv.z = fmaf(-alpha, wv.z, rv.z); rv.w = fmaf(-alpha, wv.w, rv.w);
+        x4[t] = xv; r4[t] = rv;
+        acc = fmaf(rv.x, rv.x, acc); acc = fmaf(rv.y, rv.y, acc); acc = fmaf(rv.z, rv.z, acc); acc = fmaf(rv.w, rv.w, acc);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        rr_new[blockIdx.x] = t;
+        if (blockIdx.x == 0) { scal->r0 = r1; scal->r1_last = r1; scal->iters = k; scal->active = 1; }
+    }
+}
+
+__global__ void k_cg_reset(CgScalars* scal, float* rr0, int n_rr, const float* first) {
+    // rr_part[0][0] = r.r of the initial residual, the rest zero
+    for (int t = threadIdx.x; t < n_rr; t += blockDim.x) rr0[t] = (t == 0) ? first[0] : 0.f;
+    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = first[0]; scal->iters = 0; scal->active = 1; }
+}
+
+// single-block sum (same routine as k_final_sum in kernels_pixel.hip)
+__global__ void k_sum_to(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ double smd;
+    const double t = sum_partials(part, n, &smd);
+    if (threadIdx.x == 0) out[0] = (float)t;
+}
+
+static ApplyArgs base_args(srps_ctx* ctx) {
+    Grid& G = ctx->grid;
+    ApplyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = G.d_M; a.flags = G.d_flags; a.Hg = G.Hg; a.Wg = G.Wg; a.Hs = G.Hs; a.sf = G.sf; a.plane = G.plane;
+    a.lambda = ctx->lambda;
+    a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
+    a.scal = G.d_scal;
+    a.part_out = G.d_pw_part;
+    return a;
+}
+
+int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane) {
+    Grid& G = ctx->grid;
+    ApplyArgs a = base_args(ctx);
+    a.xin = d_in_plane; a.out = d_out_plane;
+    hipLaunchKernelGGL((k_apply_simple<0>), dim3(G.nb_apply), dim3(64, 4), 0, ctx->stream, a);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+int grid_residual(srps_ctx* ctx) {
+    Grid& G = ctx->grid;
+    ApplyArgs a = base_args(ctx);
+    a.xin = G.d_x; a.r = G.d_r;
+    hipLaunchKernelGGL((k_apply_simple<1>), dim3(G.nb_apply), dim3(64, 4), 0, ctx->stream, a);
+    SRPS_LAUNCH_CHECK();
+    float* first = G.d_misc_part + 4000;
+    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, ctx->stream, G.d_pw_part, G.nb_apply, first);
+    hipLaunchKernelGGL(k_cg_reset, dim3(1), dim3(256), 0, ctx->stream, G.d_scal, G.d_rr_part, G.nb_update, first);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+int cg_launch_apply(srps_ctx* ctx, int k) {
+    Grid& G = ctx->grid;
+    ApplyArgs a = base_args(ctx);
+    float* pbuf[2] = {G.d_p, G.d_p + G.plane};
+    a.p_in = pbuf[(k + 1) & 1]; a.p_out = pbuf[k & 1]; a.r = G.d_r; a.out = G.d_w;
+    a.rr_part = G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update; a.n_rr = G.nb_update;
+    a.k = k;
+    a.tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
+    hipLaunchKernelGGL((k_apply_simple<2>), dim3(G.nb_apply), dim3(64, 4), 0, ctx->stream, a);
+    return SRPS_OK;
+}
+
+int cg_launch_update(srps_ctx* ctx, int k) {
+    Grid& G = ctx->grid;
+    float* pbuf[2] = {G.d_p, G.d_p + G.plane};
+    const float tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
+    hipLaunchKernelGGL(k_cg_update, dim3(G.nb_update), dim3(256), 0, ctx->stream, k, G.d_x, G.d_r, pbuf[k & 1], G.d_w, G.plane / 4,
+                       G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update, G.d_rr_part + (size_t)(k & 1) * G.nb_update, G.nb_update,
+                       G.d_pw_part, G.nb_apply, G.d_scal, tol2);
+    return SRPS_OK;
+}
+
+// the loop of devicecalls.cu:252-275: "while (r1 > tol^2 && k <= max_iter)" => up to max_iter+1 steps.
+// Convergence is tested on the device by every kernel; the host just enqueues the steps.
+int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
+    ctx->cg_fixed = fixed_steps;               // bench: never stop early (tol^2 := -1)
+    for (int k = 1; k <= max_steps; ++k) {
+        cg_launch_apply(ctx, k);
+        cg_launch_update(ctx, k);
+    }
+    ctx->cg_fixed = false;
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// t1 = || KT z - z0s ||^2  (devicecalls.cu:762-766): one thread per LR block of the bounding box
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_energy_t1(const float* __restrict__ zg, const int* __restrict__ lr_index,
+                                                   const float* __restrict__ z0s, int Hl, int Wl, int Hs, int sf,
+                                                   float* __restrict__ part) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    const int n = Hl * Wl;
+    const float inv = 1.0f / (float)(sf * sf);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+        const int lr = lr_index[t];
+        if (lr < 0) continue;
+        const int bj = t / Hl, bi = t - bj * Hl;
+        float S = 0.f;
+        for (int dj = 0; dj < sf; ++dj)
+            for (int di = 0; di < sf; ++di) S += inv * zg[(bj * sf + dj + PAD) * Hs + bi * sf + di + PAD];
+        const float d = S - z0s[lr];
+        acc = fmaf(d, d, acc);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+int grid_energy_t1(srps_ctx* ctx, const float* d_z0s, float* d_out) {
+    Grid& G = ctx->grid;
+    const int nb = std::max(1, std::min(cdiv(G.Hl * G.Wl, 256), 1024));
+    float* part = G.d_misc_part + 2048;
+    hipLaunchKernelGGL(k_energy_t1, dim3(nb), dim3(256), 0, ctx->stream, G.d_x, G.d_lr_index, d_z0s, G.Hl, G.Wl, G.Hs, G.sf, part);
+    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, ctx->stream, part, nb, d_out);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+}  // namespace srps

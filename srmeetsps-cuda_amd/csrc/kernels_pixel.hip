@@ -1,0 +1,628 @@
+// kernels_pixel.hip -- per-pixel phases on the compact (masked, reference-layout) arrays:
+// init kernels, normals, lighting, albedo, depth-tensor assembly and the photometric energy.
+// All of them stream I[n][c][p] once, coalesced along p; none has a stencil.
+#include "srps_internal.h"
+#include "device_utils.h"
+
+namespace srps {
+
+// =============================================================================================
+// init kernels  (reference: devicecalls.cu:95-169, SRPS.cu:223-260)
+// =============================================================================================
+__global__ void k_fill(float* __restrict__ d, size_t n, float v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = v;
+}
+int launch_fill(hipStream_t st, float* d, size_t n, float v) {
+    if (n == 0) return SRPS_OK;
+    int nb = (int)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, st, d, n, v);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// masked gather of one image (all channels): out[c][p] = full[c][imask[p]]
+// replaces thrust::copy_if with the channel-replicated mask, SRPS.cu:227-232
+__global__ void k_gather_image(const float* __restrict__ full, const int* __restrict__ imask, int P, size_t hw,
+                               float* __restrict__ out) {
+    const int c = blockIdx.y;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x)
+        out[(size_t)c * P + p] = full[(size_t)c * hw + imask[p]];
+}
+int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask, int P, int C, size_t hw, float* d_out) {
+    int nb = std::min(cdiv(P, 256), 4096);
+    hipLaunchKernelGGL(k_gather_image, dim3(nb, C), dim3(256), 0, st, d_full, d_imask, P, hw, d_out);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// xx = j - cx, yy = i - cy for the masked pixels (meshgrid_create + copy_if, dc.cu:151-158, SRPS.cu:253-258)
+__global__ void k_meshgrid_compact(const int* __restrict__ imask, int P, int h, float cx, float cy,
+                                   float* __restrict__ xx, float* __restrict__ yy) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int lin = imask[p];
+        const int j = lin / h, i = lin - j * h;
+        xx[p] = (float)j - cx;
+        yy[p] = (float)i - cy;
+    }
+}
+int launch_meshgrid_compact(hipStream_t st, const int* d_imask, int P, int h, float cx, float cy, float* xx, float* yy) {
+    int nb = std::min(cdiv(P, 256), 4096);
+    hipLaunchKernelGGL(k_meshgrid_compact, dim3(nb), dim3(256), 0, st, d_imask, P, h, cx, cy, xx, yy);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+__global__ void k_meshgrid_full(int w, int h, float K02, float K12, float* __restrict__ xx, float* __restrict__ yy) {
+    const size_t n = (size_t)w * h;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(t / h), i = (int)(t - (size_t)j * h);
+        xx[t] = (float)j - K02;
+        yy[t] = (float)i - K12;
+    }
+}
+int launch_meshgrid_full(hipStream_t st, int w, int h, float K02, float K12, float* xx, float* yy) {
+    int nb = std::min(cdiv((long long)w * h, 256), 4096);
+    hipLaunchKernelGGL(k_meshgrid_full, dim3(nb), dim3(256), 0, st, w, h, K02, K12, xx, yy);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// mean over the depth channels; zero samples are skipped but the divisor stays nc (dc.cu:95-110)
+__global__ void k_mean_channels(const float* __restrict__ data, size_t hw, int nc, float* __restrict__ mean,
+                                uint8_t* __restrict__ flag) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < hw; t += (size_t)gridDim.x * blockDim.x) {
+        float avg = 0.f;
+        uint8_t f = 0;
+        for (int c = 0; c < nc; ++c) {
+            const float v = data[(size_t)c * hw + t];
+            if (v != 0.f) avg += v; else f = 1;
+        }
+        mean[t] = avg / (float)nc;
+        flag[t] = f;
+    }
+}
+int launch_mean_channels(hipStream_t st, const float* d_data, int h, int w, int nc, float* mean, uint8_t* flag) {
+    const size_t hw = (size_t)h * w;
+    int nb = std::min(cdiv((long long)hw, 256), 4096);
+    hipLaunchKernelGGL(k_mean_channels, dim3(nb), dim3(256), 0, st, d_data, hw, nc, mean, flag);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// =============================================================================================
+// normals: one fused kernel for devicecalls.cu:171-223 (2 saxpy + 3 kernels in the reference)
+// =============================================================================================
+__global__ void k_normals(const float* __restrict__ z, const float* __restrict__ zx, const float* __restrict__ zy,
+                          const float* __restrict__ xx, const float* __restrict__ yy, int P, float fx, float fy,
+                          float* __restrict__ N, float* __restrict__ dz) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const float gx = zx[p], gy = zy[p];
+        const float n0 = fx * gx;                                  // dc.cu:204
+        const float n1 = fy * gy;                                  // dc.cu:211
+        const float n2 = -z[p] - xx[p] * gx - yy[p] * gy;          // dc.cu:174
+        const float nrm = fmaxf(1e-10f, sqrtf(n0 * n0 + n1 * n1 + n2 * n2));   // dc.cu:182
+        N[p] = n0 / nrm;                                           // dc.cu:190
+        N[(size_t)P + p] = n1 / nrm;
+        N[2 * (size_t)P + p] = n2 / nrm;
+        N[3 * (size_t)P + p] = 1.f;                                // dc.cu:175
+        dz[p] = nrm;
+    }
+}
+int launch_normals(hipStream_t st, const float* z, const float* zx, const float* zy, const float* xx,
+                   const float* yy, int P, float fx, float fy, float* N, float* dz) {
+    int nb = std::min(cdiv(P, 256), 4096);
+    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(256), 0, st, z, zx, zy, xx, yy, P, fx, fy, N, dz);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// single-block finalisation of a partial array: out[0] = sum(part[0..n))
+__global__ void k_final_sum(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ double smd;
+    const double t = sum_partials(part, n, &smd);
+    if (threadIdx.x == 0) out[0] = (float)t;
+}
+
+// =============================================================================================
+// lighting (reference: devicecalls.cu:376-444)
+//   per channel c: A_c[p][k] = rho_c[p] N_k[p];  G_c = A_c' A_c (4x4, image independent);
+//   per image i:   ATb_ic = A_c' I_ic;  s_ic <- CG(G_c, warm start s_ic, ATb_ic - G_c s_ic)
+// Pass 1 streams I once and leaves per-block partial sums; pass 2 (one thread per (i,c)) adds
+// them in a fixed order and runs the reference's CG recurrence on the 4x4 system in registers.
+// =============================================================================================
+template <int V, int IB>
+__global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__ rho, const float* __restrict__ N,
+                                                       const float* __restrict__ I, int P, int n_img, int C, int chunk,
+                                                       float* __restrict__ part_atb, float* __restrict__ part_g) {
+    __shared__ float sm[4][IB * 4 + 10];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = blockIdx.x;
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    for (int c = 0; c < C; ++c) {
+        for (int b0 = 0; b0 < n_img; b0 += IB) {
+            float acc[IB][4];
+            float g[10];
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[ii][k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) g[t] = 0.f;
+            for (int q = p0 + tid * V; q < p1; q += 256 * V) {
+                const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
+                Vec<V> nk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+                float a[4][V];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a[k][e] = r.v[e] * nk[k].v[e];       // dc.cu:381
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii) {
+                    if (b0 + ii < n_img) {                                             // wave-uniform
+                        const Vec<V> iv = ldv<V>(I + ((size_t)(b0 + ii) * C + c) * P + q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int e = 0; e < V; ++e) acc[ii][k] = fmaf(a[k][e], iv.v[e], acc[ii][k]);
+                    }
+                }
+                if (b0 == 0) {
+                    int t = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int l = k; l < 4; ++l) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                            ++t;
+                        }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = wave_sum(acc[ii][k]);
+                    if (lane == 0) sm[wv][ii * 4 + k] = v;
+                }
+            if (b0 == 0) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    const float v = wave_sum(g[t]);
+                    if (lane == 0) sm[wv][IB * 4 + t] = v;
+                }
+            }
+            __syncthreads();
+            if (tid < IB * 4) {
+                const int ii = tid >> 2, k = tid & 3;
+                if (b0 + ii < n_img)
+                    part_atb[(((size_t)blk * n_img + b0 + ii) * C + c) * 4 + k] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+            } else if (b0 == 0 && tid < IB * 4 + 10) {
+                part_g[((size_t)blk * C + c) * 10 + (tid - IB * 4)] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// one thread per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded
+__global__ void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
+                              int n_local, int C, int n_total, int img_offset, int zero_nonlocal,
+                              float* __restrict__ s, int* __restrict__ iters_max, float tol, int max_iter) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_total * C) return;
+    const int i = t / C, c = t - i * C;
+    const int li = i - img_offset;
+    float* sv = s + (size_t)t * 4;
+    if (li < 0 || li >= n_local) {
+        if (zero_nonlocal) { sv[0] = 0.f; sv[1] = 0.f; sv[2] = 0.f; sv[3] = 0.f; }
+        return;
+    }
+    double Gd[10], bd[4];
+    for (int u = 0; u < 10; ++u) Gd[u] = 0.0;
+    for (int k = 0; k < 4; ++k) bd[k] = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        for (int u = 0; u < 10; ++u) Gd[u] += (double)part_g[((size_t)b * C + c) * 10 + u];
+        for (int k = 0; k < 4; ++k) bd[k] += (double)part_atb[(((size_t)b * n_local + li) * C + c) * 4 + k];
+    }
+    float A[4][4];
+    {
+        int u = 0;
+        for (int k = 0; k < 4; ++k)
+            for (int l = k; l < 4; ++l) { A[k][l] = (float)Gd[u]; A[l][k] = A[k][l]; ++u; }    // sgemm dc.cu:422
+    }
+    float x[4], r[4], p[4], w[4];
+    for (int k = 0; k < 4; ++k) x[k] = sv[k];
+    for (int k = 0; k < 4; ++k) {                                                          // sgemv dc.cu:423-424
+        float acc = (float)bd[k];
+        for (int l = 0; l < 4; ++l) acc -= A[k][l] * x[l];
+        r[k] = acc;
+    }
+    // cuda_based_conjugate_gradient on the 4x4 system, dc.cu:251-275
+    float r1 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+    float r0 = 0.f;
+    int k = 0;
+    while (r1 > tol * tol && k <= max_iter) {
+        ++k;
+        if (k == 1) {
+            for (int u = 0; u < 4; ++u) p[u] = r[u];
+        } else {
+            const float beta = r1 / r0;
+            for (int u = 0; u < 4; ++u) p[u] = beta * p[u];
+            for (int u = 0; u < 4; ++u) p[u] = p[u] + r[u];
+        }
+        for (int u = 0; u < 4; ++u) w[u] = A[u][0] * p[0] + A[u][1] * p[1] + A[u][2] * p[2] + A[u][3] * p[3];
+        const float dot = p[0] * w[0] + p[1] * w[1] + p[2] * w[2] + p[3] * w[3];
+        const float alpha = r1 / dot;
+        for (int u = 0; u < 4; ++u) x[u] = x[u] + alpha * p[u];
+        for (int u = 0; u < 4; ++u) r[u] = r[u] - alpha * w[u];
+        r0 = r1;
+        r1 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+    }
+    for (int u = 0; u < 4; ++u) sv[u] = x[u];
+    atomicMax(iters_max, k);
+}
+
+int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
+             int n_local, int C, int n_total, int img_offset, bool zero_nonlocal) {
+    constexpr int IB = 8;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_N | (uintptr_t)d_I) % 16 == 0);
+    const int V = vec ? 4 : 1;
+    int chunk = cdiv(P, 1024);
+    chunk = std::max(256 * V, cdiv(chunk, 256 * V) * 256 * V);
+    const int nblk = cdiv(P, chunk);
+    const size_t n_atb = (size_t)nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)nblk * C * 10;
+    SRPS_TRY(ensure(ctx->ws_light, (n_atb + n_g) * sizeof(float) + 64));
+    float* part_atb = (float*)ctx->ws_light.p;
+    float* part_g = part_atb + n_atb;
+    int* d_it = (int*)(part_g + n_g);
+    SRPS_HIP(hipMemsetAsync(d_it, 0, sizeof(int), ctx->stream));
+    if (n_local > 0) {
+        if (vec)
+            hipLaunchKernelGGL((k_light_partial<4, IB>), dim3(nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, chunk, part_atb, part_g);
+        else
+            hipLaunchKernelGGL((k_light_partial<1, IB>), dim3(nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, chunk, part_atb, part_g);
+        SRPS_LAUNCH_CHECK();
+    }
+    const int nt = n_total * C;
+    hipLaunchKernelGGL(k_light_solve, dim3(cdiv(nt, 64)), dim3(64), 0, ctx->stream, part_atb, part_g, nblk, n_local, C,
+                       n_total, img_offset, zero_nonlocal ? 1 : 0, d_s, d_it, ctx->cg_tol, ctx->cg_max_iter);
+    SRPS_LAUNCH_CHECK();
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 8, d_it, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return SRPS_OK;
+}
+
+// =============================================================================================
+// albedo (reference: devicecalls.cu:447-548)
+//   sh_i[p] = N[:,p] . s_ic  (sgemm dc.cu:507);  num = sum_i sh_i I_ic, den = sum_i sh_i^2
+//   (the diagonal A'A and A'b of dc.cu:395-406);  then the reference's global CG on the
+//   diagonal system from the warm start rho_c (dc.cu:540), or its fixed point num/den.
+// =============================================================================================
+template <int V>
+__global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__ s, const float* __restrict__ N,
+                                                       const float* __restrict__ I, int P, int n_local, int C,
+                                                       int s_img_offset, float* __restrict__ num, float* __restrict__ den) {
+    const int q = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (q >= P) return;
+    Vec<V> nk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+    for (int c = 0; c < C; ++c) {
+        Vec<V> nu, de;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { nu.v[e] = 0.f; de.v[e] = 0.f; }
+        for (int i = 0; i < n_local; ++i) {
+            const float* sv = s + ((size_t)(s_img_offset + i) * C + c) * 4;      // uniform -> scalar loads
+            const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+            const Vec<V> iv = ldv<V>(I + ((size_t)i * C + c) * P + q);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float sh = nk[0].v[e] * s0 + nk[1].v[e] * s1 + nk[2].v[e] * s2 + nk[3].v[e] * s3;
+                nu.v[e] = fmaf(sh, iv.v[e], nu.v[e]);
+                de.v[e] = fmaf(sh, sh, de.v[e]);
+            }
+        }
+        stv<V>(num + (size_t)c * P + q, nu);
+        stv<V>(den + (size_t)c * P + q, de);
+    }
+}
+
+int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
+                  int C, int s_img_offset, float* d_numden) {
+    float* num = d_numden;
+    float* den = d_numden + (size_t)C * P;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_numden) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL((k_albedo_numden<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den);
+    else
+        hipLaunchKernelGGL((k_albedo_numden<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+__global__ void k_albedo_closed(float* __restrict__ rho, const float* __restrict__ num, const float* __restrict__ den, size_t n) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const float d = den[t];
+        if (d > 0.f) rho[t] = num[t] / d;
+    }
+}
+
+struct DcgScal {
+    float r0;
+    int iters;
+    int active;
+    int pad;
+};
+
+// r = num - den*rho (dc.cu:404-405); rr_part[c][0][blk] = sum r^2
+__global__ __launch_bounds__(256) void k_dcg_init(const float* __restrict__ rho, const float* __restrict__ num,
+                                                  const float* __restrict__ den, int P, float* __restrict__ r,
+                                                  float* __restrict__ rr_part, int nb, DcgScal* __restrict__ scal) {
+    __shared__ float sm[16];
+    const int c = blockIdx.y;
+    const size_t base = (size_t)c * P;
+    float acc = 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += nb * 256) {
+        const float rv = num[base + p] - den[base + p] * rho[base + p];
+        r[base + p] = rv;
+        acc = fmaf(rv, rv, acc);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        rr_part[((size_t)c * 2 + 0) * nb + blockIdx.x] = t;
+        if (blockIdx.x == 0) { scal[c].r0 = 0.f; scal[c].iters = 0; scal[c].active = 1; }
+    }
+}
+
+// first half of CG step k: p = beta p + r ; partial p.(d p)
+__global__ __launch_bounds__(256) void k_dcg_a(int k, const float* __restrict__ den, const float* __restrict__ r,
+                                               float* __restrict__ p, int P, const float* __restrict__ rr_part,
+                                               float* __restrict__ pw_part, int nb, DcgScal* __restrict__ scal, float tol2) {
+    __shared__ float sm[16];
+    __shared__ double smd;
+    const int c = blockIdx.y;
+    const float r1 = (float)sum_partials(rr_part + ((size_t)c * 2 + ((k - 1) & 1)) * nb, nb, &smd);
+    if (!(r1 > tol2)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[c].active = 0;
+        return;
+    }
+    const float beta = (k == 1) ? 0.f : r1 / scal[c].r0;
+    const size_t base = (size_t)c * P;
+    float acc = 0.f;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < P; q += nb * 256) {
+        float pn;
+        if (k == 1) pn = r[base + q];
+        else { pn = beta * p[base + q]; pn = pn + r[base + q]; }
+        p[base + q] = pn;
+        acc = fmaf(pn, den[base + q] * pn, acc);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) pw_part[(size_t)c * nb + blockIdx.x] = t;
+}
+
+// second half: alpha = r1 / p.w ; x += alpha p ; r -= alpha w ; partial r.r
+__global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ den, float* __restrict__ r,
+                                               const float* __restrict__ p, float* __restrict__ x, int P,
+                                               float* __restrict__ rr_part, const float* __restrict__ pw_part, int nb,
+                                               DcgScal* __restrict__ scal, float tol2) {
+    __shared__ float sm[16];
+    __shared__ double smd;
+    const int c = blockIdx.y;
+    const float* rr_old = rr_part + ((size_t)c * 2 + ((k - 1) & 1)) * nb;
+    float* rr_new = rr_part + ((size_t)c * 2 + (k & 1)) * nb;
+    const float r1 = (float)sum_partials(rr_old, nb, &smd);
+    if (!(r1 > tol2)) {
+        if (threadIdx.x == 0) rr_new[blockIdx.x] = rr_old[blockIdx.x];
+        return;
+    }
+    const float dot = (float)sum_partials(pw_part + (size_t)c * nb, nb, &smd);
+    const float alpha = r1 / dot;
+    const size_t base = (size_t)c * P;
+    float acc = 0.f;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < P; q += nb * 256) {
+        const float pv = p[base + q];
+        const float w = den[base + q] * pv;
+        x[base + q] = fmaf(alpha, pv, x[base + q]);
+        const float rv = fmaf(-alpha, w, r[base + q]);
+        r[base + q] = rv;
+        acc = fmaf(rv, rv, acc);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        rr_new[blockIdx.x] = t;
+        if (blockIdx.x == 0) { scal[c].r0 = r1; scal[c].iters = k; scal[c].active = 1; }
+    }
+}
+
+int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C) {
+    const float* num = d_numden;
+    const float* den = d_numden + (size_t)C * P;
+    SRPS_REQUIRE(C <= 8, SRPS_ERR_UNSUPPORTED, "albedo: at most 8 channels");
+    if (ctx->albedo_mode == SRPS_ALBEDO_CLOSED_FORM) {
+        const size_t n = (size_t)C * P;
+        hipLaunchKernelGGL(k_albedo_closed, dim3(std::min(cdiv((long long)n, 256), 4096)), dim3(256), 0, ctx->stream, d_rho, num, den, n);
+        SRPS_LAUNCH_CHECK();
+        for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = 0;
+        return SRPS_OK;
+    }
+    const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
+    const size_t nv = (size_t)C * P;
+    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + C * sizeof(DcgScal) + 256;
+    SRPS_TRY(ensure(ctx->ws_albedo, bytes));
+    float* r = (float*)ctx->ws_albedo.p;
+    float* p = r + nv;
+    float* rr_part = p + nv;                    // [C][2][nb]
+    float* pw_part = rr_part + (size_t)C * 2 * nb;
+    DcgScal* scal = (DcgScal*)(pw_part + (size_t)C * nb);
+    const float tol2 = ctx->cg_tol * ctx->cg_tol;
+    hipLaunchKernelGGL(k_dcg_init, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
+    SRPS_LAUNCH_CHECK();
+    DcgScal* hs = (DcgScal*)(ctx->h_pinned + 16);
+    const int kmax = ctx->cg_max_iter + 1;         // "k <= max_iter" => up to max_iter+1 steps (dc.cu:252)
+    for (int k = 1; k <= kmax; ++k) {
+        hipLaunchKernelGGL(k_dcg_a, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, P, rr_part, pw_part, nb, scal, tol2);
+        hipLaunchKernelGGL(k_dcg_b, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, d_rho, P, rr_part, pw_part, nb, scal, tol2);
+        if ((k % 8) == 0 || k == kmax) {
+            SRPS_LAUNCH_CHECK();
+            SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+            SRPS_HIP(hipStreamSynchronize(ctx->stream));
+            bool any = false;
+            for (int c = 0; c < C; ++c) any |= (hs[c].active != 0) && (hs[c].iters == k);
+            if (!any) break;
+        }
+    }
+    SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = hs[c].iters;
+    return SRPS_OK;
+}
+
+// =============================================================================================
+// depth: per-pixel photometric tensor (matrix-free form of devicecalls.cu:550-745)
+//   g = rho_c/dz;  a1 = g (fx s0 - xx s2), a2 = g (fy s1 - yy s2), a3 = g s2   (dc.cu:588, 597)
+//   b = I - rho_c s3 (N3 == 1)                                                (dc.cu:554, 573)
+//   v = (a1, a2, -a3);  M = sum_{c,i} v v' (6 unique),  q = sum_{c, local i} v b (3)
+// M needs only s (all images, replicated on every rank); q needs I (this rank's images).
+// Results are scattered to the grid planes the CG works on.
+// =============================================================================================
+template <int V>
+__global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict__ s, const float* __restrict__ rho,
+                                                        const float* __restrict__ I, const float* __restrict__ xx,
+                                                        const float* __restrict__ yy, const float* __restrict__ dz,
+                                                        float fx, float fy, int P, int n_local, int C, int n_total,
+                                                        int img_offset, const int* __restrict__ gofp, size_t plane,
+                                                        float* __restrict__ M, float* __restrict__ Q) {
+    const int q = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (q >= P) return;
+    const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
+    float m[6][V], qq[3][V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) m[t][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) qq[t][e] = 0.f;
+    }
+    for (int c = 0; c < C; ++c) {
+        const Vec<V> vr = ldv<V>(rho + (size_t)c * P + q);
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = vr.v[e] / vdz.v[e];
+        for (int i = 0; i < n_total; ++i) {
+            const float* sv = s + ((size_t)i * C + c) * 4;
+            const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+            const int li = i - img_offset;
+            const bool local = (li >= 0) && (li < n_local);                     // wave-uniform
+            Vec<V> iv;
+            if (local) iv = ldv<V>(I + ((size_t)li * C + c) * P + q);
+            const float fs0 = fx * s0, fs1 = fy * s1;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float v0 = g[e] * (fs0 - vxx.v[e] * s2);
+                const float v1 = g[e] * (fs1 - vyy.v[e] * s2);
+                const float v2 = -(g[e] * s2);
+                m[0][e] = fmaf(v0, v0, m[0][e]);
+                m[1][e] = fmaf(v0, v1, m[1][e]);
+                m[2][e] = fmaf(v0, v2, m[2][e]);
+                m[3][e] = fmaf(v1, v1, m[3][e]);
+                m[4][e] = fmaf(v1, v2, m[4][e]);
+                m[5][e] = fmaf(v2, v2, m[5][e]);
+                if (local) {
+                    const float b = iv.v[e] - vr.v[e] * s3;
+                    qq[0][e] = fmaf(v0, b, qq[0][e]);
+                    qq[1][e] = fmaf(v1, b, qq[1][e]);
+                    qq[2][e] = fmaf(v2, b, qq[2][e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int go = gofp[q + e];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) Q[(size_t)t * plane + go] = qq[t][e];
+    }
+}
+
+int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
+                   const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
+                   int n_total, int img_offset) {
+    Grid& G = ctx->grid;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy | (uintptr_t)d_dz) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL((k_depth_assemble<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q);
+    else
+        hipLaunchKernelGGL((k_depth_assemble<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q);
+    SRPS_LAUNCH_CHECK();
+    ctx->tensor_valid = true;
+    return SRPS_OK;
+}
+
+// photometric energy t2 = sum_{c,i,p} (a1 zx + a2 zy - a3 z - b)^2 over this rank's images
+// (= ||A z - B||^2 of devicecalls.cu:763-767 without forming A)
+template <int V>
+__global__ __launch_bounds__(256) void k_energy_partial(const float* __restrict__ s, const float* __restrict__ rho,
+                                                        const float* __restrict__ I, const float* __restrict__ xx,
+                                                        const float* __restrict__ yy, const float* __restrict__ dz,
+                                                        const float* __restrict__ z, const float* __restrict__ zx,
+                                                        const float* __restrict__ zy, float fx, float fy, int P,
+                                                        int n_local, int C, int img_offset, float* __restrict__ part) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    for (int q = (blockIdx.x * 256 + threadIdx.x) * V; q < P; q += gridDim.x * 256 * V) {
+        const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
+        const Vec<V> vz = ldv<V>(z + q), vzx = ldv<V>(zx + q), vzy = ldv<V>(zy + q);
+        for (int c = 0; c < C; ++c) {
+            const Vec<V> vr = ldv<V>(rho + (size_t)c * P + q);
+            float g[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) g[e] = vr.v[e] / vdz.v[e];
+            for (int li = 0; li < n_local; ++li) {
+                const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
+                const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+                const Vec<V> iv = ldv<V>(I + ((size_t)li * C + c) * P + q);
+                const float fs0 = fx * s0, fs1 = fy * s1;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float a1 = g[e] * (fs0 - vxx.v[e] * s2);
+                    const float a2 = g[e] * (fs1 - vyy.v[e] * s2);
+                    const float a3 = g[e] * s2;
+                    const float b = iv.v[e] - vr.v[e] * s3;
+                    const float res = a1 * vzx.v[e] + a2 * vzy.v[e] - a3 * vz.v[e] - b;
+                    acc = fmaf(res, res, acc);
+                }
+            }
+        }
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I,
+                               const float* d_xx, const float* d_yy, const float* d_dz, const float* d_z,
+                               const float* d_zx, const float* d_zy, float fx, float fy, int P, int n_local,
+                               int C, int img_offset, float* d_out) {
+    Grid& G = ctx->grid;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy |
+                                       (uintptr_t)d_dz | (uintptr_t)d_z | (uintptr_t)d_zx | (uintptr_t)d_zy) % 16 == 0);
+    const int V = vec ? 4 : 1;
+    const int nb = std::max(1, std::min(cdiv(P, 256 * V), 2048));
+    float* part = G.d_misc_part;      // 4096 floats
+    if (vec)
+        hipLaunchKernelGGL((k_energy_partial<4>), dim3(nb), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, P, n_local, C, img_offset, part);
+    else
+        hipLaunchKernelGGL((k_energy_partial<1>), dim3(nb), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, P, n_local, C, img_offset, part);
+    SRPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, ctx->stream, part, nb, d_out);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+}  // namespace srps

@@ -1,0 +1,636 @@
+// srps_api.hip -- the C ABI of include/srps.h: context, grid geometry (the host part of
+// SRPS::execute, SRPS.cu:100-270), the phase operators and the alternating loop (SRPS.cu:272-335).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include "srps_internal.h"
+
+namespace srps {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return SRPS_ERR_HIP;
+}
+int ensure(DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return SRPS_OK;
+    if (b.p) SRPS_HIP(hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+    SRPS_HIP(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return SRPS_OK;
+}
+
+template <typename T>
+static int dalloc(T** p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    SRPS_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    return SRPS_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static void grid_release(Grid& G) {
+    dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index);
+    dfree(G.d_M); dfree(G.d_q); dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_save);
+    dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); dfree(G.d_scal);
+    G.bound = false;
+}
+
+static void state_release(srps_ctx* c) {
+    dfree(c->s); dfree(c->rho); dfree(c->z); dfree(c->Nrm); dfree(c->dz); dfree(c->zx); dfree(c->zy);
+    dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); dfree(c->energy_ex);
+    c->have_state = false;
+}
+
+// Host construction of the grid structure: what SRPS.cu:151-203 expresses as index lists and the
+// COO matrices KT, Dx, Dy becomes a bounding box, a compact->grid index map and one byte per pixel.
+static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
+    Grid& G = ctx->grid;
+    grid_release(G);
+    SRPS_REQUIRE(h > 0 && w > 0 && sf >= 1, SRPS_ERR_INVALID, "bind_grid: bad dimensions h=%d w=%d sf=%d", h, w, sf);
+    SRPS_REQUIRE(h % sf == 0 && w % sf == 0, SRPS_ERR_INVALID, "bind_grid: h=%d, w=%d must be multiples of sf=%d", h, w, sf);
+    SRPS_REQUIRE(mask != nullptr, SRPS_ERR_INVALID, "bind_grid: mask is NULL");
+    const size_t hw = (size_t)h * w;
+    SRPS_REQUIRE(hw < (size_t)1 << 31, SRPS_ERR_UNSUPPORTED, "bind_grid: h*w must fit int32");
+    int imin = h, imax = -1, jmin = w, jmax = -1;
+    G.imask.clear(); G.imasks.clear();
+    for (int j = 0; j < w; ++j)
+        for (int i = 0; i < h; ++i) {
+            const float m = mask[(size_t)j * h + i];
+            // the reference indexes with mask != 0 (SRPS.cu:158) but compacts with mask == 1
+            // (devicecalls.cuh:19-24): anything but {0,1} silently corrupts it; we refuse.
+            SRPS_REQUIRE(m == 0.f || m == 1.f, SRPS_ERR_INVALID, "bind_grid: mask must be {0,1}, found %g at (%d,%d)", (double)m, i, j);
+            if (m != 0.f) {
+                G.imask.push_back((int)((size_t)j * h + i));
+                imin = std::min(imin, i); imax = std::max(imax, i); jmin = std::min(jmin, j); jmax = std::max(jmax, j);
+            }
+        }
+    G.h = h; G.w = w; G.sf = sf;
+    G.P = (int)G.imask.size();
+    SRPS_REQUIRE(G.P > 0, SRPS_ERR_INVALID, "bind_grid: empty mask");
+    G.i_lo = (imin / sf) * sf; G.j_lo = (jmin / sf) * sf;
+    const int i_hi = ((imax + sf) / sf) * sf, j_hi = ((jmax + sf) / sf) * sf;
+    G.Hg = i_hi - G.i_lo; G.Wg = j_hi - G.j_lo;
+    G.Hs = ((G.Hg + 2 * PAD + 31) / 32) * 32;
+    G.Ws = G.Wg + 2 * PAD;
+    G.plane = (size_t)G.Hs * G.Ws;
+    SRPS_REQUIRE(G.plane < ((size_t)1 << 31) - 8 * (size_t)G.Hs, SRPS_ERR_UNSUPPORTED, "bind_grid: grid plane must fit int32 offsets");
+    G.Hl = G.Hg / sf; G.Wl = G.Wg / sf;
+    auto M = [&](int i, int j) -> bool { return i >= 0 && i < h && j >= 0 && j < w && mask[(size_t)j * h + i] != 0.f; };
+    std::vector<uint8_t> flags(G.plane, 0);
+    std::vector<int> gofp(G.P);
+    for (int p = 0; p < G.P; ++p) {
+        const int lin = G.imask[p];
+        const int j = lin / h, i = lin - j * h;
+        uint8_t f = F_MASK;
+        if (M(i + 1, j)) f |= F_FY; else if (M(i - 1, j)) f |= F_BY;        // SRPS.cu:31-38
+        if (M(i, j + 1)) f |= F_FX; else if (M(i, j - 1)) f |= F_BX;        // SRPS.cu:39-46
+        const int go = (j - G.j_lo + PAD) * G.Hs + (i - G.i_lo + PAD);
+        flags[go] = f;
+        gofp[p] = go;
+    }
+    // fully masked sf x sf blocks = rows of KT (D*mask == 1 exactly, SRPS.cu:110-111, 163-183)
+    std::vector<int> lr_index((size_t)G.Hl * G.Wl, -1);
+    int ps = 0;
+    const int hs_full = h / sf;
+    for (int bj = 0; bj < G.Wl; ++bj)
+        for (int bi = 0; bi < G.Hl; ++bi) {
+            bool full = true;
+            for (int dj = 0; dj < sf && full; ++dj)
+                for (int di = 0; di < sf; ++di)
+                    if (!M(G.i_lo + bi * sf + di, G.j_lo + bj * sf + dj)) { full = false; break; }
+            if (!full) continue;
+            lr_index[(size_t)bj * G.Hl + bi] = ps++;
+            G.imasks.push_back((G.j_lo / sf + bj) * hs_full + (G.i_lo / sf + bi));
+            for (int dj = 0; dj < sf; ++dj)
+                for (int di = 0; di < sf; ++di) flags[(size_t)(bj * sf + dj + PAD) * G.Hs + bi * sf + di + PAD] |= F_KB;
+        }
+    G.Ps = ps;
+    // device copies + workspace
+    SRPS_TRY(dalloc(&G.d_gofp, G.P)); SRPS_TRY(dalloc(&G.d_imask, G.P)); SRPS_TRY(dalloc(&G.d_flags, G.plane));
+    SRPS_TRY(dalloc(&G.d_lr_index, lr_index.size()));
+    SRPS_HIP(hipMemcpy(G.d_gofp, gofp.data(), G.P * sizeof(int), hipMemcpyHostToDevice));
+    SRPS_HIP(hipMemcpy(G.d_imask, G.imask.data(), G.P * sizeof(int), hipMemcpyHostToDevice));
+    SRPS_HIP(hipMemcpy(G.d_flags, flags.data(), G.plane, hipMemcpyHostToDevice));
+    SRPS_HIP(hipMemcpy(G.d_lr_index, lr_index.data(), lr_index.size() * sizeof(int), hipMemcpyHostToDevice));
+    SRPS_TRY(dalloc(&G.d_M, 6 * G.plane)); SRPS_TRY(dalloc(&G.d_q, 3 * G.plane));
+    SRPS_TRY(dalloc(&G.d_x, G.plane)); SRPS_TRY(dalloc(&G.d_r, G.plane)); SRPS_TRY(dalloc(&G.d_p, 2 * G.plane));
+    SRPS_TRY(dalloc(&G.d_w, G.plane)); SRPS_TRY(dalloc(&G.d_save, G.plane));
+    SRPS_HIP(hipMemset(G.d_M, 0, 6 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_q, 0, 3 * G.plane * sizeof(float)));
+    SRPS_HIP(hipMemset(G.d_x, 0, G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_r, 0, G.plane * sizeof(float)));
+    SRPS_HIP(hipMemset(G.d_p, 0, 2 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_w, 0, G.plane * sizeof(float)));
+    const int nti = cdiv(G.Hg, 64), ntj = cdiv(G.Wg, 4);
+    G.nb_apply = std::max(1, std::min(nti * ntj, 1024));
+    G.nb_update = std::max(1, std::min(cdiv((long long)G.plane / 4, 256), 1024));
+    SRPS_TRY(dalloc(&G.d_pw_part, 4096)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
+    SRPS_TRY(dalloc(&G.d_scal, 1));
+    SRPS_HIP(hipMemset(G.d_pw_part, 0, 4096 * sizeof(float))); SRPS_HIP(hipMemset(G.d_rr_part, 0, 2 * (size_t)G.nb_update * sizeof(float)));
+    SRPS_HIP(hipMemset(G.d_scal, 0, sizeof(CgScalars)));
+    G.bound = true;
+    ctx->tensor_valid = false;
+    return SRPS_OK;
+}
+
+static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float* d_zx, float* d_zy) {
+    Grid& G = ctx->grid;
+    SRPS_TRY(grid_scatter(ctx, d_z, G.d_x));
+    SRPS_TRY(grid_rhs(ctx, d_z0s));                               // dc.cu:743-745
+    SRPS_TRY(grid_residual(ctx));                                 // dc.cu:758
+    SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:759 (k <= max_iter => 101 steps)
+    SRPS_TRY(grid_gather(ctx, G.d_x, d_z));
+    SRPS_TRY(grid_gradient(ctx, G.d_x, d_zx, d_zy));              // Dx z, Dy z of the NEW z (energy + normals)
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 32, G.d_scal, sizeof(CgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    return SRPS_OK;
+}
+
+}  // namespace srps
+
+using namespace srps;
+
+#define CTX_CHECK(ctx)                                                        \
+    do {                                                                      \
+        SRPS_REQUIRE((ctx) != nullptr, SRPS_ERR_INVALID, "null context");    \
+        SRPS_HIP(hipSetDevice((ctx)->device));                                \
+    } while (0)
+#define GRID_CHECK(ctx) SRPS_REQUIRE((ctx)->grid.bound, SRPS_ERR_STATE, "%s: no grid bound (call srps_bind_grid or srps_setup first)", __func__)
+#define STATE_CHECK(ctx) SRPS_REQUIRE((ctx)->have_state, SRPS_ERR_STATE, "%s: srps_setup has not been called", __func__)
+
+extern "C" {
+
+const char* srps_last_error(void) { return g_err.c_str(); }
+const char* srps_version(void) { return "srps-hip 0.1 (gfx950)"; }
+
+int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
+    SRPS_REQUIRE(out != nullptr, SRPS_ERR_INVALID, "srps_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    SRPS_HIP(hipGetDeviceCount(&ndev));
+    SRPS_REQUIRE(ndev > 0, SRPS_ERR_HIP, "srps_create: no HIP device visible");
+    SRPS_REQUIRE(device_id >= 0 && device_id < ndev, SRPS_ERR_INVALID, "srps_create: device %d out of range (0..%d)", device_id, ndev - 1);
+    SRPS_HIP(hipSetDevice(device_id));
+    srps_ctx* c = new srps_ctx();
+    c->device = device_id;
+    if (block_x > 0) c->block_x = block_x;
+    if (block_y > 0) c->block_y = block_y;
+    hipError_t e = hipStreamCreate(&c->own_stream);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    c->stream = c->own_stream;
+    e = hipHostMalloc((void**)&c->h_pinned, 256 * sizeof(float));
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
+    memset(c->h_pinned, 0, 256 * sizeof(float));
+    *out = c;
+    return SRPS_OK;
+}
+
+int srps_destroy(srps_ctx* ctx) {
+    if (!ctx) return SRPS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    state_release(ctx);
+    grid_release(ctx->grid);
+    if (ctx->ws_light.p) (void)hipFree(ctx->ws_light.p);
+    if (ctx->ws_albedo.p) (void)hipFree(ctx->ws_albedo.p);
+    if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
+    if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SRPS_OK;
+}
+
+int srps_set_stream(srps_ctx* ctx, void* hip_stream) {
+    CTX_CHECK(ctx);
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SRPS_OK;
+}
+
+int srps_synchronize(srps_ctx* ctx) {
+    CTX_CHECK(ctx);
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    return SRPS_OK;
+}
+
+int srps_set_option(srps_ctx* ctx, const char* name, int value) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(name != nullptr, SRPS_ERR_INVALID, "set_option: name is NULL");
+    if (!strcmp(name, "albedo_mode")) {
+        SRPS_REQUIRE(value == SRPS_ALBEDO_CG || value == SRPS_ALBEDO_CLOSED_FORM, SRPS_ERR_INVALID, "albedo_mode: bad value %d", value);
+        ctx->albedo_mode = value;
+    } else if (!strcmp(name, "apply_mode")) {
+        SRPS_REQUIRE(value >= SRPS_APPLY_AUTO && value <= SRPS_APPLY_MARCH, SRPS_ERR_INVALID, "apply_mode: bad value %d", value);
+        ctx->apply_mode = value;
+    } else if (!strcmp(name, "cg_max_iter")) {
+        SRPS_REQUIRE(value >= 0, SRPS_ERR_INVALID, "cg_max_iter: bad value %d", value);
+        ctx->cg_max_iter = value;
+    } else {
+        SRPS_REQUIRE(false, SRPS_ERR_INVALID, "set_option: unknown option '%s'", name);
+    }
+    return SRPS_OK;
+}
+
+// ---- init kernels ---------------------------------------------------------------------------
+int srps_mean_across_channels(srps_ctx* ctx, const float* h_data, int h, int w, int nc, float* d_mean, uint8_t* d_inpaint) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(h_data && d_mean && d_inpaint && h > 0 && w > 0 && nc > 0, SRPS_ERR_INVALID, "mean_across_channels: bad arguments");
+    const size_t n = (size_t)h * w * nc;
+    SRPS_TRY(ensure(ctx->ws_stage, n * sizeof(float)));
+    SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, h_data, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return launch_mean_channels(ctx->stream, (const float*)ctx->ws_stage.p, h, w, nc, d_mean, d_inpaint);
+}
+int srps_rho_init(srps_ctx* ctx, float* d_rho, int npix, int nc) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(d_rho && npix > 0 && nc > 0, SRPS_ERR_INVALID, "rho_init: bad arguments");
+    return launch_fill(ctx->stream, d_rho, (size_t)npix * nc, 0.5f);               // dc.cu:137
+}
+int srps_meshgrid_create(srps_ctx* ctx, int w, int h, float K02, float K12, float* d_xx, float* d_yy) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(d_xx && d_yy && w > 0 && h > 0, SRPS_ERR_INVALID, "meshgrid_create: bad arguments");
+    return launch_meshgrid_full(ctx->stream, w, h, K02, K12, d_xx, d_yy);
+}
+
+// ---- phase operators on caller-owned arrays ---------------------------------------------------
+int srps_normal_init(srps_ctx* ctx, const float* d_z, const float* d_zx, const float* d_zy, const float* d_xx,
+                     const float* d_yy, int npix, float K00, float K11, float* d_N, float* d_dz) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(d_z && d_zx && d_zy && d_xx && d_yy && d_N && d_dz && npix > 0, SRPS_ERR_INVALID, "normal_init: bad arguments");
+    return launch_normals(ctx->stream, d_z, d_zx, d_zy, d_xx, d_yy, npix, K00, K11, d_N, d_dz);
+}
+
+int srps_lightning_estimation(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I,
+                              int npix, int nimages, int nchannels) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(d_s && d_rho && d_N && d_I && npix > 0 && nimages > 0 && nchannels > 0, SRPS_ERR_INVALID, "lightning_estimation: bad arguments");
+    SRPS_TRY(lighting(ctx, d_s, d_rho, d_N, d_I, npix, nimages, nchannels, nimages, 0, false));
+    return SRPS_OK;
+}
+
+int srps_albedo_estimation(srps_ctx* ctx, const float* d_s, float* d_rho, const float* d_N, const float* d_I,
+                           int npix, int nimages, int nchannels) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(d_s && d_rho && d_N && d_I && npix > 0 && nimages > 0 && nchannels > 0, SRPS_ERR_INVALID, "albedo_estimation: bad arguments");
+    SRPS_TRY(ensure(ctx->ws_misc, 2 * (size_t)nchannels * npix * sizeof(float) + 64));
+    float* numden = (float*)ctx->ws_misc.p;
+    SRPS_TRY(albedo_numden(ctx, d_s, d_N, d_I, npix, nimages, nchannels, 0, numden));
+    return albedo_finish(ctx, d_rho, numden, npix, nchannels);
+}
+
+int srps_bind_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
+    CTX_CHECK(ctx);
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    return build_grid(ctx, h, w, sf, mask);
+}
+
+int srps_gradient(srps_ctx* ctx, const float* d_z, int npix, float* d_zx, float* d_zy) {
+    CTX_CHECK(ctx); GRID_CHECK(ctx);
+    SRPS_REQUIRE(d_z && d_zx && d_zy && npix == ctx->grid.P, SRPS_ERR_INVALID, "gradient: npix=%d does not match the bound mask (%d)", npix, ctx->grid.P);
+    SRPS_TRY(grid_scatter(ctx, d_z, ctx->grid.d_x));
+    return grid_gradient(ctx, ctx->grid.d_x, d_zx, d_zy);
+}
+
+int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_N, const float* d_I,
+                          const float* d_xx, const float* d_yy, const float* d_dz, const float* d_z0s, float* d_z,
+                          float K00, float K11, int npix, int nimages, int nchannels, float* energy) {
+    CTX_CHECK(ctx); GRID_CHECK(ctx);
+    (void)d_N;   // the linearised system uses dz, not N (N3 == 1 enters B through s3, dc.cu:573)
+    SRPS_REQUIRE(d_s && d_rho && d_I && d_xx && d_yy && d_dz && d_z0s && d_z && energy, SRPS_ERR_INVALID, "depth_estimation: null argument");
+    SRPS_REQUIRE(npix == ctx->grid.P, SRPS_ERR_INVALID, "depth_estimation: npix=%d does not match the bound mask (%d)", npix, ctx->grid.P);
+    Grid& G = ctx->grid;
+    SRPS_TRY(ensure(ctx->ws_misc, (2 * (size_t)npix + 16) * sizeof(float)));
+    float* zx = (float*)ctx->ws_misc.p;
+    float* zy = zx + npix;
+    float* e2 = zy + npix;
+    SRPS_TRY(depth_assemble(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, K00, K11, npix, nimages, nchannels, nimages, 0));
+    SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
+    SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
+    SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, e2, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];               // dc.cu:785
+    ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 32))->iters;
+    (void)G;
+    return SRPS_OK;
+}
+
+int srps_depth_operator_apply(srps_ctx* ctx, const float* d_x, int npix, float* d_y) {
+    CTX_CHECK(ctx); GRID_CHECK(ctx);
+    SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_operator_apply: no tensor assembled yet");
+    SRPS_REQUIRE(d_x && d_y && npix == ctx->grid.P, SRPS_ERR_INVALID, "depth_operator_apply: bad arguments");
+    Grid& G = ctx->grid;
+    // uses p[0] as the input plane and w as the output plane; both are rewritten by the next solve
+    SRPS_TRY(grid_scatter(ctx, d_x, G.d_p));
+    SRPS_TRY(grid_apply_plain(ctx, G.d_p, G.d_w));
+    return grid_gather(ctx, G.d_w, d_y);
+}
+
+// ---- pipeline -------------------------------------------------------------------------------
+int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(pr != nullptr, SRPS_ERR_INVALID, "setup: problem is NULL");
+    SRPS_REQUIRE(pr->mask && pr->K && pr->zs_lr && pr->z_full, SRPS_ERR_INVALID, "setup: mask, K, zs_lr and z_full are required");
+    SRPS_REQUIRE(pr->n_channels > 0 && pr->n_channels <= 8 && pr->n_images >= 0 && pr->n_images_total > 0, SRPS_ERR_INVALID, "setup: bad image counts");
+    SRPS_REQUIRE(pr->image_offset >= 0 && pr->image_offset + pr->n_images <= pr->n_images_total, SRPS_ERR_INVALID, "setup: shard [%d,%d) outside [0,%d)", pr->image_offset, pr->image_offset + pr->n_images, pr->n_images_total);
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    state_release(ctx);
+    SRPS_TRY(build_grid(ctx, pr->h, pr->w, pr->sf, pr->mask));
+    Grid& G = ctx->grid;
+    const int P = G.P, C = pr->n_channels, NL = pr->n_images, NT = pr->n_images_total;
+    ctx->C = C; ctx->N_local = NL; ctx->N_total = NT; ctx->img_offset = pr->image_offset;
+    ctx->fx = pr->K[0]; ctx->fy = pr->K[4]; ctx->cx = pr->K[6]; ctx->cy = pr->K[7];       // SRPS.cu:256, 269
+    SRPS_TRY(dalloc(&ctx->s, (size_t)NT * C * 4)); SRPS_TRY(dalloc(&ctx->rho, (size_t)C * P)); SRPS_TRY(dalloc(&ctx->z, P));
+    SRPS_TRY(dalloc(&ctx->Nrm, 4 * (size_t)P)); SRPS_TRY(dalloc(&ctx->dz, P)); SRPS_TRY(dalloc(&ctx->zx, P)); SRPS_TRY(dalloc(&ctx->zy, P));
+    SRPS_TRY(dalloc(&ctx->xx, P)); SRPS_TRY(dalloc(&ctx->yy, P)); SRPS_TRY(dalloc(&ctx->z0s, std::max(G.Ps, 1)));
+    SRPS_TRY(dalloc(&ctx->I, (size_t)std::max(NL, 1) * C * P));
+    SRPS_TRY(dalloc(&ctx->albedo_ex, 2 * (size_t)C * P)); SRPS_TRY(dalloc(&ctx->energy_ex, 4));
+    ctx->have_state = true;
+    // lighting init s = (0,0,-1,0)  SRPS.cu:209-217
+    std::vector<float> s0((size_t)NT * C * 4, 0.f);
+    for (size_t t = 0; t < (size_t)NT * C; ++t) s0[t * 4 + 2] = -1.f;
+    SRPS_HIP(hipMemcpy(ctx->s, s0.data(), s0.size() * sizeof(float), hipMemcpyHostToDevice));
+    SRPS_TRY(launch_fill(ctx->stream, ctx->rho, (size_t)C * P, 0.5f));                      // SRPS.cu:220
+    // masked LR depth and initial HR depth (copy_if SRPS.cu:237-246), gathered on the host: O(P)
+    {
+        std::vector<float> tmp(std::max(G.Ps, 1));
+        for (int t = 0; t < G.Ps; ++t) tmp[t] = pr->zs_lr[G.imasks[t]];
+        SRPS_HIP(hipMemcpy(ctx->z0s, tmp.data(), std::max(G.Ps, 1) * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> zt(P);
+        for (int p = 0; p < P; ++p) zt[p] = pr->z_full[G.imask[p]];
+        SRPS_HIP(hipMemcpy(ctx->z, zt.data(), (size_t)P * sizeof(float), hipMemcpyHostToDevice));
+    }
+    SRPS_TRY(launch_meshgrid_compact(ctx->stream, G.d_imask, P, G.h, ctx->cx, ctx->cy, ctx->xx, ctx->yy));
+    if (pr->I) {
+        const size_t per = (size_t)C * G.h * G.w;
+        for (int n = 0; n < NL; ++n) SRPS_TRY(srps_upload_image(ctx, n, pr->I + (size_t)n * per));
+    }
+    SRPS_TRY(srps_normals(ctx));                                                            // SRPS.cu:264-270
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    return SRPS_OK;
+}
+
+int srps_upload_image(srps_ctx* ctx, int li, const float* host_image) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(host_image && li >= 0 && li < ctx->N_local, SRPS_ERR_INVALID, "upload_image: bad arguments");
+    Grid& G = ctx->grid;
+    const size_t hw = (size_t)G.h * G.w, n = hw * ctx->C;
+    SRPS_TRY(ensure(ctx->ws_stage, n * sizeof(float)));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));     // staging buffer reuse
+    SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, host_image, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return launch_gather_image(ctx->stream, (const float*)ctx->ws_stage.p, G.d_imask, G.P, ctx->C, hw, ctx->I + (size_t)li * ctx->C * G.P);
+}
+
+int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, int* n_images, int* n_channels) {
+    CTX_CHECK(ctx); GRID_CHECK(ctx);
+    if (npix) *npix = ctx->grid.P;
+    if (npixs) *npixs = ctx->grid.Ps;
+    if (grid_h) *grid_h = ctx->grid.Hg;
+    if (grid_w) *grid_w = ctx->grid.Wg;
+    if (n_images) *n_images = ctx->N_local;
+    if (n_channels) *n_channels = ctx->C;
+    return SRPS_OK;
+}
+
+int srps_lighting_local(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    return lighting(ctx, ctx->s, ctx->rho, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
+                    ctx->N_local != ctx->N_total);
+}
+int srps_lighting(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(ctx->N_local == ctx->N_total, SRPS_ERR_STATE, "srps_lighting: context holds a shard; use srps_lighting_local + all-reduce");
+    return srps_lighting_local(ctx);
+}
+
+int srps_albedo_partial(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    return albedo_numden(ctx, ctx->s, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->albedo_ex);
+}
+int srps_albedo_finish(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    return albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C);
+}
+int srps_albedo(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(ctx->N_local == ctx->N_total, SRPS_ERR_STATE, "srps_albedo: context holds a shard; use the *_partial/_finish pair");
+    SRPS_TRY(srps_albedo_partial(ctx));
+    return srps_albedo_finish(ctx);
+}
+
+int srps_depth_partial(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
+                          ctx->N_total, ctx->img_offset);
+}
+int srps_depth_solve(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
+    return depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy);
+}
+int srps_energy_partial(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_TRY(grid_energy_t1(ctx, ctx->z0s, ctx->energy_ex));
+    return energy_photometric_partial(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->z, ctx->zx, ctx->zy, ctx->fx, ctx->fy,
+                                      ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->energy_ex + 1);
+}
+int srps_energy_finish(srps_ctx* ctx, float* energy) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(energy != nullptr, SRPS_ERR_INVALID, "energy_finish: energy is NULL");
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->energy_ex, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];
+    ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 32))->iters;
+    ctx->last_light_iters = *(int*)(ctx->h_pinned + 8);
+    return SRPS_OK;
+}
+int srps_depth(srps_ctx* ctx, float* energy) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(ctx->N_local == ctx->N_total, SRPS_ERR_STATE, "srps_depth: context holds a shard; use the sharded phases");
+    SRPS_TRY(srps_depth_partial(ctx));
+    SRPS_TRY(srps_depth_solve(ctx));
+    SRPS_TRY(srps_energy_partial(ctx));
+    return srps_energy_finish(ctx, energy);
+}
+
+int srps_normals(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    Grid& G = ctx->grid;
+    SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));
+    SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy));                               // SRPS.cu:310-311
+    return launch_normals(ctx->stream, ctx->z, ctx->zx, ctx->zy, ctx->xx, ctx->yy, G.P, ctx->fx, ctx->fy, ctx->Nrm, ctx->dz);  // SRPS.cu:315
+}
+
+int srps_exchange(srps_ctx* ctx, const char* which, void** d_ptr, size_t* n_floats) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(which && d_ptr && n_floats, SRPS_ERR_INVALID, "exchange: null argument");
+    Grid& G = ctx->grid;
+    if (!strcmp(which, "s")) { *d_ptr = ctx->s; *n_floats = (size_t)ctx->N_total * ctx->C * 4; }
+    else if (!strcmp(which, "albedo")) { *d_ptr = ctx->albedo_ex; *n_floats = 2 * (size_t)ctx->C * G.P; }
+    else if (!strcmp(which, "depth")) { *d_ptr = G.d_q; *n_floats = 3 * G.plane; }
+    else if (!strcmp(which, "energy")) { *d_ptr = ctx->energy_ex + 1; *n_floats = 1; }
+    else SRPS_REQUIRE(false, SRPS_ERR_INVALID, "exchange: unknown buffer '%s'", which);
+    return SRPS_OK;
+}
+
+// SRPS.cu:272-335 on one GPU
+int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    const float TOLERANCE = 5e-3f;         // SRPS.cu:85
+    const int MAX_ITERATIONS = 10;         // SRPS.cu:86
+    float last_error = NAN;                // SRPS.cu:273
+    int iteration = 1, done = 0;
+    bool stop = false;
+    do {
+        float error = 0.f;
+        SRPS_TRY(srps_lighting(ctx));      // SRPS.cu:281
+        SRPS_TRY(srps_albedo(ctx));        // SRPS.cu:287
+        SRPS_TRY(srps_depth(ctx, &error)); // SRPS.cu:293
+        const float rel_err = fabsf(last_error - error) / fabsf(error);          // SRPS.cu:298
+        if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop = true;   // SRPS.cu:299
+        last_error = error;
+        if (energies && done < max_outer) energies[done] = error;
+        SRPS_TRY(srps_normals(ctx));       // SRPS.cu:310-315
+        ++iteration; ++done;
+        if (max_outer > 0 && done >= max_outer) stop = true;
+    } while (!stop);
+    if (n_outer) *n_outer = done;
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    return SRPS_OK;
+}
+
+static int lookup(srps_ctx* ctx, const char* name, float** p, size_t* n) {
+    Grid& G = ctx->grid;
+    const size_t P = G.P;
+    if (!strcmp(name, "z")) { *p = ctx->z; *n = P; }
+    else if (!strcmp(name, "rho")) { *p = ctx->rho; *n = P * ctx->C; }
+    else if (!strcmp(name, "s")) { *p = ctx->s; *n = (size_t)ctx->N_total * ctx->C * 4; }
+    else if (!strcmp(name, "N")) { *p = ctx->Nrm; *n = 4 * P; }
+    else if (!strcmp(name, "dz")) { *p = ctx->dz; *n = P; }
+    else if (!strcmp(name, "zx")) { *p = ctx->zx; *n = P; }
+    else if (!strcmp(name, "zy")) { *p = ctx->zy; *n = P; }
+    else if (!strcmp(name, "xx")) { *p = ctx->xx; *n = P; }
+    else if (!strcmp(name, "yy")) { *p = ctx->yy; *n = P; }
+    else if (!strcmp(name, "z0s")) { *p = ctx->z0s; *n = G.Ps; }
+    else if (!strcmp(name, "I")) { *p = ctx->I; *n = (size_t)ctx->N_local * ctx->C * P; }
+    else SRPS_REQUIRE(false, SRPS_ERR_INVALID, "unknown state array '%s'", name);
+    return SRPS_OK;
+}
+
+int srps_get(srps_ctx* ctx, const char* name, float* host, size_t n) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(name && host, SRPS_ERR_INVALID, "get: null argument");
+    float* p; size_t len;
+    SRPS_TRY(lookup(ctx, name, &p, &len));
+    SRPS_REQUIRE(n == len, SRPS_ERR_INVALID, "get('%s'): buffer holds %zu floats, array has %zu", name, n, len);
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    SRPS_HIP(hipMemcpy(host, p, len * sizeof(float), hipMemcpyDeviceToHost));
+    return SRPS_OK;
+}
+int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(name && host, SRPS_ERR_INVALID, "set: null argument");
+    float* p; size_t len;
+    SRPS_TRY(lookup(ctx, name, &p, &len));
+    SRPS_REQUIRE(n == len, SRPS_ERR_INVALID, "set('%s'): buffer holds %zu floats, array has %zu", name, n, len);
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
+    return SRPS_OK;
+}
+int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(name && d_ptr && n_floats, SRPS_ERR_INVALID, "get_device_ptr: null argument");
+    float* p; size_t len;
+    SRPS_TRY(lookup(ctx, name, &p, &len));
+    *d_ptr = p; *n_floats = len;
+    return SRPS_OK;
+}
+int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters, int* lighting_iters_max) {
+    CTX_CHECK(ctx);
+    if (depth_iters) *depth_iters = ctx->last_depth_iters;
+    if (albedo_iters) for (int c = 0; c < std::min(ctx->C, 8); ++c) albedo_iters[c] = ctx->last_albedo_iters[c];
+    if (lighting_iters_max) *lighting_iters_max = ctx->last_light_iters;
+    return SRPS_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+int srps_cg_bytes(srps_ctx* ctx, double* apply_bytes, double* update_bytes) {
+    CTX_CHECK(ctx); GRID_CHECK(ctx);
+    // algorithmic bytes per masked unknown: operator kernel reads M (24),
+    // r (4), p (4), structure byte (1), writes p (4), w (4); update kernel reads x,r,p,w (16), writes x,r (8)
+    const double P = (double)ctx->grid.P;
+    if (apply_bytes) *apply_bytes = 41.0 * P;
+    if (update_bytes) *update_bytes = 24.0 * P;
+    return SRPS_OK;
+}
+
+int srps_bench_cg(srps_ctx* ctx, int solves, int iters, double* seconds, double* apply_us, double* update_us) {
+    CTX_CHECK(ctx); GRID_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "bench_cg: run a depth phase first (no system assembled)");
+    SRPS_REQUIRE(solves > 0 && iters > 0, SRPS_ERR_INVALID, "bench_cg: solves and iters must be positive");
+    Grid& G = ctx->grid;
+    hipStream_t st = ctx->stream;
+    SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));
+    SRPS_HIP(hipMemcpyAsync(G.d_save, G.d_x, G.plane * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipEvent_t e0, e1;
+    SRPS_HIP(hipEventCreate(&e0)); SRPS_HIP(hipEventCreate(&e1));
+    double total_ms = 0.0;
+    for (int sidx = 0; sidx < solves; ++sidx) {
+        SRPS_HIP(hipMemcpyAsync(G.d_x, G.d_save, G.plane * sizeof(float), hipMemcpyDeviceToDevice, st));
+        SRPS_TRY(grid_rhs(ctx, ctx->z0s));
+        SRPS_TRY(grid_residual(ctx));
+        SRPS_HIP(hipEventRecord(e0, st));
+        SRPS_TRY(grid_cg(ctx, iters, true));
+        SRPS_HIP(hipEventRecord(e1, st));
+        SRPS_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SRPS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+    }
+    if (seconds) *seconds = total_ms * 1e-3;
+    // per-kernel durations: one more solve with an event after every launch
+    if (apply_us || update_us) {
+        std::vector<hipEvent_t> ev(2 * (size_t)iters + 1);
+        for (auto& e : ev) SRPS_HIP(hipEventCreate(&e));
+        SRPS_HIP(hipMemcpyAsync(G.d_x, G.d_save, G.plane * sizeof(float), hipMemcpyDeviceToDevice, st));
+        SRPS_TRY(grid_rhs(ctx, ctx->z0s));
+        SRPS_TRY(grid_residual(ctx));
+        ctx->cg_fixed = true;
+        SRPS_HIP(hipEventRecord(ev[0], st));
+        for (int k = 1; k <= iters; ++k) {
+            cg_launch_apply(ctx, k);
+            SRPS_HIP(hipEventRecord(ev[2 * k - 1], st));
+            cg_launch_update(ctx, k);
+            SRPS_HIP(hipEventRecord(ev[2 * k], st));
+        }
+        ctx->cg_fixed = false;
+        SRPS_HIP(hipEventSynchronize(ev[2 * (size_t)iters]));
+        double a = 0, u = 0;
+        for (int k = 1; k <= iters; ++k) {
+            float ms = 0.f;
+            SRPS_HIP(hipEventElapsedTime(&ms, ev[2 * k - 2], ev[2 * k - 1])); a += ms;
+            SRPS_HIP(hipEventElapsedTime(&ms, ev[2 * k - 1], ev[2 * k])); u += ms;
+        }
+        if (apply_us) *apply_us = a * 1e3 / iters;
+        if (update_us) *update_us = u * 1e3 / iters;
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    SRPS_HIP(hipMemcpyAsync(G.d_x, G.d_save, G.plane * sizeof(float), hipMemcpyDeviceToDevice, st));
+    SRPS_HIP(hipStreamSynchronize(st));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return SRPS_OK;
+}
+
+}  // extern "C"

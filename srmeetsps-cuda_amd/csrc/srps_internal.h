@@ -1,0 +1,169 @@
+// srps_internal.h -- context, grid geometry and launch helpers shared by the HIP sources.
+// gfx950 (MI355X) only: wave = 64 lanes everywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "srps.h"
+
+namespace srps {
+
+constexpr int WAVE = 64;
+constexpr int PAD = 4;            // zero halo (rows and columns) around the bounding-box grid
+
+// per-pixel structure byte of the grid layout (what make_gradient / KT encode as sparse
+// matrices in the reference, SRPS.cu:23-71 and 170-193)
+enum : uint8_t {
+    F_MASK = 1,     // pixel is in the mask
+    F_FX = 2,       // Dx row is forward:  x[i,j+1] - x[i,j]     (SRPS.cu:39-42)
+    F_BX = 4,       // Dx row is backward: x[i,j]   - x[i,j-1]   (SRPS.cu:43-46)
+    F_FY = 8,       // Dy row is forward:  x[i+1,j] - x[i,j]     (SRPS.cu:31-34)
+    F_BY = 16,      // Dy row is backward: x[i,j]   - x[i-1,j]   (SRPS.cu:35-38)
+    F_KB = 32       // pixel belongs to a fully masked sf x sf block (row of KT, SRPS.cu:176-183)
+};
+
+// CG scalars kept on the device (no host round trip inside the 101-step loop)
+struct CgScalars {
+    float r0;        // previous r.r      (dc.cu:273)
+    float r1_last;   // last r.r seen by the update kernel
+    int iters;       // steps executed    (dc.cu:254)
+    int active;      // 1 while r1 > tol^2
+};
+
+struct Grid {
+    bool bound = false;
+    int h = 0, w = 0, sf = 0;
+    int P = 0, Ps = 0;
+    int i_lo = 0, j_lo = 0, Hg = 0, Wg = 0;     // bounding box (aligned to sf)
+    int Hs = 0, Ws = 0;                         // padded storage: plane = Ws columns of Hs rows
+    size_t plane = 0;
+    int Hl = 0, Wl = 0;                         // LR bounding box = Hg/sf x Wg/sf
+    // device
+    int* d_gofp = nullptr;        // [P]   grid offset of compact pixel p
+    int* d_imask = nullptr;       // [P]   HR linear index of compact pixel p (SRPS.cu:157-162)
+    uint8_t* d_flags = nullptr;   // [plane]
+    int* d_lr_index = nullptr;    // [Hl*Wl] compact LR index of the block, -1 if not fully masked
+    // depth workspace (grid layout)
+    float* d_M = nullptr;         // [6][plane]  photometric tensor, SoA
+    float* d_q = nullptr;         // [3][plane]  (exchange buffer for the sharded depth phase)
+    float* d_x = nullptr;         // [plane] z on the grid
+    float* d_r = nullptr;         // [plane] rhs, then residual
+    float* d_p = nullptr;         // [2][plane] search direction, double-buffered by step parity
+    float* d_w = nullptr;         // [plane] omega = A p
+    float* d_save = nullptr;      // [plane] bench: copy of x
+    // reductions
+    float* d_pw_part = nullptr;   // [nb_apply]
+    float* d_rr_part = nullptr;   // [2][nb_update]
+    float* d_misc_part = nullptr; // [4096] energy partials etc.
+    CgScalars* d_scal = nullptr;
+    int nb_apply = 0, nb_update = 0;
+    // marching-kernel decomposition
+    int seg_rows = 0, n_seg = 0, strip_cols = 0, n_strip = 0;
+    std::vector<int> imask, imasks;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace srps
+
+struct srps_ctx {
+    int device = 0;
+    int block_x = 256, block_y = 4;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int albedo_mode = SRPS_ALBEDO_CG;
+    int apply_mode = SRPS_APPLY_AUTO;
+    int cg_max_iter = 100;           // dc.cu:231
+    float cg_tol = 1e-9f;            // dc.cu:230
+    bool cg_fixed = false;           // bench: run a fixed number of steps
+    float lambda = 1.0f;             // dc.cu:644
+    srps::Grid grid;
+    // grow-only workspaces for the per-pixel phases
+    srps::DevBuf ws_light, ws_albedo, ws_stage, ws_misc;
+    float* h_pinned = nullptr;       // 256 floats of pinned host memory for scalar read-back
+    // pipeline state (srps_setup); reference layouts
+    bool have_state = false;
+    int C = 0, N_local = 0, N_total = 0, img_offset = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    float *s = nullptr, *rho = nullptr, *z = nullptr, *Nrm = nullptr, *dz = nullptr;
+    float *zx = nullptr, *zy = nullptr, *xx = nullptr, *yy = nullptr, *z0s = nullptr, *I = nullptr;
+    float* albedo_ex = nullptr;      // [2][C][P]  num, den
+    float* energy_ex = nullptr;      // [2]
+    int last_depth_iters = 0, last_light_iters = 0;
+    int last_albedo_iters[8] = {0};
+    // what the last depth assembly was built from (srps_depth_operator_apply)
+    bool tensor_valid = false;
+};
+
+namespace srps {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SRPS_HIP(expr)                                                        \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) return srps::hip_fail(e_, #expr, __FILE__, __LINE__); \
+    } while (0)
+#define SRPS_LAUNCH_CHECK() SRPS_HIP(hipGetLastError())
+#define SRPS_REQUIRE(cond, code, ...)                  \
+    do {                                               \
+        if (!(cond)) {                                 \
+            srps::set_error(__VA_ARGS__);              \
+            return (code);                             \
+        }                                              \
+    } while (0)
+#define SRPS_TRY(expr)                 \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != SRPS_OK) return rc_; \
+    } while (0)
+
+int ensure(DevBuf& b, size_t bytes);
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- kernel launchers (kernels_pixel.hip) ------------------------------------------------
+int launch_fill(hipStream_t st, float* d, size_t n, float v);
+int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask, int P, int C, size_t hw, float* d_out);
+int launch_meshgrid_compact(hipStream_t st, const int* d_imask, int P, int h, float cx, float cy, float* xx, float* yy);
+int launch_meshgrid_full(hipStream_t st, int w, int h, float K02, float K12, float* xx, float* yy);
+int launch_mean_channels(hipStream_t st, const float* d_data, int h, int w, int nc, float* mean, uint8_t* flag);
+int launch_normals(hipStream_t st, const float* z, const float* zx, const float* zy, const float* xx,
+                   const float* yy, int P, float fx, float fy, float* N, float* dz);
+int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
+             int n_local, int C, int n_total, int img_offset, bool zero_nonlocal);
+int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
+                  int C, int s_img_offset, float* d_numden);
+int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
+int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
+                   const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
+                   int n_total, int img_offset);
+int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I,
+                               const float* d_xx, const float* d_yy, const float* d_dz, const float* d_z,
+                               const float* d_zx, const float* d_zy, float fx, float fy, int P, int n_local,
+                               int C, int img_offset, float* d_out /* one float, device */);
+
+// ---- grid / CG (kernels_cg.hip) ---------------------------------------------------------
+int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
+int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact);
+int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy);
+int grid_rhs(srps_ctx* ctx, const float* d_z0s);                 // r = KT' z0s + lambda (Dx'q0 + Dy'q1 + q2)
+int grid_residual(srps_ctx* ctx);                                // r -= A_ x ; rr_part[0]
+int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
+int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);     // the 101-step loop
+int grid_energy_t1(srps_ctx* ctx, const float* d_z0s, float* d_out /* one float, device */);
+int cg_launch_apply(srps_ctx* ctx, int k);
+int cg_launch_update(srps_ctx* ctx, int k);
+
+// ---- generic CSR (kernels_csr.hip) --------------------------------------------------------
+int csr_spmv(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n_rows, int n_cols, int nnz,
+             const float* x, int transpose, float* y);
+int csr_cg(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n, int nnz, float* x, float* b, int* iters);
+
+}  // namespace srps
