@@ -171,8 +171,9 @@ int srps_energy_finish(srps_ctx* ctx, float* energy);
 int srps_exchange(srps_ctx* ctx, const char* which /* "s","albedo","depth","energy" */,
                   void** d_ptr, size_t* n_floats);
 
-/* stop rule + loop of SRPS.cu:272-335 on one GPU.  energies (may be NULL) receives up to
- * max_outer values; *n_outer the number of passes executed. */
+/* stop rule + loop of SRPS.cu:272-335 on one GPU.  max_outer <= 0: run to the reference's stop
+ * rule (at most 11 passes).  energies (may be NULL) must hold max_outer values, or 12 when
+ * max_outer <= 0; *n_outer receives the number of passes executed. */
 int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer);
 
 /* state read-back: name in {"z","rho","s","N","dz","zx","zy","xx","yy","z0s","I"}; host buffer
@@ -180,7 +181,7 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer);
 int srps_get(srps_ctx* ctx, const char* name, float* host, size_t n);
 int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n);
 int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats);
-int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters /*[C]*/, int* lighting_iters_max);
+int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters /*[8]*/, int* lighting_iters_max);
 
 /* ---- measurement --------------------------------------------------------------------------
  * Runs `solves` depth-CG solves of exactly `iters_per_solve` steps on the current system

@@ -1,0 +1,136 @@
+"""ctypes wrapper of oracle/libsrps_oracle.so (srps_oracle.c).  TEST INFRASTRUCTURE ONLY: the
+checker's C restatement and the CPU baseline ("port") of bench.py.  PARITY UNPINNED (see
+srps_oracle.py)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libsrps_oracle.so")
+if not os.path.exists(_PATH):
+    raise ImportError(f"{_PATH} not built (make -C oracle)")
+_L = C.CDLL(_PATH)
+f32 = np.float32
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+def _f(a): return a.ctypes.data_as(_fp)
+def _i(a): return a.ctypes.data_as(_ip)
+
+
+_L.oc_assemble.restype = C.c_long
+_L.oc_energy.restype = C.c_double
+_L.oc_num_threads.restype = C.c_int
+
+
+def num_threads() -> int:
+    return int(_L.oc_num_threads())
+
+
+def set_threads(n: int):
+    _L.oc_set_threads(C.c_int(n))
+
+
+class Structure:
+    """neighbour lists and KT blocks of a mask (make_gradient SRPS.cu:23-71, KT SRPS.cu:170-193)"""
+
+    def __init__(self, h, w, sf, mask):
+        mask = np.ascontiguousarray(mask, dtype=f32)
+        P = C.c_int(0); Ps = C.c_int(0)
+        _L.oc_count(h, w, sf, _f(mask), C.byref(P), C.byref(Ps))
+        self.h, self.w, self.sf, self.P, self.Ps = h, w, sf, P.value, Ps.value
+        self.imask = np.empty(self.P, np.int32); self.nb = np.empty(4 * self.P, np.int32)
+        self.blk = np.empty(self.P, np.int32); self.blk_pix = np.empty(max(1, self.Ps * sf * sf), np.int32)
+        rc = _L.oc_structure(h, w, sf, _f(mask), _i(self.imask), _i(self.nb), _i(self.blk), _i(self.blk_pix))
+        assert rc == 0
+
+
+def tensor(st: Structure, s, rho, dz, xx, yy, fx, fy, I):
+    n_img, n_ch, P = I.shape
+    M = np.empty(6 * P, f32); q = np.empty(3 * P, f32)
+    a = [np.ascontiguousarray(v, dtype=f32) for v in (s, rho, dz, xx, yy, I)]
+    _L.oc_tensor(P, n_img, n_ch, _f(a[0]), _f(a[1]), _f(a[2]), _f(a[3]), _f(a[4]), C.c_float(fx), C.c_float(fy), _f(a[5]), _f(M), _f(q))
+    return M, q
+
+
+def mf_apply(st: Structure, M, x, lam=1.0):
+    x = np.ascontiguousarray(x, f32); y = np.empty(st.P, f32); work = np.empty(3 * st.P + st.Ps + 8, f32)
+    _L.oc_mf_apply(st.P, st.Ps, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), _f(M), C.c_float(lam), _f(x), _f(y), _f(work))
+    return y
+
+
+def rhs(st: Structure, q, z0s, lam=1.0):
+    out = np.empty(st.P, f32); z0s = np.ascontiguousarray(z0s, f32)
+    _L.oc_rhs(st.P, st.sf, _i(st.nb), _i(st.blk), _f(q), _f(z0s), C.c_float(lam), _f(out))
+    return out
+
+
+def assemble(st: Structure, M, lam=1.0):
+    cap = st.P * (13 + st.sf * st.sf)
+    rowptr = np.empty(st.P + 1, np.int32); col = np.empty(cap, np.int32); val = np.empty(cap, f32)
+    nnz = _L.oc_assemble(st.P, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), _f(M), C.c_float(lam), _i(rowptr), _i(col), _f(val), C.c_long(cap))
+    assert nnz >= 0, "assemble: capacity exceeded"
+    return rowptr, col[:nnz], val[:nnz]
+
+
+def csr_spmv(rowptr, col, val, x):
+    x = np.ascontiguousarray(x, f32); y = np.empty(rowptr.size - 1, f32)
+    _L.oc_csr_spmv(rowptr.size - 1, _i(rowptr), _i(col), _f(val), _f(x), _f(y))
+    return y
+
+
+def cg_csr(rowptr, col, val, x, b, tol=1e-9, max_iter=100, fixed_iters=0):
+    return _L.oc_cg_csr(rowptr.size - 1, _i(rowptr), _i(col), _f(val), _f(x), _f(b), C.c_float(tol), max_iter, fixed_iters)
+
+
+def cg_mf(st: Structure, M, x, b, lam=1.0, tol=1e-9, max_iter=100, fixed_iters=0):
+    return _L.oc_cg_mf(st.P, st.Ps, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), _f(M), C.c_float(lam), _f(x), _f(b),
+                       C.c_float(tol), max_iter, fixed_iters)
+
+
+def energy(st: Structure, s, rho, dz, xx, yy, fx, fy, I, z0s, z, lam=1.0):
+    n_img, n_ch, P = I.shape
+    a = [np.ascontiguousarray(v, dtype=f32) for v in (s, rho, dz, xx, yy, I, z0s, z)]
+    return float(_L.oc_energy(P, st.Ps, n_img, n_ch, st.sf, _i(st.nb), _i(st.blk_pix), _f(a[0]), _f(a[1]), _f(a[2]), _f(a[3]),
+                              _f(a[4]), C.c_float(fx), C.c_float(fy), _f(a[5]), _f(a[6]), _f(a[7]), C.c_float(lam)))
+
+
+def depth_estimation(st: Structure, s, rho, I, xx, yy, dz, z0s, z, fx, fy, assembled=True):
+    """one depth step (dc.cu:636-786) in C: tensor, system, rhs, residual, CG (101 steps), energy"""
+    M, q = tensor(st, s, rho, dz, xx, yy, fx, fy, I)
+    b = rhs(st, q, z0s)
+    if assembled:
+        rp, ci, v = assemble(st, M)
+        b = (b - csr_spmv(rp, ci, v, z)).astype(f32)
+        it = cg_csr(rp, ci, v, z, b)
+    else:
+        b = (b - mf_apply(st, M, z)).astype(f32)
+        it = cg_mf(st, M, z, b)
+    return energy(st, s, rho, dz, xx, yy, fx, fy, I, z0s, z), it
+
+
+def bench_cpu_baseline(sc, budget_s=20.0):
+    """bench.py cpu_baseline leg: the reference's formulation (assembled CSR + unfused BLAS-1 CG,
+    dc.cu:229-279) on the SAME HR grid, a bounded number of steps, all host cores (OpenMP).
+    The tensor is synthetic (values do not change the cost of an iteration)."""
+    st = Structure(sc.h, sc.w, sc.sf, sc.mask)
+    rng = np.random.default_rng(0)
+    M = np.abs(rng.normal(size=(6, st.P))).astype(f32); M[[1, 2, 4]] *= 0.1
+    M = M.reshape(-1)
+    rp, ci, v = assemble(st, M)
+    x = np.zeros(st.P, f32); b = rng.normal(size=st.P).astype(f32)
+    cg_csr(rp, ci, v, x.copy(), b.copy(), fixed_iters=2)                 # warm-up
+    t0 = time.perf_counter(); cg_csr(rp, ci, v, x.copy(), b.copy(), fixed_iters=5); t5 = time.perf_counter() - t0
+    iters = int(max(5, min(101, budget_s / max(t5 / 5, 1e-6))))
+    t0 = time.perf_counter(); cg_csr(rp, ci, v, x, b, fixed_iters=iters); dt = time.perf_counter() - t0
+    x2 = np.zeros(st.P, f32); b2 = rng.normal(size=st.P).astype(f32)
+    t0 = time.perf_counter(); cg_mf(st, M, x2, b2, fixed_iters=max(5, iters // 2)); dt_mf = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "cg_iterations/s", "cores": num_threads(), "kind": "port",
+            "sample": f"{iters} CG steps of the assembled-CSR {sc.h}x{sc.w} system ({v.size / st.P:.1f} nnz/row), "
+                      f"C/OpenMP restatement of devicecalls.cu:229-279 on {num_threads()} threads",
+            "matrix_free_value": max(5, iters // 2) / dt_mf}

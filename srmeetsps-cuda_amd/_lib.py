@@ -72,6 +72,9 @@ def load():
         raise ImportError(f"{LIB_PATH} is missing: the HIP extension has not been built "
                           f"(run __graft_entry__.build() or make -C srmeetsps-cuda_amd/csrc); "
                           f"there is no fallback path")
+    # torch first: it bundles its own libamdhip64; loading it before ours makes both share ONE HIP
+    # runtime (device pointers and streams are exchanged between them)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     p, i, f, vp = C.c_void_p, C.c_int, C.c_float, C.c_void_p
     ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)

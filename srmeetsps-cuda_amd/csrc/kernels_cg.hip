@@ -286,8 +286,15 @@ static ApplyArgs base_args(srps_ctx* ctx) {
     return a;
 }
 
+bool use_march(const srps_ctx* ctx) {
+    if (ctx->apply_mode == SRPS_APPLY_SIMPLE) return false;
+    return march_supported(ctx);
+}
+int apply_blocks(const srps_ctx* ctx) { return use_march(ctx) ? march_blocks(ctx->grid) : ctx->grid.nb_apply; }
+
 int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane) {
     Grid& G = ctx->grid;
+    if (use_march(ctx)) return march_apply_plain(ctx, d_in_plane, d_out_plane);
     ApplyArgs a = base_args(ctx);
     a.xin = d_in_plane; a.out = d_out_plane;
     hipLaunchKernelGGL((k_apply_simple<0>), dim3(G.nb_apply), dim3(64, 4), 0, ctx->stream, a);
@@ -297,12 +304,16 @@ int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane)
 
 int grid_residual(srps_ctx* ctx) {
     Grid& G = ctx->grid;
-    ApplyArgs a = base_args(ctx);
-    a.xin = G.d_x; a.r = G.d_r;
-    hipLaunchKernelGGL((k_apply_simple<1>), dim3(G.nb_apply), dim3(64, 4), 0, ctx->stream, a);
-    SRPS_LAUNCH_CHECK();
+    if (use_march(ctx)) {
+        SRPS_TRY(march_residual(ctx));
+    } else {
+        ApplyArgs a = base_args(ctx);
+        a.xin = G.d_x; a.r = G.d_r;
+        hipLaunchKernelGGL((k_apply_simple<1>), dim3(G.nb_apply), dim3(64, 4), 0, ctx->stream, a);
+        SRPS_LAUNCH_CHECK();
+    }
     float* first = G.d_misc_part + 4000;
-    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, ctx->stream, G.d_pw_part, G.nb_apply, first);
+    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, ctx->stream, G.d_pw_part, apply_blocks(ctx), first);
     hipLaunchKernelGGL(k_cg_reset, dim3(1), dim3(256), 0, ctx->stream, G.d_scal, G.d_rr_part, G.nb_update, first);
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
@@ -310,6 +321,7 @@ int grid_residual(srps_ctx* ctx) {
 
 int cg_launch_apply(srps_ctx* ctx, int k) {
     Grid& G = ctx->grid;
+    if (use_march(ctx)) return march_cg_apply(ctx, k);
     ApplyArgs a = base_args(ctx);
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
     a.p_in = pbuf[(k + 1) & 1]; a.p_out = pbuf[k & 1]; a.r = G.d_r; a.out = G.d_w;
@@ -326,7 +338,7 @@ int cg_launch_update(srps_ctx* ctx, int k) {
     const float tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
     hipLaunchKernelGGL(k_cg_update, dim3(G.nb_update), dim3(256), 0, ctx->stream, k, G.d_x, G.d_r, pbuf[k & 1], G.d_w, G.plane / 4,
                        G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update, G.d_rr_part + (size_t)(k & 1) * G.nb_update, G.nb_update,
-                       G.d_pw_part, G.nb_apply, G.d_scal, tol2);
+                       G.d_pw_part, apply_blocks(ctx), G.d_scal, tol2);
     return SRPS_OK;
 }
 

@@ -1,3 +1,334 @@
-// kernels_march.hip -- placeholder, filled in below
+// kernels_march.hip -- the depth operator as a register-marching stencil for gfx950.
+//
+//   A_ x = KT'(KT x) + lambda ( Dx'u + Dy'v + w ),  (u,v,w) = M (Dx x, Dy x, x)      
+//
+// One wave (64 lanes) owns a strip of TJ grid columns times a segment of up to 248 rows:
+//   * lane l holds 4 consecutive rows (one float4 per plane and column, 16 B/lane coalesced
+//     loads of 1 KiB per wave-instruction); lanes 0 and n+1 are halo lanes (computed, not stored),
+//     so a wave needs nothing from another wave: no LDS, no barrier in the main loop;
+//   * the wave marches over the columns of its strip keeping a rolling window of x (5 columns),
+//     u (3 columns), v, w and the structure bytes in registers: the x-direction stencil is
+//     register-to-register, the y-direction neighbours (rows i-1, i+1) come from the adjacent
+//     lane through DPP wave shifts (v_mov_b32 dpp wave_shr:1 / wave_shl:1);
+//   * the sf x sf block sum of KT'KT is formed from the lane's own 4 rows and sf columns of the
+//     window (sf in {1,2,4});
+//   * in CG mode the search-direction update p = beta p + r is applied while loading (also in the
+//     halo), p and omega = A_ p are stored for the owned pixels and p.omega is reduced
+//     wave -> block (one partial per block, summed deterministically by the next kernel).
+// Every plane element of M, p, r and the structure bytes is read once per strip plus the halo
+// ((TJ+2)/TJ columns for M, (TJ+5)/TJ for p and r, 66/62 rows).
 #include "srps_internal.h"
+#include "device_utils.h"
 
+namespace srps {
+
+struct MarchArgs {
+    const float* M;
+    const uint8_t* flags;
+    const float* xin;      // MODE 0/1
+    const float* p_in;     // MODE 2
+    float* p_out;          // MODE 2
+    float* r;              // MODE 1 (in/out), MODE 2 (in)
+    float* out;            // MODE 0/2
+    const float* rr_part;
+    int n_rr;
+    float* part_out;
+    CgScalars* scal;
+    int Hg, Wg, Hs, Ws;
+    size_t plane;
+    float lambda, inv_sf4, tol2;
+    int k;
+    int own, n_seg, n_strip, n_items;
+};
+
+__device__ __forceinline__ float dpp_from_prev_lane(float v) {      // lane i <- lane i-1 ; lane 0 <- 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_next_lane(float v) {      // lane i <- lane i+1 ; lane 63 <- 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ unsigned dpp_from_prev_lane(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned dpp_from_next_lane(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ float mul_then_add(float beta, float p, float r) {
+#pragma clang fp contract(off)
+    const float t = beta * p;      // Sscal dc.cu:263
+    return t + r;                  // Saxpy dc.cu:264
+}
+
+// value if bit `bit` of the structure word is set, else +0.0 -- v_bfe_i32 + v_and_b32, no select, no branch
+template <int BIT>
+__device__ __forceinline__ float if_bit(float v, unsigned flword) {
+    const int m = __builtin_amdgcn_sbfe((int)flword, BIT, 1);      // 0 or 0xffffffff
+    return __int_as_float(__float_as_int(v) & m);
+}
+// bit positions inside one structure byte (F_* = 1 << position)
+constexpr int B_FX = 1, B_BX = 2, B_FY = 3, B_BY = 4, B_KB = 5;
+
+struct F4 {
+    float e[4];
+};
+__device__ __forceinline__ F4 ld4(const float* __restrict__ p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    F4 r; r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
+    return r;
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, const F4& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]);
+}
+__device__ __forceinline__ F4 zero4() { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0.f; return r; }
+
+template <int SF, int MODE, int TJ>
+__global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
+    constexpr int L = (SF == 4) ? 3 : 2;      // look-ahead columns of the x window
+    constexpr int NX = L + 2;                 // window holds x[c-1 .. c+L]
+    __shared__ float sm[16];
+    __shared__ double smd;
+    float beta = 0.f;
+    int first = 1;
+    if (MODE == 2) {
+        const float r1 = (float)sum_partials(a.rr_part, a.n_rr, &smd);
+        if (!(r1 > a.tol2)) return;                                   // converged: dc.cu:252
+        first = (a.k == 1);
+        if (!first) beta = r1 / a.scal->r0;                           // dc.cu:262
+    }
+    // XCD-aware block order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
+    // contiguous range of work items (neighbouring strips share halo columns through its L2)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, kk = bid >> 3;
+        bid = xcd * q + min(xcd, rem) + kk;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = bid * 4 + wave;
+    float red = 0.f;
+    if (item < a.n_items) {
+        const int strip = item / a.n_seg, seg = item - strip * a.n_seg;
+        const int Hs = a.Hs;
+        const size_t pl = a.plane;
+        const int row0 = seg * a.own + 4 * lane;                       // storage row of element 0 (PAD == halo == 4)
+        const int nl = a.own >> 2;                                     // owned lanes are 1..nl
+        const bool act = (lane <= nl + 1) && (row0 < Hs);              // lanes that take part at all
+        const bool owned = act && lane >= 1 && lane <= nl && (row0 - PAD < a.Hg);
+        const int c0 = strip * TJ + PAD;                               // first storage column of the strip
+        // Inactive lanes read rows 0..3 of the column instead: that is the zero halo of every plane
+        // (never written), so no load in the loop needs a predicate or a branch.
+        const int rowL = act ? row0 : 0;
+
+        auto load_x = [&](int col) -> F4 {
+            const size_t off = (size_t)col * Hs + rowL;
+            if (MODE != 2) return ld4(a.xin + off);
+            const F4 rv = ld4(a.r + off);
+            if (first) return rv;
+            const F4 pv = ld4(a.p_in + off);
+            F4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.e[e] = mul_then_add(beta, pv.e[e], rv.e[e]);
+            return o;
+        };
+        auto load_fl = [&](int col) -> unsigned {
+            return *reinterpret_cast<const unsigned*>(a.flags + (size_t)col * Hs + rowL);
+        };
+
+        F4 X[NX];                      // X[k] = x at column c-1+k
+        F4 Uprev = zero4(), U0 = zero4(), V0 = zero4(), W0 = zero4();
+        unsigned FLm1 = 0u, FL0 = 0u, FL1;
+        F4 Mc[6];                      // tensor of column c+1
+        F4 S = zero4();                // block sums of the current column group
+        X[0] = zero4();
+#pragma unroll
+        for (int k = 1; k < NX; ++k) X[k] = load_x(c0 - 3 + k);
+        FL1 = load_fl(c0 - 1);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) Mc[t] = ld4(a.M + (size_t)t * pl + (size_t)(c0 - 1) * Hs + rowL);
+
+        for (int c = c0 - 2; c < c0 + TJ; ++c) {
+            // ---- issue the loads of the next step -----------------------------------------------
+            const bool more = (c + 1 < c0 + TJ);
+            F4 Mn[6];
+            unsigned FLn = 0u;
+            F4 Xn = zero4();
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) Mn[t] = ld4(a.M + (size_t)t * pl + (size_t)(c + 2) * Hs + rowL);
+                FLn = load_fl(c + 2);
+                Xn = load_x(c + L + 1);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) Mn[t] = zero4();
+            }
+            // ---- (u,v,w) of column c+1 ----------------------------------------------------------
+            F4 U1, V1, W1;
+            {
+                const F4& xl = X[1];          // column c
+                const F4& xc = X[2];          // column c+1
+                const F4& xr = X[3];          // column c+2
+                const float x_up = dpp_from_prev_lane(xc.e[3]);
+                const float x_dn = dpp_from_next_lane(xc.e[0]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xv = xc.e[e];
+                    const float up = (e == 0) ? x_up : xc.e[e > 0 ? e - 1 : 0];
+                    const float dn = (e == 3) ? x_dn : xc.e[e < 3 ? e + 1 : 3];
+                    // forward / backward are exclusive (SRPS.cu:39-46, 31-38): at most one term survives
+                    const float gx = (e == 0) ? if_bit<B_FX>(xr.e[e] - xv, FL1) + if_bit<B_BX>(xv - xl.e[e], FL1)
+                                   : (e == 1) ? if_bit<B_FX + 8>(xr.e[e] - xv, FL1) + if_bit<B_BX + 8>(xv - xl.e[e], FL1)
+                                   : (e == 2) ? if_bit<B_FX + 16>(xr.e[e] - xv, FL1) + if_bit<B_BX + 16>(xv - xl.e[e], FL1)
+                                              : if_bit<B_FX + 24>(xr.e[e] - xv, FL1) + if_bit<B_BX + 24>(xv - xl.e[e], FL1);
+                    const float gy = (e == 0) ? if_bit<B_FY>(dn - xv, FL1) + if_bit<B_BY>(xv - up, FL1)
+                                   : (e == 1) ? if_bit<B_FY + 8>(dn - xv, FL1) + if_bit<B_BY + 8>(xv - up, FL1)
+                                   : (e == 2) ? if_bit<B_FY + 16>(dn - xv, FL1) + if_bit<B_BY + 16>(xv - up, FL1)
+                                              : if_bit<B_FY + 24>(dn - xv, FL1) + if_bit<B_BY + 24>(xv - up, FL1);
+                    U1.e[e] = Mc[0].e[e] * gx + Mc[1].e[e] * gy + Mc[2].e[e] * xv;
+                    V1.e[e] = Mc[1].e[e] * gx + Mc[3].e[e] * gy + Mc[4].e[e] * xv;
+                    W1.e[e] = Mc[2].e[e] * gx + Mc[4].e[e] * gy + Mc[5].e[e] * xv;
+                }
+            }
+            // ---- output column c ----------------------------------------------------------------
+            if (c >= c0) {
+                if (((c - c0) & (SF - 1)) == 0) {            // first column of an sf-group: block sums
+                    F4 cs = zero4();
+#pragma unroll
+                    for (int d = 0; d < SF; ++d)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cs.e[e] += X[1 + d].e[e];
+                    if (SF == 1) S = cs;
+                    else if (SF == 2) { S.e[0] = S.e[1] = cs.e[0] + cs.e[1]; S.e[2] = S.e[3] = cs.e[2] + cs.e[3]; }
+                    else { const float t = (cs.e[0] + cs.e[1]) + (cs.e[2] + cs.e[3]); S.e[0] = S.e[1] = S.e[2] = S.e[3] = t; }
+                }
+                const float v_up = dpp_from_prev_lane(V0.e[3]);
+                const float v_dn = dpp_from_next_lane(V0.e[0]);
+                const unsigned fl_up = dpp_from_prev_lane(FL0);     // its byte 3 = row above this lane's first row
+                const unsigned fl_dn = dpp_from_next_lane(FL0);     // its byte 0 = row below this lane's last row
+                F4 acc;
+#define SRPS_ROW(EE, FUW, FUB, FDW, FDB, VU, VD)                                                   \
+    {                                                                                              \
+        float t = W0.e[EE];                                                                        \
+        t += if_bit<B_BX + 8 * EE>(U0.e[EE], FL0) - if_bit<B_FX + 8 * EE>(U0.e[EE], FL0);          \
+        t += if_bit<B_FX + 8 * EE>(Uprev.e[EE], FLm1);                                             \
+        t -= if_bit<B_BX + 8 * EE>(U1.e[EE], FL1);                                                 \
+        t += if_bit<B_BY + 8 * EE>(V0.e[EE], FL0) - if_bit<B_FY + 8 * EE>(V0.e[EE], FL0);          \
+        t += if_bit<B_FY + FUB>(VU, FUW);                                                          \
+        t -= if_bit<B_BY + FDB>(VD, FDW);                                                          \
+        t *= a.lambda;                                                                             \
+        t += if_bit<B_KB + 8 * EE>(S.e[EE] * a.inv_sf4, FL0);                                      \
+        acc.e[EE] = t;                                                                             \
+    }
+                SRPS_ROW(0, fl_up, 24, FL0, 8, v_up, V0.e[1])
+                SRPS_ROW(1, FL0, 0, FL0, 16, V0.e[0], V0.e[2])
+                SRPS_ROW(2, FL0, 8, FL0, 24, V0.e[1], V0.e[3])
+                SRPS_ROW(3, FL0, 16, fl_dn, 0, V0.e[2], v_dn)
+#undef SRPS_ROW
+                if (owned) {
+                    const size_t off = (size_t)c * Hs + row0;
+                    if (MODE == 0) {
+                        st4(a.out + off, acc);
+                    } else if (MODE == 1) {
+                        F4 rv = ld4(a.r + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { rv.e[e] -= acc.e[e]; red = fmaf(rv.e[e], rv.e[e], red); }
+                        st4(a.r + off, rv);
+                    } else {
+                        st4(a.p_out + off, X[1]);
+                        st4(a.out + off, acc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) red = fmaf(X[1].e[e], acc.e[e], red);
+                    }
+                }
+            }
+            // ---- shift the windows --------------------------------------------------------------
+            Uprev = U0; U0 = U1; V0 = V1; W0 = W1;
+            FLm1 = FL0; FL0 = FL1; FL1 = FLn;
+#pragma unroll
+            for (int k = 0; k + 1 < NX; ++k) X[k] = X[k + 1];
+            X[NX - 1] = Xn;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) Mc[t] = Mn[t];
+        }
+    }
+    if (MODE != 0) {
+        const float t = block_sum(red, sm);
+        if (threadIdx.x == 0) a.part_out[blockIdx.x] = t;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static constexpr int MARCH_TJ = 16;
+
+bool march_supported(const srps_ctx* ctx) {
+    const int sf = ctx->grid.sf;
+    return sf == 1 || sf == 2 || sf == 4;
+}
+
+void march_plan(Grid& G) {
+    // segments of `own` rows (multiple of 4, at most 248 = 62 lanes x 4) and strips of MARCH_TJ columns
+    const int nseg0 = std::max(1, cdiv(G.Hg, 248));
+    int own = cdiv(G.Hg, nseg0);
+    own = ((own + 3) / 4) * 4;
+    G.seg_rows = own;
+    G.n_seg = cdiv(G.Hg, own);
+    G.strip_cols = MARCH_TJ;
+    G.n_strip = cdiv(G.Wg, MARCH_TJ);
+}
+
+template <int MODE>
+static int launch_march(srps_ctx* ctx, MarchArgs& a) {
+    Grid& G = ctx->grid;
+    a.own = G.seg_rows; a.n_seg = G.n_seg; a.n_strip = G.n_strip; a.n_items = G.n_seg * G.n_strip;
+    const int nb = cdiv(a.n_items, 4);
+    switch (G.sf) {
+        case 1: hipLaunchKernelGGL((k_apply_march<1, MODE, MARCH_TJ>), dim3(nb), dim3(256), 0, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_apply_march<2, MODE, MARCH_TJ>), dim3(nb), dim3(256), 0, ctx->stream, a); break;
+        case 4: hipLaunchKernelGGL((k_apply_march<4, MODE, MARCH_TJ>), dim3(nb), dim3(256), 0, ctx->stream, a); break;
+        default: set_error("march kernel: unsupported sf %d", G.sf); return SRPS_ERR_UNSUPPORTED;
+    }
+    return SRPS_OK;
+}
+
+static MarchArgs march_base(srps_ctx* ctx) {
+    Grid& G = ctx->grid;
+    MarchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = G.d_M; a.flags = G.d_flags; a.Hg = G.Hg; a.Wg = G.Wg; a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane;
+    a.lambda = ctx->lambda;
+    a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
+    a.scal = G.d_scal;
+    a.part_out = G.d_pw_part;
+    return a;
+}
+
+int march_blocks(const Grid& G) { return cdiv(G.n_seg * G.n_strip, 4); }
+
+int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane) {
+    MarchArgs a = march_base(ctx);
+    a.xin = d_in_plane; a.out = d_out_plane;
+    SRPS_TRY(launch_march<0>(ctx, a));
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+int march_residual(srps_ctx* ctx) {
+    Grid& G = ctx->grid;
+    MarchArgs a = march_base(ctx);
+    a.xin = G.d_x; a.r = G.d_r;
+    SRPS_TRY(launch_march<1>(ctx, a));
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+int march_cg_apply(srps_ctx* ctx, int k) {
+    Grid& G = ctx->grid;
+    MarchArgs a = march_base(ctx);
+    float* pbuf[2] = {G.d_p, G.d_p + G.plane};
+    a.p_in = pbuf[(k + 1) & 1]; a.p_out = pbuf[k & 1]; a.r = G.d_r; a.out = G.d_w;
+    a.rr_part = G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update; a.n_rr = G.nb_update;
+    a.k = k;
+    a.tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
+    return launch_march<2>(ctx, a);
+}
+
+}  // namespace srps

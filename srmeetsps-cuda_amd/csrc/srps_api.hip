@@ -87,7 +87,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     const int i_hi = ((imax + sf) / sf) * sf, j_hi = ((jmax + sf) / sf) * sf;
     G.Hg = i_hi - G.i_lo; G.Wg = j_hi - G.j_lo;
     G.Hs = ((G.Hg + 2 * PAD + 31) / 32) * 32;
-    G.Ws = G.Wg + 2 * PAD;
+    G.Ws = ((G.Wg + 31) / 32) * 32 + 2 * PAD;     // strips of the marching kernel stay in bounds
     G.plane = (size_t)G.Hs * G.Ws;
     SRPS_REQUIRE(G.plane < ((size_t)1 << 31) - 8 * (size_t)G.Hs, SRPS_ERR_UNSUPPORTED, "bind_grid: grid plane must fit int32 offsets");
     G.Hl = G.Hg / sf; G.Wl = G.Wg / sf;
@@ -137,9 +137,11 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     const int nti = cdiv(G.Hg, 64), ntj = cdiv(G.Wg, 4);
     G.nb_apply = std::max(1, std::min(nti * ntj, 1024));
     G.nb_update = std::max(1, std::min(cdiv((long long)G.plane / 4, 256), 1024));
-    SRPS_TRY(dalloc(&G.d_pw_part, 4096)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
+    march_plan(G);
+    const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
+    SRPS_TRY(dalloc(&G.d_pw_part, n_pw)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
     SRPS_TRY(dalloc(&G.d_scal, 1));
-    SRPS_HIP(hipMemset(G.d_pw_part, 0, 4096 * sizeof(float))); SRPS_HIP(hipMemset(G.d_rr_part, 0, 2 * (size_t)G.nb_update * sizeof(float)));
+    SRPS_HIP(hipMemset(G.d_pw_part, 0, n_pw * sizeof(float))); SRPS_HIP(hipMemset(G.d_rr_part, 0, 2 * (size_t)G.nb_update * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_scal, 0, sizeof(CgScalars)));
     G.bound = true;
     ctx->tensor_valid = false;
@@ -501,7 +503,7 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
         const float rel_err = fabsf(last_error - error) / fabsf(error);          // SRPS.cu:298
         if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop = true;   // SRPS.cu:299
         last_error = error;
-        if (energies && done < max_outer) energies[done] = error;
+        if (energies && done < (max_outer > 0 ? max_outer : 12)) energies[done] = error;
         SRPS_TRY(srps_normals(ctx));       // SRPS.cu:310-315
         ++iteration; ++done;
         if (max_outer > 0 && done >= max_outer) stop = true;
@@ -560,7 +562,7 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters, int* lighting_iters_max) {
     CTX_CHECK(ctx);
     if (depth_iters) *depth_iters = ctx->last_depth_iters;
-    if (albedo_iters) for (int c = 0; c < std::min(ctx->C, 8); ++c) albedo_iters[c] = ctx->last_albedo_iters[c];
+    if (albedo_iters) for (int c = 0; c < 8; ++c) albedo_iters[c] = ctx->last_albedo_iters[c];
     if (lighting_iters_max) *lighting_iters_max = ctx->last_light_iters;
     return SRPS_OK;
 }

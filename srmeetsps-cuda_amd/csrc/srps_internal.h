@@ -160,6 +160,16 @@ int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);     // the 101-step
 int grid_energy_t1(srps_ctx* ctx, const float* d_z0s, float* d_out /* one float, device */);
 int cg_launch_apply(srps_ctx* ctx, int k);
 int cg_launch_update(srps_ctx* ctx, int k);
+bool use_march(const srps_ctx* ctx);
+int apply_blocks(const srps_ctx* ctx);      // partial sums the operator kernel in use leaves in d_pw_part
+
+// ---- marching operator (kernels_march.hip) ------------------------------------------------
+bool march_supported(const srps_ctx* ctx);
+void march_plan(Grid& G);
+int march_blocks(const Grid& G);
+int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
+int march_residual(srps_ctx* ctx);
+int march_cg_apply(srps_ctx* ctx, int k);
 
 // ---- generic CSR (kernels_csr.hip) --------------------------------------------------------
 int csr_spmv(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n_rows, int n_cols, int nnz,
