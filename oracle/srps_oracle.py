@@ -506,3 +506,58 @@ def execute(prob: Problem, depth="faithful", max_outer=None) -> State:
         if stop or (max_outer is not None and st.iterations >= max_outer):
             break
     return st
+
+
+# --------------------------------------------------------------------------------------
+# partial sums of the image-sharded formulation -- used by tests/_oracle_engine.py to
+# exercise the host-side sharding logic under gloo; algebraically identical to the phases above
+# --------------------------------------------------------------------------------------
+def albedo_numden(s_loc, N, I_loc):
+    """num[c][p] = sum_i sh I, den[c][p] = sum_i sh^2 over the images of one shard (the diagonal
+    A'A and A'b of dc.cu:395-406 restricted to those images), fp32 accumulation in image order."""
+    n_img, n_ch, P = I_loc.shape
+    num = np.zeros((n_ch, P), dtype=f32); den = np.zeros((n_ch, P), dtype=f32)
+    for c in range(n_ch):
+        for i in range(n_img):
+            sh = (s_loc[i, c] @ N).astype(f32)
+            num[c] += sh * I_loc[i, c]; den[c] += sh * sh
+    return num, den
+
+
+def albedo_solve_numden(rho, num, den, cg_iters: list | None = None):
+    """The reference's CG (dc.cu:540) on the diagonal system diag(den) rho = num, warm start rho."""
+    for c in range(rho.shape[0]):
+        b = (num[c] - den[c] * rho[c]).astype(f32)                 # dc.cu:404-405
+        x = rho[c].copy()
+        it = conjugate_gradient(lambda v: (den[c] * v).astype(f32), x, b)
+        rho[c] = x
+        if cg_iters is not None:
+            cg_iters.append(it)
+    return rho
+
+
+def mf_tensor_split(s_all, s_loc, rho, dz, xx, yy, fx, fy, I_loc, dtype=f32):
+    """M from the lighting of ALL images (no image data needed), q and sum b^2 from the local images."""
+    n_all = s_all.shape[0]
+    dummy = np.zeros((n_all, rho.shape[0], rho.shape[1]), dtype=dtype)
+    a1, a2, a3, _ = depth_coefficients(s_all, rho, dz, xx, yy, fx, fy, dummy, dtype=dtype)
+    red = lambda t: t.sum(axis=(0, 1))
+    v0, v1, v2 = a1, a2, -a3
+    M = np.stack([red(v0 * v0), red(v0 * v1), red(v0 * v2), red(v1 * v1), red(v1 * v2), red(v2 * v2)]).astype(dtype)
+    if I_loc.shape[0] == 0:
+        return M, np.zeros((3, rho.shape[1]), dtype=dtype)
+    b1, b2, b3, B = depth_coefficients(s_loc, rho, dz, xx, yy, fx, fy, I_loc, dtype=dtype)
+    q = np.stack([red(b1 * B), red(b2 * B), red(-b3 * B)]).astype(dtype)
+    return M, q
+
+
+def energy_split(geo: Geometry, s_loc, rho, I_loc, xx, yy, dz, z0s, z, fx, fy, dtype=np.float64):
+    """(t1, t2 over the local images) of dc.cu:762-767"""
+    z = z.astype(dtype)
+    t1 = float(np.sum((geo.KT.astype(dtype) @ z - z0s.astype(dtype)) ** 2, dtype=np.float64))
+    if I_loc.shape[0] == 0:
+        return t1, 0.0
+    a1, a2, a3, B = depth_coefficients(s_loc, rho, dz, xx, yy, fx, fy, I_loc, dtype=dtype)
+    gx = geo.Dx.astype(dtype) @ z; gy = geo.Dy.astype(dtype) @ z
+    res = a1 * gx[None, None, :] + a2 * gy[None, None, :] - a3 * z[None, None, :] - B
+    return t1, float(np.sum(res * res, dtype=np.float64))
