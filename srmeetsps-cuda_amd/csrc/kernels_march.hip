@@ -257,22 +257,21 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static constexpr int MARCH_TJ = 16;
 
 bool march_supported(const srps_ctx* ctx) {
     const int sf = ctx->grid.sf;
     return sf == 1 || sf == 2 || sf == 4;
 }
 
-void march_plan(Grid& G) {
+void march_plan(Grid& G, int tj) {
     // segments of `own` rows (multiple of 4, at most 248 = 62 lanes x 4) and strips of MARCH_TJ columns
     const int nseg0 = std::max(1, cdiv(G.Hg, 248));
     int own = cdiv(G.Hg, nseg0);
     own = ((own + 3) / 4) * 4;
     G.seg_rows = own;
     G.n_seg = cdiv(G.Hg, own);
-    G.strip_cols = MARCH_TJ;
-    G.n_strip = cdiv(G.Wg, MARCH_TJ);
+    G.strip_cols = tj;
+    G.n_strip = cdiv(G.Wg, tj);
 }
 
 template <int MODE>
@@ -280,12 +279,22 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
     Grid& G = ctx->grid;
     a.own = G.seg_rows; a.n_seg = G.n_seg; a.n_strip = G.n_strip; a.n_items = G.n_seg * G.n_strip;
     const int nb = cdiv(a.n_items, 4);
+#define SRPS_MARCH_LAUNCH(SF, TJ) hipLaunchKernelGGL((k_apply_march<SF, MODE, TJ>), dim3(nb), dim3(256), 0, ctx->stream, a)
+#define SRPS_MARCH_TJ(SF)                                                   \
+    switch (G.strip_cols) {                                                 \
+        case 8: SRPS_MARCH_LAUNCH(SF, 8); break;                            \
+        case 16: SRPS_MARCH_LAUNCH(SF, 16); break;                          \
+        case 32: SRPS_MARCH_LAUNCH(SF, 32); break;                          \
+        default: set_error("march kernel: unsupported strip width %d", G.strip_cols); return SRPS_ERR_UNSUPPORTED; \
+    }
     switch (G.sf) {
-        case 1: hipLaunchKernelGGL((k_apply_march<1, MODE, MARCH_TJ>), dim3(nb), dim3(256), 0, ctx->stream, a); break;
-        case 2: hipLaunchKernelGGL((k_apply_march<2, MODE, MARCH_TJ>), dim3(nb), dim3(256), 0, ctx->stream, a); break;
-        case 4: hipLaunchKernelGGL((k_apply_march<4, MODE, MARCH_TJ>), dim3(nb), dim3(256), 0, ctx->stream, a); break;
+        case 1: SRPS_MARCH_TJ(1) break;
+        case 2: SRPS_MARCH_TJ(2) break;
+        case 4: SRPS_MARCH_TJ(4) break;
         default: set_error("march kernel: unsupported sf %d", G.sf); return SRPS_ERR_UNSUPPORTED;
     }
+#undef SRPS_MARCH_TJ
+#undef SRPS_MARCH_LAUNCH
     return SRPS_OK;
 }
 

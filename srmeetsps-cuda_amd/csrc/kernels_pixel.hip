@@ -208,26 +208,31 @@ __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__
     }
 }
 
-// one thread per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded
-__global__ void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
+// one wave per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
+// The 64 lanes add the per-block partial sums (fixed order, double), lane 0 runs the 4x4 CG.
+__global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
                               int n_local, int C, int n_total, int img_offset, int zero_nonlocal,
                               float* __restrict__ s, int* __restrict__ iters_max, float tol, int max_iter) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x;
     if (t >= n_total * C) return;
     const int i = t / C, c = t - i * C;
     const int li = i - img_offset;
     float* sv = s + (size_t)t * 4;
     if (li < 0 || li >= n_local) {
-        if (zero_nonlocal) { sv[0] = 0.f; sv[1] = 0.f; sv[2] = 0.f; sv[3] = 0.f; }
+        if (zero_nonlocal && lane < 4) sv[lane] = 0.f;
         return;
     }
     double Gd[10], bd[4];
     for (int u = 0; u < 10; ++u) Gd[u] = 0.0;
     for (int k = 0; k < 4; ++k) bd[k] = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         for (int u = 0; u < 10; ++u) Gd[u] += (double)part_g[((size_t)b * C + c) * 10 + u];
         for (int k = 0; k < 4; ++k) bd[k] += (double)part_atb[(((size_t)b * n_local + li) * C + c) * 4 + k];
     }
+    for (int u = 0; u < 10; ++u) Gd[u] = wave_sum(Gd[u]);
+    for (int k = 0; k < 4; ++k) bd[k] = wave_sum(bd[k]);
+    if (lane != 0) return;
     float A[4][4];
     {
         int u = 0;
@@ -288,7 +293,7 @@ int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, co
         SRPS_LAUNCH_CHECK();
     }
     const int nt = n_total * C;
-    hipLaunchKernelGGL(k_light_solve, dim3(cdiv(nt, 64)), dim3(64), 0, ctx->stream, part_atb, part_g, nblk, n_local, C,
+    hipLaunchKernelGGL(k_light_solve, dim3(nt), dim3(64), 0, ctx->stream, part_atb, part_g, nblk, n_local, C,
                        n_total, img_offset, zero_nonlocal ? 1 : 0, d_s, d_it, ctx->cg_tol, ctx->cg_max_iter);
     SRPS_LAUNCH_CHECK();
     SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 8, d_it, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

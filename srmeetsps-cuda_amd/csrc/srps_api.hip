@@ -137,7 +137,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     const int nti = cdiv(G.Hg, 64), ntj = cdiv(G.Wg, 4);
     G.nb_apply = std::max(1, std::min(nti * ntj, 1024));
     G.nb_update = std::max(1, std::min(cdiv((long long)G.plane / 4, 256), 1024));
-    march_plan(G);
+    march_plan(G, ctx->march_tj);
     const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
     SRPS_TRY(dalloc(&G.d_pw_part, n_pw)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
     SRPS_TRY(dalloc(&G.d_scal, 1));
@@ -237,6 +237,10 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "apply_mode")) {
         SRPS_REQUIRE(value >= SRPS_APPLY_AUTO && value <= SRPS_APPLY_MARCH, SRPS_ERR_INVALID, "apply_mode: bad value %d", value);
         ctx->apply_mode = value;
+    } else if (!strcmp(name, "march_strip")) {
+        SRPS_REQUIRE(value == 8 || value == 16 || value == 32, SRPS_ERR_INVALID, "march_strip: 8, 16 or 32");
+        ctx->march_tj = value;
+        if (ctx->grid.bound) march_plan(ctx->grid, value);
     } else if (!strcmp(name, "cg_max_iter")) {
         SRPS_REQUIRE(value >= 0, SRPS_ERR_INVALID, "cg_max_iter: bad value %d", value);
         ctx->cg_max_iter = value;

@@ -79,6 +79,7 @@ struct srps_ctx {
     hipStream_t own_stream = nullptr;
     int albedo_mode = SRPS_ALBEDO_CG;
     int apply_mode = SRPS_APPLY_AUTO;
+    int march_tj = 16;               // strip width of the marching operator (8, 16 or 32)
     int cg_max_iter = 100;           // dc.cu:231
     float cg_tol = 1e-9f;            // dc.cu:230
     bool cg_fixed = false;           // bench: run a fixed number of steps
@@ -165,7 +166,7 @@ int apply_blocks(const srps_ctx* ctx);      // partial sums the operator kernel 
 
 // ---- marching operator (kernels_march.hip) ------------------------------------------------
 bool march_supported(const srps_ctx* ctx);
-void march_plan(Grid& G);
+void march_plan(Grid& G, int strip_cols);
 int march_blocks(const Grid& G);
 int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
 int march_residual(srps_ctx* ctx);

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Development aid: time the depth-CG kernels for a few kernel options on one synthetic grid.
+   python tools/cg_sweep.py [size] [sf]"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("srmeetsps-cuda_amd")
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+sf = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+sc = pkg.synth.make_scene(size, size, sf, 2, seed=1237, mask_kind="full")
+ctx = pkg.Context(device_id=0)
+ctx.setup(pkg.DataHandler.from_scene(sc))
+pkg.alternating_loop(ctx, None, max_outer=1)
+opts = [("march_strip", v) for v in (8, 16, 32)]
+for name, v in opts:
+    ctx.set_option(name, v)
+    for rep in range(2):
+        b = ctx.bench_cg(solves=5, iters=101)
+    us = 1e6 * b["seconds"] / b["iterations"]
+    print(f"{name}={v}: {us:7.2f} us/iter  apply {b['apply_us']:6.2f} us ({b['apply_bytes']/b['apply_us']/1e3:6.0f} GB/s)  "
+          f"update {b['update_us']:6.2f} us ({b['update_bytes']/b['update_us']/1e3:6.0f} GB/s)  loop {(b['apply_bytes']+b['update_bytes'])/us/1e3:6.0f} GB/s", flush=True)
+ctx.close()
