@@ -1,0 +1,65 @@
+// Main.cpp -- command line of the reference (Main.cpp:9-44): --dstype|-t, --dsloc|-d, --device|-g,
+// --blockx|-x, --blocky|-y, --help|-h|--usage; plus --outdir|-o and --no-output for the result dumps.
+#include <cstring>
+#include <iostream>
+#include <map>
+#include "SRPS.h"
+#include "Utilities.h"
+
+static void print_message() {
+    std::cout << "Usage: srps [params]\n\n"
+                 "\t-h, --help, --usage\n\t\tprint help\n"
+                 "\t-t, --dstype (value:matlab)\n\t\tdataset type, can be matlab or images\n"
+                 "\t-d, --dsloc\n\t\tpath to dataset mat file or folder containing images\n"
+                 "\t-g, --device (value:0)\n\t\tHIP device to run the application on\n"
+                 "\t-x, --blockx (value:256)\n\t\tblock dimension x (advisory)\n"
+                 "\t-y, --blocky (value:4)\n\t\tblock dimension y (advisory)\n"
+                 "\t-o, --outdir (value:.)\n\t\tdirectory for zs_init/z_init/s/rho/z/N .mat dumps\n"
+                 "\t--no-output\n\t\tdo not write .mat dumps\n";
+}
+
+int main(int argc, char* argv[]) {
+    static const std::map<std::string, std::string> alias = {{"h", "help"}, {"usage", "help"}, {"t", "dstype"}, {"d", "dsloc"}, {"g", "device"},
+                                                            {"x", "blockx"}, {"y", "blocky"}, {"o", "outdir"}};
+    std::map<std::string, std::string> opt = {{"dstype", "matlab"}, {"device", "0"}, {"blockx", "256"}, {"blocky", "4"}, {"outdir", "."}};   // Main.cpp:11-16
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) == 0) a = a.substr(2); else if (a.rfind("-", 0) == 0) a = a.substr(1); else continue;
+        std::string key = a, val;
+        const size_t eq = a.find('=');
+        bool has_val = false;
+        if (eq != std::string::npos) { key = a.substr(0, eq); val = a.substr(eq + 1); has_val = true; }
+        auto al = alias.find(key);
+        if (al != alias.end()) key = al->second;
+        if (key == "help" || key == "no-output") { opt[key] = "true"; continue; }
+        if (!has_val && i + 1 < argc) val = argv[++i];
+        if (val.size() >= 2 && val.front() == '"' && val.back() == '"') val = val.substr(1, val.size() - 2);
+        opt[key] = val;
+    }
+    if (opt.count("help") || !opt.count("dsloc")) {                 // Main.cpp:19-26
+        print_message();
+        return 0;
+    }
+    Preferences::blockX = std::stoi(opt["blockx"]);                 // Main.cpp:27-29
+    Preferences::blockY = std::stoi(opt["blocky"]);
+    Preferences::deviceId = std::stoi(opt["device"]);
+    Preferences::outDir = opt["outdir"];
+    Preferences::writeOutputs = !opt.count("no-output");
+    try {
+        if (opt["dstype"] == "matlab") {                            // Main.cpp:31-36
+            MatFileDataHandler dh;
+            dh.loadDataFromMatFiles(opt["dsloc"].c_str());
+            SRPS srps(dh);
+            srps.execute();
+        } else if (opt["dstype"] == "images") {                     // Main.cpp:37-42
+            ImageDataHandler dh;
+            dh.loadDataFromImages(opt["dsloc"].c_str());
+            SRPS srps(dh);
+            srps.execute();
+        }
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << std::endl;                         // the reference lets it terminate(); exit code 1 either way
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,88 @@
+// SRPS.cpp -- SRPS::execute (reference SRPS.cu:84-370) driving the HIP library through the C ABI.
+#include "SRPS.h"
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include "Preprocess.h"
+
+SRPS::SRPS(DataHandler& dh) { this->dh = &dh; }
+SRPS::~SRPS() { if (ctx) srps_destroy(ctx); }
+
+static std::string out_path(const char* name) { return Preferences::outDir + "/" + name; }
+
+void SRPS::execute() {
+    const float TOLERANCE = 5e-3f;          // SRPS.cu:85
+    const int MAX_ITERATIONS = 10;          // SRPS.cu:86
+    dh->validate();
+    if (!ctx) srps_check(srps_create(Preferences::deviceId, Preferences::blockX, Preferences::blockY, &ctx));   // SRPS.cu:88-98
+
+    // Depth mean, inpainting, smoothing, up-sampling (CPU) -- SRPS.cu:117-149
+    std::cout << "Mean of depth values" << std::endl;
+    std::cout << "Inpainting depth values" << std::endl;
+    std::cout << "Smoothing depth" << std::endl;
+    std::cout << "Resample depths" << std::endl;
+    std::vector<float> zs, z_full;
+    preprocess_depth(dh->z0.data(), dh->z0_h, dh->z0_w, dh->z0_n, dh->I_h, dh->I_w, zs, z_full);
+    if (Preferences::writeOutputs) write_MAT_floats(zs.data(), zs.size(), out_path("zs_init.mat").c_str());   // SRPS.cu:143
+
+    // mask indices, KT / Dx / Dy structure, compaction, initial values -- SRPS.cu:151-270
+    std::cout << "Mask index calculation" << std::endl;
+    std::cout << "Masked resample matrix" << std::endl;
+    std::cout << "Masked gradient matrix" << std::endl;
+    std::cout << "Initialization" << std::endl;
+    srps_problem pr;
+    pr.h = dh->I_h; pr.w = dh->I_w; pr.n_channels = dh->I_c; pr.n_images = dh->I_n; pr.n_images_total = dh->I_n;
+    pr.image_offset = 0; pr.sf = (int)dh->sf;
+    pr.mask = dh->mask.data(); pr.K = dh->K.data(); pr.I = dh->I.data(); pr.zs_lr = zs.data(); pr.z_full = z_full.data();
+    srps_check(srps_setup(ctx, &pr));
+    int nimg = 0, nch = 0, gh = 0, gw = 0;
+    srps_check(srps_dims(ctx, &npix, &npixs, &gh, &gw, &nimg, &nch));
+    z.resize(npix); rho.resize((size_t)npix * nch); s.resize((size_t)nimg * nch * 4); N.resize((size_t)npix * 4);
+    if (Preferences::writeOutputs) {
+        srps_check(srps_get(ctx, "z", z.data(), z.size()));
+        write_MAT_floats(z.data(), z.size(), out_path("z_init.mat").c_str());                                  // SRPS.cu:250
+    }
+
+    // Core algorithm -- SRPS.cu:272-335
+    float last_error = NAN;
+    bool stop_loop = false;
+    int iteration = 1;
+    energies.clear();
+    do {
+        Timer timer;
+        timer.start();
+        srps_check(srps_lighting(ctx)); srps_check(srps_synchronize(ctx));                                     // SRPS.cu:281
+        timer.end();
+        printf("\n%-25s: %-6.6fs\n", "Lightning Estimation", timer.get());
+        timer.start();
+        srps_check(srps_albedo(ctx)); srps_check(srps_synchronize(ctx));                                       // SRPS.cu:287
+        timer.end();
+        printf("%-25s: %-6.6fs\n", "Albedo Estimation", timer.get());
+        timer.start();
+        float error = 0.f;
+        srps_check(srps_depth(ctx, &error));                                                                   // SRPS.cu:293
+        timer.end();
+        printf("%-25s: %-6.6fs\n", "Depth Estimation", timer.get());
+
+        const float rel_err = fabsf(last_error - error) / fabsf(error);                                        // SRPS.cu:298
+        if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop_loop = true;       // SRPS.cu:299
+        last_error = error;
+        energies.push_back(error);
+        printf("\nIteration %02d summary\n", iteration);
+        printf("%-25s: %-6.3f\n", "Error", error);
+        printf("%-25s: %-6.3f\n", "Relative Error", rel_err);
+        srps_check(srps_normals(ctx));                                                                         // SRPS.cu:310-315
+        iteration++;
+        srps_check(srps_get(ctx, "s", s.data(), s.size()));
+        srps_check(srps_get(ctx, "rho", rho.data(), rho.size()));
+        srps_check(srps_get(ctx, "z", z.data(), z.size()));
+        srps_check(srps_get(ctx, "N", N.data(), N.size()));
+        if (Preferences::writeOutputs) {                                                                       // SRPS.cu:330-333
+            write_MAT_floats(s.data(), s.size(), out_path("s.mat").c_str());
+            write_MAT_floats(rho.data(), rho.size(), out_path("rho.mat").c_str());
+            write_MAT_floats(z.data(), z.size(), out_path("z.mat").c_str());
+            write_MAT_floats(N.data(), N.size(), out_path("N.mat").c_str());
+        }
+    } while (!stop_loop);
+    std::cout << "Done!" << std::endl;                                                                         // SRPS.cu:337 (no waitKey)
+}

@@ -1,0 +1,20 @@
+// SRPS.h -- the reference's class surface (SRPS.h:10-18) on top of libsrps_hip.so
+#pragma once
+#include <vector>
+#include "Utilities.h"
+
+class SRPS {
+private:
+    DataHandler* dh;
+    srps_ctx* ctx = nullptr;
+
+public:
+    SRPS(DataHandler& dh);
+    ~SRPS();
+    void execute();                       // SRPS.cu:84-370
+
+    // results of the last execute(), in the reference's device layouts (compact masked vectors)
+    std::vector<float> z, rho, s, N;
+    std::vector<float> energies;
+    int npix = 0, npixs = 0;
+};

@@ -364,3 +364,40 @@ def test_error_behaviour(gpu_ctx, pkg):
     c2.close()
     with pytest.raises(pkg.SRPSError):
         pkg.Context(device_id=99)
+
+
+def test_command_line_program_end_to_end(pkg, oracle, tmp_path):
+    """`srps --dstype matlab --dsloc scene.mat` (C++ host: MAT5 loader, depth pre-processing,
+    SRPS::execute, MAT5 dumps) == the Python host on the same file == the oracle"""
+    import subprocess
+    import scipy.io
+    pkg.host.load()
+    sc = pkg.synth.make_scene(40, 48, 2, 4, seed=41, mask_kind="ragged")
+    h, w = sc.h, sc.w
+    I4 = np.transpose(sc.I.reshape(sc.n_img, sc.n_ch, w, h), (3, 2, 1, 0)).astype(np.float64)      # h x w x c x n
+    Kmat = sc.K.reshape(3, 3).T.astype(np.float64)
+    z0 = sc.z0.reshape(w // sc.sf, h // sc.sf).T.astype(np.float64)
+    z0[3, 4] = 0.0                                                                                   # one invalid sample -> inpainted
+    path = str(tmp_path / "scene.mat")
+    scipy.io.savemat(path, {"I": I4, "K": Kmat, "mask": sc.mask.reshape(w, h).T.astype(np.uint8), "sf": float(sc.sf), "z0": z0},
+                     do_compression=True)
+    out = subprocess.run([pkg.host.CLI, "--dstype=matlab", f"--dsloc={path}", "-o", str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "Lightning Estimation" in out.stdout and "Iteration 01 summary" in out.stdout and "Done!" in out.stdout
+    z_cli = scipy.io.loadmat(str(tmp_path / "z.mat"))["x"][:, 0]
+    rho_cli = scipy.io.loadmat(str(tmp_path / "rho.mat"))["x"][:, 0]
+    s_cli = scipy.io.loadmat(str(tmp_path / "s.mat"))["x"][:, 0]
+    # Python host on the same file, same C++ loader and pre-processing
+    dh = pkg.host.load_dataset("matlab", path)
+    np.testing.assert_array_equal(scipy.io.loadmat(str(tmp_path / "zs_init.mat"))["x"][:, 0], dh.zs_lr)
+    ctx = pkg.Context(device_id=0)
+    srps = pkg.SRPS(dh, ctx=ctx)
+    en = srps.execute()
+    np.testing.assert_array_equal(z_cli, srps.z())                  # same library, same inputs: bit-identical
+    np.testing.assert_array_equal(rho_cli, srps.rho().reshape(-1)); np.testing.assert_array_equal(s_cli, srps.s().reshape(-1))
+    assert out.stdout.count("Iteration") == len(en)
+    ctx.close()
+    # oracle on the same pre-processed inputs
+    ref = oracle.execute(oracle.Problem(h, w, sc.sf, dh.mask, dh.K, dh.I, dh.zs_lr, dh.z_full), depth="faithful")
+    assert ref.iterations == len(en)
+    assert rmse(z_cli, ref.z) < 1e-4
