@@ -31,23 +31,19 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
     return t;
 }
 
-// Sum of a partial-sum array written by a PREVIOUS kernel. Done by wave 0 of the block in a
-// fixed pattern (lane l adds elements l, l+64, ... in double, then a butterfly), so every block
-// of every kernel obtains the bit-identical value irrespective of its block size; broadcast
-// through one double of LDS.
-__device__ __forceinline__ double sum_partials(const float* __restrict__ part, int n, double* sm_d) {
+// Sum of a partial-sum array written by a PREVIOUS kernel, by a block of exactly 256 threads
+// (every kernel that calls this is launched with 256 threads): thread t adds elements t, t+256, ...
+// in double, then a wave butterfly, then the four wave sums in a fixed order.  The pattern does not
+// depend on anything but n, so every block of every kernel obtains the bit-identical value.
+__device__ __forceinline__ double sum_partials(const float* __restrict__ part, int n, double* sm_d /* [4] */) {
     const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
-    const int nt = blockDim.x * blockDim.y * blockDim.z;
     double acc = 0.0;
-    if (tid < 64) {
-        for (int i = tid; i < n; i += 64) acc += (double)part[i];
-        acc = wave_sum(acc);
-    }
-    if (nt == 64) return acc;
+    for (int i = tid; i < n; i += 256) acc += (double)part[i];
+    acc = wave_sum(acc);
+    __syncthreads();                       // protect sm_d from a previous call
+    if ((tid & 63) == 0) sm_d[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) *sm_d = acc;
-    __syncthreads();
-    return *sm_d;
+    return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
 }
 
 // ---- V-wide loads of consecutive floats (V = 1 or 4) ---------------------------------------

@@ -150,11 +150,11 @@ __device__ __forceinline__ void grad_at(const XR& X, int g, uint8_t fl, int Hs, 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_apply_simple(ApplyArgs a) {
     __shared__ float sm[16];
-    __shared__ double smd;
+    __shared__ double smd[4];
     XRead<MODE> X;
     X.x = a.xin; X.p = a.p_in; X.r = a.r; X.beta = 0.f; X.first = 1;
     if (MODE == 2) {
-        const float r1 = (float)sum_partials(a.rr_part, a.n_rr, &smd);
+        const float r1 = (float)sum_partials(a.rr_part, a.n_rr, smd);
         if (!(r1 > a.tol2)) return;                         // converged: dc.cu:252
         X.first = (a.k == 1);
         if (!X.first) X.beta = r1 / a.scal->r0;             // dc.cu:262
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void k_cg_update(int k, float* __restrict__ x,
                                                    const float* __restrict__ pw_part, int n_pw, CgScalars* __restrict__ scal,
                                                    float tol2) {
     __shared__ float sm[16];
-    __shared__ double smd;
-    const float r1 = (float)sum_partials(rr_old, n_rr, &smd);
+    __shared__ double smd[4];
+    const float r1 = (float)sum_partials(rr_old, n_rr, smd);
     if (!(r1 > tol2)) {
         if (threadIdx.x == 0) {
             rr_new[blockIdx.x] = rr_old[blockIdx.x];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int k, float* __restrict__ x,
         }
         return;
     }
-    const float dot = (float)sum_partials(pw_part, n_pw, &smd);
+    const float dot = (float)sum_partials(pw_part, n_pw, smd);
     const float alpha = r1 / dot;                                   // dc.cu:269
     float acc = 0.f;
     float4* x4 = reinterpret_cast<float4*>(x);
@@ -269,8 +269,8 @@ __global__ void k_cg_reset(CgScalars* scal, float* rr0, int n_rr, const float* f
 
 // single-block sum (same routine as k_final_sum in kernels_pixel.hip)
 __global__ void k_sum_to(const float* __restrict__ part, int n, float* __restrict__ out) {
-    __shared__ double smd;
-    const double t = sum_partials(part, n, &smd);
+    __shared__ double smd[4];
+    const double t = sum_partials(part, n, smd);
     if (threadIdx.x == 0) out[0] = (float)t;
 }
 
@@ -336,7 +336,7 @@ int cg_launch_update(srps_ctx* ctx, int k) {
     Grid& G = ctx->grid;
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
     const float tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
-    hipLaunchKernelGGL(k_cg_update, dim3(G.nb_update), dim3(256), 0, ctx->stream, k, G.d_x, G.d_r, pbuf[k & 1], G.d_w, G.plane / 4,
+    hipLaunchKernelGGL(k_cg_update, dim3(G.nb_update), dim3(256), 0, ctx->stream, k, G.d_x, G.d_r, pbuf[k & 1], G.d_w, G.used / 4,
                        G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update, G.d_rr_part + (size_t)(k & 1) * G.nb_update, G.nb_update,
                        G.d_pw_part, apply_blocks(ctx), G.d_scal, tol2);
     return SRPS_OK;

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void k_ccg_init(const float* __restrict__ b, i
 // p = beta p + b  (dc.cu:256-265)
 __global__ __launch_bounds__(256) void k_ccg_p(int k, const float* __restrict__ b, float* __restrict__ p, int n,
                                                const float* __restrict__ rr_old, int nb, const CsrCgScal* scal, float tol2) {
-    __shared__ double smd;
-    const float r1 = (float)sum_partials(rr_old, nb, &smd);
+    __shared__ double smd[4];
+    const float r1 = (float)sum_partials(rr_old, nb, smd);
     if (!(r1 > tol2)) return;
     const float beta = (k == 1) ? 0.f : r1 / scal->r0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void k_ccg_spmv(const int* __restrict__ rp, co
                                                   int n, const float* __restrict__ p, float* __restrict__ w,
                                                   const float* __restrict__ rr_old, int nb, float* __restrict__ pw_part, float tol2) {
     __shared__ float sm[16];
-    __shared__ double smd;
-    const float r1 = (float)sum_partials(rr_old, nb, &smd);
+    __shared__ double smd[4];
+    const float r1 = (float)sum_partials(rr_old, nb, smd);
     if (!(r1 > tol2)) return;
     float acc = 0.f;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += nb * 256) {
@@ -97,13 +97,13 @@ __global__ __launch_bounds__(256) void k_ccg_update(int k, float* __restrict__ x
                                                     float* __restrict__ rr_new, const float* __restrict__ pw_part, int nb,
                                                     CsrCgScal* scal, float tol2) {
     __shared__ float sm[16];
-    __shared__ double smd;
-    const float r1 = (float)sum_partials(rr_old, nb, &smd);
+    __shared__ double smd[4];
+    const float r1 = (float)sum_partials(rr_old, nb, smd);
     if (!(r1 > tol2)) {
         if (threadIdx.x == 0) { rr_new[blockIdx.x] = rr_old[blockIdx.x]; if (blockIdx.x == 0) scal->active = 0; }
         return;
     }
-    const float dot = (float)sum_partials(pw_part, nb, &smd);
+    const float dot = (float)sum_partials(pw_part, nb, smd);
     const float alpha = r1 / dot;
     float acc = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += nb * 256) {

@@ -38,7 +38,13 @@ struct MarchArgs {
     size_t plane;
     float lambda, inv_sf4, tol2;
     int k;
-    int own, n_seg, n_strip, n_items;
+    int own, n_seg, n_strip, n_items, tj;
+    // tensor-recompute mode (NC > 0): M is rebuilt per pixel from g_c = (rho_c/dz)^2 (NC planes) and
+    // 8 constants per channel derived from the lighting (see k_tensor_consts)
+    const float* G;
+    const float* consts;   // [NC][8]: Sbb, x*, y*, R00, R01, R11, 0, 0
+    float cx, cy;
+    int i_lo, j_lo;
 };
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v) {      // lane i <- lane i-1 ; lane 0 <- 0
@@ -69,6 +75,10 @@ __device__ __forceinline__ float if_bit(float v, unsigned flword) {
 // bit positions inside one structure byte (F_* = 1 << position)
 constexpr int B_FX = 1, B_BX = 2, B_FY = 3, B_BY = 4, B_KB = 5;
 
+// a structure word whose four bytes are each "interior" (F_MASK|F_FX|F_FY|F_KB = 0x2B) or empty (0)
+__device__ __forceinline__ bool is_plain(unsigned w) { return w == (w & 0x01010101u) * 0x2Bu; }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 struct F4 {
     float e[4];
 };
@@ -82,19 +92,21 @@ __device__ __forceinline__ void st4(float* __restrict__ p, const F4& a) {
 }
 __device__ __forceinline__ F4 zero4() { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0.f; return r; }
 
-template <int SF, int MODE, int TJ>
+template <int SF, int MODE, int NC>
 __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
+    const int TJ = a.tj;                      // strip width: even, multiple of SF (runtime, the loop is unrolled by two)
+    constexpr int NT = (NC > 0) ? NC : 6;     // planes streamed for the tensor: NC (recompute) or 6 (stored M)
     constexpr int L = (SF == 4) ? 3 : 2;      // look-ahead columns of the x window
     constexpr int NX = L + 2;                 // window holds x[c-1 .. c+L]
     __shared__ float sm[16];
-    __shared__ double smd;
+    __shared__ double smd[4];
     float beta = 0.f;
-    int first = 1;
     if (MODE == 2) {
-        const float r1 = (float)sum_partials(a.rr_part, a.n_rr, &smd);
+        const float r1 = (float)sum_partials(a.rr_part, a.n_rr, smd);
         if (!(r1 > a.tol2)) return;                                   // converged: dc.cu:252
-        first = (a.k == 1);
-        if (!first) beta = r1 / a.scal->r0;                           // dc.cu:262
+        // step 1: p = r (dc.cu:258).  The host passes p_in = r and beta stays 0, so that 0*r + r = r
+        // goes through the same branch-free load path as every other step.
+        if (a.k != 1) beta = r1 / a.scal->r0;                         // dc.cu:262
     }
     // XCD-aware block order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
     // contiguous range of work items (neighbouring strips share halo columns through its L2)
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         bid = xcd * q + min(xcd, rem) + kk;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int item = bid * 4 + wave;
+    const int item = __builtin_amdgcn_readfirstlane(bid * 4 + wave);      // wave-uniform: keeps the column loop scalar
     float red = 0.f;
     if (item < a.n_items) {
         const int strip = item / a.n_seg, seg = item - strip * a.n_seg;
@@ -119,49 +131,85 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         // (never written), so no load in the loop needs a predicate or a branch.
         const int rowL = act ? row0 : 0;
 
-        auto load_x = [&](int col) -> F4 {
+        const float* tens = (NC > 0) ? a.G : a.M;
+        // Loads of one step, kept RAW (unconverted) so that they can stay in flight for a whole step:
+        // tensor planes and structure word of column c+1, x of column c+L.
+        struct Raw {
+            F4 T[NT];
+            unsigned fl;
+            F4 r, p;
+        };
+        auto issue = [&](Raw& w, int c) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w.T[t] = ld4(tens + (size_t)t * pl + (size_t)(c + 1) * Hs + rowL);
+            w.fl = *reinterpret_cast<const unsigned*>(a.flags + (size_t)(c + 1) * Hs + rowL);
+            const size_t off = (size_t)(c + L) * Hs + rowL;
+            if (MODE != 2) { w.r = ld4(a.xin + off); }
+            else { w.r = ld4(a.r + off); w.p = ld4(a.p_in + off); }
+        };
+        auto convert = [&](const Raw& w) -> F4 {               // x of the loaded column (CG: p_new = beta p + r)
+            if (MODE != 2) return w.r;
+            F4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.e[e] = mul_then_add(beta, w.p.e[e], w.r.e[e]);
+            return o;
+        };
+        auto load_x = [&](int col) -> F4 {                     // prologue only (waited immediately)
             const size_t off = (size_t)col * Hs + rowL;
             if (MODE != 2) return ld4(a.xin + off);
             const F4 rv = ld4(a.r + off);
-            if (first) return rv;
             const F4 pv = ld4(a.p_in + off);
             F4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o.e[e] = mul_then_add(beta, pv.e[e], rv.e[e]);
             return o;
         };
-        auto load_fl = [&](int col) -> unsigned {
-            return *reinterpret_cast<const unsigned*>(a.flags + (size_t)col * Hs + rowL);
-        };
 
         F4 X[NX];                      // X[k] = x at column c-1+k
         F4 Uprev = zero4(), U0 = zero4(), V0 = zero4(), W0 = zero4();
-        unsigned FLm1 = 0u, FL0 = 0u, FL1;
-        F4 Mc[6];                      // tensor of column c+1
+        unsigned FLm1 = 0u, FL0 = 0u;
+        // tensor-recompute mode: M = sum_c g_c Q_c with
+        //   Q_c = [[S dx^2 + R00, S dx dy + R01, S dx], [., S dy^2 + R11, S dy], [., ., S]],  dx = xx - x*, dy = yy - y*
+        // dy depends on the row only (fixed for the lane), dx on the column only (uniform per step)
+        float kS[NC > 0 ? NC : 1], kX[NC > 0 ? NC : 1], kR00[NC > 0 ? NC : 1], kR01[NC > 0 ? NC : 1];
+        float cSdy[NC > 0 ? NC : 1][4], cQ11[NC > 0 ? NC : 1][4];          // S dy  and  S dy^2 + R11
+        if (NC > 0) {
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                const float* k8 = a.consts + ch * 8;           // uniform -> scalar loads
+                kS[ch] = k8[0]; kX[ch] = k8[1]; kR00[ch] = k8[3]; kR01[ch] = k8[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dy = ((float)(a.i_lo + row0 - PAD + e) - a.cy) - k8[2];   // yy - y*
+                    cSdy[ch][e] = k8[0] * dy;
+                    cQ11[ch][e] = (k8[0] * dy) * dy + k8[5];
+                }
+            }
+        }
         F4 S = zero4();                // block sums of the current column group
         X[0] = zero4();
 #pragma unroll
-        for (int k = 1; k < NX; ++k) X[k] = load_x(c0 - 3 + k);
-        FL1 = load_fl(c0 - 1);
-#pragma unroll
-        for (int t = 0; t < 6; ++t) Mc[t] = ld4(a.M + (size_t)t * pl + (size_t)(c0 - 1) * Hs + rowL);
+        for (int k = 1; k + 1 < NX; ++k) X[k] = load_x(c0 - 3 + k);
+        X[NX - 1] = zero4();
+        // Software pipeline: the loads of step c+1 are issued before the arithmetic of step c, into two
+        // alternating buffer sets (the loop is unrolled by two, so no in-flight register is ever copied).
+        // The last step re-reads its own columns (cache hits) instead of branching, which keeps the vmcnt
+        // bookkeeping exact.  (A distance-3 pipeline with four buffer sets measured 8 % slower.)
+        Raw bufA, bufB;
+        const int c_last = c0 + TJ - 1;
+        issue(bufA, c0 - 2);
 
-        for (int c = c0 - 2; c < c0 + TJ; ++c) {
-            // ---- issue the loads of the next step -----------------------------------------------
-            const bool more = (c + 1 < c0 + TJ);
-            F4 Mn[6];
-            unsigned FLn = 0u;
-            F4 Xn = zero4();
-            if (more) {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) Mn[t] = ld4(a.M + (size_t)t * pl + (size_t)(c + 2) * Hs + rowL);
-                FLn = load_fl(c + 2);
-                Xn = load_x(c + L + 1);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) Mn[t] = zero4();
-            }
+        auto step = [&](const int c, const Raw& cur, Raw& nxt) {
+            issue(nxt, min(c + 1, c_last));
+            X[NX - 1] = convert(cur);             // x of column c+L
+            const unsigned FL1 = cur.fl;          // structure bytes of column c+1
+            const F4* Mc = cur.T;                 // tensor data of column c+1
             // ---- (u,v,w) of column c+1 ----------------------------------------------------------
+            // Wave-uniform fast path: when every structure byte the wave touches is either "interior"
+            // (masked, forward in x and y, inside a KT block) or empty, all selects collapse to plain
+            // arithmetic.  Empty pixels have M = 0, so their u, v, w vanish by themselves.  The results are
+            // bit-identical to the general path (the same operations minus additions of +0).
+            const bool plain1 = wave_all(is_plain(FL1));
             F4 U1, V1, W1;
             {
                 const F4& xl = X[1];          // column c
@@ -169,23 +217,55 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
                 const F4& xr = X[3];          // column c+2
                 const float x_up = dpp_from_prev_lane(xc.e[3]);
                 const float x_dn = dpp_from_next_lane(xc.e[0]);
+                float q00[NC > 0 ? NC : 1], q02[NC > 0 ? NC : 1], dxc[NC > 0 ? NC : 1];
+                if (NC > 0) {
+                    const float xxv = (float)(a.j_lo + (c + 1) - PAD) - a.cx;      // xx of column c+1 (meshgrid: j - K[6])
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) {
+                        dxc[ch] = xxv - kX[ch];
+                        q02[ch] = kS[ch] * dxc[ch];                                 // S dx
+                        q00[ch] = q02[ch] * dxc[ch] + kR00[ch];                     // S dx^2 + R00
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    float m0, m1, m2, m3, m4, m5;
+                    if (NC > 0) {
+                        m0 = m1 = m2 = m3 = m4 = m5 = 0.f;
+#pragma unroll
+                        for (int ch = 0; ch < NC; ++ch) {
+                            const float g = Mc[ch].e[e];
+                            m0 = fmaf(g, q00[ch], m0);
+                            m1 = fmaf(g, fmaf(dxc[ch], cSdy[ch][e], kR01[ch]), m1);     // S dx dy + R01
+                            m2 = fmaf(g, q02[ch], m2);
+                            m3 = fmaf(g, cQ11[ch][e], m3);
+                            m4 = fmaf(g, cSdy[ch][e], m4);
+                            m5 = fmaf(g, kS[ch], m5);
+                        }
+                    } else {
+                        m0 = Mc[0].e[e]; m1 = Mc[1 % NT].e[e]; m2 = Mc[2 % NT].e[e]; m3 = Mc[3 % NT].e[e]; m4 = Mc[4 % NT].e[e]; m5 = Mc[5 % NT].e[e];
+                    }
                     const float xv = xc.e[e];
                     const float up = (e == 0) ? x_up : xc.e[e > 0 ? e - 1 : 0];
                     const float dn = (e == 3) ? x_dn : xc.e[e < 3 ? e + 1 : 3];
-                    // forward / backward are exclusive (SRPS.cu:39-46, 31-38): at most one term survives
-                    const float gx = (e == 0) ? if_bit<B_FX>(xr.e[e] - xv, FL1) + if_bit<B_BX>(xv - xl.e[e], FL1)
-                                   : (e == 1) ? if_bit<B_FX + 8>(xr.e[e] - xv, FL1) + if_bit<B_BX + 8>(xv - xl.e[e], FL1)
-                                   : (e == 2) ? if_bit<B_FX + 16>(xr.e[e] - xv, FL1) + if_bit<B_BX + 16>(xv - xl.e[e], FL1)
-                                              : if_bit<B_FX + 24>(xr.e[e] - xv, FL1) + if_bit<B_BX + 24>(xv - xl.e[e], FL1);
-                    const float gy = (e == 0) ? if_bit<B_FY>(dn - xv, FL1) + if_bit<B_BY>(xv - up, FL1)
-                                   : (e == 1) ? if_bit<B_FY + 8>(dn - xv, FL1) + if_bit<B_BY + 8>(xv - up, FL1)
-                                   : (e == 2) ? if_bit<B_FY + 16>(dn - xv, FL1) + if_bit<B_BY + 16>(xv - up, FL1)
-                                              : if_bit<B_FY + 24>(dn - xv, FL1) + if_bit<B_BY + 24>(xv - up, FL1);
-                    U1.e[e] = Mc[0].e[e] * gx + Mc[1].e[e] * gy + Mc[2].e[e] * xv;
-                    V1.e[e] = Mc[1].e[e] * gx + Mc[3].e[e] * gy + Mc[4].e[e] * xv;
-                    W1.e[e] = Mc[2].e[e] * gx + Mc[4].e[e] * gy + Mc[5].e[e] * xv;
+                    float gx, gy;
+                    if (plain1) {
+                        gx = xr.e[e] - xv;
+                        gy = dn - xv;
+                    } else {
+                        // forward / backward are exclusive (SRPS.cu:39-46, 31-38): at most one term survives
+                        gx = (e == 0) ? if_bit<B_FX>(xr.e[e] - xv, FL1) + if_bit<B_BX>(xv - xl.e[e], FL1)
+                           : (e == 1) ? if_bit<B_FX + 8>(xr.e[e] - xv, FL1) + if_bit<B_BX + 8>(xv - xl.e[e], FL1)
+                           : (e == 2) ? if_bit<B_FX + 16>(xr.e[e] - xv, FL1) + if_bit<B_BX + 16>(xv - xl.e[e], FL1)
+                                      : if_bit<B_FX + 24>(xr.e[e] - xv, FL1) + if_bit<B_BX + 24>(xv - xl.e[e], FL1);
+                        gy = (e == 0) ? if_bit<B_FY>(dn - xv, FL1) + if_bit<B_BY>(xv - up, FL1)
+                           : (e == 1) ? if_bit<B_FY + 8>(dn - xv, FL1) + if_bit<B_BY + 8>(xv - up, FL1)
+                           : (e == 2) ? if_bit<B_FY + 16>(dn - xv, FL1) + if_bit<B_BY + 16>(xv - up, FL1)
+                                      : if_bit<B_FY + 24>(dn - xv, FL1) + if_bit<B_BY + 24>(xv - up, FL1);
+                    }
+                    U1.e[e] = m0 * gx + m1 * gy + m2 * xv;
+                    V1.e[e] = m1 * gx + m3 * gy + m4 * xv;
+                    W1.e[e] = m2 * gx + m4 * gy + m5 * xv;
                 }
             }
             // ---- output column c ----------------------------------------------------------------
@@ -205,6 +285,25 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
                 const unsigned fl_up = dpp_from_prev_lane(FL0);     // its byte 3 = row above this lane's first row
                 const unsigned fl_dn = dpp_from_next_lane(FL0);     // its byte 0 = row below this lane's last row
                 F4 acc;
+                if (wave_all(is_plain(FLm1) && is_plain(FL0) && is_plain(FL1) && is_plain(fl_up) && is_plain(fl_dn))) {
+                    // interior: own rows are forward (-u, -v), left / upper neighbours are forward or empty
+                    // (+u_left, +v_up; empty ones are zero), right / lower neighbours are never backward
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float vu = (e == 0) ? v_up : V0.e[e > 0 ? e - 1 : 0];
+                        float t = W0.e[e];
+                        t += 0.f - U0.e[e];
+                        t += Uprev.e[e];
+                        t += 0.f - V0.e[e];
+                        t += vu;
+                        t *= a.lambda;
+                        t += S.e[e] * a.inv_sf4;
+                        acc.e[e] = t;
+                    }
+                    // empty pixels of the wave (outside the mask) must stay zero
+                    acc.e[0] = if_bit<0>(acc.e[0], FL0); acc.e[1] = if_bit<8>(acc.e[1], FL0);
+                    acc.e[2] = if_bit<16>(acc.e[2], FL0); acc.e[3] = if_bit<24>(acc.e[3], FL0);
+                } else {
 #define SRPS_ROW(EE, FUW, FUB, FDW, FDB, VU, VD)                                                   \
     {                                                                                              \
         float t = W0.e[EE];                                                                        \
@@ -218,11 +317,12 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         t += if_bit<B_KB + 8 * EE>(S.e[EE] * a.inv_sf4, FL0);                                      \
         acc.e[EE] = t;                                                                             \
     }
-                SRPS_ROW(0, fl_up, 24, FL0, 8, v_up, V0.e[1])
-                SRPS_ROW(1, FL0, 0, FL0, 16, V0.e[0], V0.e[2])
-                SRPS_ROW(2, FL0, 8, FL0, 24, V0.e[1], V0.e[3])
-                SRPS_ROW(3, FL0, 16, fl_dn, 0, V0.e[2], v_dn)
+                    SRPS_ROW(0, fl_up, 24, FL0, 8, v_up, V0.e[1])
+                    SRPS_ROW(1, FL0, 0, FL0, 16, V0.e[0], V0.e[2])
+                    SRPS_ROW(2, FL0, 8, FL0, 24, V0.e[1], V0.e[3])
+                    SRPS_ROW(3, FL0, 16, fl_dn, 0, V0.e[2], v_dn)
 #undef SRPS_ROW
+                }
                 if (owned) {
                     const size_t off = (size_t)c * Hs + row0;
                     if (MODE == 0) {
@@ -242,12 +342,13 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
             }
             // ---- shift the windows --------------------------------------------------------------
             Uprev = U0; U0 = U1; V0 = V1; W0 = W1;
-            FLm1 = FL0; FL0 = FL1; FL1 = FLn;
+            FLm1 = FL0; FL0 = FL1;
 #pragma unroll
             for (int k = 0; k + 1 < NX; ++k) X[k] = X[k + 1];
-            X[NX - 1] = Xn;
-#pragma unroll
-            for (int t = 0; t < 6; ++t) Mc[t] = Mn[t];
+        };
+        for (int c = c0 - 2; c <= c_last; c += 2) {
+            step(c, bufA, bufB);
+            step(c + 1, bufB, bufA);
         }
     }
     if (MODE != 0) {
@@ -258,18 +359,38 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
 
 // ---- host side ---------------------------------------------------------------------------------
 
+// channels of the tensor-recompute form in use (0 = stream the stored 6-plane tensor)
+int march_recompute_channels(const srps_ctx* ctx) {
+    if (!ctx->tensor_recompute) return 0;
+    const int C = ctx->grid.tensor_channels;
+    return (C == 1 || C == 3) ? C : 0;
+}
+
 bool march_supported(const srps_ctx* ctx) {
     const int sf = ctx->grid.sf;
     return sf == 1 || sf == 2 || sf == 4;
 }
 
+// Decomposition: segments of `own` rows (multiple of 4, at most 248 = 62 owned lanes x 4) and strips of
+// `tj` columns (multiple of 4).  A wave runs tj+2 column steps and the kernel lasts as long as the most
+// loaded SIMD: with W waves on 1024 SIMDs that is ceil(W/1024) rounds of tj+2 steps.  tj <= 0 picks the
+// width that minimises rounds * (tj + 2) (measured: 2048^2 -> 1152 waves at tj=16 take 42 us, 927 waves
+// at tj=20 take 32 us).
 void march_plan(Grid& G, int tj) {
-    // segments of `own` rows (multiple of 4, at most 248 = 62 lanes x 4) and strips of MARCH_TJ columns
     const int nseg0 = std::max(1, cdiv(G.Hg, 248));
     int own = cdiv(G.Hg, nseg0);
     own = ((own + 3) / 4) * 4;
     G.seg_rows = own;
     G.n_seg = cdiv(G.Hg, own);
+    if (tj <= 0) {
+        const int simds = 1024;                     // 256 CUs x 4 SIMDs
+        long best = -1;
+        for (int cand = 4; cand <= 128; cand += 4) {
+            const long waves = (long)G.n_seg * cdiv(G.Wg, cand);
+            const long cost = ((waves + simds - 1) / simds) * (cand + 2) * 64 + cand;      // ties: narrower strips
+            if (best < 0 || cost < best) { best = cost; tj = cand; }
+        }
+    }
     G.strip_cols = tj;
     G.n_strip = cdiv(G.Wg, tj);
 }
@@ -279,14 +400,15 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
     Grid& G = ctx->grid;
     a.own = G.seg_rows; a.n_seg = G.n_seg; a.n_strip = G.n_strip; a.n_items = G.n_seg * G.n_strip;
     const int nb = cdiv(a.n_items, 4);
-#define SRPS_MARCH_LAUNCH(SF, TJ) hipLaunchKernelGGL((k_apply_march<SF, MODE, TJ>), dim3(nb), dim3(256), 0, ctx->stream, a)
-#define SRPS_MARCH_TJ(SF)                                                   \
-    switch (G.strip_cols) {                                                 \
-        case 8: SRPS_MARCH_LAUNCH(SF, 8); break;                            \
-        case 16: SRPS_MARCH_LAUNCH(SF, 16); break;                          \
-        case 32: SRPS_MARCH_LAUNCH(SF, 32); break;                          \
-        default: set_error("march kernel: unsupported strip width %d", G.strip_cols); return SRPS_ERR_UNSUPPORTED; \
+#define SRPS_MARCH_TJ(SF)                                                                                     \
+    switch (nc) {                                                                                             \
+        case 0: hipLaunchKernelGGL((k_apply_march<SF, MODE, 0>), dim3(nb), dim3(256), 0, ctx->stream, a); break; \
+        case 1: hipLaunchKernelGGL((k_apply_march<SF, MODE, 1>), dim3(nb), dim3(256), 0, ctx->stream, a); break; \
+        case 3: hipLaunchKernelGGL((k_apply_march<SF, MODE, 3>), dim3(nb), dim3(256), 0, ctx->stream, a); break; \
+        default: set_error("march kernel: unsupported channel count %d for tensor recompute", nc); return SRPS_ERR_UNSUPPORTED; \
     }
+    const int nc = march_recompute_channels(ctx);
+    a.tj = G.strip_cols;
     switch (G.sf) {
         case 1: SRPS_MARCH_TJ(1) break;
         case 2: SRPS_MARCH_TJ(2) break;
@@ -294,7 +416,6 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
         default: set_error("march kernel: unsupported sf %d", G.sf); return SRPS_ERR_UNSUPPORTED;
     }
 #undef SRPS_MARCH_TJ
-#undef SRPS_MARCH_LAUNCH
     return SRPS_OK;
 }
 
@@ -307,6 +428,7 @@ static MarchArgs march_base(srps_ctx* ctx) {
     a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
     a.scal = G.d_scal;
     a.part_out = G.d_pw_part;
+    a.G = G.d_G; a.consts = G.d_tconsts; a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     return a;
 }
 
@@ -333,7 +455,8 @@ int march_cg_apply(srps_ctx* ctx, int k) {
     Grid& G = ctx->grid;
     MarchArgs a = march_base(ctx);
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
-    a.p_in = pbuf[(k + 1) & 1]; a.p_out = pbuf[k & 1]; a.r = G.d_r; a.out = G.d_w;
+    a.p_in = (k == 1) ? G.d_r : pbuf[(k + 1) & 1];       // step 1: p = r
+    a.p_out = pbuf[k & 1]; a.r = G.d_r; a.out = G.d_w;
     a.rr_part = G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update; a.n_rr = G.nb_update;
     a.k = k;
     a.tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;

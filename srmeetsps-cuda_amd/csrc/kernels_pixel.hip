@@ -118,8 +118,8 @@ int launch_normals(hipStream_t st, const float* z, const float* zx, const float*
 
 // single-block finalisation of a partial array: out[0] = sum(part[0..n))
 __global__ void k_final_sum(const float* __restrict__ part, int n, float* __restrict__ out) {
-    __shared__ double smd;
-    const double t = sum_partials(part, n, &smd);
+    __shared__ double smd[4];
+    const double t = sum_partials(part, n, smd);
     if (threadIdx.x == 0) out[0] = (float)t;
 }
 
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256) void k_dcg_a(int k, const float* __restrict__ 
                                                float* __restrict__ p, int P, const float* __restrict__ rr_part,
                                                float* __restrict__ pw_part, int nb, DcgScal* __restrict__ scal, float tol2) {
     __shared__ float sm[16];
-    __shared__ double smd;
+    __shared__ double smd[4];
     const int c = blockIdx.y;
-    const float r1 = (float)sum_partials(rr_part + ((size_t)c * 2 + ((k - 1) & 1)) * nb, nb, &smd);
+    const float r1 = (float)sum_partials(rr_part + ((size_t)c * 2 + ((k - 1) & 1)) * nb, nb, smd);
     if (!(r1 > tol2)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[c].active = 0;
         return;
@@ -414,16 +414,16 @@ __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ 
                                                float* __restrict__ rr_part, const float* __restrict__ pw_part, int nb,
                                                DcgScal* __restrict__ scal, float tol2) {
     __shared__ float sm[16];
-    __shared__ double smd;
+    __shared__ double smd[4];
     const int c = blockIdx.y;
     const float* rr_old = rr_part + ((size_t)c * 2 + ((k - 1) & 1)) * nb;
     float* rr_new = rr_part + ((size_t)c * 2 + (k & 1)) * nb;
-    const float r1 = (float)sum_partials(rr_old, nb, &smd);
+    const float r1 = (float)sum_partials(rr_old, nb, smd);
     if (!(r1 > tol2)) {
         if (threadIdx.x == 0) rr_new[blockIdx.x] = rr_old[blockIdx.x];
         return;
     }
-    const float dot = (float)sum_partials(pw_part + (size_t)c * nb, nb, &smd);
+    const float dot = (float)sum_partials(pw_part + (size_t)c * nb, nb, smd);
     const float alpha = r1 / dot;
     const size_t base = (size_t)c * P;
     float acc = 0.f;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
                                                         const float* __restrict__ yy, const float* __restrict__ dz,
                                                         float fx, float fy, int P, int n_local, int C, int n_total,
                                                         int img_offset, const int* __restrict__ gofp, size_t plane,
-                                                        float* __restrict__ M, float* __restrict__ Q) {
+                                                        float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp) {
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
     if (q >= P) return;
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
@@ -516,6 +516,10 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
         float g[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) g[e] = vr.v[e] / vdz.v[e];
+        if (Gp) {                                                            // g_c^2 for the tensor-recompute operator
+#pragma unroll
+            for (int e = 0; e < V; ++e) Gp[(size_t)c * plane + gofp[q + e]] = g[e] * g[e];
+        }
         for (int i = 0; i < n_total; ++i) {
             const float* sv = s + ((size_t)i * C + c) * 4;
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
@@ -554,17 +558,55 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
     }
 }
 
+// Per-channel constants of the tensor-recompute form.  With a_i = fx s_i0, a'_i = fy s_i1, b_i = s_i2
+// (image i, channel c) and sums S.. over the images:
+//   sum_i t_i t_i' ,  t_i = (a_i - xx b_i, a'_i - yy b_i, -b_i)
+//     = [[Sbb dx^2 + R00, Sbb dx dy + R01, Sbb dx], [., Sbb dy^2 + R11, Sbb dy], [., ., Sbb]]
+//   dx = xx - Sab/Sbb, dy = yy - Sa'b/Sbb, R00 = Saa - Sab^2/Sbb, R01 = Saa' - Sab Sa'b/Sbb, R11 = Sa'a' - Sa'b^2/Sbb
+// (completed squares: every term is non-negative, no cancellation).  Evaluated in double.
+__global__ void k_tensor_consts(const float* __restrict__ s, int n_total, int C, float fx, float fy, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double Saa = 0, Sab = 0, Sbb = 0, Saap = 0, Sapap = 0, Sapb = 0;
+    for (int i = 0; i < n_total; ++i) {
+        const float* sv = s + ((size_t)i * C + c) * 4;
+        const double a = (double)fx * sv[0], ap = (double)fy * sv[1], b = sv[2];
+        Saa += a * a; Sab += a * b; Sbb += b * b; Saap += a * ap; Sapap += ap * ap; Sapb += ap * b;
+    }
+    double xs = 0, ys = 0, R00 = Saa, R01 = Saap, R11 = Sapap;
+    if (Sbb > 0) { xs = Sab / Sbb; ys = Sapb / Sbb; R00 = Saa - Sab * xs; R01 = Saap - Sab * ys; R11 = Sapap - Sapb * ys; }
+    float* o = out + c * 8;
+    o[0] = (float)Sbb; o[1] = (float)xs; o[2] = (float)ys; o[3] = (float)fmax(R00, 0.0); o[4] = (float)R01; o[5] = (float)fmax(R11, 0.0); o[6] = 0.f; o[7] = 0.f;
+}
+
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset) {
+                   int n_total, int img_offset, float cx, float cy) {
     Grid& G = ctx->grid;
+    // tensor-recompute form needs the principal point (xx = j - cx, yy = i - cy are rebuilt in the kernel)
+    const bool rec = ctx->tensor_recompute && (C == 1 || C == 3) && cx == cx && cy == cy;
+    float* Gp = nullptr;
+    if (rec) {
+        if (G.G_planes < (size_t)C) {
+            if (G.d_G) SRPS_HIP(hipFree(G.d_G));
+            G.d_G = nullptr; G.G_planes = 0;
+            SRPS_HIP(hipMalloc((void**)&G.d_G, (size_t)C * G.plane * sizeof(float)));
+            SRPS_HIP(hipMemsetAsync(G.d_G, 0, (size_t)C * G.plane * sizeof(float), ctx->stream));     // zero outside the mask
+            G.G_planes = C;
+        }
+        Gp = G.d_G;
+        hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts);
+        G.tensor_channels = C; G.cx = cx; G.cy = cy;
+    } else {
+        G.tensor_channels = 0;
+    }
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy | (uintptr_t)d_dz) % 16 == 0);
     if (vec)
         hipLaunchKernelGGL((k_depth_assemble<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
-                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q);
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q, Gp);
     else
         hipLaunchKernelGGL((k_depth_assemble<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
-                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q);
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q, Gp);
     SRPS_LAUNCH_CHECK();
     ctx->tensor_valid = true;
     return SRPS_OK;

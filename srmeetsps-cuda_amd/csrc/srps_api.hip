@@ -46,7 +46,7 @@ static void dfree(T*& p) {
 
 static void grid_release(Grid& G) {
     dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index);
-    dfree(G.d_M); dfree(G.d_q); dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_save);
+    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_save);
     dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); dfree(G.d_scal);
     G.bound = false;
 }
@@ -87,7 +87,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     const int i_hi = ((imax + sf) / sf) * sf, j_hi = ((jmax + sf) / sf) * sf;
     G.Hg = i_hi - G.i_lo; G.Wg = j_hi - G.j_lo;
     G.Hs = ((G.Hg + 2 * PAD + 31) / 32) * 32;
-    G.Ws = ((G.Wg + 31) / 32) * 32 + 2 * PAD;     // strips of the marching kernel stay in bounds
+    G.Ws = G.Wg + 512 + 2 * PAD;                  // strips of the marching kernel (<= 512 columns) stay in bounds
     G.plane = (size_t)G.Hs * G.Ws;
     SRPS_REQUIRE(G.plane < ((size_t)1 << 31) - 8 * (size_t)G.Hs, SRPS_ERR_UNSUPPORTED, "bind_grid: grid plane must fit int32 offsets");
     G.Hl = G.Hg / sf; G.Wl = G.Wg / sf;
@@ -136,11 +136,12 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     SRPS_HIP(hipMemset(G.d_p, 0, 2 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_w, 0, G.plane * sizeof(float)));
     const int nti = cdiv(G.Hg, 64), ntj = cdiv(G.Wg, 4);
     G.nb_apply = std::max(1, std::min(nti * ntj, 1024));
-    G.nb_update = std::max(1, std::min(cdiv((long long)G.plane / 4, 256), 1024));
+    G.used = (size_t)G.Hs * (G.Wg + 2 * PAD);      // the CG vectors are zero (and stay zero) beyond the used columns
+    G.nb_update = std::max(1, std::min(cdiv((long long)G.used / 4, 256 * 4), 1024));
     march_plan(G, ctx->march_tj);
     const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
     SRPS_TRY(dalloc(&G.d_pw_part, n_pw)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
-    SRPS_TRY(dalloc(&G.d_scal, 1));
+    SRPS_TRY(dalloc(&G.d_scal, 1)); SRPS_TRY(dalloc(&G.d_tconsts, 64));
     SRPS_HIP(hipMemset(G.d_pw_part, 0, n_pw * sizeof(float))); SRPS_HIP(hipMemset(G.d_rr_part, 0, 2 * (size_t)G.nb_update * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_scal, 0, sizeof(CgScalars)));
     G.bound = true;
@@ -237,8 +238,10 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "apply_mode")) {
         SRPS_REQUIRE(value >= SRPS_APPLY_AUTO && value <= SRPS_APPLY_MARCH, SRPS_ERR_INVALID, "apply_mode: bad value %d", value);
         ctx->apply_mode = value;
+    } else if (!strcmp(name, "tensor_recompute")) {
+        ctx->tensor_recompute = value ? 1 : 0;
     } else if (!strcmp(name, "march_strip")) {
-        SRPS_REQUIRE(value == 8 || value == 16 || value == 32, SRPS_ERR_INVALID, "march_strip: 8, 16 or 32");
+        SRPS_REQUIRE(value == 0 || (value >= 4 && value <= 512 && value % 4 == 0), SRPS_ERR_INVALID, "march_strip: 0 (automatic) or a multiple of 4 in [4, 512]");
         ctx->march_tj = value;
         if (ctx->grid.bound) march_plan(ctx->grid, value);
     } else if (!strcmp(name, "cg_max_iter")) {
@@ -321,7 +324,8 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
     float* zx = (float*)ctx->ws_misc.p;
     float* zy = zx + npix;
     float* e2 = zy + npix;
-    SRPS_TRY(depth_assemble(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, K00, K11, npix, nimages, nchannels, nimages, 0));
+    // the operator-level call has no principal point (only xx, yy arrays): stream the stored tensor
+    SRPS_TRY(depth_assemble(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, K00, K11, npix, nimages, nchannels, nimages, 0, NAN, NAN));
     SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
     SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
     SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
@@ -439,7 +443,7 @@ int srps_albedo(srps_ctx* ctx) {
 int srps_depth_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
-                          ctx->N_total, ctx->img_offset);
+                          ctx->N_total, ctx->img_offset, ctx->cx, ctx->cy);
 }
 int srps_depth_solve(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -577,7 +581,9 @@ int srps_cg_bytes(srps_ctx* ctx, double* apply_bytes, double* update_bytes) {
     // algorithmic bytes per masked unknown: operator kernel reads M (24),
     // r (4), p (4), structure byte (1), writes p (4), w (4); update kernel reads x,r,p,w (16), writes x,r (8)
     const double P = (double)ctx->grid.P;
-    if (apply_bytes) *apply_bytes = 41.0 * P;
+    const int nc = use_march(ctx) ? march_recompute_channels(ctx) : 0;
+    // tensor-recompute form: nc planes of (rho_c/dz)^2 replace the 6 planes of M
+    if (apply_bytes) *apply_bytes = (nc > 0 ? 17.0 + 4.0 * nc : 41.0) * P;
     if (update_bytes) *update_bytes = 24.0 * P;
     return SRPS_OK;
 }

@@ -40,6 +40,7 @@ struct Grid {
     int i_lo = 0, j_lo = 0, Hg = 0, Wg = 0;     // bounding box (aligned to sf)
     int Hs = 0, Ws = 0;                         // padded storage: plane = Ws columns of Hs rows
     size_t plane = 0;
+    size_t used = 0;                            // Hs * (Wg + 2 PAD): the part of a plane that holds the grid
     int Hl = 0, Wl = 0;                         // LR bounding box = Hg/sf x Wg/sf
     // device
     int* d_gofp = nullptr;        // [P]   grid offset of compact pixel p
@@ -49,6 +50,11 @@ struct Grid {
     // depth workspace (grid layout)
     float* d_M = nullptr;         // [6][plane]  photometric tensor, SoA
     float* d_q = nullptr;         // [3][plane]  (exchange buffer for the sharded depth phase)
+    float* d_G = nullptr;         // [tensor_channels][plane]  g_c = (rho_c/dz)^2 (tensor-recompute form)
+    size_t G_planes = 0;          // planes allocated in d_G
+    float* d_tconsts = nullptr;   // [8][8] per-channel constants of the tensor-recompute form
+    int tensor_channels = 0;      // channels of the last assembly
+    float cx = 0.f, cy = 0.f;     // principal point used by the last assembly (xx = j - cx, yy = i - cy)
     float* d_x = nullptr;         // [plane] z on the grid
     float* d_r = nullptr;         // [plane] rhs, then residual
     float* d_p = nullptr;         // [2][plane] search direction, double-buffered by step parity
@@ -79,7 +85,8 @@ struct srps_ctx {
     hipStream_t own_stream = nullptr;
     int albedo_mode = SRPS_ALBEDO_CG;
     int apply_mode = SRPS_APPLY_AUTO;
-    int march_tj = 16;               // strip width of the marching operator (8, 16 or 32)
+    int march_tj = 0;                // strip width of the marching operator (multiple of 4); 0 = chosen by march_plan
+    int tensor_recompute = 1;        // rebuild M in the operator kernel from (rho_c/dz)^2 instead of streaming 6 planes
     int cg_max_iter = 100;           // dc.cu:231
     float cg_tol = 1e-9f;            // dc.cu:230
     bool cg_fixed = false;           // bench: run a fixed number of steps
@@ -144,7 +151,7 @@ int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset);
+                   int n_total, int img_offset, float cx, float cy);
 int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I,
                                const float* d_xx, const float* d_yy, const float* d_dz, const float* d_z,
                                const float* d_zx, const float* d_zy, float fx, float fy, int P, int n_local,
@@ -171,6 +178,7 @@ int march_blocks(const Grid& G);
 int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
 int march_residual(srps_ctx* ctx);
 int march_cg_apply(srps_ctx* ctx, int k);
+int march_recompute_channels(const srps_ctx* ctx);
 
 // ---- generic CSR (kernels_csr.hip) --------------------------------------------------------
 int csr_spmv(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n_rows, int n_cols, int nnz,

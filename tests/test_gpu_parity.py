@@ -265,6 +265,42 @@ def test_marching_kernel_equals_simple_kernel(gpu_ctx, oracle, pkg, sf, h, w):
     assert rel(res[2][2], A_.astype(np.float64) @ x.astype(np.float64)) < 2e-5
 
 
+@pytest.mark.parametrize("kind,sf,h,w,n", [("ragged", 2, 300, 72, 4), ("full", 4, 128, 96, 5), ("ellipse", 1, 64, 80, 3)])
+def test_tensor_recompute_equals_stored_tensor(pkg, oracle, kind, sf, h, w, n):
+    """operator kernel that rebuilds M from (rho_c/dz)^2 and 6 lighting constants per channel
+    (29 B/unknown) == the one that streams the stored 6-plane tensor (41 B/unknown) == the oracle"""
+    import torch
+    sc = pkg.synth.make_scene(h, w, sf, n, seed=51, mask_kind=kind)
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    ctx.lighting(); ctx.albedo()
+    P = ctx.dims()["npix"]
+    x = np.random.default_rng(6).normal(size=P).astype(f32)
+    out = {}
+    for rec in (0, 1):
+        ctx.set_option("tensor_recompute", rec)
+        ctx.depth_partial()
+        y = torch.empty(P, device="cuda")
+        ctx.depth_operator_apply(_t(x), P, y)
+        ctx.synchronize()
+        out[rec] = y.cpu().numpy()
+    assert rel(out[1], out[0]) < 3e-6
+    st, _ = _state(oracle, sc)
+    st.s[:] = ctx.get("s").reshape(st.s.shape); st.rho[:] = ctx.get("rho").reshape(st.rho.shape)
+    A, A_, B = oracle.assemble_depth_system(st.geo, st.s, st.rho, st.dz, st.xx, st.yy, st.fx, st.fy, st.I)
+    ref = A_.astype(np.float64) @ x.astype(np.float64)
+    assert rel(out[1], ref) < 2e-5 and rel(out[0], ref) < 2e-5
+    # whole depth step in both forms
+    z = {}
+    for rec in (0, 1):
+        ctx.set_option("tensor_recompute", rec)
+        ctx.set("z", st.z)
+        e = ctx.depth()
+        z[rec] = (ctx.get("z"), e)
+    assert rmse(z[1][0], z[0][0]) < 1e-4 and abs(z[1][1] - z[0][1]) / z[0][1] < 1e-3
+    ctx.close()
+
+
 def test_image_sharding_equals_single_context(pkg, oracle):
     """SURVEY 8e on one GPU: two contexts hold disjoint image shards; the host sums their exchange
     buffers (what the RCCL all-reduce does across GPUs) -> same result as one context with all images"""
