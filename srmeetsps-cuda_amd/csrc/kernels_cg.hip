@@ -292,8 +292,18 @@ bool use_march(const srps_ctx* ctx) {
 }
 int apply_blocks(const srps_ctx* ctx) { return use_march(ctx) ? march_blocks(ctx->grid) : ctx->grid.nb_apply; }
 
+// the kernels that stream the stored 6-plane tensor need it to exist
+static int need_stored_tensor(srps_ctx* ctx) {
+    if ((!use_march(ctx) || march_recompute_channels(ctx) == 0) && !ctx->grid.M_valid) {
+        set_error("the stored tensor was not assembled (tensor_recompute is active): set option keep_stored_tensor=1 or tensor_recompute=0 before the depth assembly");
+        return SRPS_ERR_STATE;
+    }
+    return SRPS_OK;
+}
+
 int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane) {
     Grid& G = ctx->grid;
+    SRPS_TRY(need_stored_tensor(ctx));
     if (use_march(ctx)) return march_apply_plain(ctx, d_in_plane, d_out_plane);
     ApplyArgs a = base_args(ctx);
     a.xin = d_in_plane; a.out = d_out_plane;
@@ -304,6 +314,7 @@ int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane)
 
 int grid_residual(srps_ctx* ctx) {
     Grid& G = ctx->grid;
+    SRPS_TRY(need_stored_tensor(ctx));
     if (use_march(ctx)) {
         SRPS_TRY(march_residual(ctx));
     } else {

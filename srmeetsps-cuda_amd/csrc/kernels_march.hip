@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
 int march_recompute_channels(const srps_ctx* ctx) {
     if (!ctx->tensor_recompute) return 0;
     const int C = ctx->grid.tensor_channels;
-    return (C == 1 || C == 3) ? C : 0;
+    return (C == 1 || C == 3) ? C : 0;      // 0 also when the last assembly did not produce the g_c planes
 }
 
 bool march_supported(const srps_ctx* ctx) {

@@ -159,16 +159,17 @@ __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int e = 0; e < V; ++e) a[k][e] = r.v[e] * nk[k].v[e];       // dc.cu:381
+                // All IB loads are issued back to back (no branch between them): images past the end of the
+                // batch re-read the last image (cache hits) and their sums are simply not stored.
+                Vec<V> iv[IB];
 #pragma unroll
-                for (int ii = 0; ii < IB; ++ii) {
-                    if (b0 + ii < n_img) {                                             // wave-uniform
-                        const Vec<V> iv = ldv<V>(I + ((size_t)(b0 + ii) * C + c) * P + q);
+                for (int ii = 0; ii < IB; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(b0 + ii, n_img - 1) * C + c) * P + q);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-                            for (int e = 0; e < V; ++e) acc[ii][k] = fmaf(a[k][e], iv.v[e], acc[ii][k]);
-                    }
-                }
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[ii][k]);
                 if (b0 == 0) {
                     int t = 0;
 #pragma unroll
@@ -273,8 +274,10 @@ __global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ pa
 
 int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
              int n_local, int C, int n_total, int img_offset, bool zero_nonlocal) {
-    constexpr int IB = 8;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_N | (uintptr_t)d_I) % 16 == 0);
+    // images per register batch: the block re-reads rho and N once per batch, so one batch is best
+    int IB = 4;
+    for (int cand : {4, 8, 12, 16, 20}) { IB = cand; if (n_local <= cand) break; }      // n_local > 20: batches of 20
     const int V = vec ? 4 : 1;
     int chunk = cdiv(P, 1024);
     chunk = std::max(256 * V, cdiv(chunk, 256 * V) * 256 * V);
@@ -286,10 +289,10 @@ int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, co
     int* d_it = (int*)(part_g + n_g);
     SRPS_HIP(hipMemsetAsync(d_it, 0, sizeof(int), ctx->stream));
     if (n_local > 0) {
-        if (vec)
-            hipLaunchKernelGGL((k_light_partial<4, IB>), dim3(nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, chunk, part_atb, part_g);
-        else
-            hipLaunchKernelGGL((k_light_partial<1, IB>), dim3(nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, chunk, part_atb, part_g);
+#define SRPS_LIGHT(VV, BB) hipLaunchKernelGGL((k_light_partial<VV, BB>), dim3(nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, chunk, part_atb, part_g)
+        if (vec) { switch (IB) { case 4: SRPS_LIGHT(4, 4); break; case 8: SRPS_LIGHT(4, 8); break; case 12: SRPS_LIGHT(4, 12); break; case 16: SRPS_LIGHT(4, 16); break; default: SRPS_LIGHT(4, 20); } }
+        else { switch (IB) { case 4: SRPS_LIGHT(1, 4); break; case 8: SRPS_LIGHT(1, 8); break; case 12: SRPS_LIGHT(1, 12); break; case 16: SRPS_LIGHT(1, 16); break; default: SRPS_LIGHT(1, 20); } }
+#undef SRPS_LIGHT
         SRPS_LAUNCH_CHECK();
     }
     const int nt = n_total * C;
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
         Vec<V> nu, de;
 #pragma unroll
         for (int e = 0; e < V; ++e) { nu.v[e] = 0.f; de.v[e] = 0.f; }
+#pragma unroll 4
         for (int i = 0; i < n_local; ++i) {
             const float* sv = s + ((size_t)(s_img_offset + i) * C + c) * 4;      // uniform -> scalar loads
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
@@ -363,6 +367,7 @@ struct DcgScal {
 };
 
 // r = num - den*rho (dc.cu:404-405); rr_part[c][0][blk] = sum r^2
+template <int V>
 __global__ __launch_bounds__(256) void k_dcg_init(const float* __restrict__ rho, const float* __restrict__ num,
                                                   const float* __restrict__ den, int P, float* __restrict__ r,
                                                   float* __restrict__ rr_part, int nb, DcgScal* __restrict__ scal) {
@@ -370,10 +375,12 @@ __global__ __launch_bounds__(256) void k_dcg_init(const float* __restrict__ rho,
     const int c = blockIdx.y;
     const size_t base = (size_t)c * P;
     float acc = 0.f;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += nb * 256) {
-        const float rv = num[base + p] - den[base + p] * rho[base + p];
-        r[base + p] = rv;
-        acc = fmaf(rv, rv, acc);
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * V; p < P; p += nb * 256 * V) {
+        const Vec<V> vn = ldv<V>(num + base + p), vd = ldv<V>(den + base + p), vx = ldv<V>(rho + base + p);
+        Vec<V> vr;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { vr.v[e] = vn.v[e] - vd.v[e] * vx.v[e]; acc = fmaf(vr.v[e], vr.v[e], acc); }
+        stv<V>(r + base + p, vr);
     }
     const float t = block_sum(acc, sm);
     if (threadIdx.x == 0) {
@@ -383,6 +390,7 @@ __global__ __launch_bounds__(256) void k_dcg_init(const float* __restrict__ rho,
 }
 
 // first half of CG step k: p = beta p + r ; partial p.(d p)
+template <int V>
 __global__ __launch_bounds__(256) void k_dcg_a(int k, const float* __restrict__ den, const float* __restrict__ r,
                                                float* __restrict__ p, int P, const float* __restrict__ rr_part,
                                                float* __restrict__ pw_part, int nb, DcgScal* __restrict__ scal, float tol2) {
@@ -397,18 +405,25 @@ __global__ __launch_bounds__(256) void k_dcg_a(int k, const float* __restrict__ 
     const float beta = (k == 1) ? 0.f : r1 / scal[c].r0;
     const size_t base = (size_t)c * P;
     float acc = 0.f;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < P; q += nb * 256) {
-        float pn;
-        if (k == 1) pn = r[base + q];
-        else { pn = beta * p[base + q]; pn = pn + r[base + q]; }
-        p[base + q] = pn;
-        acc = fmaf(pn, den[base + q] * pn, acc);
+    for (int q = (blockIdx.x * 256 + threadIdx.x) * V; q < P; q += nb * 256 * V) {
+        const Vec<V> vr = ldv<V>(r + base + q), vd = ldv<V>(den + base + q);
+        Vec<V> vp;
+        if (k == 1) vp = vr;
+        else {
+            vp = ldv<V>(p + base + q);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { const float t = beta * vp.v[e]; vp.v[e] = t + vr.v[e]; }      // Sscal, Saxpy (dc.cu:263-264)
+        }
+        stv<V>(p + base + q, vp);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc = fmaf(vp.v[e], vd.v[e] * vp.v[e], acc);
     }
     const float t = block_sum(acc, sm);
     if (threadIdx.x == 0) pw_part[(size_t)c * nb + blockIdx.x] = t;
 }
 
 // second half: alpha = r1 / p.w ; x += alpha p ; r -= alpha w ; partial r.r
+template <int V>
 __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ den, float* __restrict__ r,
                                                const float* __restrict__ p, float* __restrict__ x, int P,
                                                float* __restrict__ rr_part, const float* __restrict__ pw_part, int nb,
@@ -427,13 +442,18 @@ __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ 
     const float alpha = r1 / dot;
     const size_t base = (size_t)c * P;
     float acc = 0.f;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < P; q += nb * 256) {
-        const float pv = p[base + q];
-        const float w = den[base + q] * pv;
-        x[base + q] = fmaf(alpha, pv, x[base + q]);
-        const float rv = fmaf(-alpha, w, r[base + q]);
-        r[base + q] = rv;
-        acc = fmaf(rv, rv, acc);
+    for (int q = (blockIdx.x * 256 + threadIdx.x) * V; q < P; q += nb * 256 * V) {
+        const Vec<V> vp = ldv<V>(p + base + q), vd = ldv<V>(den + base + q);
+        Vec<V> vx = ldv<V>(x + base + q), vr = ldv<V>(r + base + q);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float w = vd.v[e] * vp.v[e];
+            vx.v[e] = fmaf(alpha, vp.v[e], vx.v[e]);
+            vr.v[e] = fmaf(-alpha, w, vr.v[e]);
+            acc = fmaf(vr.v[e], vr.v[e], acc);
+        }
+        stv<V>(x + base + q, vx);
+        stv<V>(r + base + q, vr);
     }
     const float t = block_sum(acc, sm);
     if (threadIdx.x == 0) {
@@ -463,13 +483,20 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     float* pw_part = rr_part + (size_t)C * 2 * nb;
     DcgScal* scal = (DcgScal*)(pw_part + (size_t)C * nb);
     const float tol2 = ctx->cg_tol * ctx->cg_tol;
-    hipLaunchKernelGGL(k_dcg_init, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_numden | (uintptr_t)r) % 16 == 0);
+    if (vec) hipLaunchKernelGGL(k_dcg_init<4>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
+    else hipLaunchKernelGGL(k_dcg_init<1>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
     SRPS_LAUNCH_CHECK();
     DcgScal* hs = (DcgScal*)(ctx->h_pinned + 16);
     const int kmax = ctx->cg_max_iter + 1;         // "k <= max_iter" => up to max_iter+1 steps (dc.cu:252)
     for (int k = 1; k <= kmax; ++k) {
-        hipLaunchKernelGGL(k_dcg_a, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, P, rr_part, pw_part, nb, scal, tol2);
-        hipLaunchKernelGGL(k_dcg_b, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, d_rho, P, rr_part, pw_part, nb, scal, tol2);
+        if (vec) {
+            hipLaunchKernelGGL(k_dcg_a<4>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, P, rr_part, pw_part, nb, scal, tol2);
+            hipLaunchKernelGGL(k_dcg_b<4>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, d_rho, P, rr_part, pw_part, nb, scal, tol2);
+        } else {
+            hipLaunchKernelGGL(k_dcg_a<1>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, P, rr_part, pw_part, nb, scal, tol2);
+            hipLaunchKernelGGL(k_dcg_b<1>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, d_rho, P, rr_part, pw_part, nb, scal, tol2);
+        }
         if ((k % 8) == 0 || k == kmax) {
             SRPS_LAUNCH_CHECK();
             SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
@@ -520,39 +547,52 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < V; ++e) Gp[(size_t)c * plane + gofp[q + e]] = g[e] * g[e];
         }
-        for (int i = 0; i < n_total; ++i) {
-            const float* sv = s + ((size_t)i * C + c) * 4;
+        // M needs the lighting of ALL images (no image data): skipped when the operator rebuilds it
+        if (M) {
+            for (int i = 0; i < n_total; ++i) {
+                const float* sv = s + ((size_t)i * C + c) * 4;
+                const float s0 = sv[0], s1 = sv[1], s2 = sv[2];
+                const float fs0 = fx * s0, fs1 = fy * s1;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float v0 = g[e] * (fs0 - vxx.v[e] * s2);
+                    const float v1 = g[e] * (fs1 - vyy.v[e] * s2);
+                    const float v2 = -(g[e] * s2);
+                    m[0][e] = fmaf(v0, v0, m[0][e]);
+                    m[1][e] = fmaf(v0, v1, m[1][e]);
+                    m[2][e] = fmaf(v0, v2, m[2][e]);
+                    m[3][e] = fmaf(v1, v1, m[3][e]);
+                    m[4][e] = fmaf(v1, v2, m[4][e]);
+                    m[5][e] = fmaf(v2, v2, m[5][e]);
+                }
+            }
+        }
+        // q needs the images of this rank
+#pragma unroll 4
+        for (int li = 0; li < n_local; ++li) {
+            const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
-            const int li = i - img_offset;
-            const bool local = (li >= 0) && (li < n_local);                     // wave-uniform
-            Vec<V> iv;
-            if (local) iv = ldv<V>(I + ((size_t)li * C + c) * P + q);
+            const Vec<V> iv = ldv<V>(I + ((size_t)li * C + c) * P + q);
             const float fs0 = fx * s0, fs1 = fy * s1;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float v0 = g[e] * (fs0 - vxx.v[e] * s2);
                 const float v1 = g[e] * (fs1 - vyy.v[e] * s2);
                 const float v2 = -(g[e] * s2);
-                m[0][e] = fmaf(v0, v0, m[0][e]);
-                m[1][e] = fmaf(v0, v1, m[1][e]);
-                m[2][e] = fmaf(v0, v2, m[2][e]);
-                m[3][e] = fmaf(v1, v1, m[3][e]);
-                m[4][e] = fmaf(v1, v2, m[4][e]);
-                m[5][e] = fmaf(v2, v2, m[5][e]);
-                if (local) {
-                    const float b = iv.v[e] - vr.v[e] * s3;
-                    qq[0][e] = fmaf(v0, b, qq[0][e]);
-                    qq[1][e] = fmaf(v1, b, qq[1][e]);
-                    qq[2][e] = fmaf(v2, b, qq[2][e]);
-                }
+                const float b = iv.v[e] - vr.v[e] * s3;
+                qq[0][e] = fmaf(v0, b, qq[0][e]);
+                qq[1][e] = fmaf(v1, b, qq[1][e]);
+                qq[2][e] = fmaf(v2, b, qq[2][e]);
             }
         }
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         const int go = gofp[q + e];
+        if (M) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
+            for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) Q[(size_t)t * plane + go] = qq[t][e];
     }
@@ -600,13 +640,16 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
     } else {
         G.tensor_channels = 0;
     }
+    // the stored tensor is only needed by the simple operator kernel and by the stored-tensor marching form
+    float* Mp = (rec && use_march(ctx) && !ctx->keep_stored_tensor) ? nullptr : G.d_M;
+    G.M_valid = Mp != nullptr;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy | (uintptr_t)d_dz) % 16 == 0);
     if (vec)
         hipLaunchKernelGGL((k_depth_assemble<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
-                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q, Gp);
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, Mp, G.d_q, Gp);
     else
         hipLaunchKernelGGL((k_depth_assemble<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
-                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, G.d_M, G.d_q, Gp);
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, Mp, G.d_q, Gp);
     SRPS_LAUNCH_CHECK();
     ctx->tensor_valid = true;
     return SRPS_OK;
@@ -631,6 +674,7 @@ __global__ __launch_bounds__(256) void k_energy_partial(const float* __restrict_
             float g[V];
 #pragma unroll
             for (int e = 0; e < V; ++e) g[e] = vr.v[e] / vdz.v[e];
+#pragma unroll 4
             for (int li = 0; li < n_local; ++li) {
                 const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
                 const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];

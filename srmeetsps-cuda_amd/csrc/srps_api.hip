@@ -240,6 +240,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->apply_mode = value;
     } else if (!strcmp(name, "tensor_recompute")) {
         ctx->tensor_recompute = value ? 1 : 0;
+    } else if (!strcmp(name, "keep_stored_tensor")) {
+        ctx->keep_stored_tensor = value ? 1 : 0;
     } else if (!strcmp(name, "march_strip")) {
         SRPS_REQUIRE(value == 0 || (value >= 4 && value <= 512 && value % 4 == 0), SRPS_ERR_INVALID, "march_strip: 0 (automatic) or a multiple of 4 in [4, 512]");
         ctx->march_tj = value;

@@ -54,6 +54,7 @@ struct Grid {
     size_t G_planes = 0;          // planes allocated in d_G
     float* d_tconsts = nullptr;   // [8][8] per-channel constants of the tensor-recompute form
     int tensor_channels = 0;      // channels of the last assembly
+    bool M_valid = false;         // d_M holds the tensor of the last assembly
     float cx = 0.f, cy = 0.f;     // principal point used by the last assembly (xx = j - cx, yy = i - cy)
     float* d_x = nullptr;         // [plane] z on the grid
     float* d_r = nullptr;         // [plane] rhs, then residual
@@ -86,6 +87,7 @@ struct srps_ctx {
     int albedo_mode = SRPS_ALBEDO_CG;
     int apply_mode = SRPS_APPLY_AUTO;
     int march_tj = 0;                // strip width of the marching operator (multiple of 4); 0 = chosen by march_plan
+    int keep_stored_tensor = 0;      // also write the 6-plane tensor when the recompute form is active (tests)
     int tensor_recompute = 1;        // rebuild M in the operator kernel from (rho_c/dz)^2 instead of streaming 6 planes
     int cg_max_iter = 100;           // dc.cu:231
     float cg_tol = 1e-9f;            // dc.cu:230
