@@ -139,18 +139,31 @@ def main():
     if rank == 0:
         # isolated inner loop + per-kernel HIP-event timings (same stream as the launches)
         b = ctx.bench_cg(solves=10, iters=101)
+        us_iter = 1e6 * b["seconds"] / b["iterations"]
         out["cg_only_it_per_s"] = b["iterations"] / b["seconds"]
-        out["cg_only_us_per_iteration"] = 1e6 * b["seconds"] / b["iterations"]
+        out["cg_only_us_per_iteration"] = us_iter
         loop_bytes = b["apply_bytes"] + b["update_bytes"]
-        out["cg_loop_roofline"] = {"bound": "hbm", "achieved": loop_bytes / (1e3 * out["cg_only_us_per_iteration"]),
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": loop_bytes / (1e3 * out["cg_only_us_per_iteration"]) / HBM_PEAK_GBS}
-        ach = b["apply_bytes"] / (1e3 * b["apply_us"])
-        out["roofline"] = {"bound": "hbm", "kernel": "depth operator (p-update + A_ p + p.Ap partial)",
+        out["cg_loop_roofline"] = {"bound": "hbm", "achieved": loop_bytes / (1e3 * us_iter), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": loop_bytes / (1e3 * us_iter) / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_iteration": loop_bytes}
+        # Per-kernel duration: events around the whole 101-step loop give the time per step (kernel boundaries
+        # overlap there); an event after EVERY launch (b["apply_us"], b["update_us"]) adds ~3 us of event /
+        # boundary cost to each kernel, so it is used only to split the step time between the two kernels.
+        share = b["apply_us"] / (b["apply_us"] + b["update_us"])
+        apply_us = us_iter * share
+        ach = b["apply_bytes"] / (1e3 * apply_us)
+        traffic = None
+        try:     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj.get(f"{H}x{W}_sf{args.sf}", {}).get("apply")
+        except Exception:
+            pass
+        out["roofline"] = {"bound": "hbm", "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial p.omega)",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "avg_launch_us": b["apply_us"], "algorithmic_bytes_per_launch": b["apply_bytes"],
-                           "update_kernel_us": b["update_us"],
-                           "update_kernel_GBs": b["update_bytes"] / (1e3 * b["update_us"])}
+                           "traffic": traffic, "avg_launch_us": apply_us, "avg_launch_us_event_bracketed": b["apply_us"],
+                           "algorithmic_bytes_per_launch": b["apply_bytes"],
+                           "update_kernel_us": us_iter - apply_us,
+                           "update_kernel_GBs": b["update_bytes"] / (1e3 * (us_iter - apply_us))}
     if not args.no_total_solve:
         # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up
         ctx.setup(dh)
