@@ -261,10 +261,61 @@ __global__ __launch_bounds__(256) void k_cg_update(int k, float* __restrict__ x,
     }
 }
 
+// Update kernel of the fused protocol (marching operator): alpha = r1 / (p.w); r -= alpha w; partial r.r.
+// x += alpha p is left to the next operator launch (or to k_cg_flush_x after the last step).
+__global__ __launch_bounds__(256) void k_cg_update_r(int k, float* __restrict__ r, const float* __restrict__ w, size_t n4,
+                                                     const float* __restrict__ rr_old, float* __restrict__ rr_new, int n_rr,
+                                                     const float* __restrict__ pw_part, int n_pw, CgScalars* __restrict__ scal,
+                                                     float tol2) {
+    __shared__ float sm[16];
+    __shared__ double smd[4];
+    const float r1 = (float)sum_partials(rr_old, n_rr, smd);
+    if (!(r1 > tol2)) {
+        if (threadIdx.x == 0) {
+            rr_new[blockIdx.x] = rr_old[blockIdx.x];
+            if (blockIdx.x == 0) scal->active = 0;
+        }
+        return;
+    }
+    const float dot = (float)sum_partials(pw_part, n_pw, smd);
+    const float alpha = r1 / dot;                                   // dc.cu:269
+    float acc = 0.f;
+    float4* r4 = reinterpret_cast<float4*>(r);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < n4; t += (size_t)gridDim.x * 256) {
+        const float4 wv = w4[t];
+        float4 rv = r4[t];
+        rv.x = fmaf(-alpha, wv.x, rv.x); rv.y = fmaf(-alpha, wv.y, rv.y); rv.z = fmaf(-alpha, wv.z, rv.z); rv.w = fmaf(-alpha, wv.w, rv.w);   // dc.cu:272
+        r4[t] = rv;
+        acc = fmaf(rv.x, rv.x, acc); acc = fmaf(rv.y, rv.y, acc); acc = fmaf(rv.z, rv.z, acc); acc = fmaf(rv.w, rv.w, acc);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        rr_new[blockIdx.x] = t;
+        if (blockIdx.x == 0) { scal->r0 = r1; scal->r1_last = r1; scal->iters = k; scal->active = 1; scal->alpha = alpha; }
+    }
+}
+
+// the one x update still pending after the last executed step: x += alpha_K p_K
+__global__ __launch_bounds__(256) void k_cg_flush_x(float* __restrict__ x, const float* __restrict__ p0, const float* __restrict__ p1,
+                                                    size_t n4, const CgScalars* __restrict__ scal) {
+    const int it = scal->iters;
+    if (it < 1) return;
+    const float alpha = scal->alpha;
+    const float4* p4 = reinterpret_cast<const float4*>((it & 1) ? p1 : p0);
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < n4; t += (size_t)gridDim.x * 256) {
+        const float4 pv = p4[t];
+        float4 xv = x4[t];
+        xv.x = fmaf(alpha, pv.x, xv.x); xv.y = fmaf(alpha, pv.y, xv.y); xv.z = fmaf(alpha, pv.z, xv.z); xv.w = fmaf(alpha, pv.w, xv.w);
+        x4[t] = xv;
+    }
+}
+
 __global__ void k_cg_reset(CgScalars* scal, float* rr0, int n_rr, const float* first) {
     // rr_part[0][0] = r.r of the initial residual, the rest zero
     for (int t = threadIdx.x; t < n_rr; t += blockDim.x) rr0[t] = (t == 0) ? first[0] : 0.f;
-    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = first[0]; scal->iters = 0; scal->active = 1; }
+    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = first[0]; scal->iters = 0; scal->active = 1; scal->alpha = 0.f; }
 }
 
 // single-block sum (same routine as k_final_sum in kernels_pixel.hip)
@@ -347,9 +398,23 @@ int cg_launch_update(srps_ctx* ctx, int k) {
     Grid& G = ctx->grid;
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
     const float tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
+    if (use_march(ctx)) {      // fused protocol: the operator kernel applies x += alpha p
+        hipLaunchKernelGGL(k_cg_update_r, dim3(G.nb_update), dim3(256), 0, ctx->stream, k, G.d_r, G.d_w, G.used / 4,
+                           G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update, G.d_rr_part + (size_t)(k & 1) * G.nb_update, G.nb_update,
+                           G.d_pw_part, apply_blocks(ctx), G.d_scal, tol2);
+        return SRPS_OK;
+    }
     hipLaunchKernelGGL(k_cg_update, dim3(G.nb_update), dim3(256), 0, ctx->stream, k, G.d_x, G.d_r, pbuf[k & 1], G.d_w, G.used / 4,
                        G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update, G.d_rr_part + (size_t)(k & 1) * G.nb_update, G.nb_update,
                        G.d_pw_part, apply_blocks(ctx), G.d_scal, tol2);
+    return SRPS_OK;
+}
+
+int cg_flush_x(srps_ctx* ctx) {
+    Grid& G = ctx->grid;
+    if (!use_march(ctx)) return SRPS_OK;       // classic protocol: k_cg_update already moved x
+    hipLaunchKernelGGL(k_cg_flush_x, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x, G.d_p, G.d_p + G.plane, G.used / 4, G.d_scal);
+    SRPS_LAUNCH_CHECK();
     return SRPS_OK;
 }
 
@@ -362,6 +427,7 @@ int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
         cg_launch_update(ctx, k);
     }
     ctx->cg_fixed = false;
+    SRPS_TRY(cg_flush_x(ctx));
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
 }

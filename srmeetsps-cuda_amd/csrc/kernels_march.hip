@@ -30,6 +30,7 @@ struct MarchArgs {
     float* p_out;          // MODE 2
     float* r;              // MODE 1 (in/out), MODE 2 (in)
     float* out;            // MODE 0/2
+    float* x;              // MODE 2: the iterate; x += alpha_prev * p_in is applied here (deferred from the last update)
     const float* rr_part;
     int n_rr;
     float* part_out;
@@ -108,6 +109,9 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         // goes through the same branch-free load path as every other step.
         if (a.k != 1) beta = r1 / a.scal->r0;                         // dc.cu:262
     }
+    // x_k = x_{k-1} + alpha_k p_k (dc.cu:270) of the PREVIOUS step is applied by this launch, which streams
+    // p_k anyway; the update kernel then only touches r and omega (12 B/unknown instead of 24)
+    const float alpha_prev = (MODE == 2 && a.k != 1) ? a.scal->alpha : 0.f;
     // XCD-aware block order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
     // contiguous range of work items (neighbouring strips share halo columns through its L2)
     int bid = blockIdx.x;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
             F4 T[NT];
             unsigned fl;
             F4 r, p;
+            F4 xo, po;         // MODE 2: x and the previous p of the column this step outputs
         };
         auto issue = [&](Raw& w, int c) {
 #pragma unroll
@@ -145,7 +150,11 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
             w.fl = *reinterpret_cast<const unsigned*>(a.flags + (size_t)(c + 1) * Hs + rowL);
             const size_t off = (size_t)(c + L) * Hs + rowL;
             if (MODE != 2) { w.r = ld4(a.xin + off); }
-            else { w.r = ld4(a.r + off); w.p = ld4(a.p_in + off); }
+            else {
+                w.r = ld4(a.r + off); w.p = ld4(a.p_in + off);
+                const size_t oo = (size_t)c * Hs + rowL;               // the column step c outputs
+                w.xo = ld4(a.x + oo); w.po = ld4(a.p_in + oo);
+            }
         };
         auto convert = [&](const Raw& w) -> F4 {               // x of the loaded column (CG: p_new = beta p + r)
             if (MODE != 2) return w.r;
@@ -335,6 +344,12 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
                     } else {
                         st4(a.p_out + off, X[1]);
                         st4(a.out + off, acc);
+                        if (a.k != 1) {                                   // uniform
+                            F4 xn;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xn.e[e] = fmaf(alpha_prev, cur.po.e[e], cur.xo.e[e]);   // Saxpy dc.cu:270
+                            st4(a.x + off, xn);
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) red = fmaf(X[1].e[e], acc.e[e], red);
                     }
@@ -456,7 +471,7 @@ int march_cg_apply(srps_ctx* ctx, int k) {
     MarchArgs a = march_base(ctx);
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
     a.p_in = (k == 1) ? G.d_r : pbuf[(k + 1) & 1];       // step 1: p = r
-    a.p_out = pbuf[k & 1]; a.r = G.d_r; a.out = G.d_w;
+    a.p_out = pbuf[k & 1]; a.r = G.d_r; a.out = G.d_w; a.x = G.d_x;
     a.rr_part = G.d_rr_part + (size_t)((k - 1) & 1) * G.nb_update; a.n_rr = G.nb_update;
     a.k = k;
     a.tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;

@@ -585,8 +585,11 @@ int srps_cg_bytes(srps_ctx* ctx, double* apply_bytes, double* update_bytes) {
     const double P = (double)ctx->grid.P;
     const int nc = use_march(ctx) ? march_recompute_channels(ctx) : 0;
     // tensor-recompute form: nc planes of (rho_c/dz)^2 replace the 6 planes of M
-    if (apply_bytes) *apply_bytes = (nc > 0 ? 17.0 + 4.0 * nc : 41.0) * P;
-    if (update_bytes) *update_bytes = 24.0 * P;
+    // marching operator also carries the deferred x update (x read + write, +8); its update kernel then
+    // reads r, w and writes r (12) instead of reading x, r, p, w and writing x, r (24)
+    const bool fused = use_march(ctx);
+    if (apply_bytes) *apply_bytes = ((nc > 0 ? 17.0 + 4.0 * nc : 41.0) + (fused ? 8.0 : 0.0)) * P;
+    if (update_bytes) *update_bytes = (fused ? 12.0 : 24.0) * P;
     return SRPS_OK;
 }
 
@@ -630,6 +633,7 @@ int srps_bench_cg(srps_ctx* ctx, int solves, int iters, double* seconds, double*
             SRPS_HIP(hipEventRecord(ev[2 * k], st));
         }
         ctx->cg_fixed = false;
+        SRPS_TRY(cg_flush_x(ctx));
         SRPS_HIP(hipEventSynchronize(ev[2 * (size_t)iters]));
         double a = 0, u = 0;
         for (int k = 1; k <= iters; ++k) {

@@ -31,6 +31,8 @@ struct CgScalars {
     float r1_last;   // last r.r seen by the update kernel
     int iters;       // steps executed    (dc.cu:254)
     int active;      // 1 while r1 > tol^2
+    float alpha;     // step length of the last update kernel; x += alpha p is applied by the NEXT operator launch
+    int pad[3];
 };
 
 struct Grid {
@@ -180,6 +182,7 @@ int march_blocks(const Grid& G);
 int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
 int march_residual(srps_ctx* ctx);
 int march_cg_apply(srps_ctx* ctx, int k);
+int cg_flush_x(srps_ctx* ctx);
 int march_recompute_channels(const srps_ctx* ctx);
 
 // ---- generic CSR (kernels_csr.hip) --------------------------------------------------------
