@@ -112,6 +112,11 @@ int srps_albedo_estimation(srps_ctx* ctx, const float* d_s, float* d_rho, const 
  * KT SRPS.cu:170-193); this library rebuilds the same operators from the mask itself and applies
  * them matrix-free, so the mask is bound once instead.  mask is HOST memory, h*w floats in {0,1}. */
 int srps_bind_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask);
+/* Optional hint for the operator-level depth call: the principal point (K[6], K[7]) the caller used for
+ * cuda_based_meshgrid_create (SRPS.cu:256).  With it the library knows that d_xx / d_yy are j - K02 and
+ * i - K12 and runs the faster tensor-recompute operator; without it the stored
+ * tensor is streamed.  Reset by srps_bind_grid. */
+int srps_set_principal_point(srps_ctx* ctx, float K02, float K12);
 /* replaces: cuda_based_depth_estimation (devicecalls.cuh:36, devicecalls.cu:550-786).
  * The nine CSR arguments of the reference (Dx, Dy, KT) are implied by srps_bind_grid.
  * d_z [npix] is updated in place (101 CG steps from the warm start); *energy receives

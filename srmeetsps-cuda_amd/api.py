@@ -183,6 +183,9 @@ class Context:
                                              nchannels, C.byref(e)))
         return e.value
 
+    def set_principal_point(self, K02, K12):
+        check(self.lib.srps_set_principal_point(self.h, float(K02), float(K12)))
+
     def gradient(self, d_z, npix, d_zx, d_zy):
         check(self.lib.srps_gradient(self.h, _ptr(d_z), npix, _ptr(d_zx), _ptr(d_zy)))
 

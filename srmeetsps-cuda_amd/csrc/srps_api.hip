@@ -303,8 +303,15 @@ int srps_albedo_estimation(srps_ctx* ctx, const float* d_s, float* d_rho, const 
 
 int srps_bind_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     CTX_CHECK(ctx);
+    ctx->op_pp_set = false;
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     return build_grid(ctx, h, w, sf, mask);
+}
+
+int srps_set_principal_point(srps_ctx* ctx, float K02, float K12) {
+    CTX_CHECK(ctx);
+    ctx->op_cx = K02; ctx->op_cy = K12; ctx->op_pp_set = true;
+    return SRPS_OK;
 }
 
 int srps_gradient(srps_ctx* ctx, const float* d_z, int npix, float* d_zx, float* d_zy) {
@@ -319,15 +326,18 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
                           float K00, float K11, int npix, int nimages, int nchannels, float* energy) {
     CTX_CHECK(ctx); GRID_CHECK(ctx);
     (void)d_N;   // the linearised system uses dz, not N (N3 == 1 enters B through s3, dc.cu:573)
-    SRPS_REQUIRE(d_s && d_rho && d_I && d_xx && d_yy && d_dz && d_z0s && d_z && energy, SRPS_ERR_INVALID, "depth_estimation: null argument");
+    SRPS_REQUIRE(d_s && d_rho && d_I && d_xx && d_yy && d_dz && d_z && energy, SRPS_ERR_INVALID, "depth_estimation: null argument");
+    SRPS_REQUIRE(d_z0s || ctx->grid.Ps == 0, SRPS_ERR_INVALID, "depth_estimation: d_z0s is NULL but the mask has %d complete blocks", ctx->grid.Ps);
     SRPS_REQUIRE(npix == ctx->grid.P, SRPS_ERR_INVALID, "depth_estimation: npix=%d does not match the bound mask (%d)", npix, ctx->grid.P);
     Grid& G = ctx->grid;
     SRPS_TRY(ensure(ctx->ws_misc, (2 * (size_t)npix + 16) * sizeof(float)));
     float* zx = (float*)ctx->ws_misc.p;
     float* zy = zx + npix;
     float* e2 = zy + npix;
-    // the operator-level call has no principal point (only xx, yy arrays): stream the stored tensor
-    SRPS_TRY(depth_assemble(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, K00, K11, npix, nimages, nchannels, nimages, 0, NAN, NAN));
+    // the reference's signature carries xx, yy as arrays and no principal point: stream the stored tensor
+    // unless the caller announced it (srps_set_principal_point)
+    SRPS_TRY(depth_assemble(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, K00, K11, npix, nimages, nchannels, nimages, 0,
+                            ctx->op_pp_set ? ctx->op_cx : NAN, ctx->op_pp_set ? ctx->op_cy : NAN));
     SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
     SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
     SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));

@@ -103,6 +103,8 @@ struct srps_ctx {
     bool have_state = false;
     int C = 0, N_local = 0, N_total = 0, img_offset = 0;
     float fx = 0, fy = 0, cx = 0, cy = 0;
+    float op_cx = 0, op_cy = 0;      // srps_set_principal_point (operator-level depth call)
+    bool op_pp_set = false;
     float *s = nullptr, *rho = nullptr, *z = nullptr, *Nrm = nullptr, *dz = nullptr;
     float *zx = nullptr, *zy = nullptr, *xx = nullptr, *yy = nullptr, *z0s = nullptr, *I = nullptr;
     float* albedo_ex = nullptr;      // [2][C][P]  num, den

@@ -96,7 +96,9 @@ def make_scene(h: int, w: int, sf: int, n_img: int, seed: int = 1234, n_ch: int 
     rng = np.random.default_rng([seed, 0])
     m2d = make_mask(h, w, sf, mask_kind)
     K = np.zeros(9, dtype=f32)
-    K[0] = 1.2 * w; K[4] = 1.2 * w; K[6] = (w - 1) / 2.0; K[7] = (h - 1) / 2.0; K[8] = 1
+    # focal length 1.2 x the longer side (field of view ~45 deg): a narrow, tall grid must not get a
+    # focal length far below its height (that makes the photometric system degenerate)
+    K[0] = 1.2 * max(h, w); K[4] = 1.2 * max(h, w); K[6] = (w - 1) / 2.0; K[7] = (h - 1) / 2.0; K[8] = 1
     iv = np.arange(h, dtype=np.float64)[:, None]          # rows i
     jv = np.arange(w, dtype=np.float64)[None, :]          # columns j
     # ground-truth depth: 1 + 0.1 * sum of 8 Gaussian bumps (separable => outer products)

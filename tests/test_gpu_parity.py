@@ -51,6 +51,18 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
 
 
+def assert_same_stop(en, en_ref):
+    """the stop rule (relative change < 5e-3, SRPS.cu:299) may fire one pass apart when the decisive
+    relative change sits within 10 % of the threshold; otherwise the pass counts must be equal"""
+    if len(en) == len(en_ref):
+        return
+    assert abs(len(en) - len(en_ref)) == 1, (en, en_ref)
+    longer = en if len(en) > len(en_ref) else en_ref
+    k = min(len(en), len(en_ref)) - 1
+    rel_k = abs(longer[k - 1] - longer[k]) / abs(longer[k])
+    assert 0.9 * 5e-3 < rel_k < 1.1 * 5e-3, (rel_k, en, en_ref)
+
+
 # ------------------------------------------------------------------------------------------
 def test_init_kernels(gpu_ctx, oracle):
     import torch
@@ -204,11 +216,14 @@ def test_full_alternating_loop(gpu_ctx, oracle, pkg, kind, sf, h, w, n):
     dh = pkg.DataHandler.from_scene(sc)
     srps = pkg.SRPS(dh, ctx=gpu_ctx)
     energies = srps.execute()
-    assert len(energies) == ref.iterations, (energies, ref.energies)
+    assert_same_stop(energies, ref.energies)
+    n_common = min(len(energies), len(ref.energies))
     # the first passes start from constant normals, where the lighting Gram is near-singular and the
     # truncated CG is far from converged: their energies are reproducible to ~1e-3..1e-2 only
-    np.testing.assert_allclose(energies, ref.energies, rtol=1e-2)
-    assert abs(energies[-1] - ref.energies[-1]) / ref.energies[-1] < 1e-3
+    np.testing.assert_allclose(energies[:n_common], ref.energies[:n_common], rtol=1e-2)
+    assert abs(energies[n_common - 1] - ref.energies[n_common - 1]) / ref.energies[n_common - 1] < 1e-3
+    if len(energies) != len(ref.energies):       # compare at the same pass count
+        ref = oracle.execute(prob, depth="faithful", max_outer=len(energies))
     assert rmse(srps.z(), ref.z) < 1e-4
     assert np.abs(srps.rho() - ref.rho).max() < 2e-3
     assert _shading_rel(srps.s(), ref.s, ref.rho, ref.N) < 2e-3, np.abs(srps.s() - ref.s).max()
@@ -299,6 +314,29 @@ def test_tensor_recompute_equals_stored_tensor(pkg, oracle, kind, sf, h, w, n):
         z[rec] = (ctx.get("z"), e)
     assert rmse(z[1][0], z[0][0]) < 1e-4 and abs(z[1][1] - z[0][1]) / z[0][1] < 1e-3
     ctx.close()
+
+
+def test_operator_level_depth_with_principal_point_hint(gpu_ctx, oracle, pkg):
+    """srps_depth_estimation (the reference's signature: xx, yy as arrays) with and without the optional
+    srps_set_principal_point hint that switches it to the tensor-recompute operator"""
+    sc = pkg.synth.make_scene(64, 80, 2, 4, seed=61, mask_kind="ragged")
+    st, _ = _state(oracle, sc)
+    oracle.lighting_estimation(st.s, st.rho, st.N, st.I); oracle.albedo_estimation(st.s, st.rho, st.N, st.I)
+    P = st.geo.npix
+    res = []
+    for hint in (False, True):
+        gpu_ctx.bind_grid(sc.h, sc.w, sc.sf, sc.mask)              # also clears a previous hint
+        if hint:
+            gpu_ctx.set_principal_point(sc.K[6], sc.K[7])
+        z_dev = _t(st.z)
+        e = gpu_ctx.depth_estimation(_t(st.s), _t(st.rho), _t(st.N), _t(st.I), _t(st.xx), _t(st.yy), _t(st.dz), _t(st.z0s),
+                                     z_dev, st.fx, st.fy, P, sc.n_img, sc.n_ch)
+        res.append((e, z_dev.cpu().numpy()))
+    z_ref = st.z.copy()
+    e_ref = oracle.depth_estimation(st.geo, st.s, st.rho, st.I, st.xx, st.yy, st.dz, st.z0s, z_ref, st.fx, st.fy)
+    for e, z in res:
+        assert rmse(z, z_ref) < 1e-4 and abs(e - e_ref) / e_ref < 1e-3
+    assert rmse(res[0][1], res[1][1]) < 1e-4
 
 
 def test_image_sharding_equals_single_context(pkg, oracle):
