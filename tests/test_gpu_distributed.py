@@ -1,0 +1,55 @@
+"""Two processes, one GPU: the real distributed driver (pkg.SRPS(distributed=True): shard_range, the
+phase-split C-ABI entry points on the torch stream, torch.distributed.all_reduce on zero-copy views of
+the library's exchange buffers) against the single-process result.  The process group uses gloo here
+because RCCL refuses two ranks on one device; on a multi-GPU node bench.py runs the same code over nccl."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n_img, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    lo, hi = pkg.shard_range(n_img, world, rank)
+    sc = pkg.synth.make_scene(48, 56, 2, n_img, seed=33, mask_kind="ragged", img_begin=lo, img_end=hi)
+    srps = pkg.SRPS(pkg.DataHandler.from_scene(sc), distributed=True)
+    en = srps.execute(max_outer=3)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), energies=np.array(en), z=srps.z(), rho=srps.rho(), s=srps.s())
+    dist.barrier()
+    srps.ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, pkg):
+    import torch.multiprocessing as mp
+    n_img = 5
+    mp.spawn(_worker, args=(2, _free_port(), n_img, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["z"], r1["z"]); np.testing.assert_array_equal(r0["s"], r1["s"])     # replicas stay bit-identical
+    np.testing.assert_array_equal(r0["energies"], r1["energies"])
+    sc = pkg.synth.make_scene(48, 56, 2, n_img, seed=33, mask_kind="ragged")
+    ctx = pkg.Context(device_id=0)
+    one = pkg.SRPS(pkg.DataHandler.from_scene(sc), ctx=ctx)
+    e1 = one.execute(max_outer=3)
+    np.testing.assert_allclose(r0["energies"], e1, rtol=5e-4)
+    assert np.sqrt(np.mean((r0["z"] - one.z()) ** 2)) < 3e-5
+    assert np.abs(r0["rho"] - one.rho()).max() < 5e-4
+    ctx.close()
