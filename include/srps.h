@@ -62,7 +62,7 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out);
 int srps_destroy(srps_ctx* ctx);
 int srps_set_stream(srps_ctx* ctx, void* hip_stream);      /* NULL = the context's own stream */
 int srps_synchronize(srps_ctx* ctx);
-int srps_set_option(srps_ctx* ctx, const char* name, int value); /* "albedo_mode", "apply_mode", "cg_max_iter", "march_strip" (16|32), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1) */
+int srps_set_option(srps_ctx* ctx, const char* name, int value); /* "albedo_mode", "apply_mode", "cg_max_iter", "march_strip" (16|32), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1), "march_snake" (0|1) */
 
 /* ---- generic sparse operators (device pointers) -------------------------------------------*/
 /* replaces: cuda_based_host_COO_to_device_CSR (devicecalls.cuh:37, devicecalls.cu:51-67) incl.

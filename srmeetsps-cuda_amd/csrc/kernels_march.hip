@@ -18,6 +18,7 @@
 // Every plane element of M, p, r and the structure bytes is read once per strip plus the halo
 // ((TJ+2)/TJ columns for M, (TJ+5)/TJ for p and r, 66/62 rows).
 #include "srps_internal.h"
+#include <type_traits>
 #include "device_utils.h"
 
 namespace srps {
@@ -39,7 +40,7 @@ struct MarchArgs {
     size_t plane;
     float lambda, inv_sf4, tol2;
     int k;
-    int own, n_seg, n_strip, n_items, tj;
+    int own, n_seg, n_strip, n_items, tj, snake;
     // tensor-recompute mode (NC > 0): M is rebuilt per pixel from g_c = (rho_c/dz)^2 (NC planes) and
     // 8 constants per channel derived from the lighting (see k_tensor_consts)
     const float* G;
@@ -122,8 +123,14 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane(bid * 4 + wave);      // wave-uniform: keeps the column loop scalar
     float red = 0.f;
-    if (item < a.n_items) {
-        const int strip = item / a.n_seg, seg = item - strip * a.n_seg;
+    const int strip = (item < a.n_items) ? item / a.n_seg : 0;
+    // D = +1: the wave marches left to right over its strip, D = -1: right to left.  Odd strips march
+    // backwards ("snake"): two neighbouring strips then reach their shared halo columns at the same time
+    // (both at the start or both at the end of their march), so the second reader hits the XCD's L2
+    // instead of fetching the columns again from the fabric a whole kernel later.
+    auto body = [&](auto dtag) {
+        constexpr int D = decltype(dtag)::value;
+        const int seg = item - strip * a.n_seg;
         const int Hs = a.Hs;
         const size_t pl = a.plane;
         const int row0 = seg * a.own + 4 * lane;                       // storage row of element 0 (PAD == halo == 4)
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
 
         const float* tens = (NC > 0) ? a.G : a.M;
         // Loads of one step, kept RAW (unconverted) so that they can stay in flight for a whole step:
-        // tensor planes and structure word of column c+1, x of column c+L.
+        // tensor planes and structure word of the next column (c+D), x of column c+D*L.
         struct Raw {
             F4 T[NT];
             unsigned fl;
@@ -146,9 +153,9 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         };
         auto issue = [&](Raw& w, int c) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w.T[t] = ld4(tens + (size_t)t * pl + (size_t)(c + 1) * Hs + rowL);
-            w.fl = *reinterpret_cast<const unsigned*>(a.flags + (size_t)(c + 1) * Hs + rowL);
-            const size_t off = (size_t)(c + L) * Hs + rowL;
+            for (int t = 0; t < NT; ++t) w.T[t] = ld4(tens + (size_t)t * pl + (size_t)(c + D) * Hs + rowL);
+            w.fl = *reinterpret_cast<const unsigned*>(a.flags + (size_t)(c + D) * Hs + rowL);
+            const size_t off = (size_t)(c + D * L) * Hs + rowL;
             if (MODE != 2) { w.r = ld4(a.xin + off); }
             else {
                 w.r = ld4(a.r + off); w.p = ld4(a.p_in + off);
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
             return o;
         };
 
-        F4 X[NX];                      // X[k] = x at column c-1+k
+        F4 X[NX];                      // X[k] = x at column c + D*(k-1): [previous, current, next, next+1, ...] in march order
         F4 Uprev = zero4(), U0 = zero4(), V0 = zero4(), W0 = zero4();
         unsigned FLm1 = 0u, FL0 = 0u;
         // tensor-recompute mode: M = sum_c g_c Q_c with
@@ -197,22 +204,24 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         }
         F4 S = zero4();                // block sums of the current column group
         X[0] = zero4();
+        const int c_first = (D > 0) ? c0 - 2 : c0 + TJ + 1;      // two priming steps before the strip
+        const int c_final = (D > 0) ? c0 + TJ - 1 : c0;          // last output column
 #pragma unroll
-        for (int k = 1; k + 1 < NX; ++k) X[k] = load_x(c0 - 3 + k);
+        for (int k = 1; k + 1 < NX; ++k) X[k] = load_x(c_first + D * (k - 1));
         X[NX - 1] = zero4();
         // Software pipeline: the loads of step c+1 are issued before the arithmetic of step c, into two
         // alternating buffer sets (the loop is unrolled by two, so no in-flight register is ever copied).
         // The last step re-reads its own columns (cache hits) instead of branching, which keeps the vmcnt
         // bookkeeping exact.  (A distance-3 pipeline with four buffer sets measured 8 % slower.)
         Raw bufA, bufB;
-        const int c_last = c0 + TJ - 1;
-        issue(bufA, c0 - 2);
+        issue(bufA, c_first);
 
-        auto step = [&](const int c, const Raw& cur, Raw& nxt) {
-            issue(nxt, min(c + 1, c_last));
-            X[NX - 1] = convert(cur);             // x of column c+L
-            const unsigned FL1 = cur.fl;          // structure bytes of column c+1
-            const F4* Mc = cur.T;                 // tensor data of column c+1
+        auto step = [&](const int m, const Raw& cur, Raw& nxt) {      // m = march index: -2, -1 prime, 0..TJ-1 output
+            const int c = c_first + D * (m + 2);
+            issue(nxt, (D > 0) ? min(c + 1, c_final) : max(c - 1, c_final));
+            X[NX - 1] = convert(cur);             // x of column c+D*L
+            const unsigned FL1 = cur.fl;          // structure bytes of the next column (c+D)
+            const F4* Mc = cur.T;                 // tensor data of the next column
             // ---- (u,v,w) of column c+1 ----------------------------------------------------------
             // Wave-uniform fast path: when every structure byte the wave touches is either "interior"
             // (masked, forward in x and y, inside a KT block) or empty, all selects collapse to plain
@@ -221,14 +230,14 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
             const bool plain1 = wave_all(is_plain(FL1));
             F4 U1, V1, W1;
             {
-                const F4& xl = X[1];          // column c
-                const F4& xc = X[2];          // column c+1
-                const F4& xr = X[3];          // column c+2
+                const F4& xc = X[2];                       // next column n = c+D
+                const F4& xl = (D > 0) ? X[1] : X[3];     // column n-1
+                const F4& xr = (D > 0) ? X[3] : X[1];     // column n+1
                 const float x_up = dpp_from_prev_lane(xc.e[3]);
                 const float x_dn = dpp_from_next_lane(xc.e[0]);
                 float q00[NC > 0 ? NC : 1], q02[NC > 0 ? NC : 1], dxc[NC > 0 ? NC : 1];
                 if (NC > 0) {
-                    const float xxv = (float)(a.j_lo + (c + 1) - PAD) - a.cx;      // xx of column c+1 (meshgrid: j - K[6])
+                    const float xxv = (float)(a.j_lo + (c + D) - PAD) - a.cx;      // xx of the next column (meshgrid: j - K[6])
 #pragma unroll
                     for (int ch = 0; ch < NC; ++ch) {
                         dxc[ch] = xxv - kX[ch];
@@ -278,8 +287,13 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
                 }
             }
             // ---- output column c ----------------------------------------------------------------
-            if (c >= c0) {
-                if (((c - c0) & (SF - 1)) == 0) {            // first column of an sf-group: block sums
+            if (m >= 0) {
+                // left / right neighbours of the output column in march terms
+                const F4& Uleft = (D > 0) ? Uprev : U1;
+                const F4& Uright = (D > 0) ? U1 : Uprev;
+                const unsigned FLleft = (D > 0) ? FLm1 : FL1;
+                const unsigned FLright = (D > 0) ? FL1 : FLm1;
+                if ((m & (SF - 1)) == 0) {                   // first visited column of an sf-group: block sums
                     F4 cs = zero4();
 #pragma unroll
                     for (int d = 0; d < SF; ++d)
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
                 const unsigned fl_up = dpp_from_prev_lane(FL0);     // its byte 3 = row above this lane's first row
                 const unsigned fl_dn = dpp_from_next_lane(FL0);     // its byte 0 = row below this lane's last row
                 F4 acc;
-                if (wave_all(is_plain(FLm1) && is_plain(FL0) && is_plain(FL1) && is_plain(fl_up) && is_plain(fl_dn))) {
+                if (wave_all(is_plain(FLleft) && is_plain(FL0) && is_plain(FLright) && is_plain(fl_up) && is_plain(fl_dn))) {
                     // interior: own rows are forward (-u, -v), left / upper neighbours are forward or empty
                     // (+u_left, +v_up; empty ones are zero), right / lower neighbours are never backward
 #pragma unroll
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
                         const float vu = (e == 0) ? v_up : V0.e[e > 0 ? e - 1 : 0];
                         float t = W0.e[e];
                         t += 0.f - U0.e[e];
-                        t += Uprev.e[e];
+                        t += Uleft.e[e];
                         t += 0.f - V0.e[e];
                         t += vu;
                         t *= a.lambda;
@@ -317,8 +331,8 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
     {                                                                                              \
         float t = W0.e[EE];                                                                        \
         t += if_bit<B_BX + 8 * EE>(U0.e[EE], FL0) - if_bit<B_FX + 8 * EE>(U0.e[EE], FL0);          \
-        t += if_bit<B_FX + 8 * EE>(Uprev.e[EE], FLm1);                                             \
-        t -= if_bit<B_BX + 8 * EE>(U1.e[EE], FL1);                                                 \
+        t += if_bit<B_FX + 8 * EE>(Uleft.e[EE], FLleft);                                           \
+        t -= if_bit<B_BX + 8 * EE>(Uright.e[EE], FLright);                                         \
         t += if_bit<B_BY + 8 * EE>(V0.e[EE], FL0) - if_bit<B_FY + 8 * EE>(V0.e[EE], FL0);          \
         t += if_bit<B_FY + FUB>(VU, FUW);                                                          \
         t -= if_bit<B_BY + FDB>(VD, FDW);                                                          \
@@ -361,10 +375,14 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
 #pragma unroll
             for (int k = 0; k + 1 < NX; ++k) X[k] = X[k + 1];
         };
-        for (int c = c0 - 2; c <= c_last; c += 2) {
-            step(c, bufA, bufB);
-            step(c + 1, bufB, bufA);
+        for (int m = -2; m < TJ; m += 2) {
+            step(m, bufA, bufB);
+            step(m + 1, bufB, bufA);
         }
+    };
+    if (item < a.n_items) {
+        if (a.snake && (strip & 1)) body(std::integral_constant<int, -1>{});
+        else body(std::integral_constant<int, 1>{});
     }
     if (MODE != 0) {
         const float t = block_sum(red, sm);
@@ -424,6 +442,7 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
     }
     const int nc = march_recompute_channels(ctx);
     a.tj = G.strip_cols;
+    a.snake = ctx->march_snake;
     switch (G.sf) {
         case 1: SRPS_MARCH_TJ(1) break;
         case 2: SRPS_MARCH_TJ(2) break;

@@ -240,6 +240,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->apply_mode = value;
     } else if (!strcmp(name, "tensor_recompute")) {
         ctx->tensor_recompute = value ? 1 : 0;
+    } else if (!strcmp(name, "march_snake")) {
+        ctx->march_snake = value ? 1 : 0;
     } else if (!strcmp(name, "keep_stored_tensor")) {
         ctx->keep_stored_tensor = value ? 1 : 0;
     } else if (!strcmp(name, "march_strip")) {

@@ -90,6 +90,7 @@ struct srps_ctx {
     int apply_mode = SRPS_APPLY_AUTO;
     int march_tj = 0;                // strip width of the marching operator (multiple of 4); 0 = chosen by march_plan
     int keep_stored_tensor = 0;      // also write the 6-plane tensor when the recompute form is active (tests)
+    int march_snake = 1;             // odd strips march right-to-left (halo columns shared through L2)
     int tensor_recompute = 1;        // rebuild M in the operator kernel from (rho_c/dz)^2 instead of streaming 6 planes
     int cg_max_iter = 100;           // dc.cu:231
     float cg_tol = 1e-9f;            // dc.cu:230

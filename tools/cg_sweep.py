@@ -12,7 +12,7 @@ sc = pkg.synth.make_scene(hh, ww, sf, 2, seed=1237, mask_kind="full")
 ctx = pkg.Context(device_id=0)
 ctx.setup(pkg.DataHandler.from_scene(sc))
 pkg.alternating_loop(ctx, None, max_outer=1)
-opts = [("tensor_recompute", 1)] + [("march_strip", int(v)) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0,16,20".split(","))]
+opts = [("march_snake", 0), ("march_snake", 1)] + [("march_strip", int(v)) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0,16,20".split(","))]
 for name, v in opts:
     ctx.set_option(name, v)
     if name == 'tensor_recompute':
