@@ -88,3 +88,11 @@ def load_dataset(dstype: str, dsloc: str, preprocess: bool = True) -> DataHandle
     if preprocess:
         dh.zs_lr, dh.z_full = preprocess_depth(z0, dh.z0_h, dh.z0_w, z0_n, I_h, I_w)
     return dh
+
+
+def write_view(kind: str, data, imask, rows: int, cols: int, path: str, nchannels: int = 3, scale: float = 1.0):
+    """PNG of one of the reference's views (Utilities.cpp:242-320): kind in {"normals", "albedo", "depth"}"""
+    k = {"normals": 0, "albedo": 1, "depth": 2}[kind]
+    d = np.ascontiguousarray(data, dtype=f32).reshape(-1); im = np.ascontiguousarray(imask, dtype=np.int32)
+    _check(load().srps_host_write_view(k, _f(d), im.ctypes.data_as(C.POINTER(C.c_int)), int(im.size), rows, cols, nchannels,
+                                       C.c_float(scale), path.encode()))

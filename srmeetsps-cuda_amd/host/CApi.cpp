@@ -6,6 +6,7 @@
 #include "PngIO.h"
 #include "Preprocess.h"
 #include "Utilities.h"
+#include "Visualize.h"
 
 static thread_local std::string g_host_err;
 #define HOST_TRY(...) try { __VA_ARGS__; return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
@@ -68,5 +69,13 @@ int srps_host_data_copy(srps_host_data* d, float* I, float* mask, float* K, floa
     return 0;
 }
 void srps_host_data_free(srps_host_data* d) { delete d; }
+// kind: 0 normals (N[4][P]), 1 albedo (rho[C][P]), 2 depth (z[P]); imask = HR linear indices of the masked pixels
+int srps_host_write_view(int kind, const float* data, const int* imask, int P, int rows, int cols, int nchannels, float scale, const char* path) {
+    HOST_TRY({
+        std::vector<int> im(imask, imask + P);
+        RgbImage v = kind == 0 ? normals_image(data, im, rows, cols) : kind == 1 ? albedo_image(data, im, rows, cols, nchannels) : depth_image(data, im, rows, cols);
+        png_write_rgb8(path, scale == 1.f ? v : resize_bilinear(v, scale));
+    })
+}
 int srps_host_write_mat_floats(const float* data, size_t n, const char* filename) { HOST_TRY({ write_MAT_floats(data, n, filename); }) }
 }

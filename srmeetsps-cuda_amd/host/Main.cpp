@@ -15,7 +15,8 @@ static void print_message() {
                  "\t-x, --blockx (value:256)\n\t\tblock dimension x (advisory)\n"
                  "\t-y, --blocky (value:4)\n\t\tblock dimension y (advisory)\n"
                  "\t-o, --outdir (value:.)\n\t\tdirectory for zs_init/z_init/s/rho/z/N .mat dumps\n"
-                 "\t--no-output\n\t\tdo not write .mat dumps\n";
+                 "\t--no-output\n\t\tdo not write .mat dumps\n"
+                 "\t--images\n\t\twrite the reference's three views (normals initial/current, albedo) and the depth map as PNG\n";
 }
 
 int main(int argc, char* argv[]) {
@@ -31,7 +32,7 @@ int main(int argc, char* argv[]) {
         if (eq != std::string::npos) { key = a.substr(0, eq); val = a.substr(eq + 1); has_val = true; }
         auto al = alias.find(key);
         if (al != alias.end()) key = al->second;
-        if (key == "help" || key == "no-output") { opt[key] = "true"; continue; }
+        if (key == "help" || key == "no-output" || key == "images") { opt[key] = "true"; continue; }
         if (!has_val && i + 1 < argc) val = argv[++i];
         if (val.size() >= 2 && val.front() == '"' && val.back() == '"') val = val.substr(1, val.size() - 2);
         opt[key] = val;
@@ -45,6 +46,7 @@ int main(int argc, char* argv[]) {
     Preferences::deviceId = std::stoi(opt["device"]);
     Preferences::outDir = opt["outdir"];
     Preferences::writeOutputs = !opt.count("no-output");
+    Preferences::writeImages = opt.count("images") > 0;
     try {
         if (opt["dstype"] == "matlab") {                            // Main.cpp:31-36
             MatFileDataHandler dh;

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <iostream>
 #include "Preprocess.h"
+#include "Visualize.h"
 
 SRPS::SRPS(DataHandler& dh) { this->dh = &dh; }
 SRPS::~SRPS() { if (ctx) srps_destroy(ctx); }
@@ -43,6 +44,15 @@ void SRPS::execute() {
         write_MAT_floats(z.data(), z.size(), out_path("z_init.mat").c_str());                                  // SRPS.cu:250
     }
 
+    // pixel index list for the visualisations (imask of SRPS.cu:157-162)
+    std::vector<int> imask;
+    std::vector<float> N_init;
+    if (Preferences::writeImages) {
+        for (int i = 0; i < dh->I_h * dh->I_w; ++i) if (dh->mask[i] != 0.f) imask.push_back(i);
+        N_init.resize(N.size());
+        srps_check(srps_get(ctx, "N", N_init.data(), N_init.size()));                                          // d_init_N, SRPS.cu:270
+    }
+
     // Core algorithm -- SRPS.cu:272-335
     float last_error = NAN;
     bool stop_loop = false;
@@ -77,6 +87,13 @@ void SRPS::execute() {
         srps_check(srps_get(ctx, "rho", rho.data(), rho.size()));
         srps_check(srps_get(ctx, "z", z.data(), z.size()));
         srps_check(srps_get(ctx, "N", N.data(), N.size()));
+        if (Preferences::writeImages) {                                                                        // SRPS.cu:319-327, scale 0.425
+            const float scale = 0.425f;
+            png_write_rgb8(out_path("Normals-Initial.png"), resize_bilinear(normals_image(N_init.data(), imask, dh->I_h, dh->I_w), scale));
+            png_write_rgb8(out_path("Normals-Current-Iteration.png"), resize_bilinear(normals_image(N.data(), imask, dh->I_h, dh->I_w), scale));
+            png_write_rgb8(out_path("Albedo.png"), resize_bilinear(albedo_image(rho.data(), imask, dh->I_h, dh->I_w, nch), scale));
+            png_write_rgb8(out_path("Depth.png"), resize_bilinear(depth_image(z.data(), imask, dh->I_h, dh->I_w), 0.4f));
+        }
         if (Preferences::writeOutputs) {                                                                       // SRPS.cu:330-333
             write_MAT_floats(s.data(), s.size(), out_path("s.mat").c_str());
             write_MAT_floats(rho.data(), rho.size(), out_path("rho.mat").c_str());

@@ -12,6 +12,7 @@ int Preferences::blockX = 256;          // Main.cpp:5-7
 int Preferences::blockY = 4;
 int Preferences::deviceId = 0;
 bool Preferences::writeOutputs = true;
+bool Preferences::writeImages = false;
 std::string Preferences::outDir = ".";
 
 void DataHandler::freeMemory() {

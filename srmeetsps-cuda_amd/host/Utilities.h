@@ -22,6 +22,7 @@ struct Preferences {
     static int blockY;
     static int deviceId;
     static bool writeOutputs;     // new: dump s/rho/z/N .mat after every pass (SRPS.cu:330-333)
+    static bool writeImages;      // new: write the three imshow views (SRPS.cu:319-327) as PNG files
     static std::string outDir;
 
 private:

@@ -455,8 +455,11 @@ def test_command_line_program_end_to_end(pkg, oracle, tmp_path):
     path = str(tmp_path / "scene.mat")
     scipy.io.savemat(path, {"I": I4, "K": Kmat, "mask": sc.mask.reshape(w, h).T.astype(np.uint8), "sf": float(sc.sf), "z0": z0},
                      do_compression=True)
-    out = subprocess.run([pkg.host.CLI, "--dstype=matlab", f"--dsloc={path}", "-o", str(tmp_path)], capture_output=True, text=True)
+    out = subprocess.run([pkg.host.CLI, "--dstype=matlab", f"--dsloc={path}", "-o", str(tmp_path), "--images"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+    from PIL import Image
+    for name in ("Normals-Initial.png", "Normals-Current-Iteration.png", "Albedo.png", "Depth.png"):     # the imshow windows of SRPS.cu:321-327
+        assert Image.open(str(tmp_path / name)).mode == "RGB"
     assert "Lightning Estimation" in out.stdout and "Iteration 01 summary" in out.stdout and "Done!" in out.stdout
     z_cli = scipy.io.loadmat(str(tmp_path / "z.mat"))["x"][:, 0]
     rho_cli = scipy.io.loadmat(str(tmp_path / "rho.mat"))["x"][:, 0]

@@ -179,6 +179,34 @@ def test_preprocess_chain_on_clean_depth(host, oracle):
     np.testing.assert_allclose(zf.reshape(zw * sf, zh * sf), host.resize_cubic(sm, zw * sf, zh * sf), rtol=1e-6)
 
 
+def test_headless_views_replace_imshow(host, tmp_path):
+    """normals / albedo / depth views of Utilities.cpp:242-320 written as PNG and read back with PIL"""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    rows, cols = 12, 10
+    m = rng.uniform(size=(rows, cols)) > 0.3
+    imask = np.nonzero(_cm(m))[0].astype(np.int32)
+    P = imask.size
+    N = rng.normal(size=(4, P)).astype(f32); N[:3] /= np.linalg.norm(N[:3], axis=0); N[3] = 1
+    host.write_view("normals", N, imask, rows, cols, str(tmp_path / "n.png"))
+    img = np.asarray(Image.open(tmp_path / "n.png")).astype(np.float64) / 255
+    ref = np.zeros((rows, cols, 3))
+    rr, cc = imask % rows, imask // rows
+    ref[rr, cc, 0] = np.clip(0.5 + 0.5 * N[0], 0, 1); ref[rr, cc, 1] = np.clip(0.5 + 0.5 * N[1], 0, 1); ref[rr, cc, 2] = np.clip(0.5 - 0.5 * N[2], 0, 1)
+    ref = (ref - ref.min()) / (ref.max() - ref.min())
+    assert img.shape == (rows, cols, 3) and np.abs(img - ref).max() <= 0.5 / 255 + 1e-6
+    rho = rng.uniform(0.1, 0.9, size=(3, P)).astype(f32); rho[1, 0] = 50.0                      # an outlier is capped at median + 5 sigma
+    host.write_view("albedo", rho, imask, rows, cols, str(tmp_path / "a.png"))
+    img = np.asarray(Image.open(tmp_path / "a.png")).astype(np.float64) / 255
+    cap = np.median(rho, axis=1) + 5 * rho.std(axis=1)
+    ref = np.zeros((rows, cols, 3)); ref[rr, cc] = np.clip(np.minimum(rho, cap[:, None]), 0, 1).T
+    assert np.abs(img - ref).max() <= 0.5 / 255 + 2e-3
+    z = rng.uniform(1, 2, size=P).astype(f32)
+    host.write_view("depth", z, imask, rows, cols, str(tmp_path / "z.png"), scale=0.5)
+    img = np.asarray(Image.open(tmp_path / "z.png"))
+    assert img.shape == (6, 5, 3) and img.max() > 100
+
+
 def test_cli_help_and_errors(host, pkg):
     cli = pkg.host.CLI
     out = subprocess.run([cli, "--help"], capture_output=True, text=True)
