@@ -99,7 +99,10 @@ def main():
     sc = pkg.synth.make_scene(H, W, args.sf, n_total, seed=1234 + 3, mask_kind="full", img_begin=lo, img_end=hi)
     dh = pkg.DataHandler.from_scene(sc)
     ctx = pkg.Context(device_id=local_rank)
-    ctx.use_torch_stream()
+    # one explicit torch stream carries the library's kernels and the collectives' dependencies (N > 1)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     if args.apply_mode:
         ctx.set_option("apply_mode", args.apply_mode)
     ctx.setup(dh)

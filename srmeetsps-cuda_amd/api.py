@@ -339,20 +339,29 @@ class SRPS:
         self.energies: list[float] = []
 
     def execute(self, max_outer: int | None = None, verbose: bool = False):
-        if self.distributed:
-            import torch
-            import torch.distributed as dist
-            self.ctx.use_torch_stream()
-        self.ctx.setup(self.dh)
         cb = None
         if verbose:
             def cb(it, err, rel):
                 print(f"\nIteration {it:02d} summary\n{'Error':<25}: {err:<6.3f}\n{'Relative Error':<25}: {rel:<6.3f}")
         if self.distributed:
-            def ar(t):
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            self.energies = alternating_loop(self.ctx, ar, max_outer, cb)
-        elif verbose or max_outer is not None:
+            import torch
+            import torch.distributed as dist
+            # One explicit (non-default) torch stream carries BOTH the library's kernels and the
+            # collectives' stream dependencies: torch.distributed orders a collective after the work
+            # already enqueued on the current stream and makes the current stream wait for its result.
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                self.ctx.set_stream(stream.cuda_stream)
+                self.ctx.setup(self.dh)
+
+                def ar(t):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                self.energies = alternating_loop(self.ctx, ar, max_outer, cb)
+                self.ctx.synchronize()
+            self.ctx.set_stream(None)
+            return self.energies
+        self.ctx.setup(self.dh)
+        if verbose or max_outer is not None:
             self.energies = alternating_loop(self.ctx, None, max_outer, cb)
         else:
             self.energies = self.ctx.execute(0)       # the loop inside the library (C++)
