@@ -53,3 +53,35 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, pkg):
     assert np.sqrt(np.mean((r0["z"] - one.z()) ** 2)) < 3e-5
     assert np.abs(r0["rho"] - one.rho()).max() < 5e-4
     ctx.close()
+
+
+def _nccl_single(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    sc = pkg.synth.make_scene(48, 56, 2, 4, seed=35, mask_kind="ragged")
+    srps = pkg.SRPS(pkg.DataHandler.from_scene(sc), distributed=True)
+    en = srps.execute(max_outer=2)
+    np.savez(os.path.join(out_dir, "nccl.npz"), energies=np.array(en), z=srps.z())
+    srps.ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_backend_accepts_the_exchange_buffers(tmp_path, pkg):
+    """backend "nccl" (= RCCL) with one rank: the collectives run on zero-copy views of memory the library
+    allocated with hipMalloc (not torch's caching allocator), on the explicit torch stream the kernels use"""
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_single, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl.npz")
+    sc = pkg.synth.make_scene(48, 56, 2, 4, seed=35, mask_kind="ragged")
+    ctx = pkg.Context(device_id=0)
+    one = pkg.SRPS(pkg.DataHandler.from_scene(sc), ctx=ctx)
+    e1 = one.execute(max_outer=2)
+    np.testing.assert_array_equal(r["energies"], np.array(e1))
+    np.testing.assert_array_equal(r["z"], one.z())
+    ctx.close()
