@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-total-solve", action="store_true")
     ap.add_argument("--apply-mode", type=int, default=0)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="srps_set_option before setup (A/B runs)")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +106,9 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     if args.apply_mode:
         ctx.set_option("apply_mode", args.apply_mode)
+    for kv in args.option:
+        name, val = kv.split("=")
+        ctx.set_option(name, int(val))
     ctx.setup(dh)
     dims = ctx.dims()
 

@@ -62,7 +62,11 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out);
 int srps_destroy(srps_ctx* ctx);
 int srps_set_stream(srps_ctx* ctx, void* hip_stream);      /* NULL = the context's own stream */
 int srps_synchronize(srps_ctx* ctx);
-int srps_set_option(srps_ctx* ctx, const char* name, int value); /* "albedo_mode", "apply_mode", "cg_max_iter", "march_strip" (16|32), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1), "march_snake" (0|1) */
+/* options: "albedo_mode" (SRPS_ALBEDO_*), "apply_mode" (SRPS_APPLY_*), "cg_max_iter", "march_strip" (0 = automatic,
+ * or a multiple of 4 in [4,512]), "march_snake" (0|1), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1),
+ * "fuse_energy_lighting" (0|1: the energy sweep over I also leaves the lighting sums of the next pass),
+ * "albedo_persistent" (0|1: albedo CG in registers, one cooperative launch, when the mask fits) */
+int srps_set_option(srps_ctx* ctx, const char* name, int value);
 
 /* ---- generic sparse operators (device pointers) -------------------------------------------*/
 /* replaces: cuda_based_host_COO_to_device_CSR (devicecalls.cuh:37, devicecalls.cu:51-67) incl.
@@ -185,6 +189,8 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer);
  * of n floats (must equal the array length). */
 int srps_get(srps_ctx* ctx, const char* name, float* host, size_t n);
 int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n);
+/* The device array itself. The call drops the partial sums cached between phases ("fuse_energy_lighting"); a caller
+ * that keeps the pointer and writes through it later must call this again (or srps_set) before the next phase. */
 int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats);
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters /*[8]*/, int* lighting_iters_max);
 

@@ -46,7 +46,14 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
 }
 
-// ---- V-wide loads of consecutive floats (V = 1 or 4) ---------------------------------------
+// p = beta p + r the way the reference's CG does it: Sscal (dc.cu:263) then Saxpy (dc.cu:264), two roundings
+__device__ __forceinline__ float scal_then_axpy(float beta, float p, float r) {
+#pragma clang fp contract(off)
+    const float t = beta * p;
+    return t + r;
+}
+
+// ---- V-wide loads of consecutive floats (V = 1, 2 or 4) ---------------------------------------
 template <int V>
 struct Vec {
     float v[V];
@@ -64,6 +71,13 @@ __device__ __forceinline__ Vec<4> ldv<4>(const float* __restrict__ p) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     Vec<4> r;
     r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    return r;
+}
+template <>
+__device__ __forceinline__ Vec<2> ldv<2>(const float* __restrict__ p) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    Vec<2> r;
+    r.v[0] = t.x; r.v[1] = t.y;
     return r;
 }
 template <int V>

@@ -101,12 +101,6 @@ int grid_rhs(srps_ctx* ctx, const float* d_z0s) {
 // MODE 2: CG step k: x := p_new = beta p + r (p_new = r when k == 1), out = A_ p_new,
 //         p_out = p_new, partial p_new.out (devicecalls.cu:256-268)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float scal_then_axpy(float beta, float p, float r) {
-#pragma clang fp contract(off)
-    const float t = beta * p;                 // Sscal  dc.cu:263
-    return t + r;                             // Saxpy  dc.cu:264 (two roundings, as in the reference)
-}
-
 template <int MODE>
 struct XRead {
     const float* x;

@@ -92,18 +92,28 @@ int launch_mean_channels(hipStream_t st, const float* d_data, int h, int w, int 
 // =============================================================================================
 // normals: one fused kernel for devicecalls.cu:171-223 (2 saxpy + 3 kernels in the reference)
 // =============================================================================================
+// Shared by k_normals and the fused energy + lighting pass, which must produce the same bits: every
+// multiply-add is spelled out so that the compiler's contraction choices cannot differ between the two.
+__device__ __forceinline__ void perspective_normal(float fx, float fy, float z, float gx, float gy, float x, float y,
+                                                   float& n0, float& n1, float& n2, float& nrm) {
+    const float u0 = fx * gx;                                      // dc.cu:204
+    const float u1 = fy * gy;                                      // dc.cu:211
+    const float u2 = fmaf(-y, gy, fmaf(-x, gx, -z));               // dc.cu:174
+    nrm = fmaxf(1e-10f, sqrtf(fmaf(u2, u2, fmaf(u1, u1, u0 * u0))));   // dc.cu:182
+    n0 = u0 / nrm;                                                 // dc.cu:190
+    n1 = u1 / nrm;
+    n2 = u2 / nrm;
+}
+
 __global__ void k_normals(const float* __restrict__ z, const float* __restrict__ zx, const float* __restrict__ zy,
                           const float* __restrict__ xx, const float* __restrict__ yy, int P, float fx, float fy,
                           float* __restrict__ N, float* __restrict__ dz) {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const float gx = zx[p], gy = zy[p];
-        const float n0 = fx * gx;                                  // dc.cu:204
-        const float n1 = fy * gy;                                  // dc.cu:211
-        const float n2 = -z[p] - xx[p] * gx - yy[p] * gy;          // dc.cu:174
-        const float nrm = fmaxf(1e-10f, sqrtf(n0 * n0 + n1 * n1 + n2 * n2));   // dc.cu:182
-        N[p] = n0 / nrm;                                           // dc.cu:190
-        N[(size_t)P + p] = n1 / nrm;
-        N[2 * (size_t)P + p] = n2 / nrm;
+        float n0, n1, n2, nrm;
+        perspective_normal(fx, fy, z[p], zx[p], zy[p], xx[p], yy[p], n0, n1, n2, nrm);
+        N[p] = n0;
+        N[(size_t)P + p] = n1;
+        N[2 * (size_t)P + p] = n2;
         N[3 * (size_t)P + p] = 1.f;                                // dc.cu:175
         dz[p] = nrm;
     }
@@ -130,15 +140,29 @@ __global__ void k_final_sum(const float* __restrict__ part, int n, float* __rest
 // Pass 1 streams I once and leaves per-block partial sums; pass 2 (one thread per (i,c)) adds
 // them in a fixed order and runs the reference's CG recurrence on the 4x4 system in registers.
 // =============================================================================================
-template <int V, int IB>
+// With ENERGY the same sweep over I also evaluates the photometric energy of the depth that was just
+// solved (k_energy_partial's sum, with the lighting / albedo / dz the system was built from) and takes the
+// normals of that depth from z, zx, zy instead of reading N: the energy pass of outer iteration k and the
+// lighting pass of iteration k+1 read I once instead of twice.
+struct EnergyArgs {
+    const float *s, *xx, *yy, *dz, *z, *zx, *zy;
+    float fx, fy;
+    int img_offset;
+    float* part_e;
+};
+
+template <int V, int IB, bool ENERGY>
 __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__ rho, const float* __restrict__ N,
                                                        const float* __restrict__ I, int P, int n_img, int C, int chunk,
-                                                       float* __restrict__ part_atb, float* __restrict__ part_g) {
+                                                       float* __restrict__ part_atb, float* __restrict__ part_g,
+                                                       EnergyArgs ea) {
     __shared__ float sm[4][IB * 4 + 10];
+    __shared__ float sme[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int blk = blockIdx.x;
     const int p0 = blk * chunk;
     const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
     for (int c = 0; c < C; ++c) {
         for (int b0 = 0; b0 < n_img; b0 += IB) {
             float acc[IB][4];
@@ -152,8 +176,23 @@ __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__
             for (int q = p0 + tid * V; q < p1; q += 256 * V) {
                 const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
                 Vec<V> nk[4];
+                Vec<V> vxx, vyy, vz, vzx, vzy, vg;
+                if constexpr (ENERGY) {
+                    vxx = ldv<V>(ea.xx + q); vyy = ldv<V>(ea.yy + q);
+                    vz = ldv<V>(ea.z + q); vzx = ldv<V>(ea.zx + q); vzy = ldv<V>(ea.zy + q);
+                    const Vec<V> vdz = ldv<V>(ea.dz + q);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+                    for (int e = 0; e < V; ++e) {
+                        float nrm;
+                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e],
+                                           nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
+                        nk[3].v[e] = 1.f;
+                        vg.v[e] = r.v[e] / vdz.v[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+                }
                 float a[4][V];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -170,6 +209,25 @@ __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
                         for (int e = 0; e < V; ++e) acc[ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[ii][k]);
+                if constexpr (ENERGY) {
+#pragma unroll
+                    for (int ii = 0; ii < IB; ++ii) {
+                        if (b0 + ii < n_img) {                                   // wave-uniform
+                            const float* sv = ea.s + ((size_t)(ea.img_offset + b0 + ii) * C + c) * 4;
+                            const float s2 = sv[2], s3 = sv[3];
+                            const float fs0 = ea.fx * sv[0], fs1 = ea.fy * sv[1];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                const float a1 = vg.v[e] * (fs0 - vxx.v[e] * s2);
+                                const float a2 = vg.v[e] * (fs1 - vyy.v[e] * s2);
+                                const float a3 = vg.v[e] * s2;
+                                const float b = iv[ii].v[e] - r.v[e] * s3;
+                                const float res = a1 * vzx.v[e] + a2 * vzy.v[e] - a3 * vz.v[e] - b;
+                                e_acc = fmaf(res, res, e_acc);
+                            }
+                        }
+                    }
+                }
                 if (b0 == 0) {
                     int t = 0;
 #pragma unroll
@@ -206,6 +264,10 @@ __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__
             }
             __syncthreads();
         }
+    }
+    if constexpr (ENERGY) {
+        const float t = block_sum(e_acc, sme);
+        if (tid == 0) ea.part_e[blk] = t;
     }
 }
 
@@ -272,34 +334,85 @@ __global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ pa
     atomicMax(iters_max, k);
 }
 
-int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
-             int n_local, int C, int n_total, int img_offset, bool zero_nonlocal) {
-    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_N | (uintptr_t)d_I) % 16 == 0);
+struct LightPlan {
+    int V, IB, chunk, nblk;
+    float *part_atb, *part_g;
+    int* d_it;
+};
+static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightPlan& L, bool fused = false) {
     // images per register batch: the block re-reads rho and N once per batch, so one batch is best
-    int IB = 4;
-    for (int cand : {4, 8, 12, 16, 20}) { IB = cand; if (n_local <= cand) break; }      // n_local > 20: batches of 20
-    const int V = vec ? 4 : 1;
+    L.IB = 4;
+    for (int cand : {4, 8, 12, 16, 20}) { L.IB = cand; if (n_local <= cand) break; }      // n_local > 20: batches of 20
+    // the fused sweep holds 7 more planes per pixel: 2 pixels per thread keep it at 2 waves per SIMD
+    // (334 us against 504 us at 2048^2, 20 images); alone the lighting sweep is faster with 4 (250 / 268 us)
+    L.V = vec ? (fused ? 2 : 4) : 1;
     int chunk = cdiv(P, 1024);
-    chunk = std::max(256 * V, cdiv(chunk, 256 * V) * 256 * V);
-    const int nblk = cdiv(P, chunk);
-    const size_t n_atb = (size_t)nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)nblk * C * 10;
+    L.chunk = std::max(256 * L.V, cdiv(chunk, 256 * L.V) * 256 * L.V);
+    L.nblk = cdiv(P, L.chunk);
+    const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
     SRPS_TRY(ensure(ctx->ws_light, (n_atb + n_g) * sizeof(float) + 64));
-    float* part_atb = (float*)ctx->ws_light.p;
-    float* part_g = part_atb + n_atb;
-    int* d_it = (int*)(part_g + n_g);
-    SRPS_HIP(hipMemsetAsync(d_it, 0, sizeof(int), ctx->stream));
-    if (n_local > 0) {
-#define SRPS_LIGHT(VV, BB) hipLaunchKernelGGL((k_light_partial<VV, BB>), dim3(nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, chunk, part_atb, part_g)
-        if (vec) { switch (IB) { case 4: SRPS_LIGHT(4, 4); break; case 8: SRPS_LIGHT(4, 8); break; case 12: SRPS_LIGHT(4, 12); break; case 16: SRPS_LIGHT(4, 16); break; default: SRPS_LIGHT(4, 20); } }
-        else { switch (IB) { case 4: SRPS_LIGHT(1, 4); break; case 8: SRPS_LIGHT(1, 8); break; case 12: SRPS_LIGHT(1, 12); break; case 16: SRPS_LIGHT(1, 16); break; default: SRPS_LIGHT(1, 20); } }
+    L.part_atb = (float*)ctx->ws_light.p;
+    L.part_g = L.part_atb + n_atb;
+    L.d_it = (int*)(L.part_g + n_g);
+    return SRPS_OK;
+}
+template <bool ENERGY>
+static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* d_rho, const float* d_N, const float* d_I,
+                                int P, int n_local, int C, const EnergyArgs& ea) {
+#define SRPS_LIGHT(VV, BB) hipLaunchKernelGGL((k_light_partial<VV, BB, ENERGY>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, L.chunk, L.part_atb, L.part_g, ea)
+    if (L.V == 4) { if constexpr (!ENERGY) switch (L.IB) { case 4: SRPS_LIGHT(4, 4); break; case 8: SRPS_LIGHT(4, 8); break; case 12: SRPS_LIGHT(4, 12); break; case 16: SRPS_LIGHT(4, 16); break; default: SRPS_LIGHT(4, 20); } }
+    else if (L.V == 2) { if constexpr (ENERGY) switch (L.IB) { case 4: SRPS_LIGHT(2, 4); break; case 8: SRPS_LIGHT(2, 8); break; case 12: SRPS_LIGHT(2, 12); break; case 16: SRPS_LIGHT(2, 16); break; default: SRPS_LIGHT(2, 20); } }
+    else { switch (L.IB) { case 4: SRPS_LIGHT(1, 4); break; case 8: SRPS_LIGHT(1, 8); break; case 12: SRPS_LIGHT(1, 12); break; case 16: SRPS_LIGHT(1, 16); break; default: SRPS_LIGHT(1, 20); } }
 #undef SRPS_LIGHT
-        SRPS_LAUNCH_CHECK();
-    }
-    const int nt = n_total * C;
-    hipLaunchKernelGGL(k_light_solve, dim3(nt), dim3(64), 0, ctx->stream, part_atb, part_g, nblk, n_local, C,
-                       n_total, img_offset, zero_nonlocal ? 1 : 0, d_s, d_it, ctx->cg_tol, ctx->cg_max_iter);
     SRPS_LAUNCH_CHECK();
-    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 8, d_it, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return SRPS_OK;
+}
+
+// use_cache: the partial sums left by energy_light_fused for exactly these arrays are still in ws_light
+int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
+             int n_local, int C, int n_total, int img_offset, bool zero_nonlocal, bool use_cache) {
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_N | (uintptr_t)d_I) % 16 == 0);
+    LightPlan L;
+    const bool cached = use_cache && ctx->light_cache_valid && ctx->light_cache_normals;
+    ctx->light_cache_valid = false;
+    if (cached) {
+        L = LightPlan{ctx->light_cache_V, 0, 0, ctx->light_cache_nblk, nullptr, nullptr, nullptr};
+        const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
+        L.part_atb = (float*)ctx->ws_light.p;
+        L.part_g = L.part_atb + n_atb;
+        L.d_it = (int*)(L.part_g + n_g);
+    } else {
+        SRPS_TRY(light_plan(ctx, vec, P, n_local, C, L));
+    }
+    SRPS_HIP(hipMemsetAsync(L.d_it, 0, sizeof(int), ctx->stream));
+    if (n_local > 0 && !cached) SRPS_TRY(light_partial_launch<false>(ctx, L, d_rho, d_N, d_I, P, n_local, C, EnergyArgs{}));
+    const int nt = n_total * C;
+    hipLaunchKernelGGL(k_light_solve, dim3(nt), dim3(64), 0, ctx->stream, L.part_atb, L.part_g, L.nblk, n_local, C,
+                       n_total, img_offset, zero_nonlocal ? 1 : 0, d_s, L.d_it, ctx->cg_tol, ctx->cg_max_iter);
+    SRPS_LAUNCH_CHECK();
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 8, L.d_it, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return SRPS_OK;
+}
+
+// Photometric energy of the depth just solved (k_energy_partial's quantity) and, in the same sweep over I, the
+// lighting partial sums of the next outer iteration (normals of the new depth computed in registers). The sums
+// stay in ws_light; lighting(..., use_cache) consumes them.
+int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
+                       const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
+                       float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out) {
+    Grid& G = ctx->grid;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy |
+                                       (uintptr_t)d_dz | (uintptr_t)d_z | (uintptr_t)d_zx | (uintptr_t)d_zy) % 16 == 0);
+    LightPlan L;
+    SRPS_TRY(light_plan(ctx, vec, P, n_local, C, L, /*fused=*/true));
+    EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part};
+    SRPS_TRY(light_partial_launch<true>(ctx, L, d_rho, nullptr, d_I, P, n_local, C, ea));
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, ctx->stream, G.d_misc_part, L.nblk, d_out);
+    SRPS_LAUNCH_CHECK();
+    ctx->light_cache_valid = true;
+    ctx->light_cache_normals = false;
+    ctx->light_cache_V = L.V;
+    ctx->light_cache_nblk = L.nblk;
     return SRPS_OK;
 }
 
@@ -412,7 +525,7 @@ __global__ __launch_bounds__(256) void k_dcg_a(int k, const float* __restrict__ 
         else {
             vp = ldv<V>(p + base + q);
 #pragma unroll
-            for (int e = 0; e < V; ++e) { const float t = beta * vp.v[e]; vp.v[e] = t + vr.v[e]; }      // Sscal, Saxpy (dc.cu:263-264)
+            for (int e = 0; e < V; ++e) vp.v[e] = scal_then_axpy(beta, vp.v[e], vr.v[e]);             // dc.cu:263-264
         }
         stv<V>(p + base + q, vp);
 #pragma unroll
@@ -462,6 +575,134 @@ __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the same CG for masks that fit the register file (P <= CUs * 4096 * 5, i.e. up
+// to 5.2 M pixels on 256 CUs): one cooperative launch, one block of 1024 threads per CU, every thread
+// keeps x, r, p and the diagonal of its 4*NV pixels in registers for the whole solve of a channel and
+// the two dot products of a step are grid-wide reductions (grid_sum below; every block adds the per-block
+// partial sums in the same fixed order, in double). HBM traffic: 16 B per pixel and channel
+// instead of 16 + 40 B per CG step. The element-wise arithmetic is that of k_dcg_init / _a / _b.
+// ---------------------------------------------------------------------------------------------
+struct F4 {
+    float e[4];
+};
+// Grid-wide sum without read-modify-write atomics (256 device-scope atomics on one address serialise in the
+// fabric: the library's grid barrier costs 33 us on 256 CUs). Every block publishes {generation, partial sum} as
+// one 64-bit device-scope store; thread t of every block polls entry t until it carries this generation; then
+// every block adds the same values in the same order. Nothing but these entries travels between blocks, so no
+// other fences are needed. Two slots: a block can be at most one reduction ahead of the slowest one.
+__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm, double* smd) {
+    const int nb = gridDim.x, tid = threadIdx.x;
+    unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
+    const float t = block_sum(v, sm);
+    if (tid == 0)
+        __hip_atomic_store(&slot[blockIdx.x], ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(t),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double a = 0.0;
+    for (int i = tid; i < nb; i += 1024) {
+        unsigned long long w;
+        while ((unsigned)((w = __hip_atomic_load(&slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen)
+            __builtin_amdgcn_s_sleep(1);
+        a += (double)__uint_as_float((unsigned)w);
+    }
+    a = wave_sum(a);
+    __syncthreads();
+    if ((tid & 63) == 0) smd[tid >> 6] = a;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += smd[i];
+    return (float)tot;
+}
+
+template <int NV>
+__global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho, const float* __restrict__ num,
+                                                         const float* __restrict__ den, int P, int C,
+                                                         unsigned long long* ent /* [2][gridDim.x], zeroed */,
+                                                         DcgScal* __restrict__ scal, float tol2, int max_iter) {
+    __shared__ float sm[16];
+    __shared__ double smd[16];
+    const int nb = gridDim.x, tid = threadIdx.x;
+    unsigned gen = 0;                  // generations start at 1: the entries are zeroed before the launch
+    for (int c = 0; c < C; ++c) {
+        const size_t base = (size_t)c * P;
+        F4 x[NV], r[NV], p[NV], d[NV];
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * 1024 + tid) * 4;
+            if (q < (size_t)P) {
+                const Vec<4> vn = ldv<4>(num + base + q), vd = ldv<4>(den + base + q), vx = ldv<4>(rho + base + q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[j].e[e] = vx.v[e]; d[j].e[e] = vd.v[e];
+                    r[j].e[e] = vn.v[e] - vd.v[e] * vx.v[e];                      // dc.cu:404-405
+                    acc = fmaf(r[j].e[e], r[j].e[e], acc);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[j].e[e] = 0.f; d[j].e[e] = 0.f; r[j].e[e] = 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[j].e[e] = 0.f;
+        }
+        float r1 = grid_sum(acc, ent, ++gen, sm, smd);
+        float r0 = 0.f;
+        int k = 0;
+        while (r1 > tol2 && k <= max_iter) {                                      // dc.cu:252
+            ++k;
+            const float beta = (k == 1) ? 0.f : r1 / r0;
+            acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[j].e[e] = (k == 1) ? r[j].e[e] : scal_then_axpy(beta, p[j].e[e], r[j].e[e]);
+                    acc = fmaf(p[j].e[e], d[j].e[e] * p[j].e[e], acc);
+                }
+            const float dot = grid_sum(acc, ent, ++gen, sm, smd);
+            const float alpha = r1 / dot;
+            acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float w = d[j].e[e] * p[j].e[e];
+                    x[j].e[e] = fmaf(alpha, p[j].e[e], x[j].e[e]);
+                    r[j].e[e] = fmaf(-alpha, w, r[j].e[e]);
+                    acc = fmaf(r[j].e[e], r[j].e[e], acc);
+                }
+            r0 = r1;
+            r1 = grid_sum(acc, ent, ++gen, sm, smd);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * 1024 + tid) * 4;
+            if (q < (size_t)P) {
+                Vec<4> vx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vx.v[e] = x[j].e[e];
+                stv<4>(rho + base + q, vx);
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) { scal[c].r0 = r0; scal[c].iters = k; scal[c].active = (r1 > tol2) ? 1 : 0; }
+    }
+}
+
+// 0 when the persistent form cannot be used (mask too large for the register file, unaligned arrays)
+static int dcg_persistent_plan(srps_ctx* ctx, int P, bool vec, int& NV, int& nb) {
+    if (!vec || !ctx->albedo_persistent) return 0;
+    const int cus = ctx->num_cus;
+    for (int cand : {1, 2, 4, 5}) {
+        if ((long long)cand * cus * 4096 >= P) {
+            NV = cand;
+            nb = cdiv(P, cand * 4096);
+            return 1;
+        }
+    }
+    return 0;
+}
+
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C) {
     const float* num = d_numden;
     const float* den = d_numden + (size_t)C * P;
@@ -475,7 +716,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     }
     const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
     const size_t nv = (size_t)C * P;
-    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + C * sizeof(DcgScal) + 256;
+    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + 2 * 1024 * sizeof(unsigned long long) + 256;
     SRPS_TRY(ensure(ctx->ws_albedo, bytes));
     float* r = (float*)ctx->ws_albedo.p;
     float* p = r + nv;
@@ -484,10 +725,27 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     DcgScal* scal = (DcgScal*)(pw_part + (size_t)C * nb);
     const float tol2 = ctx->cg_tol * ctx->cg_tol;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_numden | (uintptr_t)r) % 16 == 0);
+    DcgScal* hs = (DcgScal*)(ctx->h_pinned + 16);
+    int pNV = 0, pnb = 0;
+    if (dcg_persistent_plan(ctx, P, vec, pNV, pnb)) {
+        // [2][pnb] behind the C <= 8 scalar records, 8-byte aligned
+        unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 7) & ~(uintptr_t)7);
+        SRPS_HIP(hipMemsetAsync(ent, 0, 2 * (size_t)pnb * sizeof(unsigned long long), ctx->stream));
+        float tol2v = tol2;
+        int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
+        float* rho_v = d_rho;
+        void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &scal, &tol2v, &maxit};
+        const void* fn = pNV == 1 ? (const void*)k_dcg_persistent<1> : pNV == 2 ? (const void*)k_dcg_persistent<2>
+                       : pNV == 4 ? (const void*)k_dcg_persistent<4> : (const void*)k_dcg_persistent<5>;
+        SRPS_HIP(hipLaunchCooperativeKernel(fn, dim3(pnb), dim3(1024), args, 0, ctx->stream));
+        SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+        SRPS_HIP(hipStreamSynchronize(ctx->stream));
+        for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = hs[c].iters;
+        return SRPS_OK;
+    }
     if (vec) hipLaunchKernelGGL(k_dcg_init<4>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
     else hipLaunchKernelGGL(k_dcg_init<1>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
     SRPS_LAUNCH_CHECK();
-    DcgScal* hs = (DcgScal*)(ctx->h_pinned + 16);
     const int kmax = ctx->cg_max_iter + 1;         // "k <= max_iter" => up to max_iter+1 steps (dc.cu:252)
     for (int k = 1; k <= kmax; ++k) {
         if (vec) {

@@ -190,6 +190,13 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     c->device = device_id;
     if (block_x > 0) c->block_x = block_x;
     if (block_y > 0) c->block_y = block_y;
+    {
+        int cus = 0, coop = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
+        (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device_id);
+        c->num_cus = cus > 0 ? cus : 1;
+        if (!coop) c->albedo_persistent = 0;
+    }
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     c->stream = c->own_stream;
@@ -242,6 +249,11 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->tensor_recompute = value ? 1 : 0;
     } else if (!strcmp(name, "march_snake")) {
         ctx->march_snake = value ? 1 : 0;
+    } else if (!strcmp(name, "fuse_energy_lighting")) {
+        ctx->fuse_energy_lighting = value ? 1 : 0;
+        ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "albedo_persistent")) {
+        ctx->albedo_persistent = value ? 1 : 0;
     } else if (!strcmp(name, "keep_stored_tensor")) {
         ctx->keep_stored_tensor = value ? 1 : 0;
     } else if (!strcmp(name, "march_strip")) {
@@ -366,6 +378,7 @@ int srps_depth_operator_apply(srps_ctx* ctx, const float* d_x, int npix, float* 
 int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     CTX_CHECK(ctx);
     SRPS_REQUIRE(pr != nullptr, SRPS_ERR_INVALID, "setup: problem is NULL");
+    ctx->light_cache_valid = false;
     SRPS_REQUIRE(pr->mask && pr->K && pr->zs_lr && pr->z_full, SRPS_ERR_INVALID, "setup: mask, K, zs_lr and z_full are required");
     SRPS_REQUIRE(pr->n_channels > 0 && pr->n_channels <= 8 && pr->n_images >= 0 && pr->n_images_total > 0, SRPS_ERR_INVALID, "setup: bad image counts");
     SRPS_REQUIRE(pr->image_offset >= 0 && pr->image_offset + pr->n_images <= pr->n_images_total, SRPS_ERR_INVALID, "setup: shard [%d,%d) outside [0,%d)", pr->image_offset, pr->image_offset + pr->n_images, pr->n_images_total);
@@ -409,6 +422,7 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
 int srps_upload_image(srps_ctx* ctx, int li, const float* host_image) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(host_image && li >= 0 && li < ctx->N_local, SRPS_ERR_INVALID, "upload_image: bad arguments");
+    ctx->light_cache_valid = false;
     Grid& G = ctx->grid;
     const size_t hw = (size_t)G.h * G.w, n = hw * ctx->C;
     SRPS_TRY(ensure(ctx->ws_stage, n * sizeof(float)));
@@ -431,7 +445,7 @@ int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, in
 int srps_lighting_local(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     return lighting(ctx, ctx->s, ctx->rho, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
-                    ctx->N_local != ctx->N_total);
+                    ctx->N_local != ctx->N_total, /*use_cache=*/true);
 }
 int srps_lighting(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -445,6 +459,7 @@ int srps_albedo_partial(srps_ctx* ctx) {
 }
 int srps_albedo_finish(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    ctx->light_cache_valid = false;      // rho changes
     return albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C);
 }
 int srps_albedo(srps_ctx* ctx) {
@@ -462,11 +477,16 @@ int srps_depth_partial(srps_ctx* ctx) {
 int srps_depth_solve(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
+    ctx->light_cache_valid = false;      // z changes
     return depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy);
 }
 int srps_energy_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_TRY(grid_energy_t1(ctx, ctx->z0s, ctx->energy_ex));
+    // the sweep over I that evaluates the energy also leaves the lighting sums of the next outer iteration
+    if (ctx->fuse_energy_lighting && ctx->N_local > 0)
+        return energy_light_fused(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->z, ctx->zx, ctx->zy, ctx->fx, ctx->fy,
+                                  ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->energy_ex + 1);
     return energy_photometric_partial(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->z, ctx->zx, ctx->zy, ctx->fx, ctx->fy,
                                       ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->energy_ex + 1);
 }
@@ -494,6 +514,7 @@ int srps_normals(srps_ctx* ctx) {
     Grid& G = ctx->grid;
     SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));
     SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy));                               // SRPS.cu:310-311
+    ctx->light_cache_normals = true;
     return launch_normals(ctx->stream, ctx->z, ctx->zx, ctx->zy, ctx->xx, ctx->yy, G.P, ctx->fx, ctx->fy, ctx->Nrm, ctx->dz);  // SRPS.cu:315
 }
 
@@ -569,6 +590,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     float* p; size_t len;
     SRPS_TRY(lookup(ctx, name, &p, &len));
     SRPS_REQUIRE(n == len, SRPS_ERR_INVALID, "set('%s'): buffer holds %zu floats, array has %zu", name, n, len);
+    ctx->light_cache_valid = false;
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
     return SRPS_OK;
@@ -579,6 +601,7 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
     float* p; size_t len;
     SRPS_TRY(lookup(ctx, name, &p, &len));
     *d_ptr = p; *n_floats = len;
+    ctx->light_cache_valid = false;      // the caller may write through the pointer
     return SRPS_OK;
 }
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters, int* lighting_iters_max) {

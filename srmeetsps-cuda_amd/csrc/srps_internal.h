@@ -114,6 +114,13 @@ struct srps_ctx {
     int last_albedo_iters[8] = {0};
     // what the last depth assembly was built from (srps_depth_operator_apply)
     bool tensor_valid = false;
+    // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
+    int fuse_energy_lighting = 1;
+    int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
+    int num_cus = 256;
+    bool light_cache_valid = false;
+    bool light_cache_normals = false;     // srps_normals ran on the depth the sums were taken from (Nrm is current)
+    int light_cache_V = 0, light_cache_nblk = 0;
 };
 
 namespace srps {
@@ -152,7 +159,10 @@ int launch_mean_channels(hipStream_t st, const float* d_data, int h, int w, int 
 int launch_normals(hipStream_t st, const float* z, const float* zx, const float* zy, const float* xx,
                    const float* yy, int P, float fx, float fy, float* N, float* dz);
 int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
-             int n_local, int C, int n_total, int img_offset, bool zero_nonlocal);
+             int n_local, int C, int n_total, int img_offset, bool zero_nonlocal, bool use_cache = false);
+int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
+                       const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
+                       float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out);
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
                   int C, int s_img_offset, float* d_numden);
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);

@@ -124,6 +124,29 @@ def test_scalar_paths_when_pixel_count_is_not_a_multiple_of_four(pkg, oracle):
     assert z.size % 4 != 0
 
 
+@pytest.mark.parametrize("h,w,sf,n_ch", [(40, 32, 2, 3), (600, 700, 4, 3), (1024, 1536, 4, 2), (2304, 2200, 4, 1)])
+def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
+    """the albedo CG that keeps x, r, p and the diagonal in registers for the whole solve (one cooperative
+    launch, grid-wide sums through generation-tagged flags; 1, 2, 4 and 5 float4 per thread) against the
+    kernel-per-half-step form: same iteration counts, same albedo up to the order of the dot products"""
+    sc = pkg.synth.make_scene(h, w, sf, 2, seed=h + 7, n_ch=n_ch, mask_kind="ellipse" if h < 2000 else "full")
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    ctx.lighting()
+    rho0 = ctx.get("rho")
+    out = {}
+    for pers in (0, 1):
+        ctx.set_option("albedo_persistent", pers)
+        ctx.set("rho", rho0)
+        ctx.albedo()
+        out[pers] = (ctx.get("rho"), ctx.last_cg_iterations()["albedo"][:n_ch])
+    ctx.close()
+    assert all(k > 1 for k in out[1][1]), out[1][1]
+    assert all(abs(a - b) <= 1 for a, b in zip(out[0][1], out[1][1])), (out[0][1], out[1][1])
+    assert np.all(np.isfinite(out[1][0]))
+    assert np.abs(out[1][0] - out[0][0]).max() < 2e-6
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json's full HR grid: properties that do not need the oracle at that size
 # ------------------------------------------------------------------------------------------------

@@ -316,6 +316,39 @@ def test_tensor_recompute_equals_stored_tensor(pkg, oracle, kind, sf, h, w, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("kind,sf,h,w,n,n_ch", [("ragged", 2, 96, 72, 5, 3), ("full", 4, 64, 48, 23, 3), ("ellipse", 1, 50, 46, 2, 1)])
+def test_fused_energy_and_lighting_sweep_equals_separate_passes(pkg, kind, sf, h, w, n, n_ch):
+    """the sweep over I that evaluates the energy of pass k also leaves the lighting sums of pass k+1
+    (normals recomputed in registers): same lighting, albedo, depth and energies as the two separate
+    passes up to the summation order; stale sums are never used after the state was written"""
+    sc = pkg.synth.make_scene(h, w, sf, n, seed=77, n_ch=n_ch, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    res = {}
+    for fuse in (0, 1):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("fuse_energy_lighting", fuse)
+        ctx.setup(dh)
+        en = pkg.alternating_loop(ctx, None, max_outer=3)
+        res[fuse] = (en, ctx.get("s"), ctx.get("rho"), ctx.get("z"), ctx.get("N"))
+        if fuse:
+            # overwrite rho after an energy pass: the cached sums must be dropped, not reused
+            ctx.energy_partial(); ctx.energy_finish()
+            ctx.normals()
+            ctx.set("rho", (res[1][2] * 0.5).astype(f32))
+            ctx.lighting()
+            s_after = ctx.get("s")
+            ctx.set_option("fuse_energy_lighting", 0)
+            ctx.lighting()                                  # warm start = the converged s: must not move much
+            np.testing.assert_allclose(ctx.get("s"), s_after, rtol=1e-2, atol=1e-3)
+            assert not np.allclose(s_after, res[1][1], rtol=1e-2)          # the lighting did react to the new rho
+        ctx.close()
+    # the fused sweep adds in a different order (2 pixels per thread instead of 4): equal up to rounding
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-3)
+    for k in (1, 2, 3, 4):
+        np.testing.assert_allclose(res[1][k], res[0][k], rtol=2e-3, atol=1e-3)
+    assert rmse(res[1][3], res[0][3]) < 2e-5
+
+
 def test_operator_level_depth_with_principal_point_hint(gpu_ctx, oracle, pkg):
     """srps_depth_estimation (the reference's signature: xx, yy as arrays) with and without the optional
     srps_set_principal_point hint that switches it to the tensor-recompute operator"""
