@@ -46,6 +46,36 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
 }
 
+// ---- grid-wide sum of a persistent (cooperative) launch: blocks of up to 1024 threads (a multiple of 64) ----
+// Grid-wide sum without read-modify-write atomics (256 device-scope atomics on one address serialise in the
+// fabric: the library's grid barrier costs 33 us on 256 CUs). Every block publishes {generation, partial sum} as
+// one 64-bit device-scope store; thread t of every block polls entry t until it carries this generation; then
+// every block adds the same values in the same order. Nothing but these entries travels between blocks, so no
+// other fences are needed. Two slots: a block can be at most one reduction ahead of the slowest one.
+__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm, double* smd) {
+    const int nb = gridDim.x, tid = threadIdx.x;
+    unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
+    const float t = block_sum(v, sm);
+    if (tid == 0)
+        __hip_atomic_store(&slot[blockIdx.x], ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(t),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double a = 0.0;
+    for (int i = tid; i < nb; i += (int)blockDim.x) {
+        unsigned long long w;
+        while ((unsigned)((w = __hip_atomic_load(&slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen)
+            __builtin_amdgcn_s_sleep(1);
+        a += (double)__uint_as_float((unsigned)w);
+    }
+    a = wave_sum(a);
+    __syncthreads();
+    if ((tid & 63) == 0) smd[tid >> 6] = a;
+    __syncthreads();
+    double tot = 0.0;
+    const int nw = (int)blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) tot += smd[i];
+    return (float)tot;
+}
+
 // p = beta p + r the way the reference's CG does it: Sscal (dc.cu:263) then Saxpy (dc.cu:264), two roundings
 __device__ __forceinline__ float scal_then_axpy(float beta, float p, float r) {
 #pragma clang fp contract(off)

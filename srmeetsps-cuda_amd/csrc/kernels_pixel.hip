@@ -586,35 +586,6 @@ __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ 
 struct F4 {
     float e[4];
 };
-// Grid-wide sum without read-modify-write atomics (256 device-scope atomics on one address serialise in the
-// fabric: the library's grid barrier costs 33 us on 256 CUs). Every block publishes {generation, partial sum} as
-// one 64-bit device-scope store; thread t of every block polls entry t until it carries this generation; then
-// every block adds the same values in the same order. Nothing but these entries travels between blocks, so no
-// other fences are needed. Two slots: a block can be at most one reduction ahead of the slowest one.
-__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm, double* smd) {
-    const int nb = gridDim.x, tid = threadIdx.x;
-    unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
-    const float t = block_sum(v, sm);
-    if (tid == 0)
-        __hip_atomic_store(&slot[blockIdx.x], ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(t),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double a = 0.0;
-    for (int i = tid; i < nb; i += 1024) {
-        unsigned long long w;
-        while ((unsigned)((w = __hip_atomic_load(&slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen)
-            __builtin_amdgcn_s_sleep(1);
-        a += (double)__uint_as_float((unsigned)w);
-    }
-    a = wave_sum(a);
-    __syncthreads();
-    if ((tid & 63) == 0) smd[tid >> 6] = a;
-    __syncthreads();
-    double tot = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) tot += smd[i];
-    return (float)tot;
-}
-
 template <int NV>
 __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho, const float* __restrict__ num,
                                                          const float* __restrict__ den, int P, int C,

@@ -1,0 +1,607 @@
+// kernels_resident.hip -- the truncated depth CG (devicecalls.cu:229-279 on A_ = KT'KT + lambda A'A) as ONE
+// persistent launch whose whole state lives on the chip.
+//
+// One block of 512 threads per CU owns a tile of 256 rows x 64 columns of the grid; thread (wave w, lane l)
+// owns rows 4l..4l+3 of columns 8w..8w+7 and keeps p, r, x, omega, one g plane and the structure bytes of its
+// 32 pixels in registers (two waves per SIMD, 256 registers each) for all 101 steps; the other two g planes sit in LDS (128 KiB).  2048 x 2048 is exactly
+// 256 tiles: 117 MB of CG state in 128 MB of registers + 40 MB of LDS.  Per step nothing is streamed from HBM:
+//   * the two dot products are grid-wide sums (grid_sum: 8-byte {generation, value} granules, no atomics);
+//   * a tile needs r on the one-pixel ring around it: every block publishes the r of its four edges as
+//     generation-tagged granules after the update and keeps its own copy of p on the ring (same recurrence,
+//     same bits as the owner);
+//   * inside a block, columns cross waves through a 16 KiB LDS buffer and rows cross lanes through DPP.
+// The operator is the one of kernels_march.hip (same per-pixel formulas, tensor rebuilt from g_c); the
+// contributions of the neighbours are added in a different order, so results agree to rounding.
+// Masks that need more than one tile per CU fall back to the streaming kernels (kernels_march.hip).
+#include "srps_internal.h"
+#include "device_utils.h"
+
+namespace srps {
+
+namespace {
+
+constexpr int TR = 256, TC = 64;               // tile rows, columns
+constexpr int NT = 512, NWV = NT / 64;          // threads, waves per block
+constexpr int CPT = TC / NWV;                  // columns per thread (8)
+constexpr int RING_COL = 264;                  // ring column: rows -4..259 (row r at index r + 4, float4-aligned)
+constexpr int RING_ROW = 72;                   // ring row: columns -4..67
+constexpr int RING = 2 * RING_COL + 2 * RING_ROW;
+constexpr int HALO_N = 2 * TR + 2 * TC;        // granules a block publishes per step: first/last column, first/last row
+constexpr int B_FX = 1, B_BX = 2, B_FY = 3, B_BY = 4, B_KB = 5;
+
+__device__ __forceinline__ int ring_colL(int row) { return 4 + row; }
+__device__ __forceinline__ int ring_colR(int row) { return RING_COL + 4 + row; }
+__device__ __forceinline__ int ring_rowT(int col) { return 2 * RING_COL + 4 + col; }
+__device__ __forceinline__ int ring_rowB(int col) { return 2 * RING_COL + RING_ROW + 4 + col; }
+
+struct F4 {
+    float e[4];
+};
+__device__ __forceinline__ F4 ld4(const float* __restrict__ p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    F4 r; r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
+    return r;
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, const F4& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]);
+}
+__device__ __forceinline__ F4 zero4() { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0.f; return r; }
+
+__device__ __forceinline__ float dpp_from_prev_lane(float v) {      // lane i <- lane i-1 ; lane 0 <- 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_next_lane(float v) {      // lane i <- lane i+1 ; lane 63 <- 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+// bit BIT of the structure word as an all-ones / all-zeros mask. Written in assembly: the compiler turns the
+// portable forms into and + compare + select (three instructions and a scalar register pair per use).
+template <int BIT>
+__device__ __forceinline__ int msk(unsigned flword) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(flword), "n"(BIT));
+    return m;
+}
+__device__ __forceinline__ float andm(float v, int m) { return __int_as_float(__float_as_int(v) & m); }
+#define SRPS_MSK(B, e, FL) ((e) == 0 ? msk<(B)>(FL) : (e) == 1 ? msk<(B) + 8>(FL) : (e) == 2 ? msk<(B) + 16>(FL) : msk<(B) + 24>(FL))
+__device__ __forceinline__ float if_bit_rt(float v, unsigned flword, int bit) {
+    return ((flword >> bit) & 1u) ? v : 0.f;
+}
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ F4 as_f4(v4i v) {
+    F4 r; r.e[0] = __int_as_float(v.x); r.e[1] = __int_as_float(v.y); r.e[2] = __int_as_float(v.z); r.e[3] = __int_as_float(v.w);
+    return r;
+}
+__device__ __forceinline__ v4i as_v4i(const F4& a) {
+    v4i v; v.x = __float_as_int(a.e[0]); v.y = __float_as_int(a.e[1]); v.z = __float_as_int(a.e[2]); v.w = __float_as_int(a.e[3]);
+    return v;
+}
+
+struct ResidentArgs {
+    const float* G;            // [NC][plane]
+    const uint8_t* flags;      // [plane]
+    const float* consts;       // [NC][8]: S, x*, y*, R00, R01, R11
+    float* x;                  // [plane] in/out
+    const float* r;            // [plane] residual b - A_ x0
+    const float* rr_first;     // r.r of that residual
+    unsigned long long* ent;   // [2][tiles]          reduction granules, zeroed before the launch
+    unsigned long long* halo;  // [tiles][2][HALO_N]  edge granules, zeroed before the launch
+    CgScalars* scal;
+    int Hs, Ws;
+    size_t plane;
+    int nbr, nbc;              // tiles per column / per row of tiles
+    float lambda, inv_sf4, tol2;
+    int max_steps;
+    float cx, cy;
+    int i_lo, j_lo;
+};
+
+// per-channel constants of the tensor-recompute form (uniform)
+template <int NC>
+struct TensorConsts {
+    float kS[NC], kX[NC], kY[NC], kR00[NC], kR01[NC], kR11[NC];
+};
+
+// (u, v, w) = M (gx, gy, xv) of one pixel; M = sum_c g_c Q_c(dx, dy)
+template <int NC, bool NEED_U, bool NEED_V, bool NEED_W>
+__device__ __forceinline__ void uvw_pixel(const TensorConsts<NC>& K, const float (&g)[NC], const float (&dxc)[NC],
+                                          const float (&q00)[NC], const float (&q02)[NC], const float (&sdy)[NC],
+                                          const float (&q11)[NC], float gx, float gy, float xv, float& U, float& V, float& W) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+        if (NEED_U) m0 = fmaf(g[ch], q00[ch], m0);
+        if (NEED_U || NEED_V) m1 = fmaf(g[ch], fmaf(dxc[ch], sdy[ch], K.kR01[ch]), m1);
+        if (NEED_U || NEED_W) m2 = fmaf(g[ch], q02[ch], m2);
+        if (NEED_V) m3 = fmaf(g[ch], q11[ch], m3);
+        if (NEED_V || NEED_W) m4 = fmaf(g[ch], sdy[ch], m4);
+        if (NEED_W) m5 = fmaf(g[ch], K.kS[ch], m5);
+    }
+    if (NEED_U) U = m0 * gx + m1 * gy + m2 * xv;
+    if (NEED_V) V = m1 * gx + m3 * gy + m4 * xv;
+    if (NEED_W) W = m2 * gx + m4 * gy + m5 * xv;
+}
+
+template <int SF, int NC>
+__global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
+    extern __shared__ float4 lds4[];
+    // LDS map: [NC==3: g0, g1 as float4 [CPT][NT]] | ex, ex2 (float4 [NT]) | ring (floats): hp, hg[NC], hfl
+    constexpr int GL = (NC == 3) ? 2 : 0;                 // g planes kept in LDS
+    float4* lg = lds4;                                    // [GL][CPT][NT]
+    float4* ex = lds4 + GL * CPT * NT;                    // [NT]
+    float4* ex2 = ex + NT;                                // [NT]
+    float* hp = reinterpret_cast<float*>(ex2 + NT);       // [RING]
+    float* hg = hp + RING;                                // [NC][RING]
+    unsigned* hfl = reinterpret_cast<unsigned*>(hg + NC * RING);   // [RING]
+    float* sm = reinterpret_cast<float*>(hfl + RING);     // [16]
+    double* smd = reinterpret_cast<double*>(sm + 16);     // [16]
+    int* sflag = reinterpret_cast<int*>(smd + 16);        // [4] block-wide structure summary
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int ntile = a.nbr * a.nbc;
+    // XCD-aware tile order: the blocks of one XCD (b, b+8, ...) get a contiguous range of tiles
+    int tile = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = tile & 7, kk = tile >> 3;
+        tile = xcd * q + min(xcd, rem) + kk;
+    }
+    const int bc = tile / a.nbr, br = tile - bc * a.nbr;          // consecutive tiles are vertical neighbours
+    const int Hs = a.Hs;
+    const size_t pl = a.plane;
+
+    TensorConsts<NC> K;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+        const float* k8 = a.consts + ch * 8;
+        K.kS[ch] = k8[0]; K.kX[ch] = k8[1]; K.kY[ch] = k8[2]; K.kR00[ch] = k8[3]; K.kR01[ch] = k8[4]; K.kR11[ch] = k8[5];
+    }
+
+    // ---- own pixels -------------------------------------------------------------------------------------
+    const int grow0 = br * TR + 4 * lane;                  // grid row of element 0
+    const int gcol0 = bc * TC + CPT * wave;                  // grid column of column 0
+    const int srow0 = grow0 + PAD;
+    const bool act = srow0 < Hs;                           // Hs is a multiple of 32: the float4 is inside or outside as a whole
+    const int rowL = act ? srow0 : 0;                      // rows 0..3 are the zero halo of every plane
+    F4 p[CPT], r[CPT], w[CPT];
+    unsigned fl[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const size_t off = (size_t)(gcol0 + c + PAD) * Hs + rowL;
+        r[c] = ld4(a.r + off);
+        fl[c] = *reinterpret_cast<const unsigned*>(a.flags + off);
+#pragma unroll
+        for (int t = 0; t < GL; ++t) lg[(t * CPT + c) * NT + tid] = *reinterpret_cast<const float4*>(a.G + (size_t)t * pl + off);
+        p[c] = zero4(); w[c] = zero4();
+    }
+
+    // ---- ring ---------------------------------------------------------------------------------------------
+    // ring pixels: 0..257 left column (rows -1..256), 258..515 right column, 516..581 top row (columns -1..64),
+    // 582..647 bottom row; thread t looks after ring pixels t and t + NT
+    constexpr int NRING = 648, RPT = (NRING + NT - 1) / NT;
+    int ridx[RPT];                                         // index into the ring arrays, -1: none
+    const unsigned long long* hsrc[RPT];                   // granule of the ring pixel in its owner's edge arrays (slot 0)
+    float rh[RPT];                                         // r on the ring pixel
+    unsigned rflags = 0u;                                  // union of the ring pixels' structure bytes
+    for (int t = tid; t < RING; t += NT) { hp[t] = 0.f; hfl[t] = 0u; }
+    for (int t = tid; t < NC * RING; t += NT) hg[t] = 0.f;
+    if (tid < 4) sflag[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int i = tid + q * NT;
+        ridx[q] = -1; hsrc[q] = nullptr; rh[q] = 0.f;
+        if (i >= NRING) continue;
+        int kind, u;
+        if (i < 258) { kind = 0; u = i - 1; }
+        else if (i < 516) { kind = 1; u = i - 258 - 1; }
+        else if (i < 582) { kind = 2; u = i - 516 - 1; }
+        else { kind = 3; u = i - 582 - 1; }
+        const int pr = (kind == 0 || kind == 1) ? u : (kind == 2 ? -1 : TR);
+        const int pc = (kind == 0) ? -1 : (kind == 1) ? TC : u;
+        ridx[q] = (kind == 0) ? ring_colL(u) : (kind == 1) ? ring_colR(u) : (kind == 2) ? ring_rowT(u) : ring_rowB(u);
+        const int dbr = pr < 0 ? -1 : (pr >= TR ? 1 : 0), dbc = pc < 0 ? -1 : (pc >= TC ? 1 : 0);
+        const int nbr_ = br + dbr, nbc_ = bc + dbc;
+        const int lr = pr - TR * dbr, lc = pc - TC * dbc;      // coordinates inside the owning tile
+        if (nbr_ >= 0 && nbr_ < a.nbr && nbc_ >= 0 && nbc_ < a.nbc) {
+            const int nt = nbc_ * a.nbr + nbr_;
+            int gi;
+            if (lc == 0) gi = lr;                               // its first column
+            else if (lc == TC - 1) gi = TR + lr;                // last column
+            else if (lr == 0) gi = 2 * TR + lc;                 // first row
+            else gi = 2 * TR + TC + lc;                         // last row
+            hsrc[q] = a.halo + (size_t)nt * 2 * HALO_N + gi;
+        }
+        const int srow = br * TR + pr + PAD, scol = bc * TC + pc + PAD;
+        if (srow >= 0 && srow < Hs && scol >= 0 && scol < a.Ws) {
+            const size_t rstor = (size_t)scol * Hs + srow;
+            rh[q] = a.r[rstor];
+            const unsigned f = a.flags[rstor];
+            hfl[ridx[q]] = f;
+            rflags |= f;
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) hg[ch * RING + ridx[q]] = a.G[(size_t)ch * pl + rstor];
+        }
+    }
+    // structure summary of the block: is there any backward difference in x (own pixels or ring) / in y
+    {
+        unsigned any = 0u;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) any |= fl[c];
+        const unsigned rf = rflags;
+        const bool bx = ((any | rf * 0x01010101u) & (0x01010101u << B_BX)) != 0u;
+        const bool by = ((any | rf * 0x01010101u) & (0x01010101u << B_BY)) != 0u;
+        if (bx) sflag[0] = 1;
+        if (by) sflag[1] = 1;
+    }
+    __syncthreads();
+    const bool any_bx = sflag[0] != 0;
+    const bool any_by = sflag[1] != 0;
+
+    // row-dependent tensor terms of the own rows:  dy = yy - y*,  S dy,  S dy^2 + R11   (recomputed per use: registers)
+    auto row_terms = [&](int grow, float (&sdy)[NC], float (&q11)[NC]) {
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            const float dy = ((float)(a.i_lo + grow) - a.cy) - K.kY[ch];
+            sdy[ch] = K.kS[ch] * dy;
+            q11[ch] = (K.kS[ch] * dy) * dy + K.kR11[ch];
+        }
+    };
+    auto col_terms = [&](int gcol, float (&dxc)[NC], float (&q00)[NC], float (&q02)[NC]) {
+        const float xxv = (float)(a.j_lo + gcol) - a.cx;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            dxc[ch] = xxv - K.kX[ch];
+            q02[ch] = K.kS[ch] * dxc[ch];
+            q00[ch] = q02[ch] * dxc[ch] + K.kR00[ch];
+        }
+    };
+
+    // the plane sizes of the bench shapes stay far below the 4 GiB a descriptor can address
+    const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, (int)(pl * sizeof(float)), 0x00020000);
+    unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
+    float r1 = a.rr_first[0];
+    float r0 = 0.f, alpha = 0.f;
+    int k = 0;
+    while (r1 > a.tol2 && k < a.max_steps) {               // dc.cu:252 (max_steps = max_iter + 1)
+        ++k;
+        const float beta = (k == 1) ? 0.f : r1 / r0;      // dc.cu:262
+        // An opaque zero added to every coordinate: without it the compiler hoists the (step-invariant) tensor terms
+        // and the LDS reads of g out of the CG loop and keeps ~100 more values per thread alive than there are registers.
+        int oz = 0;
+        asm volatile("" : "+s"(oz));
+        // ---- p = beta p + r, own pixels and ring ----------------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[c].e[e] = (k == 1) ? r[c].e[e] : scal_then_axpy(beta, p[c].e[e], r[c].e[e]);
+#pragma unroll
+        for (int q = 0; q < RPT; ++q)
+            if (ridx[q] >= 0) hp[ridx[q]] = (k == 1) ? rh[q] : scal_then_axpy(beta, hp[ridx[q]], rh[q]);
+        ex[tid] = make_float4(p[0].e[0], p[0].e[1], p[0].e[2], p[0].e[3]);
+        ex2[tid] = make_float4(p[CPT - 1].e[0], p[CPT - 1].e[1], p[CPT - 1].e[2], p[CPT - 1].e[3]);
+        __syncthreads();
+
+        // ---- omega = A_ p ------------------------------------------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) w[c] = zero4();
+        F4 u3 = zero4();                                   // forward-x u of the last column: goes to the next wave
+        F4 u0 = zero4();                                   // backward-x u of the first column: goes to the previous wave
+        float ksum[CPT / 4] = {};                          // SF == 4: sums of the thread's 4 x 4 blocks
+        F4 S[CPT];
+        // the last g plane is streamed one column ahead (read-only, 2 MB per XCD: it stays in the L2)
+        // streamed planes go through buffer descriptors: one per-lane row offset (voffset) serves every column, the
+        // column offset is a scalar (soffset) -- no per-column address registers
+        const unsigned rowLb = (unsigned)rowL * 4u, srowb = (unsigned)srow0 * 4u;
+        const unsigned colb = (unsigned)__builtin_amdgcn_readfirstlane((gcol0 + PAD + oz) * Hs * 4);
+        const unsigned hsb = (unsigned)Hs * 4u;
+        F4 gnext = as_f4(__builtin_amdgcn_raw_buffer_load_b128(g_rsrc, rowLb, colb, 0));
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const F4 grc = gnext;
+            if (c + 1 < CPT) gnext = as_f4(__builtin_amdgcn_raw_buffer_load_b128(g_rsrc, rowLb, colb + (c + 1) * hsb, 0));
+            float dxc[NC], q00[NC], q02[NC];
+            int ozc = 0;
+            asm volatile("" : "+s"(ozc));                  // per column: keeps the column's tensor terms from being formed early
+            col_terms(gcol0 + c + ozc, dxc, q00, q02);
+            F4 g0v, g1v;
+            if (GL == 2) {
+                const float4 t0 = lg[(0 * CPT + c) * NT + tid + oz], t1 = lg[(1 * CPT + c) * NT + tid + oz];
+                g0v.e[0] = t0.x; g0v.e[1] = t0.y; g0v.e[2] = t0.z; g0v.e[3] = t0.w;
+                g1v.e[0] = t1.x; g1v.e[1] = t1.y; g1v.e[2] = t1.z; g1v.e[3] = t1.w;
+            }
+            const F4& xc = p[c];
+            // the neighbour columns in the next / previous wave (or on the ring) are fetched where they are used
+            F4 pedge = zero4();
+            if (c == CPT - 1) {                                // compile-time
+                const float* src = (wave < NWV - 1) ? reinterpret_cast<const float*>(ex + tid + 64) : hp + ring_colR(4 * lane);
+                pedge = ld4(src);
+            }
+            if (c == 0) {                                      // only backward differences read the column to the left
+                const float* src = (wave > 0) ? reinterpret_cast<const float*>(ex2 + tid - 64) : hp + ring_colL(4 * lane);
+                pedge = ld4(src);
+            }
+            const F4& xr = (c < CPT - 1) ? p[c < CPT - 1 ? c + 1 : CPT - 1] : pedge;
+            const F4& xl = (c > 0) ? p[c > 0 ? c - 1 : 0] : pedge;
+            float x_up = dpp_from_prev_lane(xc.e[3]);
+            float x_dn = dpp_from_next_lane(xc.e[0]);
+            {   // no branches inside the column body: a branch splits the block and the compiler then sinks half of the
+                // column's arithmetic (and everything it reads) below the loop
+                const float rt = hp[ring_rowT(CPT * wave + c)], rb = hp[ring_rowB(CPT * wave + c)];
+                x_up = (lane == 0) ? rt : x_up;
+                x_dn = (lane == 63) ? rb : x_dn;
+            }
+            unsigned FL = fl[c];
+            asm volatile("" : "+v"(FL));             // opaque: the 16 masks per column derived from it are not worth 16 registers
+            float send_dn = 0.f, send_up = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sdy[NC], q11[NC];
+                row_terms(grow0 + e + ozc, sdy, q11);
+                float g[NC];
+                if (NC == 3) { g[0] = g0v.e[e]; g[1 % NC] = g1v.e[e]; g[2 % NC] = grc.e[e]; }
+                else g[0] = grc.e[e];
+                const float xv = xc.e[e];
+                const float up = (e == 0) ? x_up : xc.e[e > 0 ? e - 1 : 0];
+                const float dn = (e == 3) ? x_dn : xc.e[e < 3 ? e + 1 : 3];
+                // forward / backward are exclusive (SRPS.cu:39-46, 31-38)
+                const int mfx = SRPS_MSK(B_FX, e, FL), mbx = SRPS_MSK(B_BX, e, FL);
+                const int mfy = SRPS_MSK(B_FY, e, FL), mby = SRPS_MSK(B_BY, e, FL);
+                const float gx = andm(xr.e[e] - xv, mfx) + andm(xv - xl.e[e], mbx);
+                const float gy = andm(dn - xv, mfy) + andm(xv - up, mby);
+                float U, V, W;
+                uvw_pixel<NC, true, true, true>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+                const float fxU = andm(U, mfx), bxU = andm(U, mbx);
+                const float fyV = andm(V, mfy), byV = andm(V, mby);
+                w[c].e[e] += W + (bxU - fxU) + (byV - fyV);        // A'(u, v, w) at the pixel itself
+                if (c < CPT - 1) w[c < CPT - 1 ? c + 1 : CPT - 1].e[e] += fxU; else u3.e[e] = fxU;      // Dx': +u at the right neighbour of a forward pixel
+                if (c > 0) w[c > 0 ? c - 1 : 0].e[e] -= bxU; else u0.e[e] = bxU;      //      -u at the left neighbour of a backward pixel
+                if (e < 3) w[c].e[e < 3 ? e + 1 : 3] += fyV; else send_dn = fyV;      // Dy': +v at the lower neighbour of a forward pixel
+                if (e > 0) w[c].e[e > 0 ? e - 1 : 0] -= byV; else send_up = byV;      //      -v at the upper neighbour of a backward pixel
+            }
+            w[c].e[0] += dpp_from_prev_lane(send_dn);
+            w[c].e[3] -= dpp_from_next_lane(send_up);
+            // block sums of KT'KT
+            if (SF == 1) S[c] = xc;
+            else if (SF == 2) {
+                S[c].e[0] = S[c].e[1] = xc.e[0] + xc.e[1];
+                S[c].e[2] = S[c].e[3] = xc.e[2] + xc.e[3];
+            } else ksum[c / 4] += (xc.e[0] + xc.e[1]) + (xc.e[2] + xc.e[3]);
+            // pin what this column produced: otherwise the compiler sinks the arithmetic (with all its inputs) to where omega
+            // is first read, after the loop
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm volatile("" : "+v"(w[c].e[e]));
+                if (c + 1 < CPT) asm volatile("" : "+v"(w[c + 1 < CPT ? c + 1 : c].e[e]));
+                if (c > 0) asm volatile("" : "+v"(w[c > 0 ? c - 1 : 0].e[e]));
+            }
+            asm volatile("" : "+v"(u3.e[0]), "+v"(u3.e[1]), "+v"(u3.e[2]), "+v"(u3.e[3]));
+            __builtin_amdgcn_sched_barrier(0);             // one column at a time: interleaving them costs registers
+        }
+        if (SF == 2) {
+#pragma unroll
+            for (int c = 0; c < CPT; c += 2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = S[c].e[e] + S[c + 1].e[e]; S[c].e[e] = S[c + 1].e[e] = t; }
+        }
+        // ring rows: the pixels above row 0 (forward in y) and, where the mask has backward differences in y, below row 255
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            float dxc[NC], q00[NC], q02[NC];
+            col_terms(gcol0 + c + oz, dxc, q00, q02);
+            const int cc = CPT * wave + c;
+            {
+                const int it = ring_rowT(cc);
+                const unsigned f = hfl[it];
+                float sdy[NC], q11[NC], g[NC];
+                row_terms(br * TR - 1 + oz, sdy, q11);
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + it];
+                const float xv = hp[it];
+                const float gx = if_bit_rt(hp[it + 1] - xv, f, B_FX) + if_bit_rt(xv - hp[it - 1], f, B_BX);
+                const float gy = p[c].e[0] - xv;                       // used only if the ring pixel is forward in y
+                float U, V, W;
+                uvw_pixel<NC, false, true, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+                w[c].e[0] += (lane == 0) ? if_bit_rt(V, f, B_FY) : 0.f;
+            }
+            if (any_by) {
+                const int ib = ring_rowB(cc);
+                const unsigned f = hfl[ib];
+                float sdy[NC], q11[NC], g[NC];
+                row_terms(br * TR + TR + oz, sdy, q11);
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + ib];
+                const float xv = hp[ib];
+                const float gx = if_bit_rt(hp[ib + 1] - xv, f, B_FX) + if_bit_rt(xv - hp[ib - 1], f, B_BX);
+                const float gy = xv - p[c].e[3];                       // backward in y
+                float U, V, W;
+                uvw_pixel<NC, false, true, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+                w[c].e[3] -= (lane == 63) ? if_bit_rt(V, f, B_BY) : 0.f;
+            }
+        }
+        // ring columns: the pixels left of column 0 (forward in x) and right of column 63 (backward in x)
+        if (wave == 0) {
+            float dxc[NC], q00[NC], q02[NC];
+            col_terms(bc * TC - 1 + oz, dxc, q00, q02);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int il = ring_colL(4 * lane + e);
+                const unsigned f = hfl[il];
+                float sdy[NC], q11[NC], g[NC];
+                row_terms(grow0 + e + oz, sdy, q11);
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + il];
+                const float xv = hp[il];
+                const float gx = p[0].e[e] - xv;                       // used only if the ring pixel is forward in x
+                const float gy = if_bit_rt(hp[il + 1] - xv, f, B_FY) + if_bit_rt(xv - hp[il - 1], f, B_BY);
+                float U, V, W;
+                uvw_pixel<NC, true, false, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+                w[0].e[e] += if_bit_rt(U, f, B_FX);
+            }
+        }
+        if (any_bx && wave == NWV - 1) {
+            float dxc[NC], q00[NC], q02[NC];
+            col_terms(bc * TC + TC + oz, dxc, q00, q02);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int irr = ring_colR(4 * lane + e);
+                const unsigned f = hfl[irr];
+                float sdy[NC], q11[NC], g[NC];
+                row_terms(grow0 + e + oz, sdy, q11);
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + irr];
+                const float xv = hp[irr];
+                const float gx = xv - p[CPT - 1].e[e];                 // backward in x
+                const float gy = if_bit_rt(hp[irr + 1] - xv, f, B_FY) + if_bit_rt(xv - hp[irr - 1], f, B_BY);
+                float U, V, W;
+                uvw_pixel<NC, true, false, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+                w[CPT - 1].e[e] -= if_bit_rt(U, f, B_BX);
+            }
+        }
+        // u across the wave boundaries
+        __syncthreads();                                   // every wave has read the p columns in ex / ex2
+        ex[tid] = make_float4(u3.e[0], u3.e[1], u3.e[2], u3.e[3]);
+        if (any_bx) ex2[tid] = make_float4(u0.e[0], u0.e[1], u0.e[2], u0.e[3]);
+        __syncthreads();
+        if (wave > 0) {
+            const float4 t = ex[tid - 64];
+            w[0].e[0] += t.x; w[0].e[1] += t.y; w[0].e[2] += t.z; w[0].e[3] += t.w;
+        }
+        if (any_bx && wave < NWV - 1) {
+            const float4 t = ex2[tid + 64];
+            w[CPT - 1].e[0] -= t.x; w[CPT - 1].e[1] -= t.y; w[CPT - 1].e[2] -= t.z; w[CPT - 1].e[3] -= t.w;
+        }
+        // omega = lambda * (...) + KT'KT p ; partial p.omega
+        float red = 0.f;
+        unsigned flk[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) { flk[c] = fl[c]; asm volatile("" : "+v"(flk[c])); }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s = ((SF == 4) ? ksum[c / 4] : S[c].e[e]) * a.inv_sf4;
+                w[c].e[e] = w[c].e[e] * a.lambda + andm(s, SRPS_MSK(B_KB, e, flk[c]));
+                red = fmaf(p[c].e[e], w[c].e[e], red);
+            }
+        // x is the one vector that does not fit on the chip: it is read here, while the dot product travels, and written
+        // back below (8 B per pixel and step, off the critical path)
+        F4 xv[CPT];
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) xv[c] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, srowb, colb + c * hsb, 0));
+        }
+        const float dot = grid_sum(red, a.ent, ++gen, sm, smd);
+        alpha = r1 / dot;                                  // dc.cu:269
+        // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[c].e[e] = fmaf(alpha, p[c].e[e], xv[c].e[e]);      // dc.cu:270
+                __builtin_amdgcn_raw_buffer_store_b128(as_v4i(xv[c]), x_rsrc, srowb, colb + c * hsb, 0);
+            }
+        }
+        red = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
+                red = fmaf(r[c].e[e], r[c].e[e], red);
+            }
+        // publish the r of the tile's edges (generation k, slot k & 1)
+        {
+            unsigned long long* hb = a.halo + ((size_t)tile * 2 + (k & 1)) * HALO_N;
+            const unsigned long long tag = (unsigned long long)(unsigned)k << 32;
+            if (wave == 0 || wave == NWV - 1) {
+                const F4& rc = (wave == 0) ? r[0] : r[CPT - 1];
+                unsigned long long* d = hb + (wave == 0 ? 0 : TR) + 4 * lane;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __hip_atomic_store(d + e, tag | (unsigned long long)__float_as_uint(rc.e[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0 || lane == 63) {
+                unsigned long long* d = hb + 2 * TR + (lane == 0 ? 0 : TC) + CPT * wave;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+                    __hip_atomic_store(d + c, tag | (unsigned long long)__float_as_uint(lane == 0 ? r[c].e[0] : r[c].e[3]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        r0 = r1;
+        r1 = grid_sum(red, a.ent, ++gen, sm, smd);
+        // r on the ring: the neighbours' edges of generation k
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            if (ridx[q] >= 0 && hsrc[q] != nullptr) {
+                const unsigned long long* s = hsrc[q] + (size_t)(k & 1) * HALO_N;
+                unsigned long long v;
+                while ((unsigned)((v = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)k)
+                    __builtin_amdgcn_s_sleep(1);
+                rh[q] = __uint_as_float((unsigned)v);
+            }
+        }
+    }
+    // ---- results ---------------------------------------------------------------------------------------------
+    if (blockIdx.x == 0 && tid == 0) {
+        a.scal->r0 = r0; a.scal->r1_last = r1; a.scal->iters = k; a.scal->active = (r1 > a.tol2) ? 1 : 0;
+        a.scal->alpha = 0.f;                               // nothing pending: x is final
+    }
+    (void)ntile;
+}
+
+size_t resident_lds_bytes(int NC) {
+    const size_t gl = (NC == 3) ? 2 : 0;
+    return (gl * CPT * NT + 2 * NT) * sizeof(float4) + (size_t)RING * sizeof(float) * (1 + NC + 1) + 16 * sizeof(float) + 16 * sizeof(double) + 16;
+}
+
+}  // namespace
+
+bool resident_supported(const srps_ctx* ctx) {
+    const Grid& G = ctx->grid;
+    if (!ctx->cg_resident || !use_march(ctx)) return false;
+    const int nc = march_recompute_channels(ctx);
+    if (nc != 1 && nc != 3) return false;
+    if (G.sf != 1 && G.sf != 2 && G.sf != 4) return false;
+    const long tiles = (long)cdiv(G.Hg, TR) * cdiv(G.Wg, TC);
+    return tiles <= ctx->num_cus;
+}
+
+double resident_bytes_per_step() { return 0.0; }
+
+// the whole CG of devicecalls.cu:252-275 after grid_residual(): G.d_r holds b - A_ x0, `first` its r.r
+int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
+    Grid& G = ctx->grid;
+    const int nc = march_recompute_channels(ctx);
+    const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc;
+    const size_t need = (size_t)tiles * 2 * sizeof(unsigned long long) + (size_t)tiles * 2 * HALO_N * sizeof(unsigned long long);
+    SRPS_TRY(ensure(ctx->ws_resident, need));
+    SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));
+    ResidentArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.r = G.d_r;
+    a.rr_first = G.d_misc_part + 4000;
+    a.ent = (unsigned long long*)ctx->ws_resident.p;
+    a.halo = a.ent + (size_t)tiles * 2;
+    a.scal = G.d_scal;
+    a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = nbr; a.nbc = nbc;
+    a.lambda = ctx->lambda;
+    a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
+    a.tol2 = fixed_steps ? -1.f : ctx->cg_tol * ctx->cg_tol;
+    a.max_steps = max_steps;
+    a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
+    const void* fn = nullptr;
+#define SRPS_RES(SFV, NCV) fn = (const void*)k_cg_resident<SFV, NCV>
+    if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else if (G.sf == 2) SRPS_RES(2, 3); else SRPS_RES(4, 3); }
+    else { if (G.sf == 1) SRPS_RES(1, 1); else if (G.sf == 2) SRPS_RES(2, 1); else SRPS_RES(4, 1); }
+#undef SRPS_RES
+    const size_t lds = resident_lds_bytes(nc);
+    SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {&a};
+    SRPS_HIP(hipLaunchCooperativeKernel(fn, dim3(tiles), dim3(NT), args, lds, ctx->stream));
+    return SRPS_OK;
+}
+
+}  // namespace srps

@@ -195,7 +195,7 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
         (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device_id);
         c->num_cus = cus > 0 ? cus : 1;
-        if (!coop) c->albedo_persistent = 0;
+        if (!coop) { c->albedo_persistent = 0; c->cg_resident = 0; }
     }
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
@@ -214,6 +214,7 @@ int srps_destroy(srps_ctx* ctx) {
     state_release(ctx);
     grid_release(ctx->grid);
     if (ctx->ws_light.p) (void)hipFree(ctx->ws_light.p);
+    if (ctx->ws_resident.p) (void)hipFree(ctx->ws_resident.p);
     if (ctx->ws_albedo.p) (void)hipFree(ctx->ws_albedo.p);
     if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
     if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
@@ -252,6 +253,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "fuse_energy_lighting")) {
         ctx->fuse_energy_lighting = value ? 1 : 0;
         ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "cg_resident")) {
+        ctx->cg_resident = value ? 1 : 0;
     } else if (!strcmp(name, "albedo_persistent")) {
         ctx->albedo_persistent = value ? 1 : 0;
     } else if (!strcmp(name, "keep_stored_tensor")) {

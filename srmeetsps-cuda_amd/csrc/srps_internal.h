@@ -116,6 +116,8 @@ struct srps_ctx {
     bool tensor_valid = false;
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
     int fuse_energy_lighting = 1;
+    int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
+    srps::DevBuf ws_resident;
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;
     bool light_cache_valid = false;
@@ -175,6 +177,8 @@ int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_r
                                int C, int img_offset, float* d_out /* one float, device */);
 
 // ---- grid / CG (kernels_cg.hip) ---------------------------------------------------------
+bool resident_supported(const srps_ctx* ctx);
+int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
 int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact);
 int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy);
