@@ -153,24 +153,40 @@ def main():
         out["cg_loop_roofline"] = {"bound": "hbm", "achieved": loop_bytes / (1e3 * us_iter), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": loop_bytes / (1e3 * us_iter) / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_iteration": loop_bytes}
-        # Per-kernel duration: events around the whole 101-step loop give the time per step (kernel boundaries
-        # overlap there); an event after EVERY launch (b["apply_us"], b["update_us"]) adds ~3 us of event /
-        # boundary cost to each kernel, so it is used only to split the step time between the two kernels.
-        share = b["apply_us"] / (b["apply_us"] + b["update_us"])
-        apply_us = us_iter * share
-        ach = b["apply_bytes"] / (1e3 * apply_us)
         traffic = None
+        resident = bool(ctx.get_option("cg_resident_active"))
         try:     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = tj.get(f"{H}x{W}_sf{args.sf}", {}).get("apply")
+            traffic = tj.get(f"{H}x{W}_sf{args.sf}", {}).get("resident" if resident else "apply")
         except Exception:
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial p.omega)",
-                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "avg_launch_us": apply_us, "avg_launch_us_event_bracketed": b["apply_us"],
-                           "algorithmic_bytes_per_launch": b["apply_bytes"],
-                           "update_kernel_us": us_iter - apply_us,
-                           "update_kernel_GBs": b["update_bytes"] / (1e3 * (us_iter - apply_us))}
+        if resident:
+            # ONE launch runs all 101 steps with the CG state in registers + LDS (kernels_resident.hip).  `achieved` is,
+            # as for the streaming kernels, the ALGORITHMIC bytes of the CG loop (49 B per unknown and step: what a
+            # kernel-per-half-step CG has to move) over the measured launch time; the state never leaves the chip, so
+            # this can exceed the HBM peak -- `traffic` (PMC) is what really crossed the fabric.
+            launch_us = 1e6 * b["seconds"] / (b["iterations"] / 101)
+            bytes_launch = loop_bytes * 101
+            ach = bytes_launch / (1e3 * launch_us)
+            out["roofline"] = {"bound": "hbm", "kernel": "k_cg_resident: the whole truncated CG (101 steps of p = beta p + r, omega = A_ p, "
+                                                         "x += alpha p, r -= alpha omega, two grid-wide dot products) in one persistent launch",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": traffic, "avg_launch_us": launch_us, "steps_per_launch": 101,
+                               "algorithmic_bytes_per_launch": bytes_launch,
+                               "note": "state resident in registers/LDS; frac > 1 means faster than any kernel that streams the CG vectors from HBM could be"}
+        else:
+            # Per-kernel duration: events around the whole 101-step loop give the time per step (kernel boundaries
+            # overlap there); an event after EVERY launch (b["apply_us"], b["update_us"]) adds ~3 us of event /
+            # boundary cost to each kernel, so it is used only to split the step time between the two kernels.
+            share = b["apply_us"] / (b["apply_us"] + b["update_us"])
+            apply_us = us_iter * share
+            ach = b["apply_bytes"] / (1e3 * apply_us)
+            out["roofline"] = {"bound": "hbm", "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial p.omega)",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": traffic, "avg_launch_us": apply_us, "avg_launch_us_event_bracketed": b["apply_us"],
+                               "algorithmic_bytes_per_launch": b["apply_bytes"],
+                               "update_kernel_us": us_iter - apply_us,
+                               "update_kernel_GBs": b["update_bytes"] / (1e3 * (us_iter - apply_us))}
     if not args.no_total_solve:
         # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up
         ctx.setup(dh)

@@ -65,8 +65,13 @@ int srps_synchronize(srps_ctx* ctx);
 /* options: "albedo_mode" (SRPS_ALBEDO_*), "apply_mode" (SRPS_APPLY_*), "cg_max_iter", "march_strip" (0 = automatic,
  * or a multiple of 4 in [4,512]), "march_snake" (0|1), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1),
  * "fuse_energy_lighting" (0|1: the energy sweep over I also leaves the lighting sums of the next pass),
- * "albedo_persistent" (0|1: albedo CG in registers, one cooperative launch, when the mask fits) */
+ * "albedo_persistent" (0|1: albedo CG in registers, one cooperative launch, when the mask fits),
+ * "cg_resident" (0|1: depth CG as one persistent launch with its state in registers and LDS, when the grid fits one
+ * 256 x 64 tile per CU; otherwise, and with 0, one operator + one update kernel per step) */
 int srps_set_option(srps_ctx* ctx, const char* name, int value);
+/* reads an option back; also "cg_resident_active" (1 when the bound grid fits one tile per CU and the depth CG
+ * therefore runs as the persistent on-chip kernel) and "num_cus" */
+int srps_get_option(srps_ctx* ctx, const char* name, int* value);
 
 /* ---- generic sparse operators (device pointers) -------------------------------------------*/
 /* replaces: cuda_based_host_COO_to_device_CSR (devicecalls.cuh:37, devicecalls.cu:51-67) incl.

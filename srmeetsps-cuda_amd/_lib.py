@@ -86,6 +86,7 @@ def load():
         "srps_set_stream": (i, [vp, vp]),
         "srps_synchronize": (i, [vp]),
         "srps_set_option": (i, [vp, C.c_char_p, i]),
+        "srps_get_option": (i, [vp, C.c_char_p, C.POINTER(i)]),
         "srps_host_COO_to_device_CSR": (i, [vp, ip, ip, fp, i, i, i, p, p, p]),
         "srps_sparsemat_densevec_mul": (i, [vp, p, p, p, i, i, i, p, i, p]),
         "srps_conjugate_gradient": (i, [vp, p, p, p, i, i, p, p, ip]),

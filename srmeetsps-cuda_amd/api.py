@@ -134,6 +134,11 @@ class Context:
     def set_option(self, name: str, value: int):
         check(self.lib.srps_set_option(self.h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        check(self.lib.srps_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     # -- operator level (devicecalls.cuh) ------------------------------------------------------
     def host_COO_to_device_CSR(self, row, col, val, n_row, n_col, d_row_ptr, d_col_ind, d_val):
         row = _host(row, np.int32); col = _host(col, np.int32); val = _host(val)

@@ -1,18 +1,27 @@
 // kernels_resident.hip -- the truncated depth CG (devicecalls.cu:229-279 on A_ = KT'KT + lambda A'A) as ONE
-// persistent launch whose whole state lives on the chip.
+// persistent launch whose state lives on the chip.
 //
 // One block of 512 threads per CU owns a tile of 256 rows x 64 columns of the grid; thread (wave w, lane l)
-// owns rows 4l..4l+3 of columns 8w..8w+7 and keeps p, r, x, omega, one g plane and the structure bytes of its
-// 32 pixels in registers (two waves per SIMD, 256 registers each) for all 101 steps; the other two g planes sit in LDS (128 KiB).  2048 x 2048 is exactly
-// 256 tiles: 117 MB of CG state in 128 MB of registers + 40 MB of LDS.  Per step nothing is streamed from HBM:
-//   * the two dot products are grid-wide sums (grid_sum: 8-byte {generation, value} granules, no atomics);
+// owns rows 4l..4l+3 of columns 8w..8w+7 and keeps p, r, x and omega of its 32 pixels in registers (two waves
+// per SIMD, 256 registers each) for all 101 steps; two of the three g planes sit in LDS (128 KiB), the third is
+// re-read every step through the XCD's L2 (2 MB per XCD, it stays there).  2048 x 2048 is exactly 256 tiles.
+// Per step nothing else moves:
+//   * the two dot products are grid-wide sums (device_utils.h grid_sum: 8-byte {generation, value} granules,
+//     no read-modify-write atomics);
 //   * a tile needs r on the one-pixel ring around it: every block publishes the r of its four edges as
 //     generation-tagged granules after the update and keeps its own copy of p on the ring (same recurrence,
 //     same bits as the owner);
-//   * inside a block, columns cross waves through a 16 KiB LDS buffer and rows cross lanes through DPP.
+//   * inside a block, columns cross waves through two 8 KiB LDS buffers and rows cross lanes through DPP.
 // The operator is the one of kernels_march.hip (same per-pixel formulas, tensor rebuilt from g_c); the
 // contributions of the neighbours are added in a different order, so results agree to rounding.
-// Masks that need more than one tile per CU fall back to the streaming kernels (kernels_march.hip).
+// Grids that need more than one tile per CU fall back to the streaming kernels (kernels_march.hip).
+//
+// Three things keep the compiler from spilling (it would otherwise need > 500 registers per thread):
+//   * an opaque zero (asm) added to every coordinate: the step-invariant tensor terms, masks and LDS reads are
+//     not hoisted out of the CG loop;
+//   * the column body has no branches and its results are pinned by empty asm statements: otherwise the
+//     arithmetic is sunk to the first use of omega, after the loop, together with everything it reads;
+//   * structure masks are formed by v_bfe_i32 in assembly (the portable forms become and + compare + select).
 #include "srps_internal.h"
 #include "device_utils.h"
 
@@ -94,6 +103,7 @@ struct ResidentArgs {
     int max_steps;
     float cx, cy;
     int i_lo, j_lo;
+    int debug;                 // timing experiments only: 1 = no grid-wide sums, no ring polls (wrong results)
 };
 
 // per-channel constants of the tensor-recompute form (uniform)
@@ -163,12 +173,13 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     const int srow0 = grow0 + PAD;
     const bool act = srow0 < Hs;                           // Hs is a multiple of 32: the float4 is inside or outside as a whole
     const int rowL = act ? srow0 : 0;                      // rows 0..3 are the zero halo of every plane
-    F4 p[CPT], r[CPT], w[CPT];
+    F4 p[CPT], r[CPT], w[CPT], x[CPT];
     unsigned fl[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const size_t off = (size_t)(gcol0 + c + PAD) * Hs + rowL;
         r[c] = ld4(a.r + off);
+        x[c] = ld4(a.x + off);
         fl[c] = *reinterpret_cast<const unsigned*>(a.flags + off);
 #pragma unroll
         for (int t = 0; t < GL; ++t) lg[(t * CPT + c) * NT + tid] = *reinterpret_cast<const float4*>(a.G + (size_t)t * pl + off);
@@ -259,7 +270,6 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 
     // the plane sizes of the bench shapes stay far below the 4 GiB a descriptor can address
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
-    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, (int)(pl * sizeof(float)), 0x00020000);
     unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
     float r1 = a.rr_first[0];
     float r0 = 0.f, alpha = 0.f;
@@ -291,9 +301,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         float ksum[CPT / 4] = {};                          // SF == 4: sums of the thread's 4 x 4 blocks
         F4 S[CPT];
         // the last g plane is streamed one column ahead (read-only, 2 MB per XCD: it stays in the L2)
-        // streamed planes go through buffer descriptors: one per-lane row offset (voffset) serves every column, the
-        // column offset is a scalar (soffset) -- no per-column address registers
-        const unsigned rowLb = (unsigned)rowL * 4u, srowb = (unsigned)srow0 * 4u;
+        // the streamed plane goes through a buffer descriptor: one per-lane row offset (voffset) serves every column,
+        // the column offset is a scalar (soffset) -- no per-column address registers
+        const unsigned rowLb = (unsigned)rowL * 4u;
         const unsigned colb = (unsigned)__builtin_amdgcn_readfirstlane((gcol0 + PAD + oz) * Hs * 4);
         const unsigned hsb = (unsigned)Hs * 4u;
         F4 gnext = as_f4(__builtin_amdgcn_raw_buffer_load_b128(g_rsrc, rowLb, colb, 0));
@@ -419,6 +429,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 uvw_pixel<NC, false, true, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
                 w[c].e[3] -= (lane == 63) ? if_bit_rt(V, f, B_BY) : 0.f;
             }
+            asm volatile("" : "+v"(w[c].e[0]), "+v"(w[c].e[3]));
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ring columns: the pixels left of column 0 (forward in x) and right of column 63 (backward in x)
         if (wave == 0) {
@@ -485,29 +497,15 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 w[c].e[e] = w[c].e[e] * a.lambda + andm(s, SRPS_MSK(B_KB, e, flk[c]));
                 red = fmaf(p[c].e[e], w[c].e[e], red);
             }
-        // x is the one vector that does not fit on the chip: it is read here, while the dot product travels, and written
-        // back below (8 B per pixel and step, off the critical path)
-        F4 xv[CPT];
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) xv[c] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, srowb, colb + c * hsb, 0));
-        }
-        const float dot = grid_sum(red, a.ent, ++gen, sm, smd);
+        const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm, smd);
         alpha = r1 / dot;                                  // dc.cu:269
         // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xv[c].e[e] = fmaf(alpha, p[c].e[e], xv[c].e[e]);      // dc.cu:270
-                __builtin_amdgcn_raw_buffer_store_b128(as_v4i(xv[c]), x_rsrc, srowb, colb + c * hsb, 0);
-            }
-        }
         red = 0.f;
 #pragma unroll
         for (int c = 0; c < CPT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
                 r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
                 red = fmaf(r[c].e[e], r[c].e[e], red);
             }
@@ -531,11 +529,11 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             }
         }
         r0 = r1;
-        r1 = grid_sum(red, a.ent, ++gen, sm, smd);
+        r1 = (a.debug & 1) ? fminf(fmaxf(block_sum(red, sm), 1.f), 2.f) : grid_sum(red, a.ent, ++gen, sm, smd);
         // r on the ring: the neighbours' edges of generation k
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            if (ridx[q] >= 0 && hsrc[q] != nullptr) {
+            if (ridx[q] >= 0 && hsrc[q] != nullptr && !(a.debug & 1)) {
                 const unsigned long long* s = hsrc[q] + (size_t)(k & 1) * HALO_N;
                 unsigned long long v;
                 while ((unsigned)((v = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)k)
@@ -545,6 +543,10 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         }
     }
     // ---- results ---------------------------------------------------------------------------------------------
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) st4(a.x + (size_t)(gcol0 + c + PAD) * Hs + srow0, x[c]);
+    }
     if (blockIdx.x == 0 && tid == 0) {
         a.scal->r0 = r0; a.scal->r1_last = r1; a.scal->iters = k; a.scal->active = (r1 > a.tol2) ? 1 : 0;
         a.scal->alpha = 0.f;                               // nothing pending: x is final
@@ -569,8 +571,6 @@ bool resident_supported(const srps_ctx* ctx) {
     return tiles <= ctx->num_cus;
 }
 
-double resident_bytes_per_step() { return 0.0; }
-
 // the whole CG of devicecalls.cu:252-275 after grid_residual(): G.d_r holds b - A_ x0, `first` its r.r
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     Grid& G = ctx->grid;
@@ -592,6 +592,7 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.tol2 = fixed_steps ? -1.f : ctx->cg_tol * ctx->cg_tol;
     a.max_steps = max_steps;
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
+    a.debug = ctx->cg_resident_debug;
     const void* fn = nullptr;
 #define SRPS_RES(SFV, NCV) fn = (const void*)k_cg_resident<SFV, NCV>
     if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else if (G.sf == 2) SRPS_RES(2, 3); else SRPS_RES(4, 3); }
@@ -600,7 +601,12 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const size_t lds = resident_lds_bytes(nc);
     SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {&a};
-    SRPS_HIP(hipLaunchCooperativeKernel(fn, dim3(tiles), dim3(NT), args, lds, ctx->stream));
+    const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(tiles), dim3(NT), args, lds, ctx->stream);
+    if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorLaunchOutOfResources || le == hipErrorNotSupported) {
+        (void)hipGetLastError();
+        return SRPS_ERR_UNSUPPORTED;                       // the caller falls back to the streaming kernels
+    }
+    SRPS_HIP(le);
     return SRPS_OK;
 }
 

@@ -255,6 +255,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "cg_resident")) {
         ctx->cg_resident = value ? 1 : 0;
+    } else if (!strcmp(name, "cg_resident_debug")) {
+        ctx->cg_resident_debug = value;
     } else if (!strcmp(name, "albedo_persistent")) {
         ctx->albedo_persistent = value ? 1 : 0;
     } else if (!strcmp(name, "keep_stored_tensor")) {
@@ -269,6 +271,25 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else {
         SRPS_REQUIRE(false, SRPS_ERR_INVALID, "set_option: unknown option '%s'", name);
     }
+    return SRPS_OK;
+}
+
+int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(name != nullptr && value != nullptr, SRPS_ERR_INVALID, "get_option: null argument");
+    if (!strcmp(name, "albedo_mode")) *value = ctx->albedo_mode;
+    else if (!strcmp(name, "apply_mode")) *value = ctx->apply_mode;
+    else if (!strcmp(name, "tensor_recompute")) *value = ctx->tensor_recompute;
+    else if (!strcmp(name, "march_snake")) *value = ctx->march_snake;
+    else if (!strcmp(name, "march_strip")) *value = ctx->grid.bound ? ctx->grid.strip_cols : ctx->march_tj;
+    else if (!strcmp(name, "keep_stored_tensor")) *value = ctx->keep_stored_tensor;
+    else if (!strcmp(name, "fuse_energy_lighting")) *value = ctx->fuse_energy_lighting;
+    else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
+    else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
+    else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
+    else if (!strcmp(name, "num_cus")) *value = ctx->num_cus;
+    else if (!strcmp(name, "cg_resident_active")) *value = (ctx->grid.bound && resident_supported(ctx)) ? 1 : 0;
+    else SRPS_REQUIRE(false, SRPS_ERR_INVALID, "get_option: unknown option '%s'", name);
     return SRPS_OK;
 }
 

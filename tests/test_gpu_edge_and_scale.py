@@ -147,6 +147,35 @@ def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
     assert np.abs(out[1][0] - out[0][0]).max() < 2e-6
 
 
+@pytest.mark.parametrize("h,w,sf,n_ch,kind", [(40, 32, 2, 3, "ragged"), (300, 200, 1, 3, "ragged"), (520, 136, 4, 1, "ellipse"),
+                                               (257, 65, 1, 3, "full"), (1024, 640, 4, 3, "ellipse"), (768, 1280, 2, 3, "ragged")])
+def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind):
+    """the depth CG as one persistent launch (state in registers + LDS, grid-wide sums and tile edges through
+    generation-tagged granules) against the kernel-per-half-step form: one tile / many tiles, tiles cut by the
+    grid border, ragged masks (backward differences, incomplete KT blocks), 1 and 3 channels, sf 1, 2, 4;
+    101 truncated steps amplify rounding differences, hence the tolerance; two resident runs are bit-identical"""
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=h + w, n_ch=n_ch, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for res in (0, 1, 1):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("cg_resident", res)
+        ctx.setup(dh)
+        ctx.lighting(); ctx.albedo()
+        e = ctx.depth()
+        out.setdefault(res, []).append((e, ctx.get("z"), ctx.last_cg_iterations()["depth"]))
+        ctx.close()
+    (e0, z0, i0), = out[0]
+    (e1, z1, i1), (e2, z2, i2) = out[1]
+    assert i0 == i1 == 101
+    assert e1 == e2
+    np.testing.assert_array_equal(z1, z2)
+    assert rmse(z1, z0) < 2e-5 and abs(e1 - e0) <= 2e-3 * abs(e0)
+    if h * w <= 300 * 200:                                   # and against the oracle's faithful (assembled) solve
+        ref = oracle.execute(oracle.Problem(sc.h, sc.w, sc.sf, sc.mask, sc.K, sc.I, sc.zs_lr, sc.z_init), depth="faithful", max_outer=1)
+        assert rmse(z1, ref.z) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json's full HR grid: properties that do not need the oracle at that size
 # ------------------------------------------------------------------------------------------------
