@@ -52,13 +52,16 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
 // one 64-bit device-scope store; thread t of every block polls entry t until it carries this generation; then
 // every block adds the same values in the same order. Nothing but these entries travels between blocks, so no
 // other fences are needed. Two slots: a block can be at most one reduction ahead of the slowest one.
-__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm, double* smd) {
-    const int nb = gridDim.x, tid = threadIdx.x;
-    unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
+__device__ __forceinline__ void grid_sum_publish(float v, unsigned long long* ent, unsigned gen, float* sm) {
+    unsigned long long* slot = ent + (size_t)(gen & 1u) * gridDim.x;
     const float t = block_sum(v, sm);
-    if (tid == 0)
+    if (threadIdx.x == 0)
         __hip_atomic_store(&slot[blockIdx.x], ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(t),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsigned gen, double* smd) {
+    const int nb = gridDim.x, tid = threadIdx.x;
+    unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
     double a = 0.0;
     for (int i = tid; i < nb; i += (int)blockDim.x) {
         unsigned long long w;
@@ -74,6 +77,10 @@ __device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsi
     const int nw = (int)blockDim.x >> 6;
     for (int i = 0; i < nw; ++i) tot += smd[i];
     return (float)tot;
+}
+__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm, double* smd) {
+    grid_sum_publish(v, ent, gen, sm);
+    return grid_sum_collect(ent, gen, smd);
 }
 
 // p = beta p + r the way the reference's CG does it: Sscal (dc.cu:263) then Saxpy (dc.cu:264), two roundings

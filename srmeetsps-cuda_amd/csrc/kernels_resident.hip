@@ -64,6 +64,7 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {      // lane i <-
 }
 // bit BIT of the structure word as an all-ones / all-zeros mask. Written in assembly: the compiler turns the
 // portable forms into and + compare + select (three instructions and a scalar register pair per use).
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 template <int BIT>
 __device__ __forceinline__ int msk(unsigned flword) {
     int m;
@@ -77,6 +78,9 @@ __device__ __forceinline__ float if_bit_rt(float v, unsigned flword, int bit) {
 }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f andm2(v2f v, v2i m) { return __builtin_bit_cast(v2f, __builtin_bit_cast(v2i, v) & m); }
 __device__ __forceinline__ F4 as_f4(v4i v) {
     F4 r; r.e[0] = __int_as_float(v.x); r.e[1] = __int_as_float(v.y); r.e[2] = __int_as_float(v.z); r.e[3] = __int_as_float(v.w);
     return r;
@@ -247,7 +251,6 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     }
     __syncthreads();
     const bool any_bx = sflag[0] != 0;
-    const bool any_by = sflag[1] != 0;
 
     // row-dependent tensor terms of the own rows:  dy = yy - y*,  S dy,  S dy^2 + R11   (recomputed per use: registers)
     auto row_terms = [&](int grow, float (&sdy)[NC], float (&q11)[NC]) {
@@ -345,30 +348,52 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             unsigned FL = fl[c];
             asm volatile("" : "+v"(FL));             // opaque: the 16 masks per column derived from it are not worth 16 registers
             float send_dn = 0.f, send_up = 0.f;
+            // two rows per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): rows (0,1), then rows (2,3)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float sdy[NC], q11[NC];
-                row_terms(grow0 + e + ozc, sdy, q11);
-                float g[NC];
-                if (NC == 3) { g[0] = g0v.e[e]; g[1 % NC] = g1v.e[e]; g[2 % NC] = grc.e[e]; }
-                else g[0] = grc.e[e];
-                const float xv = xc.e[e];
-                const float up = (e == 0) ? x_up : xc.e[e > 0 ? e - 1 : 0];
-                const float dn = (e == 3) ? x_dn : xc.e[e < 3 ? e + 1 : 3];
+            for (int h = 0; h < 2; ++h) {
+                const int e0 = 2 * h, e1 = 2 * h + 1;
+                const v2f yyv = {(float)(a.i_lo + grow0 + e0 + ozc) - a.cy, (float)(a.i_lo + grow0 + e1 + ozc) - a.cy};
+                v2f m0 = {0.f, 0.f}, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0;
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) {
+                    v2f g;
+                    if (NC == 3) g = (ch == 0) ? (v2f){g0v.e[e0], g0v.e[e1]} : (ch == 1) ? (v2f){g1v.e[e0], g1v.e[e1]} : (v2f){grc.e[e0], grc.e[e1]};
+                    else g = (v2f){grc.e[e0], grc.e[e1]};
+                    const v2f dy = yyv - K.kY[ch];
+                    const v2f sdy = K.kS[ch] * dy;
+                    const v2f q11 = sdy * dy + K.kR11[ch];
+                    m0 = g * q00[ch] + m0;
+                    m1 = g * (dxc[ch] * sdy + K.kR01[ch]) + m1;
+                    m2 = g * q02[ch] + m2;
+                    m3 = g * q11 + m3;
+                    m4 = g * sdy + m4;
+                    m5 = g * K.kS[ch] + m5;
+                }
+                const v2f xv = {xc.e[e0], xc.e[e1]};
+                const v2f up = {(h == 0) ? x_up : xc.e[1], (h == 0) ? xc.e[0] : xc.e[2]};
+                const v2f dn = {(h == 0) ? xc.e[1] : xc.e[3], (h == 0) ? xc.e[2] : x_dn};
+                const v2f xrv = {xr.e[e0], xr.e[e1]}, xlv = {xl.e[e0], xl.e[e1]};
                 // forward / backward are exclusive (SRPS.cu:39-46, 31-38)
-                const int mfx = SRPS_MSK(B_FX, e, FL), mbx = SRPS_MSK(B_BX, e, FL);
-                const int mfy = SRPS_MSK(B_FY, e, FL), mby = SRPS_MSK(B_BY, e, FL);
-                const float gx = andm(xr.e[e] - xv, mfx) + andm(xv - xl.e[e], mbx);
-                const float gy = andm(dn - xv, mfy) + andm(xv - up, mby);
-                float U, V, W;
-                uvw_pixel<NC, true, true, true>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
-                const float fxU = andm(U, mfx), bxU = andm(U, mbx);
-                const float fyV = andm(V, mfy), byV = andm(V, mby);
-                w[c].e[e] += W + (bxU - fxU) + (byV - fyV);        // A'(u, v, w) at the pixel itself
-                if (c < CPT - 1) w[c < CPT - 1 ? c + 1 : CPT - 1].e[e] += fxU; else u3.e[e] = fxU;      // Dx': +u at the right neighbour of a forward pixel
-                if (c > 0) w[c > 0 ? c - 1 : 0].e[e] -= bxU; else u0.e[e] = bxU;      //      -u at the left neighbour of a backward pixel
-                if (e < 3) w[c].e[e < 3 ? e + 1 : 3] += fyV; else send_dn = fyV;      // Dy': +v at the lower neighbour of a forward pixel
-                if (e > 0) w[c].e[e > 0 ? e - 1 : 0] -= byV; else send_up = byV;      //      -v at the upper neighbour of a backward pixel
+                const v2i mfx = {SRPS_MSK(B_FX, e0, FL), SRPS_MSK(B_FX, e1, FL)}, mbx = {SRPS_MSK(B_BX, e0, FL), SRPS_MSK(B_BX, e1, FL)};
+                const v2i mfy = {SRPS_MSK(B_FY, e0, FL), SRPS_MSK(B_FY, e1, FL)}, mby = {SRPS_MSK(B_BY, e0, FL), SRPS_MSK(B_BY, e1, FL)};
+                const v2f gx = andm2(xrv - xv, mfx) + andm2(xv - xlv, mbx);
+                const v2f gy = andm2(dn - xv, mfy) + andm2(xv - up, mby);
+                const v2f U = m0 * gx + m1 * gy + m2 * xv;
+                const v2f V = m1 * gx + m3 * gy + m4 * xv;
+                const v2f W = m2 * gx + m4 * gy + m5 * xv;
+                const v2f fxU = andm2(U, mfx), bxU = andm2(U, mbx);
+                const v2f fyV = andm2(V, mfy), byV = andm2(V, mby);
+                const v2f own = W + (bxU - fxU) + (byV - fyV);        // A'(u, v, w) at the pixel itself
+                w[c].e[e0] += own.x; w[c].e[e1] += own.y;
+                if (c < CPT - 1) { w[c < CPT - 1 ? c + 1 : CPT - 1].e[e0] += fxU.x; w[c < CPT - 1 ? c + 1 : CPT - 1].e[e1] += fxU.y; }      // Dx': +u right of a forward pixel
+                else { u3.e[e0] = fxU.x; u3.e[e1] = fxU.y; }
+                if (c > 0) { w[c > 0 ? c - 1 : 0].e[e0] -= bxU.x; w[c > 0 ? c - 1 : 0].e[e1] -= bxU.y; }                                  //      -u left of a backward pixel
+                else { u0.e[e0] = bxU.x; u0.e[e1] = bxU.y; }
+                // Dy': +v below a forward pixel, -v above a backward pixel
+                w[c].e[e1] += fyV.x;
+                if (h == 0) w[c].e[2] += fyV.y; else send_dn = fyV.y;
+                w[c].e[e0] -= byV.y;
+                if (h == 1) w[c].e[1] -= byV.x; else send_up = byV.x;
             }
             w[c].e[0] += dpp_from_prev_lane(send_dn);
             w[c].e[3] -= dpp_from_next_lane(send_up);
@@ -395,42 +420,39 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float t = S[c].e[e] + S[c + 1].e[e]; S[c].e[e] = S[c + 1].e[e] = t; }
         }
-        // ring rows: the pixels above row 0 (forward in y) and, where the mask has backward differences in y, below row 255
+        // ring rows: the pixels above row 0 (they act on row 0 when they are forward in y) and below row 255 (on row 255
+        // when backward in y). Only lane 0 / lane 63 own the rows they act on, so instead of every lane repeating the
+        // work per column, lanes 0..7 take the top ring pixel of columns 0..7 and lanes 8..15 the bottom one; the row-0 /
+        // row-255 values travel through v_readlane.
+        {
+            const int j = lane & (CPT - 1);
+            const bool bot = (lane & CPT) != 0;
+            float pown = 0.f;                                  // p of the own pixel next to the ring pixel
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            float dxc[NC], q00[NC], q02[NC];
-            col_terms(gcol0 + c + oz, dxc, q00, q02);
-            const int cc = CPT * wave + c;
-            {
-                const int it = ring_rowT(cc);
-                const unsigned f = hfl[it];
-                float sdy[NC], q11[NC], g[NC];
-                row_terms(br * TR - 1 + oz, sdy, q11);
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + it];
-                const float xv = hp[it];
-                const float gx = if_bit_rt(hp[it + 1] - xv, f, B_FX) + if_bit_rt(xv - hp[it - 1], f, B_BX);
-                const float gy = p[c].e[0] - xv;                       // used only if the ring pixel is forward in y
-                float U, V, W;
-                uvw_pixel<NC, false, true, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
-                w[c].e[0] += (lane == 0) ? if_bit_rt(V, f, B_FY) : 0.f;
+            for (int c = 0; c < CPT; ++c) {
+                const float t0 = readlane_f(p[c].e[0], 0), t3 = readlane_f(p[c].e[3], 63);
+                pown = (j == c) ? (bot ? t3 : t0) : pown;
             }
-            if (any_by) {
-                const int ib = ring_rowB(cc);
-                const unsigned f = hfl[ib];
-                float sdy[NC], q11[NC], g[NC];
-                row_terms(br * TR + TR + oz, sdy, q11);
+            const int cc = CPT * wave + j;
+            const int ir = bot ? ring_rowB(cc) : ring_rowT(cc);
+            const unsigned f = hfl[ir];
+            float dxc[NC], q00[NC], q02[NC], sdy[NC], q11[NC], g[NC];
+            col_terms(gcol0 + j + oz, dxc, q00, q02);
+            row_terms((bot ? br * TR + TR : br * TR - 1) + oz, sdy, q11);
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + ib];
-                const float xv = hp[ib];
-                const float gx = if_bit_rt(hp[ib + 1] - xv, f, B_FX) + if_bit_rt(xv - hp[ib - 1], f, B_BX);
-                const float gy = xv - p[c].e[3];                       // backward in y
-                float U, V, W;
-                uvw_pixel<NC, false, true, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
-                w[c].e[3] -= (lane == 63) ? if_bit_rt(V, f, B_BY) : 0.f;
+            for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + ir];
+            const float xv = hp[ir];
+            const float gx = if_bit_rt(hp[ir + 1] - xv, f, B_FX) + if_bit_rt(xv - hp[ir - 1], f, B_BX);
+            const float gy = bot ? (xv - pown) : (pown - xv);     // bottom: backward in y; top: forward in y
+            float U, V, W;
+            uvw_pixel<NC, false, true, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+            const float cv = if_bit_rt(V, f, bot ? B_BY : B_FY);
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const float tt = readlane_f(cv, c), tb = readlane_f(cv, CPT + c);
+                w[c].e[0] += (lane == 0) ? tt : 0.f;
+                w[c].e[3] -= (lane == 63) ? tb : 0.f;
             }
-            asm volatile("" : "+v"(w[c].e[0]), "+v"(w[c].e[3]));
-            __builtin_amdgcn_sched_barrier(0);
         }
         // ring columns: the pixels left of column 0 (forward in x) and right of column 63 (backward in x)
         if (wave == 0) {
@@ -529,16 +551,28 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             }
         }
         r0 = r1;
-        r1 = (a.debug & 1) ? fminf(fmaxf(block_sum(red, sm), 1.f), 2.f) : grid_sum(red, a.ent, ++gen, sm, smd);
-        // r on the ring: the neighbours' edges of generation k
+        // r.r, and r on the ring (the neighbours' edges of generation k): the ring granules are requested before the wait
+        // for the partial sums, so that both arrive within one round trip
+        if (a.debug & 1) r1 = fminf(fmaxf(block_sum(red, sm), 1.f), 2.f);
+        else {
+            ++gen;
+            grid_sum_publish(red, a.ent, gen, sm);
+            unsigned long long hv[RPT];
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            if (ridx[q] >= 0 && hsrc[q] != nullptr && !(a.debug & 1)) {
-                const unsigned long long* s = hsrc[q] + (size_t)(k & 1) * HALO_N;
-                unsigned long long v;
-                while ((unsigned)((v = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)k)
-                    __builtin_amdgcn_s_sleep(1);
-                rh[q] = __uint_as_float((unsigned)v);
+            for (int q = 0; q < RPT; ++q)
+                hv[q] = (ridx[q] >= 0 && hsrc[q] != nullptr)
+                            ? __hip_atomic_load(hsrc[q] + (size_t)(k & 1) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            r1 = grid_sum_collect(a.ent, gen, smd);
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                if (ridx[q] >= 0 && hsrc[q] != nullptr) {
+                    const unsigned long long* s = hsrc[q] + (size_t)(k & 1) * HALO_N;
+                    while ((unsigned)(hv[q] >> 32) != (unsigned)k) {
+                        __builtin_amdgcn_s_sleep(1);
+                        hv[q] = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    rh[q] = __uint_as_float((unsigned)hv[q]);
+                }
             }
         }
     }

@@ -1,3 +1,2 @@
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout 300 python bench.py --steps 10 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_res.json; python -c "
-import json; d=json.load(open('gpurun_out/bench_res.json')); print({k:d[k] for k in ('value','ms_per_step','cg_only_us_per_iteration','total_solve_s')}); print(d['roofline'])"
+timeout 300 python tools/_res_check.py 2>&1 | grep -v amdgpu.ids
+for o in "cg_resident=1" "cg_resident_debug=1"; do timeout 300 python bench.py --steps 5 --no-cpu-baseline --no-total-solve --option $o 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$o', 'value', round(d['value']), 'cg_only us/it', round(d['cg_only_us_per_iteration'],2))"; done
