@@ -46,41 +46,94 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
 }
 
+// ---- wave totals through DPP (no LDS traffic; ds_bpermute-based shuffles cost ~150 cycles each) -------------
+// Fixed order: four row_shr steps leave each row's total in its lane 15, row_bcast:15 / row_bcast:31 carry them
+// to lane 63, v_readlane broadcasts.  Invalid source lanes read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ float wave_total(float v) {
+    v += dpp_f<0x111, 0xf>(v);       // row_shr:1
+    v += dpp_f<0x112, 0xf>(v);       // row_shr:2
+    v += dpp_f<0x114, 0xf>(v);       // row_shr:4
+    v += dpp_f<0x118, 0xf>(v);       // row_shr:8
+    v += dpp_f<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_f<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v += dpp_d<0x111, 0xf>(v);
+    v += dpp_d<0x112, 0xf>(v);
+    v += dpp_d<0x114, 0xf>(v);
+    v += dpp_d<0x118, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);
+    v += dpp_d<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 // ---- grid-wide sum of a persistent (cooperative) launch: blocks of up to 1024 threads (a multiple of 64) ----
-// Grid-wide sum without read-modify-write atomics (256 device-scope atomics on one address serialise in the
-// fabric: the library's grid barrier costs 33 us on 256 CUs). Every block publishes {generation, partial sum} as
-// one 64-bit device-scope store; thread t of every block polls entry t until it carries this generation; then
-// every block adds the same values in the same order. Nothing but these entries travels between blocks, so no
-// other fences are needed. Two slots: a block can be at most one reduction ahead of the slowest one.
+// No read-modify-write atomics (256 device-scope atomics on one address serialise in the fabric: the library's grid
+// barrier costs 33 us on 256 CUs).  Every block publishes {generation, partial sum} as one 64-bit device-scope store;
+// the first wave of every block then collects all the entries (lane l polls entries 4l..4l+3 until they carry this
+// generation; more polling waves cost fabric bandwidth: 8 per block made the step 15 % slower) and adds them in a fixed
+// order, in double: all blocks obtain the same bits.  Nothing but these entries travels between blocks, so no other fences are needed.  Two slots per
+// block: a block can be at most one reduction ahead of the slowest one.  sm: 40 floats (blocks of at most 16 waves).
 __device__ __forceinline__ void grid_sum_publish(float v, unsigned long long* ent, unsigned gen, float* sm) {
-    unsigned long long* slot = ent + (size_t)(gen & 1u) * gridDim.x;
-    const float t = block_sum(v, sm);
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&slot[blockIdx.x], ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(t),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsigned gen, double* smd) {
-    const int nb = gridDim.x, tid = threadIdx.x;
-    unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
-    double a = 0.0;
-    for (int i = tid; i < nb; i += (int)blockDim.x) {
-        unsigned long long w;
-        while ((unsigned)((w = __hip_atomic_load(&slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen)
-            __builtin_amdgcn_s_sleep(1);
-        a += (double)__uint_as_float((unsigned)w);
+    const int tid = threadIdx.x, nw = (int)blockDim.x >> 6;
+    float* s = sm + (gen & 1u) * 16;                       // alternating: the previous reduction may still be read
+    const float t = wave_total(v);
+    if ((tid & 63) == 0) s[tid >> 6] = t;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < nw; ++i) tot += s[i];
+        __hip_atomic_store(&ent[(size_t)(gen & 1u) * gridDim.x + blockIdx.x],
+                           ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(tot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    a = wave_sum(a);
-    __syncthreads();
-    if ((tid & 63) == 0) smd[tid >> 6] = a;
-    __syncthreads();
-    double tot = 0.0;
-    const int nw = (int)blockDim.x >> 6;
-    for (int i = 0; i < nw; ++i) tot += smd[i];
-    return (float)tot;
 }
-__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm, double* smd) {
+__device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsigned gen, float* sm) {
+    const int nb = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
+    float* res = sm + 32 + (gen & 1u);                     // behind the two sets of wave partials
+    if (tid < 64) {                                        // one polling wave per block: pollers cost fabric bandwidth
+        double a = 0.0;
+        for (int base = 0; base < nb; base += 256) {
+            unsigned long long w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = base + 4 * lane + i;
+                w[i] = (idx < nb) ? __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)gen << 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = base + 4 * lane + i;
+                while ((unsigned)(w[i] >> 32) != gen) {
+                    __builtin_amdgcn_s_sleep(1);
+                    w[i] = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                a += (double)__uint_as_float((unsigned)w[i]);
+            }
+        }
+        const float tot = (float)wave_total(a);
+        if (lane == 0) *res = tot;
+    }
+    __syncthreads();
+    return *res;
+}
+__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm) {
     grid_sum_publish(v, ent, gen, sm);
-    return grid_sum_collect(ent, gen, smd);
+    return grid_sum_collect(ent, gen, sm);
 }
 
 // p = beta p + r the way the reference's CG does it: Sscal (dc.cu:263) then Saxpy (dc.cu:264), two roundings

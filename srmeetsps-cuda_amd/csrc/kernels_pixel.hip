@@ -591,8 +591,7 @@ __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho
                                                          const float* __restrict__ den, int P, int C,
                                                          unsigned long long* ent /* [2][gridDim.x], zeroed */,
                                                          DcgScal* __restrict__ scal, float tol2, int max_iter) {
-    __shared__ float sm[16];
-    __shared__ double smd[16];
+    __shared__ float sm[40];
     const int nb = gridDim.x, tid = threadIdx.x;
     unsigned gen = 0;                  // generations start at 1: the entries are zeroed before the launch
     for (int c = 0; c < C; ++c) {
@@ -617,7 +616,7 @@ __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho
 #pragma unroll
             for (int e = 0; e < 4; ++e) p[j].e[e] = 0.f;
         }
-        float r1 = grid_sum(acc, ent, ++gen, sm, smd);
+        float r1 = grid_sum(acc, ent, ++gen, sm);
         float r0 = 0.f;
         int k = 0;
         while (r1 > tol2 && k <= max_iter) {                                      // dc.cu:252
@@ -631,7 +630,7 @@ __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho
                     p[j].e[e] = (k == 1) ? r[j].e[e] : scal_then_axpy(beta, p[j].e[e], r[j].e[e]);
                     acc = fmaf(p[j].e[e], d[j].e[e] * p[j].e[e], acc);
                 }
-            const float dot = grid_sum(acc, ent, ++gen, sm, smd);
+            const float dot = grid_sum(acc, ent, ++gen, sm);
             const float alpha = r1 / dot;
             acc = 0.f;
 #pragma unroll
@@ -644,7 +643,7 @@ __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho
                     acc = fmaf(r[j].e[e], r[j].e[e], acc);
                 }
             r0 = r1;
-            r1 = grid_sum(acc, ent, ++gen, sm, smd);
+            r1 = grid_sum(acc, ent, ++gen, sm);
         }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {

@@ -147,9 +147,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     float* hp = reinterpret_cast<float*>(ex2 + NT);       // [RING]
     float* hg = hp + RING;                                // [NC][RING]
     unsigned* hfl = reinterpret_cast<unsigned*>(hg + NC * RING);   // [RING]
-    float* sm = reinterpret_cast<float*>(hfl + RING);     // [16]
-    double* smd = reinterpret_cast<double*>(sm + 16);     // [16]
-    int* sflag = reinterpret_cast<int*>(smd + 16);        // [4] block-wide structure summary
+    float* sm = reinterpret_cast<float*>(hfl + RING);     // [40]
+    int* sflag = reinterpret_cast<int*>(sm + 40);         // [4] block-wide structure summary
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -519,7 +518,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 w[c].e[e] = w[c].e[e] * a.lambda + andm(s, SRPS_MSK(B_KB, e, flk[c]));
                 red = fmaf(p[c].e[e], w[c].e[e], red);
             }
-        const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm, smd);
+        const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
         alpha = r1 / dot;                                  // dc.cu:269
         // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
         red = 0.f;
@@ -562,7 +561,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             for (int q = 0; q < RPT; ++q)
                 hv[q] = (ridx[q] >= 0 && hsrc[q] != nullptr)
                             ? __hip_atomic_load(hsrc[q] + (size_t)(k & 1) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            r1 = grid_sum_collect(a.ent, gen, smd);
+            r1 = grid_sum_collect(a.ent, gen, sm);
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 if (ridx[q] >= 0 && hsrc[q] != nullptr) {
@@ -590,7 +589,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 
 size_t resident_lds_bytes(int NC) {
     const size_t gl = (NC == 3) ? 2 : 0;
-    return (gl * CPT * NT + 2 * NT) * sizeof(float4) + (size_t)RING * sizeof(float) * (1 + NC + 1) + 16 * sizeof(float) + 16 * sizeof(double) + 16;
+    return (gl * CPT * NT + 2 * NT) * sizeof(float4) + (size_t)RING * sizeof(float) * (1 + NC + 1) + 40 * sizeof(float) + 16;
 }
 
 }  // namespace
