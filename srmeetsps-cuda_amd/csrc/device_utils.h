@@ -1,5 +1,8 @@
 // device_utils.h -- wave-64 reductions and small vector helpers (gfx950).
 #pragma once
+#ifndef SRPS_POLL_SLEEP
+#define SRPS_POLL_SLEEP 1
+#endif
 #include <hip/hip_runtime.h>
 
 namespace srps {
@@ -119,7 +122,7 @@ __device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsig
             for (int i = 0; i < 4; ++i) {
                 const int idx = base + 4 * lane + i;
                 while ((unsigned)(w[i] >> 32) != gen) {
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
                     w[i] = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 a += (double)__uint_as_float((unsigned)w[i]);

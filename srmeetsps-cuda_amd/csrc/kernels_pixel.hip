@@ -673,6 +673,14 @@ static int dcg_persistent_plan(srps_ctx* ctx, int P, bool vec, int& NV, int& nb)
     return 0;
 }
 
+// after a stream synchronisation: move the counts of the last persistent albedo solve out of the pinned buffer
+void albedo_iters_collect(srps_ctx* ctx) {
+    if (ctx->albedo_iters_pending <= 0) return;
+    const DcgScal* hs = (const DcgScal*)(ctx->h_pinned + 16);
+    for (int c = 0; c < ctx->albedo_iters_pending; ++c) ctx->last_albedo_iters[c] = hs[c].iters;
+    ctx->albedo_iters_pending = 0;
+}
+
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C) {
     const float* num = d_numden;
     const float* den = d_numden + (size_t)C * P;
@@ -684,6 +692,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
         for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = 0;
         return SRPS_OK;
     }
+    ctx->albedo_iters_pending = 0;
     const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
     const size_t nv = (size_t)C * P;
     const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + 2 * 1024 * sizeof(unsigned long long) + 256;
@@ -708,9 +717,10 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
         const void* fn = pNV == 1 ? (const void*)k_dcg_persistent<1> : pNV == 2 ? (const void*)k_dcg_persistent<2>
                        : pNV == 4 ? (const void*)k_dcg_persistent<4> : (const void*)k_dcg_persistent<5>;
         SRPS_HIP(hipLaunchCooperativeKernel(fn, dim3(pnb), dim3(1024), args, 0, ctx->stream));
+        // no host synchronisation here: the iteration counts are picked up from the pinned buffer the next time the host
+        // waits for the stream anyway (albedo_iters_collect)
         SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
-        SRPS_HIP(hipStreamSynchronize(ctx->stream));
-        for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = hs[c].iters;
+        ctx->albedo_iters_pending = C;
         return SRPS_OK;
     }
     if (vec) hipLaunchKernelGGL(k_dcg_init<4>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);

@@ -157,7 +157,7 @@ static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float
     SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:759 (k <= max_iter => 101 steps)
     SRPS_TRY(grid_gather(ctx, G.d_x, d_z));
     SRPS_TRY(grid_gradient(ctx, G.d_x, d_zx, d_zy));              // Dx z, Dy z of the NEW z (energy + normals)
-    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 32, G.d_scal, sizeof(CgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 64, G.d_scal, sizeof(CgScalars), hipMemcpyDeviceToHost, ctx->stream));
     return SRPS_OK;
 }
 
@@ -381,8 +381,9 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
     SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
     SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, e2, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    albedo_iters_collect(ctx);
     *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];               // dc.cu:785
-    ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 32))->iters;
+    ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 64))->iters;
     (void)G;
     return SRPS_OK;
 }
@@ -403,6 +404,7 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     CTX_CHECK(ctx);
     SRPS_REQUIRE(pr != nullptr, SRPS_ERR_INVALID, "setup: problem is NULL");
     ctx->light_cache_valid = false;
+    ctx->grad_current = false;
     SRPS_REQUIRE(pr->mask && pr->K && pr->zs_lr && pr->z_full, SRPS_ERR_INVALID, "setup: mask, K, zs_lr and z_full are required");
     SRPS_REQUIRE(pr->n_channels > 0 && pr->n_channels <= 8 && pr->n_images >= 0 && pr->n_images_total > 0, SRPS_ERR_INVALID, "setup: bad image counts");
     SRPS_REQUIRE(pr->image_offset >= 0 && pr->image_offset + pr->n_images <= pr->n_images_total, SRPS_ERR_INVALID, "setup: shard [%d,%d) outside [0,%d)", pr->image_offset, pr->image_offset + pr->n_images, pr->n_images_total);
@@ -502,7 +504,10 @@ int srps_depth_solve(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
     ctx->light_cache_valid = false;      // z changes
-    return depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy);
+    ctx->grad_current = false;
+    SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy));
+    ctx->grad_current = true;            // depth_solve_impl leaves Dx z, Dy z of the new z in zx, zy
+    return SRPS_OK;
 }
 int srps_energy_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -519,8 +524,9 @@ int srps_energy_finish(srps_ctx* ctx, float* energy) {
     SRPS_REQUIRE(energy != nullptr, SRPS_ERR_INVALID, "energy_finish: energy is NULL");
     SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->energy_ex, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    albedo_iters_collect(ctx);
     *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];
-    ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 32))->iters;
+    ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 64))->iters;
     ctx->last_light_iters = *(int*)(ctx->h_pinned + 8);
     return SRPS_OK;
 }
@@ -536,8 +542,11 @@ int srps_depth(srps_ctx* ctx, float* energy) {
 int srps_normals(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     Grid& G = ctx->grid;
-    SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));
-    SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy));                               // SRPS.cu:310-311
+    if (!ctx->grad_current) {
+        SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));
+        SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy));                           // SRPS.cu:310-311
+        ctx->grad_current = true;
+    }
     ctx->light_cache_normals = true;
     return launch_normals(ctx->stream, ctx->z, ctx->zx, ctx->zy, ctx->xx, ctx->yy, G.P, ctx->fx, ctx->fy, ctx->Nrm, ctx->dz);  // SRPS.cu:315
 }
@@ -615,6 +624,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     SRPS_TRY(lookup(ctx, name, &p, &len));
     SRPS_REQUIRE(n == len, SRPS_ERR_INVALID, "set('%s'): buffer holds %zu floats, array has %zu", name, n, len);
     ctx->light_cache_valid = false;
+    ctx->grad_current = false;
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
     return SRPS_OK;
@@ -626,10 +636,15 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
     SRPS_TRY(lookup(ctx, name, &p, &len));
     *d_ptr = p; *n_floats = len;
     ctx->light_cache_valid = false;      // the caller may write through the pointer
+    ctx->grad_current = false;
     return SRPS_OK;
 }
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters, int* lighting_iters_max) {
     CTX_CHECK(ctx);
+    if (ctx->albedo_iters_pending > 0) {
+        SRPS_HIP(hipStreamSynchronize(ctx->stream));
+        albedo_iters_collect(ctx);
+    }
     if (depth_iters) *depth_iters = ctx->last_depth_iters;
     if (albedo_iters) for (int c = 0; c < 8; ++c) albedo_iters[c] = ctx->last_albedo_iters[c];
     if (lighting_iters_max) *lighting_iters_max = ctx->last_light_iters;

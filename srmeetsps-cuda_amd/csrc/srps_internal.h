@@ -112,6 +112,7 @@ struct srps_ctx {
     float* energy_ex = nullptr;      // [2]
     int last_depth_iters = 0, last_light_iters = 0;
     int last_albedo_iters[8] = {0};
+    int albedo_iters_pending = 0;    // channels whose counts still sit in the pinned buffer (persistent albedo CG)
     // what the last depth assembly was built from (srps_depth_operator_apply)
     bool tensor_valid = false;
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
@@ -122,6 +123,7 @@ struct srps_ctx {
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;
     bool light_cache_valid = false;
+    bool grad_current = false;            // zx, zy (and the grid copy of z) belong to the current z: srps_normals need not redo them
     bool light_cache_normals = false;     // srps_normals ran on the depth the sums were taken from (Nrm is current)
     int light_cache_V = 0, light_cache_nblk = 0;
 };
@@ -169,6 +171,7 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
                   int C, int s_img_offset, float* d_numden);
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
+void albedo_iters_collect(srps_ctx* ctx);
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
                    int n_total, int img_offset, float cx, float cy);
