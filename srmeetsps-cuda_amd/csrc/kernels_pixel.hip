@@ -271,6 +271,126 @@ __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__
     }
 }
 
+// The same sums with the images dealt to the four waves of the block (wave w takes images b0 + w*IBW .. + IBW-1 of every
+// batch of 4*IBW); all four waves sweep the block's whole pixel range.  20 accumulators per thread instead of 80 (the
+// kernel above holds 209 registers in its fused form, two waves per SIMD, and reaches 3.4 TB/s); the geometry planes
+// are read by each wave (they hit the L1 / L2: same CU, same time).
+template <int V, int IBW, bool ENERGY>
+__global__ __launch_bounds__(256) void k_light_wavesplit(const float* __restrict__ rho, const float* __restrict__ N,
+                                                         const float* __restrict__ I, int P, int n_img, int C, int chunk,
+                                                         float* __restrict__ part_atb, float* __restrict__ part_g,
+                                                         EnergyArgs ea) {
+    __shared__ float sme[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x;
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
+            const int ib = b0 + wv * IBW;                  // first image of this wave (may be past the end: nothing stored)
+            const bool gram = (b0 == 0 && wv == 0);
+            float acc[IBW][4];
+            float g[10];
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[ii][k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) g[t] = 0.f;
+            for (int q = p0 + lane * V; q < p1; q += 64 * V) {
+                const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
+                Vec<V> nk[4];
+                Vec<V> vxx, vyy, vz, vzx, vzy, vg;
+                if constexpr (ENERGY) {
+                    vxx = ldv<V>(ea.xx + q); vyy = ldv<V>(ea.yy + q);
+                    vz = ldv<V>(ea.z + q); vzx = ldv<V>(ea.zx + q); vzy = ldv<V>(ea.zy + q);
+                    const Vec<V> vdz = ldv<V>(ea.dz + q);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float nrm;
+                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e],
+                                           nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
+                        nk[3].v[e] = 1.f;
+                        vg.v[e] = r.v[e] / vdz.v[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+                }
+                float a[4][V];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a[k][e] = r.v[e] * nk[k].v[e];       // dc.cu:381
+                Vec<V> iv[IBW];                                      // images past the end re-read the last one
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[ii][k]);
+                if constexpr (ENERGY) {
+                    // residual a1 zx + a2 zy - a3 z - (I - rho s3) of k_energy_partial, factored by the lighting vector:
+                    // (g fx zx) s0 + (g fy zy) s1 - g (xx zx + yy zy + z) s2 + rho s3 - I   (5 instead of 11 operations per image)
+                    float E[3][V];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        E[0][e] = vg.v[e] * (ea.fx * vzx.v[e]);
+                        E[1][e] = vg.v[e] * (ea.fy * vzy.v[e]);
+                        E[2][e] = -vg.v[e] * fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < IBW; ++ii) {
+                        if (ib + ii < n_img) {                                   // wave-uniform
+                            const float* sv = ea.s + ((size_t)(ea.img_offset + ib + ii) * C + c) * 4;
+                            const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                const float res = fmaf(E[0][e], s0, fmaf(E[1][e], s1, fmaf(E[2][e], s2, fmaf(r.v[e], s3, -iv[ii].v[e]))));
+                                e_acc = fmaf(res, res, e_acc);
+                            }
+                        }
+                    }
+                }
+                if (gram) {                                                      // wave-uniform
+                    int t = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int l = k; l < 4; ++l) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                            ++t;
+                        }
+                }
+            }
+            // each wave owns its images: no cross-wave sum
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = wave_sum(acc[ii][k]);
+                    if (lane == 0 && ib + ii < n_img) part_atb[(((size_t)blk * n_img + ib + ii) * C + c) * 4 + k] = v;
+                }
+            if (gram) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    const float v = wave_sum(g[t]);
+                    if (lane == 0) part_g[((size_t)blk * C + c) * 10 + t] = v;
+                }
+            }
+        }
+    }
+    if constexpr (ENERGY) {
+        const float t = block_sum(e_acc, sme);
+        if (tid == 0) ea.part_e[blk] = t;
+    }
+}
+
 // one wave per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
 // The 64 lanes add the per-block partial sums (fixed order, double), lane 0 runs the 4x4 CG.
 __global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
@@ -345,7 +465,7 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     for (int cand : {4, 8, 12, 16, 20}) { L.IB = cand; if (n_local <= cand) break; }      // n_local > 20: batches of 20
     // the fused sweep holds 7 more planes per pixel: 2 pixels per thread keep it at 2 waves per SIMD
     // (334 us against 504 us at 2048^2, 20 images); alone the lighting sweep is faster with 4 (250 / 268 us)
-    L.V = vec ? (fused ? 2 : 4) : 1;
+    L.V = vec ? ((fused && !ctx->light_wavesplit) ? 2 : 4) : 1;
     int chunk = cdiv(P, 1024);
     L.chunk = std::max(256 * L.V, cdiv(chunk, 256 * L.V) * 256 * L.V);
     L.nblk = cdiv(P, L.chunk);
@@ -359,6 +479,14 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
 template <bool ENERGY>
 static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* d_rho, const float* d_N, const float* d_I,
                                 int P, int n_local, int C, const EnergyArgs& ea) {
+    if (ctx->light_wavesplit && L.V == 4) {
+        const int ibw = std::min(5, cdiv(n_local, 4));
+#define SRPS_LWS(BB) hipLaunchKernelGGL((k_light_wavesplit<4, BB, ENERGY>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, L.chunk, L.part_atb, L.part_g, ea)
+        switch (ibw) { case 1: SRPS_LWS(1); break; case 2: SRPS_LWS(2); break; case 3: SRPS_LWS(3); break; case 4: SRPS_LWS(4); break; default: SRPS_LWS(5); }
+#undef SRPS_LWS
+        SRPS_LAUNCH_CHECK();
+        return SRPS_OK;
+    }
 #define SRPS_LIGHT(VV, BB) hipLaunchKernelGGL((k_light_partial<VV, BB, ENERGY>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, L.chunk, L.part_atb, L.part_g, ea)
     if (L.V == 4) { if constexpr (!ENERGY) switch (L.IB) { case 4: SRPS_LIGHT(4, 4); break; case 8: SRPS_LIGHT(4, 8); break; case 12: SRPS_LIGHT(4, 12); break; case 16: SRPS_LIGHT(4, 16); break; default: SRPS_LIGHT(4, 20); } }
     else if (L.V == 2) { if constexpr (ENERGY) switch (L.IB) { case 4: SRPS_LIGHT(2, 4); break; case 8: SRPS_LIGHT(2, 8); break; case 12: SRPS_LIGHT(2, 12); break; case 16: SRPS_LIGHT(2, 16); break; default: SRPS_LIGHT(2, 20); } }

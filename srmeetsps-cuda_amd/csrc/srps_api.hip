@@ -257,6 +257,9 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->cg_resident = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident_debug")) {
         ctx->cg_resident_debug = value;
+    } else if (!strcmp(name, "light_wavesplit")) {
+        ctx->light_wavesplit = value ? 1 : 0;
+        ctx->light_cache_valid = false;
     } else if (!strcmp(name, "albedo_persistent")) {
         ctx->albedo_persistent = value ? 1 : 0;
     } else if (!strcmp(name, "keep_stored_tensor")) {

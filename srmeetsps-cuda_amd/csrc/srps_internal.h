@@ -117,6 +117,7 @@ struct srps_ctx {
     bool tensor_valid = false;
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
     int fuse_energy_lighting = 1;
+    int light_wavesplit = 1;         // lighting sweep with the images dealt to the four waves of a block
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
