@@ -1,15 +1,8 @@
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 cd /tmp && export TMPDIR=/tmp
-for o in 0 1; do
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ws$o -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --no-cpu-baseline --no-total-solve --option light_wavesplit=$o > $GRAFT_REPO_ROOT/gpurun_out/ws$o.json 2>/dev/null
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o p -- python3 $R/bench.py --steps 5 --no-cpu-baseline --no-total-solve > $R/gpurun_out/prof_bench.json 2>/dev/null
+for c in FETCH_SIZE WRITE_SIZE; do
+rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- python3 $R/tools/cg_prof.py 2048 4 1 0 101 1 > /dev/null 2>&1
 done
-cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import csv,glob,json
-for o in (0,1):
-    d=json.loads(open("gpurun_out/ws%d.json"%o).read().strip().split('\n')[-1])
-    print("wavesplit",o,"value",round(d['value']),"ms",round(d['ms_per_step'],3))
-    f=glob.glob("gpurun_out/ws%d/**/*kernel_stats.csv"%o,recursive=True)[0]
-    for r in csv.DictReader(open(f)):
-        if "k_light" in r["Name"]: print("   ",r["Name"][:60], r["Calls"], round(float(r["AverageNs"])/1e3,1))
-PY
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $R/gpurun_out/pmc_TCC -o p -- python3 $R/tools/cg_prof.py 2048 4 1 0 101 1 > /dev/null 2>&1
+cd $R; ls gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_TCC | head; tail -1 gpurun_out/prof_bench.json | cut -c1-600
