@@ -331,6 +331,30 @@ static ApplyArgs base_args(srps_ctx* ctx) {
     return a;
 }
 
+// A kernel with grid-wide sums deadlocks unless all its blocks are resident together.  The occupancy query gives the
+// blocks one CU takes; with blocks <= CUs x that number a plain launch has the same residency as a cooperative one
+// (the cooperative API only adds the same check at launch time, and 11 us of queue time before and after the kernel).
+// SRPS_ERR_UNSUPPORTED: does not fit, the caller uses its streaming form.
+int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes) {
+    int per_cu = 0;
+    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds_bytes);
+    if (oe != hipSuccess || per_cu < 1 || (long)blocks > (long)per_cu * ctx->num_cus) {
+        (void)hipGetLastError();
+        return SRPS_ERR_UNSUPPORTED;
+    }
+    if (ctx->coop_launch) {
+        const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(threads), args, lds_bytes, ctx->stream);
+        if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorLaunchOutOfResources || le == hipErrorNotSupported) {
+            (void)hipGetLastError();
+            return SRPS_ERR_UNSUPPORTED;
+        }
+        SRPS_HIP(le);
+        return SRPS_OK;
+    }
+    SRPS_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_bytes, ctx->stream));
+    return SRPS_OK;
+}
+
 bool use_march(const srps_ctx* ctx) {
     if (ctx->apply_mode == SRPS_APPLY_SIMPLE) return false;
     return march_supported(ctx);

@@ -844,12 +844,16 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
         void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &scal, &tol2v, &maxit};
         const void* fn = pNV == 1 ? (const void*)k_dcg_persistent<1> : pNV == 2 ? (const void*)k_dcg_persistent<2>
                        : pNV == 4 ? (const void*)k_dcg_persistent<4> : (const void*)k_dcg_persistent<5>;
-        SRPS_HIP(hipLaunchCooperativeKernel(fn, dim3(pnb), dim3(1024), args, 0, ctx->stream));
-        // no host synchronisation here: the iteration counts are picked up from the pinned buffer the next time the host
-        // waits for the stream anyway (albedo_iters_collect)
-        SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
-        ctx->albedo_iters_pending = C;
-        return SRPS_OK;
+        const int lrc = launch_persistent(ctx, fn, pnb, 1024, args, 0);
+        if (lrc == SRPS_ERR_UNSUPPORTED) ctx->albedo_persistent = 0;     // fall through to the streaming form below
+        else {
+            SRPS_TRY(lrc);
+            // no host synchronisation here: the iteration counts are picked up from the pinned buffer the next time the
+            // host waits for the stream anyway (albedo_iters_collect)
+            SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->albedo_iters_pending = C;
+            return SRPS_OK;
+        }
     }
     if (vec) hipLaunchKernelGGL(k_dcg_init<4>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
     else hipLaunchKernelGGL(k_dcg_init<1>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);

@@ -634,13 +634,7 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const size_t lds = resident_lds_bytes(nc);
     SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {&a};
-    const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(tiles), dim3(NT), args, lds, ctx->stream);
-    if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorLaunchOutOfResources || le == hipErrorNotSupported) {
-        (void)hipGetLastError();
-        return SRPS_ERR_UNSUPPORTED;                       // the caller falls back to the streaming kernels
-    }
-    SRPS_HIP(le);
-    return SRPS_OK;
+    return launch_persistent(ctx, fn, tiles, NT, args, lds);      // SRPS_ERR_UNSUPPORTED: the caller falls back to the streaming kernels
 }
 
 }  // namespace srps

@@ -253,6 +253,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "fuse_energy_lighting")) {
         ctx->fuse_energy_lighting = value ? 1 : 0;
         ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "coop_launch")) {
+        ctx->coop_launch = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident")) {
         ctx->cg_resident = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident_debug")) {

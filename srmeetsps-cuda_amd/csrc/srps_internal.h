@@ -118,6 +118,7 @@ struct srps_ctx {
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
     int fuse_energy_lighting = 1;
     int light_wavesplit = 1;         // lighting sweep with the images dealt to the four waves of a block
+    int coop_launch = 0;             // 1: hipLaunchCooperativeKernel (launch-time residency check by the runtime, +11 us before and after)
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
@@ -182,6 +183,8 @@ int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_r
                                int C, int img_offset, float* d_out /* one float, device */);
 
 // ---- grid / CG (kernels_cg.hip) ---------------------------------------------------------
+// launch of a kernel whose blocks wait for each other (grid-wide sums): all blocks must be resident at once
+int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes);
 bool resident_supported(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
