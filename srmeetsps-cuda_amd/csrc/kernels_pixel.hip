@@ -466,8 +466,16 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     // the fused sweep holds 7 more planes per pixel: 2 pixels per thread keep it at 2 waves per SIMD
     // (334 us against 504 us at 2048^2, 20 images); alone the lighting sweep is faster with 4 (250 / 268 us)
     L.V = vec ? ((fused && !ctx->light_wavesplit) ? 2 : 4) : 1;
-    int chunk = cdiv(P, 1024);
-    L.chunk = std::max(256 * L.V, cdiv(chunk, 256 * L.V) * 256 * L.V);
+    if (ctx->light_wavesplit && L.V == 4) {
+        // one round of blocks: the sweep keeps 3 (fused, 135 registers) or 5 (96 registers) blocks per CU resident; with
+        // 1024 blocks the last third of the kernel ran at a third of the occupancy
+        const int target = ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * (fused ? 3 : 5);
+        const int gran = 64 * L.V;                         // a wave covers 64 V pixels per iteration
+        L.chunk = std::max(gran, cdiv(cdiv(P, target), gran) * gran);
+    } else {
+        const int chunk = cdiv(P, 1024);
+        L.chunk = std::max(256 * L.V, cdiv(chunk, 256 * L.V) * 256 * L.V);
+    }
     L.nblk = cdiv(P, L.chunk);
     const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
     SRPS_TRY(ensure(ctx->ws_light, (n_atb + n_g) * sizeof(float) + 64));
