@@ -118,7 +118,7 @@ struct srps_ctx {
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
     int fuse_energy_lighting = 1;
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
-    int light_wavesplit = 1;         // lighting sweep with the images dealt to the four waves of a block
+    int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 0;             // 1: hipLaunchCooperativeKernel (launch-time residency check by the runtime, +11 us before and after)
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
