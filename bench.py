@@ -187,6 +187,22 @@ def main():
                                "algorithmic_bytes_per_launch": b["apply_bytes"],
                                "update_kernel_us": us_iter - apply_us,
                                "update_kernel_GBs": b["update_bytes"] / (1e3 * (us_iter - apply_us))}
+    if rank == 0:
+        # measured device-copy ceiling: 1 GiB device-to-device copy, read + write bytes over the event time
+        try:
+            n = 256 * 1024 * 1024
+            src = torch.empty(n, dtype=torch.float32, device="cuda"); dst = torch.empty_like(src)
+            src.fill_(1.0); dst.copy_(src)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record(); e1.synchronize()
+            out["device_copy_GBs"] = 5 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e6)
+            del src, dst
+        except Exception as exc:                      # never fail the bench line because of the side measurement
+            out["device_copy_GBs"] = None
+            out["device_copy_error"] = str(exc)
     if not args.no_total_solve:
         # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up
         ctx.setup(dh)

@@ -332,9 +332,11 @@ static ApplyArgs base_args(srps_ctx* ctx) {
 }
 
 // A kernel with grid-wide sums deadlocks unless all its blocks are resident together.  The occupancy query gives the
-// blocks one CU takes; with blocks <= CUs x that number a plain launch has the same residency as a cooperative one
-// (the cooperative API only adds the same check at launch time, and 11 us of queue time before and after the kernel).
-// SRPS_ERR_UNSUPPORTED: does not fit, the caller uses its streaming form.
+// blocks one CU takes; blocks <= CUs x that number is checked here.  Default: hipLaunchCooperativeKernel -- besides
+// repeating that check, the runtime sends cooperative kernels through one queue per device, so two persistent kernels of
+// this process (two contexts on one GPU) cannot interleave their blocks and wait for each other forever.  coop_launch = 0
+// is a plain launch (same residency, 11 us less queue time before and after the kernel): for a context that has the
+// device to itself.  SRPS_ERR_UNSUPPORTED: does not fit, the caller uses its streaming form.
 int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes) {
     int per_cu = 0;
     const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds_bytes);

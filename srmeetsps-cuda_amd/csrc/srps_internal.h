@@ -119,7 +119,8 @@ struct srps_ctx {
     int fuse_energy_lighting = 1;
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
-    int coop_launch = 0;             // 1: hipLaunchCooperativeKernel (launch-time residency check by the runtime, +11 us before and after)
+    int coop_launch = 1;             // 1: hipLaunchCooperativeKernel (the runtime's cooperative queue keeps two such kernels of one
+                                     // process from interleaving their blocks; +11 us before and after); 0: plain launch
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
