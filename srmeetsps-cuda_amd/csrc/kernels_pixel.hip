@@ -729,8 +729,8 @@ __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent form of the same CG for masks that fit the register file (P <= CUs * 4096 * 5, i.e. up
-// to 5.2 M pixels on 256 CUs): one cooperative launch, one block of 1024 threads per CU, every thread
+// Persistent form of the same CG for masks that fit the register file (P <= CUs * 2048 * 10, i.e. up
+// to 5.2 M pixels on 256 CUs): one cooperative launch, one block of 512 threads per CU, every thread
 // keeps x, r, p and the diagonal of its 4*NV pixels in registers for the whole solve of a channel and
 // the two dot products of a step are grid-wide reductions (grid_sum below; every block adds the per-block
 // partial sums in the same fixed order, in double). HBM traffic: 16 B per pixel and channel
@@ -739,8 +739,8 @@ __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ 
 struct F4 {
     float e[4];
 };
-template <int NV>
-__global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho, const float* __restrict__ num,
+template <int NV, int BT>
+__global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, const float* __restrict__ num,
                                                          const float* __restrict__ den, int P, int C,
                                                          unsigned long long* ent /* [2][gridDim.x], zeroed */,
                                                          DcgScal* __restrict__ scal, float tol2, int max_iter) {
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const size_t q = ((size_t)(j * nb + blockIdx.x) * 1024 + tid) * 4;
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * BT + tid) * 4;
             if (q < (size_t)P) {
                 const Vec<4> vn = ldv<4>(num + base + q), vd = ldv<4>(den + base + q), vx = ldv<4>(rho + base + q);
 #pragma unroll
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho
         }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const size_t q = ((size_t)(j * nb + blockIdx.x) * 1024 + tid) * 4;
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * BT + tid) * 4;
             if (q < (size_t)P) {
                 Vec<4> vx;
 #pragma unroll
@@ -813,13 +813,15 @@ __global__ __launch_bounds__(1024) void k_dcg_persistent(float* __restrict__ rho
 }
 
 // 0 when the persistent form cannot be used (mask too large for the register file, unaligned arrays)
+// blocks of 512 threads (8 waves: cheaper block barriers in the grid-wide sums than 16 waves) with 2, 4 or 8 float4 per
+// thread and array; 10 float4 (160 of 256 registers) for masks up to 5.2 M pixels
 static int dcg_persistent_plan(srps_ctx* ctx, int P, bool vec, int& NV, int& nb) {
     if (!vec || !ctx->albedo_persistent) return 0;
     const int cus = ctx->num_cus;
-    for (int cand : {1, 2, 4, 5}) {
-        if ((long long)cand * cus * 4096 >= P) {
+    for (int cand : {2, 4, 8, 10}) {
+        if ((long long)cand * cus * 2048 >= P) {
             NV = cand;
-            nb = cdiv(P, cand * 4096);
+            nb = cdiv(P, cand * 2048);
             return 1;
         }
     }
@@ -867,9 +869,9 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
         int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
         float* rho_v = d_rho;
         void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &scal, &tol2v, &maxit};
-        const void* fn = pNV == 1 ? (const void*)k_dcg_persistent<1> : pNV == 2 ? (const void*)k_dcg_persistent<2>
-                       : pNV == 4 ? (const void*)k_dcg_persistent<4> : (const void*)k_dcg_persistent<5>;
-        const int lrc = launch_persistent(ctx, fn, pnb, 1024, args, 0);
+        const void* fn = pNV == 2 ? (const void*)k_dcg_persistent<2, 512> : pNV == 4 ? (const void*)k_dcg_persistent<4, 512>
+                       : pNV == 8 ? (const void*)k_dcg_persistent<8, 512> : (const void*)k_dcg_persistent<10, 512>;
+        const int lrc = launch_persistent(ctx, fn, pnb, 512, args, 0);
         if (lrc == SRPS_ERR_UNSUPPORTED) ctx->albedo_persistent = 0;     // fall through to the streaming form below
         else {
             SRPS_TRY(lrc);

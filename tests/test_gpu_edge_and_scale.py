@@ -127,7 +127,7 @@ def test_scalar_paths_when_pixel_count_is_not_a_multiple_of_four(pkg, oracle):
 @pytest.mark.parametrize("h,w,sf,n_ch", [(40, 32, 2, 3), (600, 700, 4, 3), (1024, 1536, 4, 2), (2304, 2200, 4, 1)])
 def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
     """the albedo CG that keeps x, r, p and the diagonal in registers for the whole solve (one cooperative
-    launch, grid-wide sums through generation-tagged flags; 1, 2, 4 and 5 float4 per thread) against the
+    launch of 512-thread blocks, grid-wide sums through generation-tagged flags; 2, 4, 8 and 10 float4 per thread) against the
     kernel-per-half-step form: same iteration counts, same albedo up to the order of the dot products"""
     sc = pkg.synth.make_scene(h, w, sf, 2, seed=h + 7, n_ch=n_ch, mask_kind="ellipse" if h < 2000 else "full")
     ctx = pkg.Context(device_id=0)
