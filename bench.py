@@ -173,7 +173,7 @@ def main():
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "avg_launch_us": launch_us, "steps_per_launch": 101,
                                "algorithmic_bytes_per_launch": bytes_launch,
-                               "note": "state resident in registers/LDS; frac > 1 means faster than any kernel that streams the CG vectors from HBM could be"}
+                               "note": "state resident in registers/LDS; the launch also forms the initial residual b - A x (one more operator pass, not counted in the bytes); frac > 1 means faster than any kernel that streams the CG vectors from HBM could be"}
         else:
             # Per-kernel duration: events around the whole 101-step loop give the time per step (kernel boundaries
             # overlap there); an event after EVERY launch (b["apply_us"], b["update_us"]) adds ~3 us of event /

@@ -438,15 +438,16 @@ int cg_flush_x(srps_ctx* ctx) {
     return SRPS_OK;
 }
 
-// the loop of devicecalls.cu:252-275: "while (r1 > tol^2 && k <= max_iter)" => up to max_iter+1 steps.
+// the residual of devicecalls.cu:758 (G.d_r: b -> b - A_ x) and the loop of devicecalls.cu:252-275: "while (r1 > tol^2 && k <= max_iter)" => up to max_iter+1 steps.
 // Convergence is tested on the device by every kernel; the host just enqueues the steps.
 int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
-    if (resident_supported(ctx)) {
+    if (resident_supported(ctx)) {                 // residual and CG in one persistent launch
         const int rc = resident_cg(ctx, max_steps, fixed_steps);
         if (rc != SRPS_ERR_UNSUPPORTED) return rc;
-        ctx->cg_resident = 0;                      // the device refused the cooperative launch: stream from now on
+        ctx->cg_resident = 0;                      // the device refused the launch: stream from now on
     }
-    ctx->cg_fixed = fixed_steps;               // bench: never stop early (tol^2 := -1)
+    SRPS_TRY(grid_residual(ctx));                  // dc.cu:758
+    ctx->cg_fixed = fixed_steps;                   // bench: never stop early (tol^2 := -1)
     for (int k = 1; k <= max_steps; ++k) {
         cg_launch_apply(ctx, k);
         cg_launch_update(ctx, k);

@@ -95,8 +95,7 @@ struct ResidentArgs {
     const uint8_t* flags;      // [plane]
     const float* consts;       // [NC][8]: S, x*, y*, R00, R01, R11
     float* x;                  // [plane] in/out
-    const float* r;            // [plane] residual b - A_ x0
-    const float* rr_first;     // r.r of that residual
+    const float* r;            // [plane] right-hand side b (the kernel forms the residual b - A_ x0 itself)
     unsigned long long* ent;   // [2][tiles]          reduction granules, zeroed before the launch
     unsigned long long* halo;  // [tiles][2][HALO_N]  edge granules, zeroed before the launch
     CgScalars* scal;
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         const int srow = br * TR + pr + PAD, scol = bc * TC + pc + PAD;
         if (srow >= 0 && srow < Hs && scol >= 0 && scol < a.Ws) {
             const size_t rstor = (size_t)scol * Hs + srow;
-            rh[q] = a.r[rstor];
+            rh[q] = a.x[rstor];                             // the residual pass applies the operator to x
             const unsigned f = a.flags[rstor];
             hfl[ridx[q]] = f;
             rflags |= f;
@@ -273,24 +272,31 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     // the plane sizes of the bench shapes stay far below the 4 GiB a descriptor can address
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
     unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
-    float r1 = a.rr_first[0];
-    float r0 = 0.f, alpha = 0.f;
+    float r1 = 0.f, r0 = 0.f, alpha = 0.f;
     int k = 0;
-    while (r1 > a.tol2 && k < a.max_steps) {               // dc.cu:252 (max_steps = max_iter + 1)
-        ++k;
-        const float beta = (k == 1) ? 0.f : r1 / r0;      // dc.cu:262
+    // Pass 0 forms the residual r = b - A_ x0 (devicecalls.cu:758) with the same operator code: p := x, then r -= omega.
+    // The CG steps k = 1.. follow (dc.cu:252: while r1 > tol^2 and k <= max_iter, max_steps = max_iter + 1).
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) p[c] = x[c];
+    bool pass0 = true;
+    while (pass0 || (r1 > a.tol2 && k < a.max_steps)) {
+        if (!pass0) ++k;
+        const bool first = pass0 || k == 1;               // p is taken as it is (x, or r), not updated
+        const float beta = first ? 0.f : r1 / r0;         // dc.cu:262
         // An opaque zero added to every coordinate: without it the compiler hoists the (step-invariant) tensor terms
         // and the LDS reads of g out of the CG loop and keeps ~100 more values per thread alive than there are registers.
         int oz = 0;
         asm volatile("" : "+s"(oz));
-        // ---- p = beta p + r, own pixels and ring ----------------------------------------------------------
+        // ---- p = beta p + r, own pixels and ring (pass 0: p = x, set before the loop) ----------------------------------
+        if (!pass0) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c)
+            for (int c = 0; c < CPT; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) p[c].e[e] = (k == 1) ? r[c].e[e] : scal_then_axpy(beta, p[c].e[e], r[c].e[e]);
+                for (int e = 0; e < 4; ++e) p[c].e[e] = (k == 1) ? r[c].e[e] : scal_then_axpy(beta, p[c].e[e], r[c].e[e]);
+        }
 #pragma unroll
         for (int q = 0; q < RPT; ++q)
-            if (ridx[q] >= 0) hp[ridx[q]] = (k == 1) ? rh[q] : scal_then_axpy(beta, hp[ridx[q]], rh[q]);
+            if (ridx[q] >= 0) hp[ridx[q]] = first ? rh[q] : scal_then_axpy(beta, hp[ridx[q]], rh[q]);
         ex[tid] = make_float4(p[0].e[0], p[0].e[1], p[0].e[2], p[0].e[3]);
         ex2[tid] = make_float4(p[CPT - 1].e[0], p[CPT - 1].e[1], p[CPT - 1].e[2], p[CPT - 1].e[3]);
         __syncthreads();
@@ -518,22 +524,35 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 w[c].e[e] = w[c].e[e] * a.lambda + andm(s, SRPS_MSK(B_KB, e, flk[c]));
                 red = fmaf(p[c].e[e], w[c].e[e], red);
             }
-        const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
-        alpha = r1 / dot;                                  // dc.cu:269
-        // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
-        red = 0.f;
+        if (pass0) {
+            // ---- r = b - A_ x ; r.r ---------------------------------------------------------------------------------
+            red = 0.f;
 #pragma unroll
-        for (int c = 0; c < CPT; ++c)
+            for (int c = 0; c < CPT; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
-                r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
-                red = fmaf(r[c].e[e], r[c].e[e], red);
-            }
-        // publish the r of the tile's edges (generation k, slot k & 1)
+                for (int e = 0; e < 4; ++e) {
+                    r[c].e[e] -= w[c].e[e];
+                    red = fmaf(r[c].e[e], r[c].e[e], red);
+                }
+        } else {
+            const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
+            alpha = r1 / dot;                              // dc.cu:269
+            // ---- x += alpha p ; r -= alpha omega ; r.r ----------------------------------------------------------------
+            red = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
+                    r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
+                    red = fmaf(r[c].e[e], r[c].e[e], red);
+                }
+        }
+        // publish the r of the tile's edges: generation k + 1 (0 means "never written"), slot (k + 1) & 1
+        const unsigned hgen = (unsigned)k + 1u;
         {
-            unsigned long long* hb = a.halo + ((size_t)tile * 2 + (k & 1)) * HALO_N;
-            const unsigned long long tag = (unsigned long long)(unsigned)k << 32;
+            unsigned long long* hb = a.halo + ((size_t)tile * 2 + (hgen & 1u)) * HALO_N;
+            const unsigned long long tag = (unsigned long long)hgen << 32;
             if (wave == 0 || wave == NWV - 1) {
                 const F4& rc = (wave == 0) ? r[0] : r[CPT - 1];
                 unsigned long long* d = hb + (wave == 0 ? 0 : TR) + 4 * lane;
@@ -549,8 +568,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        r0 = r1;
-        // r.r, and r on the ring (the neighbours' edges of generation k): the ring granules are requested before the wait
+        if (!pass0) r0 = r1;
+        // r.r, and r on the ring (the neighbours' edges of this generation): the ring granules are requested before the wait
         // for the partial sums, so that both arrive within one round trip
         if (a.debug & 1) r1 = fminf(fmaxf(block_sum(red, sm), 1.f), 2.f);
         else {
@@ -560,19 +579,24 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
                 hv[q] = (ridx[q] >= 0 && hsrc[q] != nullptr)
-                            ? __hip_atomic_load(hsrc[q] + (size_t)(k & 1) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                            ? __hip_atomic_load(hsrc[q] + (size_t)(hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             r1 = grid_sum_collect(a.ent, gen, sm);
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 if (ridx[q] >= 0 && hsrc[q] != nullptr) {
-                    const unsigned long long* s = hsrc[q] + (size_t)(k & 1) * HALO_N;
-                    while ((unsigned)(hv[q] >> 32) != (unsigned)k) {
+                    const unsigned long long* s = hsrc[q] + (size_t)(hgen & 1u) * HALO_N;
+                    while ((unsigned)(hv[q] >> 32) != hgen) {
                         __builtin_amdgcn_s_sleep(1);
                         hv[q] = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     rh[q] = __uint_as_float((unsigned)hv[q]);
                 }
             }
+        }
+        if (pass0) {
+            // ring pixels outside every tile (beyond the grid) carried x = 0 and carry r = 0: nothing to do; in the timing
+            // build (no polls) the ring simply keeps its values
+            pass0 = false;
         }
     }
     // ---- results ---------------------------------------------------------------------------------------------
@@ -604,7 +628,7 @@ bool resident_supported(const srps_ctx* ctx) {
     return tiles <= ctx->num_cus;
 }
 
-// the whole CG of devicecalls.cu:252-275 after grid_residual(): G.d_r holds b - A_ x0, `first` its r.r
+// the residual b - A_ x0 (devicecalls.cu:758) and the whole CG of devicecalls.cu:252-275: G.d_r holds b, G.d_x holds x0
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     Grid& G = ctx->grid;
     const int nc = march_recompute_channels(ctx);
@@ -615,7 +639,6 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     ResidentArgs a;
     memset(&a, 0, sizeof(a));
     a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.r = G.d_r;
-    a.rr_first = G.d_misc_part + 4000;
     a.ent = (unsigned long long*)ctx->ws_resident.p;
     a.halo = a.ent + (size_t)tiles * 2;
     a.scal = G.d_scal;

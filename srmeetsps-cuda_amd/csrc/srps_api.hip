@@ -153,8 +153,7 @@ static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float
     Grid& G = ctx->grid;
     SRPS_TRY(grid_scatter(ctx, d_z, G.d_x));
     SRPS_TRY(grid_rhs(ctx, d_z0s));                               // dc.cu:743-745
-    SRPS_TRY(grid_residual(ctx));                                 // dc.cu:758
-    SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:759 (k <= max_iter => 101 steps)
+    SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:758-759 (residual; k <= max_iter => 101 steps)
     SRPS_TRY(grid_gather(ctx, G.d_x, d_z));
     SRPS_TRY(grid_gradient(ctx, G.d_x, d_zx, d_zy));              // Dx z, Dy z of the NEW z (energy + normals)
     SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 64, G.d_scal, sizeof(CgScalars), hipMemcpyDeviceToHost, ctx->stream));
@@ -690,9 +689,8 @@ int srps_bench_cg(srps_ctx* ctx, int solves, int iters, double* seconds, double*
     for (int sidx = 0; sidx < solves; ++sidx) {
         SRPS_HIP(hipMemcpyAsync(G.d_x, G.d_save, G.plane * sizeof(float), hipMemcpyDeviceToDevice, st));
         SRPS_TRY(grid_rhs(ctx, ctx->z0s));
-        SRPS_TRY(grid_residual(ctx));
         SRPS_HIP(hipEventRecord(e0, st));
-        SRPS_TRY(grid_cg(ctx, iters, true));
+        SRPS_TRY(grid_cg(ctx, iters, true));              // residual + `iters` steps
         SRPS_HIP(hipEventRecord(e1, st));
         SRPS_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
