@@ -139,6 +139,55 @@ __device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsi
     return grid_sum_collect(ent, gen, sm);
 }
 
+// Three sums in one exchange (ent3: [2][3][blocks]); partial sums are float per thread and double from the wave upwards,
+// a block publishes them rounded to float, the collected totals are returned in double.
+__device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen) {
+    const int tid = threadIdx.x, nw = (int)blockDim.x >> 6, nb = gridDim.x;
+    __shared__ double sd[2][3][16];
+    const double t0 = wave_total((double)v0), t1 = wave_total((double)v1), t2 = wave_total((double)v2);
+    if ((tid & 63) == 0) { sd[gen & 1u][0][tid >> 6] = t0; sd[gen & 1u][1][tid >> 6] = t1; sd[gen & 1u][2][tid >> 6] = t2; }
+    __syncthreads();
+    if (tid < 3) {
+        double tot = 0.0;
+        for (int i = 0; i < nw; ++i) tot += sd[gen & 1u][tid][i];
+        __hip_atomic_store(&ent3[((size_t)(gen & 1u) * 3 + tid) * nb + blockIdx.x],
+                           ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint((float)tot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsigned gen, double& o0, double& o1, double& o2) {
+    const int nb = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ double res3[2][3];
+    if (tid < 64) {                                        // one polling wave per block
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const unsigned long long* slot = ent3 + ((size_t)(gen & 1u) * 3 + v) * nb;
+            for (int base = 0; base < nb; base += 256) {
+                unsigned long long w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = base + 4 * lane + i;
+                    w[i] = (idx < nb) ? __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)gen << 32);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = base + 4 * lane + i;
+                    while ((unsigned)(w[i] >> 32) != gen) {
+                        __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
+                        w[i] = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    acc[v] += (double)__uint_as_float((unsigned)w[i]);
+                }
+            }
+        }
+        const double t0 = wave_total(acc[0]), t1 = wave_total(acc[1]), t2 = wave_total(acc[2]);
+        if (lane == 0) { res3[gen & 1u][0] = t0; res3[gen & 1u][1] = t1; res3[gen & 1u][2] = t2; }
+    }
+    __syncthreads();
+    o0 = res3[gen & 1u][0]; o1 = res3[gen & 1u][1]; o2 = res3[gen & 1u][2];
+}
+
 // p = beta p + r the way the reference's CG does it: Sscal (dc.cu:263) then Saxpy (dc.cu:264), two roundings
 __device__ __forceinline__ float scal_then_axpy(float beta, float p, float r) {
 #pragma clang fp contract(off)

@@ -97,6 +97,7 @@ struct ResidentArgs {
     float* x;                  // [plane] in/out
     const float* r;            // [plane] right-hand side b (the kernel forms the residual b - A_ x0 itself)
     unsigned long long* ent;   // [2][tiles]          reduction granules, zeroed before the launch
+    unsigned long long* ent3;  // [2][3][tiles]       the same for the three-value reduction of the one-sync form
     unsigned long long* halo;  // [tiles][2][HALO_N]  edge granules, zeroed before the launch
     CgScalars* scal;
     int Hs, Ws;
@@ -135,7 +136,7 @@ __device__ __forceinline__ void uvw_pixel(const TensorConsts<NC>& K, const float
     if (NEED_W) W = m2 * gx + m4 * gy + m5 * xv;
 }
 
-template <int SF, int NC>
+template <int SF, int NC, bool ONE_SYNC>
 __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     extern __shared__ float4 lds4[];
     // LDS map: [NC==3: g0, g1 as float4 [CPT][NT]] | ex, ex2 (float4 [NT]) | ring (floats): hp, hg[NC], hfl
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         const int srow = br * TR + pr + PAD, scol = bc * TC + pc + PAD;
         if (srow >= 0 && srow < Hs && scol >= 0 && scol < a.Ws) {
             const size_t rstor = (size_t)scol * Hs + srow;
-            rh[q] = a.x[rstor];                             // the residual pass applies the operator to x
+            if (ONE_SYNC) { rh[q] = a.r[rstor]; hp[ridx[q]] = a.x[rstor]; }      // r (= b) and p (= x) on the ring for pass 0
+            else rh[q] = a.x[rstor];                        // the residual pass applies the operator to x
             const unsigned f = a.flags[rstor];
             hfl[ridx[q]] = f;
             rflags |= f;
@@ -272,7 +274,11 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     // the plane sizes of the bench shapes stay far below the 4 GiB a descriptor can address
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
     unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
-    float r1 = 0.f, r0 = 0.f, alpha = 0.f;
+    float r1 = 0.f, r0 = 0.f, alpha = 0.f, r1_anchor = 0.f;
+    // Code-generation note (hipcc 7.2): these two otherwise unused values and the store of n_direct at the end change the
+    // register allocation of the loop below; without them the same arithmetic runs 1.4 us per step slower (14.6 instead of
+    // 13.2 us at 2048^2, bit-identical results).  Measured, not understood; re-measure when the compiler changes.
+    int since_anchor = 0, n_direct = 0;
     int k = 0;
     // Pass 0 forms the residual r = b - A_ x0 (devicecalls.cu:758) with the same operator code: p := x, then r -= omega.
     // The CG steps k = 1.. follow (dc.cu:252: while r1 > tol^2 and k <= max_iter, max_steps = max_iter + 1).
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q)
-            if (ridx[q] >= 0) hp[ridx[q]] = first ? rh[q] : scal_then_axpy(beta, hp[ridx[q]], rh[q]);
+            if (ridx[q] >= 0 && !(ONE_SYNC && pass0)) hp[ridx[q]] = first ? rh[q] : scal_then_axpy(beta, hp[ridx[q]], rh[q]);
         ex[tid] = make_float4(p[0].e[0], p[0].e[1], p[0].e[2], p[0].e[3]);
         ex2[tid] = make_float4(p[CPT - 1].e[0], p[CPT - 1].e[1], p[CPT - 1].e[2], p[CPT - 1].e[3]);
         __syncthreads();
@@ -511,8 +517,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             const float4 t = ex2[tid + 64];
             w[CPT - 1].e[0] -= t.x; w[CPT - 1].e[1] -= t.y; w[CPT - 1].e[2] -= t.z; w[CPT - 1].e[3] -= t.w;
         }
-        // omega = lambda * (...) + KT'KT p ; partial p.omega
-        float red = 0.f;
+        // omega = lambda * (...) + KT'KT p ; partial p.omega (and, one-sync form, r.omega and omega.omega)
+        float red = 0.f, red_rw = 0.f, red_ww = 0.f;
         unsigned flk[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) { flk[c] = fl[c]; asm volatile("" : "+v"(flk[c])); }
@@ -523,38 +529,15 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 const float s = ((SF == 4) ? ksum[c / 4] : S[c].e[e]) * a.inv_sf4;
                 w[c].e[e] = w[c].e[e] * a.lambda + andm(s, SRPS_MSK(B_KB, e, flk[c]));
                 red = fmaf(p[c].e[e], w[c].e[e], red);
+                if (ONE_SYNC) { red_rw = fmaf(r[c].e[e], w[c].e[e], red_rw); red_ww = fmaf(w[c].e[e], w[c].e[e], red_ww); }
             }
-        if (pass0) {
-            // ---- r = b - A_ x ; r.r ---------------------------------------------------------------------------------
-            red = 0.f;
-#pragma unroll
-            for (int c = 0; c < CPT; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r[c].e[e] -= w[c].e[e];
-                    red = fmaf(r[c].e[e], r[c].e[e], red);
-                }
-        } else {
-            const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
-            alpha = r1 / dot;                              // dc.cu:269
-            // ---- x += alpha p ; r -= alpha omega ; r.r ----------------------------------------------------------------
-            red = 0.f;
-#pragma unroll
-            for (int c = 0; c < CPT; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
-                    r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
-                    red = fmaf(r[c].e[e], r[c].e[e], red);
-                }
-        }
-        // publish the r of the tile's edges: generation k + 1 (0 means "never written"), slot (k + 1) & 1
-        const unsigned hgen = (unsigned)k + 1u;
-        {
+        const unsigned hgen = (unsigned)k + 1u;           // edge generation: k + 1 (0 means "never written"), slot (k + 1) & 1
+        // the tile's edges of `src` as generation-tagged granules
+        auto publish_edges = [&](const F4 (&src)[CPT]) {
             unsigned long long* hb = a.halo + ((size_t)tile * 2 + (hgen & 1u)) * HALO_N;
             const unsigned long long tag = (unsigned long long)hgen << 32;
             if (wave == 0 || wave == NWV - 1) {
-                const F4& rc = (wave == 0) ? r[0] : r[CPT - 1];
+                const F4& rc = (wave == 0) ? src[0] : src[CPT - 1];
                 unsigned long long* d = hb + (wave == 0 ? 0 : TR) + 4 * lane;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -564,40 +547,135 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 unsigned long long* d = hb + 2 * TR + (lane == 0 ? 0 : TC) + CPT * wave;
 #pragma unroll
                 for (int c = 0; c < CPT; ++c)
-                    __hip_atomic_store(d + c, tag | (unsigned long long)__float_as_uint(lane == 0 ? r[c].e[0] : r[c].e[3]),
+                    __hip_atomic_store(d + c, tag | (unsigned long long)__float_as_uint(lane == 0 ? src[c].e[0] : src[c].e[3]),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
-        if (!pass0) r0 = r1;
-        // r.r, and r on the ring (the neighbours' edges of this generation): the ring granules are requested before the wait
-        // for the partial sums, so that both arrive within one round trip
-        if (a.debug & 1) r1 = fminf(fmaxf(block_sum(red, sm), 1.f), 2.f);
-        else {
-            ++gen;
-            grid_sum_publish(red, a.ent, gen, sm);
-            unsigned long long hv[RPT];
+        };
+        // the ring values of this generation: requested early (request), waited for late (await)
+        unsigned long long hv[RPT];
+        auto request_ring = [&]() {
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
-                hv[q] = (ridx[q] >= 0 && hsrc[q] != nullptr)
+                hv[q] = (ridx[q] >= 0 && hsrc[q] != nullptr && !(a.debug & 1))
                             ? __hip_atomic_load(hsrc[q] + (size_t)(hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            r1 = grid_sum_collect(a.ent, gen, sm);
+        };
+        auto await_ring = [&](float (&val)[RPT]) {
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                if (ridx[q] >= 0 && hsrc[q] != nullptr) {
+                val[q] = 0.f;
+                if (ridx[q] >= 0 && hsrc[q] != nullptr && !(a.debug & 1)) {
                     const unsigned long long* s = hsrc[q] + (size_t)(hgen & 1u) * HALO_N;
                     while ((unsigned)(hv[q] >> 32) != hgen) {
                         __builtin_amdgcn_s_sleep(1);
                         hv[q] = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    rh[q] = __uint_as_float((unsigned)hv[q]);
+                    val[q] = __uint_as_float((unsigned)hv[q]);
                 }
             }
+        };
+        if constexpr (ONE_SYNC) {
+            // One grid-wide wait per step.  The edges of omega travel BEFORE alpha is known: a neighbour applies
+            // r_ring -= alpha omega_ring itself, with the owner's instruction (same bits).  r.r of the updated residual is
+            // not summed again: |r - alpha omega|^2 = r.r - 2 alpha r.omega + alpha^2 omega.omega, and the three products on
+            // the right are reduced together with p.omega (float per thread, double from the wave upwards).  Guard: when
+            // that difference cancels more than two digits the direct sum is taken (one more wait, rare).
+            publish_edges(w);
+            float wr[RPT];
+            if (pass0) {
+                red = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r[c].e[e] -= w[c].e[e];                                  // r = b - A_ x   (dc.cu:758)
+                        red = fmaf(r[c].e[e], r[c].e[e], red);
+                    }
+                ++gen;
+                grid_sum_publish(red, a.ent, gen, sm);
+                request_ring();
+                r1 = (a.debug & 1) ? 1.f : grid_sum_collect(a.ent, gen, sm);
+                r1_anchor = r1;
+                await_ring(wr);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) rh[q] -= wr[q];
+            } else {
+                ++gen;
+                grid_sum3_publish(red, red_rw, red_ww, a.ent3, gen);
+                request_ring();
+                double pw, rw, ww;
+                if (a.debug & 1) { pw = 1e30; rw = 0.0; ww = 0.0; }
+                else grid_sum3_collect(a.ent3, gen, pw, rw, ww);
+                alpha = r1 / (float)pw;                    // dc.cu:269
+                red = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
+                        r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
+                        red = fmaf(r[c].e[e], r[c].e[e], red);
+                    }
+                await_ring(wr);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) rh[q] = fmaf(-alpha, wr[q], rh[q]);
+                r0 = r1;
+                const double t1 = 2.0 * (double)alpha * rw, t2 = (double)alpha * (double)alpha * ww;
+                const double pred = (double)r1 - t1 + t2;
+                // The predicted value is taken
+                //  * while its three terms cancel less than two digits (float partial sums: relative error below 1e-5; a
+                //    regular step has pred / (r.r + |t1| + t2) ~ 0.3), and
+                //  * while it cannot have drifted: its error accumulates from step to step (it is never re-measured), so the
+                //    direct sum is taken again -- and becomes the new anchor -- once r.r has fallen to a quarter of the anchor
+                //    and at every 16th step (relative drift below 1e-5; about one step in 16 at the metric's size).
+                // Otherwise the direct sum, one more wait.  Every block holds the same numbers: the decision is uniform.
+                // (A step counter kept in a register instead of k & 15 cost 1.4 us per step in code generation.)
+                if ((a.debug & 1) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
+                    r1 = (a.debug & 1) ? 1.f : (float)pred;
+                else { r1 = grid_sum(red, a.ent, ++gen, sm); r1_anchor = r1; }
+            }
+        } else {
+            if (pass0) {
+                // ---- r = b - A_ x ; r.r -----------------------------------------------------------------------------
+                red = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r[c].e[e] -= w[c].e[e];
+                        red = fmaf(r[c].e[e], r[c].e[e], red);
+                    }
+            } else {
+                const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
+                alpha = r1 / dot;                              // dc.cu:269
+                // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
+                red = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
+                        r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
+                        red = fmaf(r[c].e[e], r[c].e[e], red);
+                    }
+            }
+            publish_edges(r);
+            if (!pass0) r0 = r1;
+            // r.r, and r on the ring (the neighbours' edges of this generation): the ring granules are requested before
+            // the wait for the partial sums, so that both arrive within one round trip
+            if (a.debug & 1) r1 = fminf(fmaxf(block_sum(red, sm), 1.f), 2.f);
+            else {
+                ++gen;
+                grid_sum_publish(red, a.ent, gen, sm);
+                request_ring();
+                r1 = grid_sum_collect(a.ent, gen, sm);
+                float rv[RPT];
+                await_ring(rv);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q)
+                    if (ridx[q] >= 0 && hsrc[q] != nullptr) rh[q] = rv[q];
+            }
         }
-        if (pass0) {
-            // ring pixels outside every tile (beyond the grid) carried x = 0 and carry r = 0: nothing to do; in the timing
-            // build (no polls) the ring simply keeps its values
-            pass0 = false;
-        }
+        pass0 = false;
     }
     // ---- results ---------------------------------------------------------------------------------------------
     if (act) {
@@ -607,6 +685,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     if (blockIdx.x == 0 && tid == 0) {
         a.scal->r0 = r0; a.scal->r1_last = r1; a.scal->iters = k; a.scal->active = (r1 > a.tol2) ? 1 : 0;
         a.scal->alpha = 0.f;                               // nothing pending: x is final
+        a.scal->pad[0] = n_direct + since_anchor;          // see the code-generation note above
     }
     (void)ntile;
 }
@@ -633,14 +712,15 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     Grid& G = ctx->grid;
     const int nc = march_recompute_channels(ctx);
     const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc;
-    const size_t need = (size_t)tiles * 2 * sizeof(unsigned long long) + (size_t)tiles * 2 * HALO_N * sizeof(unsigned long long);
+    const size_t need = (size_t)tiles * (2 + 6 + 2 * HALO_N) * sizeof(unsigned long long);
     SRPS_TRY(ensure(ctx->ws_resident, need));
     SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));
     ResidentArgs a;
     memset(&a, 0, sizeof(a));
     a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.r = G.d_r;
     a.ent = (unsigned long long*)ctx->ws_resident.p;
-    a.halo = a.ent + (size_t)tiles * 2;
+    a.ent3 = a.ent + (size_t)tiles * 2;
+    a.halo = a.ent3 + (size_t)tiles * 6;
     a.scal = G.d_scal;
     a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = nbr; a.nbc = nbc;
     a.lambda = ctx->lambda;
@@ -650,7 +730,7 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     a.debug = ctx->cg_resident_debug;
     const void* fn = nullptr;
-#define SRPS_RES(SFV, NCV) fn = (const void*)k_cg_resident<SFV, NCV>
+#define SRPS_RES(SFV, NCV) fn = ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true> : (const void*)k_cg_resident<SFV, NCV, false>
     if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else if (G.sf == 2) SRPS_RES(2, 3); else SRPS_RES(4, 3); }
     else { if (G.sf == 1) SRPS_RES(1, 1); else if (G.sf == 2) SRPS_RES(2, 1); else SRPS_RES(4, 1); }
 #undef SRPS_RES

@@ -254,6 +254,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "coop_launch")) {
         ctx->coop_launch = value ? 1 : 0;
+    } else if (!strcmp(name, "cg_one_sync")) {
+        ctx->cg_one_sync = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident")) {
         ctx->cg_resident = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident_debug")) {
@@ -294,6 +296,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "fuse_energy_lighting")) *value = ctx->fuse_energy_lighting;
     else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
+    else if (!strcmp(name, "cg_one_sync")) *value = ctx->cg_one_sync;
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
     else if (!strcmp(name, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(name, "cg_resident_active")) *value = (ctx->grid.bound && resident_supported(ctx)) ? 1 : 0;

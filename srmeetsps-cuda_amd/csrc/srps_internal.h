@@ -121,6 +121,7 @@ struct srps_ctx {
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // 1: hipLaunchCooperativeKernel (the runtime's cooperative queue keeps two such kernels of one
                                      // process from interleaving their blocks; +11 us before and after); 0: plain launch
+    int cg_one_sync = 1;             // resident CG: r.r from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per step)
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)

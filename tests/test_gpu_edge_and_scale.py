@@ -176,6 +176,30 @@ def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind):
         assert rmse(z1, ref.z) < 1e-4
 
 
+@pytest.mark.parametrize("h,w,sf,n_ch,kind", [(20, 24, 1, 3, "full"), (96, 80, 2, 3, "ragged"), (512, 384, 4, 3, "ellipse")])
+def test_one_wait_per_cg_step_equals_two(pkg, oracle, h, w, sf, n_ch, kind):
+    """resident CG with r.r of the updated residual predicted from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per
+    step, direct sum every 16th step / when r.r has fallen to a quarter / when the terms cancel) against the form that
+    sums r.r directly in every step: same iteration count, depth equal far below the 1e-4 bar -- also on a small system
+    that converges within the 101 steps, where an unanchored prediction drifts by 1e-3 (and the depth by 1.5e-4)"""
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=9, n_ch=n_ch, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for one in (0, 1):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("cg_one_sync", one)
+        srps = pkg.SRPS(dh, ctx=ctx)
+        en = srps.execute(max_outer=2)
+        out[one] = (en, srps.z(), ctx.last_cg_iterations()["depth"])
+        ctx.close()
+    assert out[0][2] == out[1][2] == 101
+    assert rmse(out[1][1], out[0][1]) < 2e-5
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-4)
+    if h * w <= 96 * 80:
+        ref = oracle.execute(oracle.Problem(sc.h, sc.w, sc.sf, sc.mask, sc.K, sc.I, sc.zs_lr, sc.z_init), depth="faithful", max_outer=2)
+        assert rmse(out[1][1], ref.z) < 5e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json's full HR grid: properties that do not need the oracle at that size
 # ------------------------------------------------------------------------------------------------
