@@ -1,3 +1,4 @@
+"""Development aid: depth phase with the resident CG against the streaming CG on a few shapes (python tools/resident_check.py, on a GPU box)."""
 import importlib, sys, time, numpy as np
 sys.path.insert(0, ".")
 pkg = importlib.import_module("srmeetsps-cuda_amd"); pkg.load()
