@@ -149,9 +149,9 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     return SRPS_OK;
 }
 
-static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float* d_zx, float* d_zy) {
+static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float* d_zx, float* d_zy, bool plane_current = false) {
     Grid& G = ctx->grid;
-    SRPS_TRY(grid_scatter(ctx, d_z, G.d_x));
+    if (!plane_current) SRPS_TRY(grid_scatter(ctx, d_z, G.d_x));      // the last solve left z on the grid plane
     SRPS_TRY(grid_rhs(ctx, d_z0s));                               // dc.cu:743-745
     SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:758-759 (residual; k <= max_iter => 101 steps)
     SRPS_TRY(grid_gather(ctx, G.d_x, d_z));
@@ -387,6 +387,7 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
     // unless the caller announced it (srps_set_principal_point)
     SRPS_TRY(depth_assemble(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, K00, K11, npix, nimages, nchannels, nimages, 0,
                             ctx->op_pp_set ? ctx->op_cx : NAN, ctx->op_pp_set ? ctx->op_cy : NAN));
+    ctx->plane_holds_z = false;
     SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
     SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
     SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
@@ -515,9 +516,12 @@ int srps_depth_solve(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
     ctx->light_cache_valid = false;      // z changes
+    const bool plane_current = ctx->grad_current && ctx->plane_holds_z;      // nothing wrote z or the plane since the last solve
     ctx->grad_current = false;
-    SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy));
+    ctx->plane_holds_z = false;
+    SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy, plane_current));
     ctx->grad_current = true;            // depth_solve_impl leaves Dx z, Dy z of the new z in zx, zy
+    ctx->plane_holds_z = true;           // ... and z itself on the grid plane
     return SRPS_OK;
 }
 int srps_energy_partial(srps_ctx* ctx) {

@@ -128,6 +128,7 @@ struct srps_ctx {
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;
     bool light_cache_valid = false;
+    bool plane_holds_z = false;           // the grid plane d_x holds the current z (left there by the last solve)
     bool grad_current = false;            // zx, zy (and the grid copy of z) belong to the current z: srps_normals need not redo them
     bool light_cache_normals = false;     // srps_normals ran on the depth the sums were taken from (Nrm is current)
     int light_cache_V = 0, light_cache_nblk = 0;
