@@ -85,8 +85,69 @@ __global__ void k_rhs(const float* __restrict__ Q, const uint8_t* __restrict__ f
     }
     rhs[g] = acc;
 }
+// the same, four rows per thread (float4 loads; sf in {1, 2, 4}: a thread's rows lie in one LR block row group)
+template <int SF>
+__global__ __launch_bounds__(256) void k_rhs4(const float* __restrict__ Q, const uint8_t* __restrict__ flags, const int* __restrict__ lr_index,
+                                              const float* __restrict__ z0s, int Hg, int Wg, int Hs, size_t plane, int Hl, float lambda,
+                                              float* __restrict__ rhs) {
+    const int i = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;          // first of the thread's four rows
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= Hg || j >= Wg) return;
+    const size_t g = (size_t)(j + PAD) * Hs + i + PAD;                 // multiple of 4: aligned float4 / word
+    const unsigned fw = *reinterpret_cast<const unsigned*>(flags + g);
+    if ((fw & 0x01010101u) == 0u) return;                              // no masked pixel among the four (rhs stays 0)
+    const unsigned fl_l = *reinterpret_cast<const unsigned*>(flags + g - Hs), fl_r = *reinterpret_cast<const unsigned*>(flags + g + Hs);
+    const unsigned f_up = flags[g - 1], f_dn = flags[g + 4];
+    const float* q0 = Q;
+    const float* q1 = Q + plane;
+    const float* q2 = Q + 2 * plane;
+    const float4 a0 = *reinterpret_cast<const float4*>(q0 + g), al = *reinterpret_cast<const float4*>(q0 + g - Hs), ar = *reinterpret_cast<const float4*>(q0 + g + Hs);
+    const float4 b0 = *reinterpret_cast<const float4*>(q1 + g), c0 = *reinterpret_cast<const float4*>(q2 + g);
+    const float b_up = q1[g - 1], b_dn = q1[g + 4];
+    const float q0c[4] = {a0.x, a0.y, a0.z, a0.w}, q0l[4] = {al.x, al.y, al.z, al.w}, q0r[4] = {ar.x, ar.y, ar.z, ar.w};
+    const float q1c[6] = {b_up, b0.x, b0.y, b0.z, b0.w, b_dn};
+    const float q2c[4] = {c0.x, c0.y, c0.z, c0.w};
+    float kt[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+#pragma unroll
+        for (int e = 0; e < 4; e += SF) {                                // one LR block per SF rows
+            if ((fw >> (8 * e)) & F_KB) {
+                const float v = z0s[lr_index[(j / SF) * Hl + (i + e) / SF]] / (float)(SF * SF);      // KT value 1/sf^2, SRPS.cu:188
+#pragma unroll
+                for (int d = 0; d < SF; ++d) kt[e + d] = v;
+            }
+        }
+    }
+    float out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned fl = (fw >> (8 * e)) & 0xffu;
+        const unsigned fu = (e == 0) ? f_up : ((fw >> (8 * (e - 1))) & 0xffu);
+        const unsigned fd = (e == 3) ? f_dn : ((fw >> (8 * (e + 1))) & 0xffu);
+        float acc = q2c[e];
+        if (fl & F_FX) acc -= q0c[e]; else if (fl & F_BX) acc += q0c[e];
+        if ((fl_l >> (8 * e)) & F_FX) acc += q0l[e];
+        if ((fl_r >> (8 * e)) & F_BX) acc -= q0r[e];
+        if (fl & F_FY) acc -= q1c[e + 1]; else if (fl & F_BY) acc += q1c[e + 1];
+        if (fu & F_FY) acc += q1c[e];
+        if (fd & F_BY) acc -= q1c[e + 2];
+        acc *= lambda;
+        if (fl & F_KB) acc += kt[e];
+        out[e] = (fl & F_MASK) ? acc : 0.f;
+    }
+    *reinterpret_cast<float4*>(rhs + g) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 int grid_rhs(srps_ctx* ctx, const float* d_z0s) {
     Grid& G = ctx->grid;
+    if (G.sf == 1 || G.sf == 2 || G.sf == 4) {
+        dim3 grd(cdiv(G.Hg, 256), cdiv(G.Wg, 4));
+#define SRPS_RHS4(SFV) hipLaunchKernelGGL((k_rhs4<SFV>), grd, dim3(256), 0, ctx->stream, G.d_q, G.d_flags, G.d_lr_index, d_z0s, G.Hg, G.Wg, G.Hs, G.plane, G.Hl, ctx->lambda, G.d_r)
+        if (G.sf == 1) SRPS_RHS4(1); else if (G.sf == 2) SRPS_RHS4(2); else SRPS_RHS4(4);
+#undef SRPS_RHS4
+        SRPS_LAUNCH_CHECK();
+        return SRPS_OK;
+    }
     dim3 blk(64, 4), grd(cdiv(G.Hg, 64), cdiv(G.Wg, 4));
     hipLaunchKernelGGL(k_rhs, grd, blk, 0, ctx->stream, G.d_q, G.d_flags, G.d_lr_index, d_z0s, G.Hg, G.Wg, G.Hs, G.plane, G.sf, G.Hl, ctx->lambda, G.d_r);
     SRPS_LAUNCH_CHECK();
