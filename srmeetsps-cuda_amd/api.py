@@ -316,13 +316,15 @@ def alternating_loop(engine, all_reduce=None, max_outer: int | None = None, on_i
         engine.depth_solve()
         engine.energy_partial()
         if ar: ar(engine.exchange("energy"))
+        # The normals of the new depth (SRPS.cu:310-315) do not depend on the stop test: they are enqueued before the host
+        # waits for the energy, so the GPU is not idle during the read-back.
+        engine.normals()
         error = float(f32(engine.energy_finish()))
         with np.errstate(invalid="ignore", divide="ignore"):
             rel_err = float(abs(f32(last_error) - f32(error)) / abs(f32(error)))       # SRPS.cu:298
         stop = (error > last_error) or (rel_err < TOLERANCE) or (iteration > MAX_ITERATIONS)   # SRPS.cu:299
         last_error = error
         energies.append(error)
-        engine.normals()                                          # SRPS.cu:310-315
         if on_iteration:
             on_iteration(iteration, error, rel_err)
         iteration += 1

@@ -393,11 +393,11 @@ static ApplyArgs base_args(srps_ctx* ctx) {
 }
 
 // A kernel with grid-wide sums deadlocks unless all its blocks are resident together.  The occupancy query gives the
-// blocks one CU takes; blocks <= CUs x that number is checked here.  Default: hipLaunchCooperativeKernel -- besides
-// repeating that check, the runtime sends cooperative kernels through one queue per device, so two persistent kernels of
-// this process (two contexts on one GPU) cannot interleave their blocks and wait for each other forever.  coop_launch = 0
-// is a plain launch (same residency, 11 us less queue time before and after the kernel): for a context that has the
-// device to itself.  SRPS_ERR_UNSUPPORTED: does not fit, the caller uses its streaming form.
+// blocks one CU takes; blocks <= CUs x that number is checked here.  Two persistent kernels launched at the same time on
+// one device could still interleave their blocks and wait for each other forever: hipLaunchCooperativeKernel sends such
+// kernels through one queue per device and rules that out, at the price of 13 us of queue time before and after the
+// kernel.  Default (coop_launch = 2): the cooperative launch only while this process has more than one live context on the
+// device, a plain launch (same residency) otherwise.  SRPS_ERR_UNSUPPORTED: does not fit, the caller streams instead.
 int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes) {
     int per_cu = 0;
     const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds_bytes);
@@ -405,7 +405,7 @@ int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, vo
         (void)hipGetLastError();
         return SRPS_ERR_UNSUPPORTED;
     }
-    if (ctx->coop_launch) {
+    if (ctx->coop_launch == 1 || (ctx->coop_launch == 2 && contexts_on_device(ctx->device) > 1)) {
         const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(threads), args, lds_bytes, ctx->stream);
         if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorLaunchOutOfResources || le == hipErrorNotSupported) {
             (void)hipGetLastError();

@@ -164,6 +164,12 @@ static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float
 
 using namespace srps;
 
+#include <atomic>
+static std::atomic<int> g_live_contexts[64];
+namespace srps {
+int contexts_on_device(int device) { return (device >= 0 && device < 64) ? g_live_contexts[device].load() : 2; }
+}
+
 #define CTX_CHECK(ctx)                                                        \
     do {                                                                      \
         SRPS_REQUIRE((ctx) != nullptr, SRPS_ERR_INVALID, "null context");    \
@@ -202,6 +208,7 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     e = hipHostMalloc((void**)&c->h_pinned, 256 * sizeof(float));
     if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
     memset(c->h_pinned, 0, 256 * sizeof(float));
+    if (device_id < 64) g_live_contexts[device_id].fetch_add(1);
     *out = c;
     return SRPS_OK;
 }
@@ -210,6 +217,7 @@ int srps_destroy(srps_ctx* ctx) {
     if (!ctx) return SRPS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->device >= 0 && ctx->device < 64) g_live_contexts[ctx->device].fetch_sub(1);
     state_release(ctx);
     grid_release(ctx->grid);
     if (ctx->ws_light.p) (void)hipFree(ctx->ws_light.p);
@@ -253,7 +261,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->fuse_energy_lighting = value ? 1 : 0;
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "coop_launch")) {
-        ctx->coop_launch = value ? 1 : 0;
+        SRPS_REQUIRE(value >= 0 && value <= 2, SRPS_ERR_INVALID, "coop_launch: 0 (plain), 1 (cooperative) or 2 (cooperative when the device is shared)");
+        ctx->coop_launch = value;
     } else if (!strcmp(name, "cg_one_sync")) {
         ctx->cg_one_sync = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident")) {
@@ -590,12 +599,15 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
         float error = 0.f;
         SRPS_TRY(srps_lighting(ctx));      // SRPS.cu:281
         SRPS_TRY(srps_albedo(ctx));        // SRPS.cu:287
-        SRPS_TRY(srps_depth(ctx, &error)); // SRPS.cu:293
+        SRPS_TRY(srps_depth_partial(ctx)); // SRPS.cu:293
+        SRPS_TRY(srps_depth_solve(ctx));
+        SRPS_TRY(srps_energy_partial(ctx));
+        SRPS_TRY(srps_normals(ctx));       // SRPS.cu:310-315, enqueued before the host waits for the energy
+        SRPS_TRY(srps_energy_finish(ctx, &error));
         const float rel_err = fabsf(last_error - error) / fabsf(error);          // SRPS.cu:298
         if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop = true;   // SRPS.cu:299
         last_error = error;
         if (energies && done < (max_outer > 0 ? max_outer : 12)) energies[done] = error;
-        SRPS_TRY(srps_normals(ctx));       // SRPS.cu:310-315
         ++iteration; ++done;
         if (max_outer > 0 && done >= max_outer) stop = true;
     } while (!stop);

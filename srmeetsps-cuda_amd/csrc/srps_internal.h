@@ -119,8 +119,10 @@ struct srps_ctx {
     int fuse_energy_lighting = 1;
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
-    int coop_launch = 1;             // 1: hipLaunchCooperativeKernel (the runtime's cooperative queue keeps two such kernels of one
-                                     // process from interleaving their blocks; +11 us before and after); 0: plain launch
+    int coop_launch = 2;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (one cooperative queue per
+                                     // device: two such kernels of this process cannot interleave their blocks and wait for each
+                                     // other forever; +13 us of queue time before and after), 0 = plain launch behind the same
+                                     // occupancy check, 2 = plain while this is the only live context of the process on its device
     int cg_one_sync = 1;             // resident CG: r.r from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per step)
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
@@ -188,6 +190,7 @@ int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_r
 
 // ---- grid / CG (kernels_cg.hip) ---------------------------------------------------------
 // launch of a kernel whose blocks wait for each other (grid-wide sums): all blocks must be resident at once
+int contexts_on_device(int device);      // live srps contexts of this process on that device
 int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes);
 bool resident_supported(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
