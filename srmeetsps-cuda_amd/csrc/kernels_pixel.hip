@@ -739,10 +739,11 @@ __global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ 
 struct F4 {
     float e[4];
 };
-template <int NV, int BT>
+template <int NV, int BT, bool ONE>
 __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, const float* __restrict__ num,
                                                          const float* __restrict__ den, int P, int C,
                                                          unsigned long long* ent /* [2][gridDim.x], zeroed */,
+                                                         unsigned long long* ent3 /* [2][3][gridDim.x], zeroed */,
                                                          DcgScal* __restrict__ scal, float tol2, int max_iter) {
     __shared__ float sm[40];
     const int nb = gridDim.x, tid = threadIdx.x;
@@ -769,9 +770,56 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) p[j].e[e] = 0.f;
         }
-        float r1 = grid_sum(acc, ent, ++gen, sm);
-        float r0 = 0.f;
+        float r1, r0 = 0.f;
         int k = 0;
+        if constexpr (ONE) {
+            // One grid-wide wait per step: p.(D p) of the NEXT direction p' = r' + beta p is
+            //   r'.D r' + 2 beta r'.D p + beta^2 p.D p,
+            // and the first two products can be summed together with r'.r' before beta is known.  r.r, the quantity the
+            // stop test looks at, is still summed directly; the solve converges (11 - 15 steps to 1e-9), so the rounding of
+            // the predicted p.(D p) (relative 1e-6) does not reach the result.
+            float a_rdr = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { p[j].e[e] = r[j].e[e]; a_rdr = fmaf(r[j].e[e], d[j].e[e] * r[j].e[e], a_rdr); }      // k = 1: p = r
+            double s_rr, s_pw, s_x;
+            ++gen;
+            grid_sum3_publish(acc, a_rdr, 0.f, ent3, gen);
+            grid_sum3_collect(ent3, gen, s_rr, s_pw, s_x);
+            r1 = (float)s_rr;
+            double pw = s_pw;
+            while (r1 > tol2 && k <= max_iter) {                                  // dc.cu:252
+                ++k;
+                const float alpha = r1 / (float)pw;
+                float a_rr = 0.f, a_rdp = 0.f;
+                a_rdr = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float w = d[j].e[e] * p[j].e[e];
+                        x[j].e[e] = fmaf(alpha, p[j].e[e], x[j].e[e]);
+                        r[j].e[e] = fmaf(-alpha, w, r[j].e[e]);
+                        a_rr = fmaf(r[j].e[e], r[j].e[e], a_rr);
+                        a_rdr = fmaf(r[j].e[e], d[j].e[e] * r[j].e[e], a_rdr);
+                        a_rdp = fmaf(r[j].e[e], w, a_rdp);
+                    }
+                double s_rdr, s_rdp;
+                ++gen;
+                grid_sum3_publish(a_rr, a_rdr, a_rdp, ent3, gen);
+                grid_sum3_collect(ent3, gen, s_rr, s_rdr, s_rdp);
+                r0 = r1;
+                r1 = (float)s_rr;
+                const float beta = r1 / r0;
+                pw = s_rdr + 2.0 * (double)beta * s_rdp + (double)beta * (double)beta * pw;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[j].e[e] = scal_then_axpy(beta, p[j].e[e], r[j].e[e]);
+            }
+        } else {
+        r1 = grid_sum(acc, ent, ++gen, sm);
         while (r1 > tol2 && k <= max_iter) {                                      // dc.cu:252
             ++k;
             const float beta = (k == 1) ? 0.f : r1 / r0;
@@ -797,6 +845,7 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
                 }
             r0 = r1;
             r1 = grid_sum(acc, ent, ++gen, sm);
+        }
         }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -850,7 +899,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     ctx->albedo_iters_pending = 0;
     const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
     const size_t nv = (size_t)C * P;
-    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + 2 * 1024 * sizeof(unsigned long long) + 256;
+    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + (2 + 6) * 1024 * sizeof(unsigned long long) + 256;
     SRPS_TRY(ensure(ctx->ws_albedo, bytes));
     float* r = (float*)ctx->ws_albedo.p;
     float* p = r + nv;
@@ -864,13 +913,15 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     if (dcg_persistent_plan(ctx, P, vec, pNV, pnb)) {
         // [2][pnb] behind the C <= 8 scalar records, 8-byte aligned
         unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 7) & ~(uintptr_t)7);
-        SRPS_HIP(hipMemsetAsync(ent, 0, 2 * (size_t)pnb * sizeof(unsigned long long), ctx->stream));
+        unsigned long long* ent3 = ent + 2 * 1024;
+        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 6 * (size_t)pnb) * sizeof(unsigned long long), ctx->stream));
         float tol2v = tol2;
         int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
         float* rho_v = d_rho;
-        void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &scal, &tol2v, &maxit};
-        const void* fn = pNV == 2 ? (const void*)k_dcg_persistent<2, 512> : pNV == 4 ? (const void*)k_dcg_persistent<4, 512>
-                       : pNV == 8 ? (const void*)k_dcg_persistent<8, 512> : (const void*)k_dcg_persistent<10, 512>;
+        void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &ent3, &scal, &tol2v, &maxit};
+#define SRPS_DCG(NVV) (ctx->albedo_one_sync ? (const void*)k_dcg_persistent<NVV, 512, true> : (const void*)k_dcg_persistent<NVV, 512, false>)
+        const void* fn = pNV == 2 ? SRPS_DCG(2) : pNV == 4 ? SRPS_DCG(4) : pNV == 8 ? SRPS_DCG(8) : SRPS_DCG(10);
+#undef SRPS_DCG
         const int lrc = launch_persistent(ctx, fn, pnb, 512, args, 0);
         if (lrc == SRPS_ERR_UNSUPPORTED) ctx->albedo_persistent = 0;     // fall through to the streaming form below
         else {

@@ -276,6 +276,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "light_grouped")) {
         ctx->light_grouped = value ? 1 : 0;
         ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "albedo_one_sync")) {
+        ctx->albedo_one_sync = value ? 1 : 0;
     } else if (!strcmp(name, "albedo_persistent")) {
         ctx->albedo_persistent = value ? 1 : 0;
     } else if (!strcmp(name, "keep_stored_tensor")) {

@@ -127,6 +127,7 @@ struct srps_ctx {
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
+    int albedo_one_sync = 1;         // persistent albedo CG: p.(D p) of the next direction predicted from three products summed with r.r
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;
     bool light_cache_valid = false;

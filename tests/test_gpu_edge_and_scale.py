@@ -135,16 +135,18 @@ def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
     ctx.lighting()
     rho0 = ctx.get("rho")
     out = {}
-    for pers in (0, 1):
+    for pers, one in ((0, 0), (1, 0), (1, 1)):
         ctx.set_option("albedo_persistent", pers)
+        ctx.set_option("albedo_one_sync", one)       # p.(D p) of the next direction predicted: one grid-wide wait per step
         ctx.set("rho", rho0)
         ctx.albedo()
-        out[pers] = (ctx.get("rho"), ctx.last_cg_iterations()["albedo"][:n_ch])
+        out[(pers, one)] = (ctx.get("rho"), ctx.last_cg_iterations()["albedo"][:n_ch])
     ctx.close()
-    assert all(k > 1 for k in out[1][1]), out[1][1]
-    assert all(abs(a - b) <= 1 for a, b in zip(out[0][1], out[1][1])), (out[0][1], out[1][1])
-    assert np.all(np.isfinite(out[1][0]))
-    assert np.abs(out[1][0] - out[0][0]).max() < 2e-6
+    for key in ((1, 0), (1, 1)):
+        assert all(k > 1 for k in out[key][1]), out[key][1]
+        assert all(abs(a - b) <= 1 for a, b in zip(out[(0, 0)][1], out[key][1])), (out[(0, 0)][1], out[key][1])
+        assert np.all(np.isfinite(out[key][0]))
+        assert np.abs(out[key][0] - out[(0, 0)][0]).max() < 2e-6
 
 
 @pytest.mark.parametrize("h,w,sf,n_ch,kind", [(40, 32, 2, 3, "ragged"), (300, 200, 1, 3, "ragged"), (520, 136, 4, 1, "ellipse"),
