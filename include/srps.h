@@ -67,7 +67,7 @@ int srps_synchronize(srps_ctx* ctx);
  * "fuse_energy_lighting" (0|1: the energy sweep over I also leaves the lighting sums of the next pass),
  * "albedo_persistent" (0|1: albedo CG in registers, one cooperative launch, when the mask fits),
  * "cg_resident" (0|1: depth CG as one persistent launch with its state in registers and LDS, when the grid fits one
- * 256 x 64 tile per CU; otherwise, and with 0, one operator + one update kernel per step), "light_grouped" (0|1),
+ * 256 x 64 tile per CU; otherwise, and with 0, one operator + one update kernel per step), "light_grouped" (0|1), "light_channel_inner" (0|1),
  * "light_blocks" (0 = automatic), "coop_launch" (0 plain | 1 hipLaunchCooperativeKernel | 2 cooperative only when the process has several contexts on the device),
  * "albedo_one_sync" (0|1: persistent albedo CG with one grid-wide wait per step),
  * "cg_one_sync" (0|1: resident CG with one grid-wide wait per step),

@@ -405,6 +405,135 @@ __global__ __launch_bounds__(256) void k_light_grouped(const float* __restrict__
     }
 }
 
+// The fused energy + lighting sweep with the channels in the INNER loop (NCH = C known at compile time): the six geometry
+// planes are loaded and the normal is formed once per pixel and image group instead of once per channel (k_light_grouped:
+// 12 reads of the geometry per pixel, about a third of them from HBM).  Same arithmetic, same sums, same bits as
+// k_light_grouped<V, IBW, true>; the Gram matrix of channel c is accumulated by image group c.
+template <int V, int IBW, int NCH>
+__global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict__ rho, const float* __restrict__ I, int P, int n_img,
+                                                          int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
+                                                          EnergyArgs ea) {
+    constexpr int C = NCH;
+    __shared__ float sme[16];
+    __shared__ float smr[4][NCH * IBW * 4 + 10];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, t8 = blockIdx.x >> 3;
+    const int grp = t8 & 3;
+    const int blk = (t8 >> 2) * 8 + xcd;                    // pixel range
+    if (blk * chunk >= P) { if (tid == 0) ea.part_e[blockIdx.x] = 0.f; return; }
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
+    for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
+        const int ib = b0 + grp * IBW;                     // first image of this block (may be past the end: nothing stored)
+        const int gram_c = (b0 == 0 && grp < NCH) ? grp : -1;      // the channel whose Gram matrix this block accumulates
+        float acc[NCH][IBW][4];
+        float g[10];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c][ii][k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) g[t] = 0.f;
+        for (int q = p0 + tid * V; q < p1; q += 256 * V) {
+            Vec<V> nk[3], T[3];
+            const Vec<V> vdz = ldv<V>(ea.dz + q);
+            {
+                const Vec<V> vxx = ldv<V>(ea.xx + q), vyy = ldv<V>(ea.yy + q);
+                const Vec<V> vz = ldv<V>(ea.z + q), vzx = ldv<V>(ea.zx + q), vzy = ldv<V>(ea.zy + q);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float nrm;
+                    perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
+                    T[0].v[e] = ea.fx * vzx.v[e];
+                    T[1].v[e] = ea.fy * vzy.v[e];
+                    T[2].v[e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
+                float a[4][V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    a[0][e] = r.v[e] * nk[0].v[e]; a[1][e] = r.v[e] * nk[1].v[e]; a[2][e] = r.v[e] * nk[2].v[e];       // dc.cu:381
+                    a[3][e] = r.v[e] * 1.f;
+                }
+                Vec<V> iv[IBW];                                      // images past the end re-read the last one
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[c][ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[c][ii][k]);
+                float E[3][V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float vg = r.v[e] / vdz.v[e];
+                    E[0][e] = vg * T[0].v[e];
+                    E[1][e] = vg * T[1].v[e];
+                    E[2][e] = -vg * T[2].v[e];
+                }
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii) {
+                    if (ib + ii < n_img) {                                   // wave-uniform
+                        const float* sv = ea.s + ((size_t)(ea.img_offset + ib + ii) * C + c) * 4;
+                        const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float res = fmaf(E[0][e], s0, fmaf(E[1][e], s1, fmaf(E[2][e], s2, fmaf(r.v[e], s3, -iv[ii].v[e]))));
+                            e_acc = fmaf(res, res, e_acc);
+                        }
+                    }
+                }
+                if (c == gram_c) {                                           // wave-uniform
+                    int t = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int l = k; l < 4; ++l) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                            ++t;
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = wave_sum(acc[c][ii][k]);
+                    if (lane == 0) smr[wv][(c * IBW + ii) * 4 + k] = v;
+                }
+        if (gram_c >= 0) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float v = wave_sum(g[t]);
+                if (lane == 0) smr[wv][NCH * IBW * 4 + t] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < NCH * IBW * 4) {
+            const int c = tid / (IBW * 4), ii = (tid / 4) % IBW, k = tid & 3;
+            if (ib + ii < n_img)
+                part_atb[(((size_t)blk * n_img + ib + ii) * C + c) * 4 + k] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
+        } else if (gram_c >= 0 && tid < NCH * IBW * 4 + 10) {
+            part_g[((size_t)blk * C + gram_c) * 10 + (tid - NCH * IBW * 4)] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
+        }
+        __syncthreads();
+    }
+    const float t = block_sum(e_acc, sme);
+    if (tid == 0) ea.part_e[blockIdx.x] = t;
+}
+
 // one wave per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
 // The 64 lanes add the per-block partial sums (fixed order, double), lane 0 runs the 4x4 CG.
 __global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
@@ -506,6 +635,14 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
     if (ctx->light_grouped && L.V == 4) {
         const int ibw = std::min(5, cdiv(n_local, 4));
         const int nb4 = cdiv(L.nblk, 8) * 8 * 4;            // four image groups per pixel range, ranges in sets of 8 (one per XCD)
+        if (ENERGY && ctx->light_channel_inner && (C == 1 || C == 3)) {
+#define SRPS_LCI(BB, CC) hipLaunchKernelGGL((k_light_fused_ci<4, BB, CC>), dim3(nb4), dim3(256), 0, ctx->stream, d_rho, d_I, P, n_local, L.chunk, L.part_atb, L.part_g, ea)
+            if (C == 3) { switch (ibw) { case 1: SRPS_LCI(1, 3); break; case 2: SRPS_LCI(2, 3); break; case 3: SRPS_LCI(3, 3); break; case 4: SRPS_LCI(4, 3); break; default: SRPS_LCI(5, 3); } }
+            else { switch (ibw) { case 1: SRPS_LCI(1, 1); break; case 2: SRPS_LCI(2, 1); break; case 3: SRPS_LCI(3, 1); break; case 4: SRPS_LCI(4, 1); break; default: SRPS_LCI(5, 1); } }
+#undef SRPS_LCI
+            SRPS_LAUNCH_CHECK();
+            return SRPS_OK;
+        }
 #define SRPS_LGR(BB) hipLaunchKernelGGL((k_light_grouped<4, BB, ENERGY>), dim3(nb4), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, L.chunk, L.part_atb, L.part_g, ea)
         switch (ibw) { case 1: SRPS_LGR(1); break; case 2: SRPS_LGR(2); break; case 3: SRPS_LGR(3); break; case 4: SRPS_LGR(4); break; default: SRPS_LGR(5); }
 #undef SRPS_LGR

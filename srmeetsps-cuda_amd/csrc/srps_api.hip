@@ -273,6 +273,9 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         SRPS_REQUIRE(value >= 0 && value <= 65536, SRPS_ERR_INVALID, "light_blocks: bad value %d", value);
         ctx->light_blocks = value;
         ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "light_channel_inner")) {
+        ctx->light_channel_inner = value ? 1 : 0;
+        ctx->light_cache_valid = false;
     } else if (!strcmp(name, "light_grouped")) {
         ctx->light_grouped = value ? 1 : 0;
         ctx->light_cache_valid = false;

@@ -118,6 +118,7 @@ struct srps_ctx {
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
     int fuse_energy_lighting = 1;
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
+    int light_channel_inner = 1;     // fused energy + lighting sweep with the channels in the inner loop (C in {1, 3})
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 2;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (one cooperative queue per
                                      // device: two such kernels of this process cannot interleave their blocks and wait for each
