@@ -37,11 +37,12 @@ int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact) {
 // zx = Dx z, zy = Dy z  (rows of make_gradient, SRPS.cu:29-47) -> compact outputs
 // ---------------------------------------------------------------------------------------------
 __global__ void k_gradient(const float* __restrict__ zg, const uint8_t* __restrict__ flags, const int* __restrict__ gofp,
-                           int P, int Hs, float* __restrict__ zx, float* __restrict__ zy) {
+                           int P, int Hs, float* __restrict__ zx, float* __restrict__ zy, float* __restrict__ zc /* may be null */) {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const int g = gofp[p];
         const uint8_t fl = flags[g];
         const float xc = zg[g];
+        if (zc) zc[p] = xc;                                 // the gather of the plane into the compact layout, in the same pass
         float gx = 0.f, gy = 0.f;
         if (fl & F_FX) gx = zg[g + Hs] - xc; else if (fl & F_BX) gx = xc - zg[g - Hs];
         if (fl & F_FY) gy = zg[g + 1] - xc; else if (fl & F_BY) gy = xc - zg[g - 1];
@@ -49,9 +50,9 @@ __global__ void k_gradient(const float* __restrict__ zg, const uint8_t* __restri
         zy[p] = gy;
     }
 }
-int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy) {
+int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy, float* d_compact) {
     Grid& G = ctx->grid;
-    hipLaunchKernelGGL(k_gradient, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_plane, G.d_flags, G.d_gofp, G.P, G.Hs, d_zx, d_zy);
+    hipLaunchKernelGGL(k_gradient, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_plane, G.d_flags, G.d_gofp, G.P, G.Hs, d_zx, d_zy, d_compact);
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
 }

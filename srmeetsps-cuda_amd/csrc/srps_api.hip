@@ -154,8 +154,7 @@ static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float
     if (!plane_current) SRPS_TRY(grid_scatter(ctx, d_z, G.d_x));      // the last solve left z on the grid plane
     SRPS_TRY(grid_rhs(ctx, d_z0s));                               // dc.cu:743-745
     SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:758-759 (residual; k <= max_iter => 101 steps)
-    SRPS_TRY(grid_gather(ctx, G.d_x, d_z));
-    SRPS_TRY(grid_gradient(ctx, G.d_x, d_zx, d_zy));              // Dx z, Dy z of the NEW z (energy + normals)
+    SRPS_TRY(grid_gradient(ctx, G.d_x, d_zx, d_zy, d_z));         // the new z in the compact layout, and Dx z, Dy z (energy + normals)
     SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 64, G.d_scal, sizeof(CgScalars), hipMemcpyDeviceToHost, ctx->stream));
     return SRPS_OK;
 }

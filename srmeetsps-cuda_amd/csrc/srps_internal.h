@@ -198,7 +198,7 @@ bool resident_supported(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
 int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact);
-int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy);
+int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy, float* d_compact = nullptr);      // also gathers the plane when d_compact is given
 int grid_rhs(srps_ctx* ctx, const float* d_z0s);                 // r = KT' z0s + lambda (Dx'q0 + Dy'q1 + q2)
 int grid_residual(srps_ctx* ctx);                                // r -= A_ x ; rr_part[0]
 int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
