@@ -949,11 +949,19 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
                 r0 = r1;
                 r1 = (float)s_rr;
                 const float beta = r1 / r0;
-                pw = s_rdr + 2.0 * (double)beta * s_rdp + (double)beta * (double)beta * pw;
+                const double t_sq = s_rdr + (double)beta * (double)beta * pw;      // >= |2 beta r.Dp| (Cauchy-Schwarz)
+                pw = t_sq + 2.0 * (double)beta * s_rdp;
+                float a_pdp = 0.f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) p[j].e[e] = scal_then_axpy(beta, p[j].e[e], r[j].e[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        p[j].e[e] = scal_then_axpy(beta, p[j].e[e], r[j].e[e]);
+                        a_pdp = fmaf(p[j].e[e], d[j].e[e] * p[j].e[e], a_pdp);
+                    }
+                // guard: when the three terms cancel two digits the product is summed directly (one more wait; every block
+                // holds the same numbers, so the decision is uniform)
+                if (!(pw > 1e-2 * t_sq) && r1 > tol2) pw = (double)grid_sum(a_pdp, ent, ++gen, sm);
             }
         } else {
         r1 = grid_sum(acc, ent, ++gen, sm);
