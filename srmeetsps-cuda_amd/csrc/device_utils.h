@@ -195,6 +195,20 @@ __device__ __forceinline__ float scal_then_axpy(float beta, float p, float r) {
     return t + r;
 }
 
+// ---- perspective normal (devicecalls.cu:171-223) -----------------------------------------------
+// Shared by k_normals and the fused energy + lighting pass, which must produce the same bits: every
+// multiply-add is spelled out so that the compiler's contraction choices cannot differ between the two.
+__device__ __forceinline__ void perspective_normal(float fx, float fy, float z, float gx, float gy, float x, float y,
+                                                   float& n0, float& n1, float& n2, float& nrm) {
+    const float u0 = fx * gx;                                      // dc.cu:204
+    const float u1 = fy * gy;                                      // dc.cu:211
+    const float u2 = fmaf(-y, gy, fmaf(-x, gx, -z));               // dc.cu:174
+    nrm = fmaxf(1e-10f, sqrtf(fmaf(u2, u2, fmaf(u1, u1, u0 * u0))));   // dc.cu:182
+    n0 = u0 / nrm;                                                 // dc.cu:190
+    n1 = u1 / nrm;
+    n2 = u2 / nrm;
+}
+
 // ---- V-wide loads of consecutive floats (V = 1, 2 or 4) ---------------------------------------
 template <int V>
 struct Vec {

@@ -1,0 +1,408 @@
+// kernels_albedo.hip -- albedo estimation (devicecalls.cu:447-548): the per-pixel sums over the images, then the reference's
+// CG on the diagonal system: persistent (in registers, one launch) for masks up to 5.2 M pixels, one kernel per half step
+// otherwise, or the fixed point num / den.
+#include "srps_internal.h"
+#include "device_utils.h"
+
+namespace srps {
+
+// =============================================================================================
+// albedo (reference: devicecalls.cu:447-548)
+//   sh_i[p] = N[:,p] . s_ic  (sgemm dc.cu:507);  num = sum_i sh_i I_ic, den = sum_i sh_i^2
+//   (the diagonal A'A and A'b of dc.cu:395-406);  then the reference's global CG on the
+//   diagonal system from the warm start rho_c (dc.cu:540), or its fixed point num/den.
+// =============================================================================================
+template <int V>
+__global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__ s, const float* __restrict__ N,
+                                                       const float* __restrict__ I, int P, int n_local, int C,
+                                                       int s_img_offset, float* __restrict__ num, float* __restrict__ den) {
+    const int q = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (q >= P) return;
+    Vec<V> nk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+    for (int c = 0; c < C; ++c) {
+        Vec<V> nu, de;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { nu.v[e] = 0.f; de.v[e] = 0.f; }
+#pragma unroll 4
+        for (int i = 0; i < n_local; ++i) {
+            const float* sv = s + ((size_t)(s_img_offset + i) * C + c) * 4;      // uniform -> scalar loads
+            const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+            const Vec<V> iv = ldv<V>(I + ((size_t)i * C + c) * P + q);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float sh = nk[0].v[e] * s0 + nk[1].v[e] * s1 + nk[2].v[e] * s2 + nk[3].v[e] * s3;
+                nu.v[e] = fmaf(sh, iv.v[e], nu.v[e]);
+                de.v[e] = fmaf(sh, sh, de.v[e]);
+            }
+        }
+        stv<V>(num + (size_t)c * P + q, nu);
+        stv<V>(den + (size_t)c * P + q, de);
+    }
+}
+
+int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
+                  int C, int s_img_offset, float* d_numden) {
+    float* num = d_numden;
+    float* den = d_numden + (size_t)C * P;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_numden) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL((k_albedo_numden<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den);
+    else
+        hipLaunchKernelGGL((k_albedo_numden<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+__global__ void k_albedo_closed(float* __restrict__ rho, const float* __restrict__ num, const float* __restrict__ den, size_t n) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const float d = den[t];
+        if (d > 0.f) rho[t] = num[t] / d;
+    }
+}
+
+struct DcgScal {
+    float r0;
+    int iters;
+    int active;
+    int pad;
+};
+
+// r = num - den*rho (dc.cu:404-405); rr_part[c][0][blk] = sum r^2
+template <int V>
+__global__ __launch_bounds__(256) void k_dcg_init(const float* __restrict__ rho, const float* __restrict__ num,
+                                                  const float* __restrict__ den, int P, float* __restrict__ r,
+                                                  float* __restrict__ rr_part, int nb, DcgScal* __restrict__ scal) {
+    __shared__ float sm[16];
+    const int c = blockIdx.y;
+    const size_t base = (size_t)c * P;
+    float acc = 0.f;
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * V; p < P; p += nb * 256 * V) {
+        const Vec<V> vn = ldv<V>(num + base + p), vd = ldv<V>(den + base + p), vx = ldv<V>(rho + base + p);
+        Vec<V> vr;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { vr.v[e] = vn.v[e] - vd.v[e] * vx.v[e]; acc = fmaf(vr.v[e], vr.v[e], acc); }
+        stv<V>(r + base + p, vr);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        rr_part[((size_t)c * 2 + 0) * nb + blockIdx.x] = t;
+        if (blockIdx.x == 0) { scal[c].r0 = 0.f; scal[c].iters = 0; scal[c].active = 1; }
+    }
+}
+
+// first half of CG step k: p = beta p + r ; partial p.(d p)
+template <int V>
+__global__ __launch_bounds__(256) void k_dcg_a(int k, const float* __restrict__ den, const float* __restrict__ r,
+                                               float* __restrict__ p, int P, const float* __restrict__ rr_part,
+                                               float* __restrict__ pw_part, int nb, DcgScal* __restrict__ scal, float tol2) {
+    __shared__ float sm[16];
+    __shared__ double smd[4];
+    const int c = blockIdx.y;
+    const float r1 = (float)sum_partials(rr_part + ((size_t)c * 2 + ((k - 1) & 1)) * nb, nb, smd);
+    if (!(r1 > tol2)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[c].active = 0;
+        return;
+    }
+    const float beta = (k == 1) ? 0.f : r1 / scal[c].r0;
+    const size_t base = (size_t)c * P;
+    float acc = 0.f;
+    for (int q = (blockIdx.x * 256 + threadIdx.x) * V; q < P; q += nb * 256 * V) {
+        const Vec<V> vr = ldv<V>(r + base + q), vd = ldv<V>(den + base + q);
+        Vec<V> vp;
+        if (k == 1) vp = vr;
+        else {
+            vp = ldv<V>(p + base + q);
+#pragma unroll
+            for (int e = 0; e < V; ++e) vp.v[e] = scal_then_axpy(beta, vp.v[e], vr.v[e]);             // dc.cu:263-264
+        }
+        stv<V>(p + base + q, vp);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc = fmaf(vp.v[e], vd.v[e] * vp.v[e], acc);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) pw_part[(size_t)c * nb + blockIdx.x] = t;
+}
+
+// second half: alpha = r1 / p.w ; x += alpha p ; r -= alpha w ; partial r.r
+template <int V>
+__global__ __launch_bounds__(256) void k_dcg_b(int k, const float* __restrict__ den, float* __restrict__ r,
+                                               const float* __restrict__ p, float* __restrict__ x, int P,
+                                               float* __restrict__ rr_part, const float* __restrict__ pw_part, int nb,
+                                               DcgScal* __restrict__ scal, float tol2) {
+    __shared__ float sm[16];
+    __shared__ double smd[4];
+    const int c = blockIdx.y;
+    const float* rr_old = rr_part + ((size_t)c * 2 + ((k - 1) & 1)) * nb;
+    float* rr_new = rr_part + ((size_t)c * 2 + (k & 1)) * nb;
+    const float r1 = (float)sum_partials(rr_old, nb, smd);
+    if (!(r1 > tol2)) {
+        if (threadIdx.x == 0) rr_new[blockIdx.x] = rr_old[blockIdx.x];
+        return;
+    }
+    const float dot = (float)sum_partials(pw_part + (size_t)c * nb, nb, smd);
+    const float alpha = r1 / dot;
+    const size_t base = (size_t)c * P;
+    float acc = 0.f;
+    for (int q = (blockIdx.x * 256 + threadIdx.x) * V; q < P; q += nb * 256 * V) {
+        const Vec<V> vp = ldv<V>(p + base + q), vd = ldv<V>(den + base + q);
+        Vec<V> vx = ldv<V>(x + base + q), vr = ldv<V>(r + base + q);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float w = vd.v[e] * vp.v[e];
+            vx.v[e] = fmaf(alpha, vp.v[e], vx.v[e]);
+            vr.v[e] = fmaf(-alpha, w, vr.v[e]);
+            acc = fmaf(vr.v[e], vr.v[e], acc);
+        }
+        stv<V>(x + base + q, vx);
+        stv<V>(r + base + q, vr);
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        rr_new[blockIdx.x] = t;
+        if (blockIdx.x == 0) { scal[c].r0 = r1; scal[c].iters = k; scal[c].active = 1; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the same CG for masks that fit the register file (P <= CUs * 2048 * 10, i.e. up
+// to 5.2 M pixels on 256 CUs): one cooperative launch, one block of 512 threads per CU, every thread
+// keeps x, r, p and the diagonal of its 4*NV pixels in registers for the whole solve of a channel and
+// the two dot products of a step are grid-wide reductions (grid_sum below; every block adds the per-block
+// partial sums in the same fixed order, in double). HBM traffic: 16 B per pixel and channel
+// instead of 16 + 40 B per CG step. The element-wise arithmetic is that of k_dcg_init / _a / _b.
+// ---------------------------------------------------------------------------------------------
+struct F4 {
+    float e[4];
+};
+template <int NV, int BT, bool ONE>
+__global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, const float* __restrict__ num,
+                                                         const float* __restrict__ den, int P, int C,
+                                                         unsigned long long* ent /* [2][gridDim.x], zeroed */,
+                                                         unsigned long long* ent3 /* [2][3][gridDim.x], zeroed */,
+                                                         DcgScal* __restrict__ scal, float tol2, int max_iter) {
+    __shared__ float sm[40];
+    const int nb = gridDim.x, tid = threadIdx.x;
+    unsigned gen = 0;                  // generations start at 1: the entries are zeroed before the launch
+    for (int c = 0; c < C; ++c) {
+        const size_t base = (size_t)c * P;
+        F4 x[NV], r[NV], p[NV], d[NV];
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * BT + tid) * 4;
+            if (q < (size_t)P) {
+                const Vec<4> vn = ldv<4>(num + base + q), vd = ldv<4>(den + base + q), vx = ldv<4>(rho + base + q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[j].e[e] = vx.v[e]; d[j].e[e] = vd.v[e];
+                    r[j].e[e] = vn.v[e] - vd.v[e] * vx.v[e];                      // dc.cu:404-405
+                    acc = fmaf(r[j].e[e], r[j].e[e], acc);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[j].e[e] = 0.f; d[j].e[e] = 0.f; r[j].e[e] = 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[j].e[e] = 0.f;
+        }
+        float r1, r0 = 0.f;
+        int k = 0;
+        if constexpr (ONE) {
+            // One grid-wide wait per step: p.(D p) of the NEXT direction p' = r' + beta p is
+            //   r'.D r' + 2 beta r'.D p + beta^2 p.D p,
+            // and the first two products can be summed together with r'.r' before beta is known.  r.r, the quantity the
+            // stop test looks at, is still summed directly; the solve converges (11 - 15 steps to 1e-9), so the rounding of
+            // the predicted p.(D p) (relative 1e-6) does not reach the result.
+            float a_rdr = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { p[j].e[e] = r[j].e[e]; a_rdr = fmaf(r[j].e[e], d[j].e[e] * r[j].e[e], a_rdr); }      // k = 1: p = r
+            double s_rr, s_pw, s_x;
+            ++gen;
+            grid_sum3_publish(acc, a_rdr, 0.f, ent3, gen);
+            grid_sum3_collect(ent3, gen, s_rr, s_pw, s_x);
+            r1 = (float)s_rr;
+            double pw = s_pw;
+            while (r1 > tol2 && k <= max_iter) {                                  // dc.cu:252
+                ++k;
+                const float alpha = r1 / (float)pw;
+                float a_rr = 0.f, a_rdp = 0.f;
+                a_rdr = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float w = d[j].e[e] * p[j].e[e];
+                        x[j].e[e] = fmaf(alpha, p[j].e[e], x[j].e[e]);
+                        r[j].e[e] = fmaf(-alpha, w, r[j].e[e]);
+                        a_rr = fmaf(r[j].e[e], r[j].e[e], a_rr);
+                        a_rdr = fmaf(r[j].e[e], d[j].e[e] * r[j].e[e], a_rdr);
+                        a_rdp = fmaf(r[j].e[e], w, a_rdp);
+                    }
+                double s_rdr, s_rdp;
+                ++gen;
+                grid_sum3_publish(a_rr, a_rdr, a_rdp, ent3, gen);
+                grid_sum3_collect(ent3, gen, s_rr, s_rdr, s_rdp);
+                r0 = r1;
+                r1 = (float)s_rr;
+                const float beta = r1 / r0;
+                const double t_sq = s_rdr + (double)beta * (double)beta * pw;      // >= |2 beta r.Dp| (Cauchy-Schwarz)
+                pw = t_sq + 2.0 * (double)beta * s_rdp;
+                float a_pdp = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p[j].e[e] = scal_then_axpy(beta, p[j].e[e], r[j].e[e]);
+                        a_pdp = fmaf(p[j].e[e], d[j].e[e] * p[j].e[e], a_pdp);
+                    }
+                // guard: when the three terms cancel two digits the product is summed directly (one more wait; every block
+                // holds the same numbers, so the decision is uniform)
+                if (!(pw > 1e-2 * t_sq) && r1 > tol2) pw = (double)grid_sum(a_pdp, ent, ++gen, sm);
+            }
+        } else {
+        r1 = grid_sum(acc, ent, ++gen, sm);
+        while (r1 > tol2 && k <= max_iter) {                                      // dc.cu:252
+            ++k;
+            const float beta = (k == 1) ? 0.f : r1 / r0;
+            acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[j].e[e] = (k == 1) ? r[j].e[e] : scal_then_axpy(beta, p[j].e[e], r[j].e[e]);
+                    acc = fmaf(p[j].e[e], d[j].e[e] * p[j].e[e], acc);
+                }
+            const float dot = grid_sum(acc, ent, ++gen, sm);
+            const float alpha = r1 / dot;
+            acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float w = d[j].e[e] * p[j].e[e];
+                    x[j].e[e] = fmaf(alpha, p[j].e[e], x[j].e[e]);
+                    r[j].e[e] = fmaf(-alpha, w, r[j].e[e]);
+                    acc = fmaf(r[j].e[e], r[j].e[e], acc);
+                }
+            r0 = r1;
+            r1 = grid_sum(acc, ent, ++gen, sm);
+        }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * BT + tid) * 4;
+            if (q < (size_t)P) {
+                Vec<4> vx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vx.v[e] = x[j].e[e];
+                stv<4>(rho + base + q, vx);
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) { scal[c].r0 = r0; scal[c].iters = k; scal[c].active = (r1 > tol2) ? 1 : 0; }
+    }
+}
+
+// 0 when the persistent form cannot be used (mask too large for the register file, unaligned arrays)
+// blocks of 512 threads (8 waves: cheaper block barriers in the grid-wide sums than 16 waves) with 2, 4 or 8 float4 per
+// thread and array; 10 float4 (160 of 256 registers) for masks up to 5.2 M pixels
+static int dcg_persistent_plan(srps_ctx* ctx, int P, bool vec, int& NV, int& nb) {
+    if (!vec || !ctx->albedo_persistent) return 0;
+    const int cus = ctx->num_cus;
+    for (int cand : {2, 4, 8, 10}) {
+        if ((long long)cand * cus * 2048 >= P) {
+            NV = cand;
+            nb = cdiv(P, cand * 2048);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+// after a stream synchronisation: move the counts of the last persistent albedo solve out of the pinned buffer
+void albedo_iters_collect(srps_ctx* ctx) {
+    if (ctx->albedo_iters_pending <= 0) return;
+    const DcgScal* hs = (const DcgScal*)(ctx->h_pinned + 16);
+    for (int c = 0; c < ctx->albedo_iters_pending; ++c) ctx->last_albedo_iters[c] = hs[c].iters;
+    ctx->albedo_iters_pending = 0;
+}
+
+int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C) {
+    const float* num = d_numden;
+    const float* den = d_numden + (size_t)C * P;
+    SRPS_REQUIRE(C <= 8, SRPS_ERR_UNSUPPORTED, "albedo: at most 8 channels");
+    if (ctx->albedo_mode == SRPS_ALBEDO_CLOSED_FORM) {
+        const size_t n = (size_t)C * P;
+        hipLaunchKernelGGL(k_albedo_closed, dim3(std::min(cdiv((long long)n, 256), 4096)), dim3(256), 0, ctx->stream, d_rho, num, den, n);
+        SRPS_LAUNCH_CHECK();
+        for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = 0;
+        return SRPS_OK;
+    }
+    ctx->albedo_iters_pending = 0;
+    const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
+    const size_t nv = (size_t)C * P;
+    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + (2 + 6) * 1024 * sizeof(unsigned long long) + 256;
+    SRPS_TRY(ensure(ctx->ws_albedo, bytes));
+    float* r = (float*)ctx->ws_albedo.p;
+    float* p = r + nv;
+    float* rr_part = p + nv;                    // [C][2][nb]
+    float* pw_part = rr_part + (size_t)C * 2 * nb;
+    DcgScal* scal = (DcgScal*)(pw_part + (size_t)C * nb);
+    const float tol2 = ctx->cg_tol * ctx->cg_tol;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_numden | (uintptr_t)r) % 16 == 0);
+    DcgScal* hs = (DcgScal*)(ctx->h_pinned + 16);
+    int pNV = 0, pnb = 0;
+    if (dcg_persistent_plan(ctx, P, vec, pNV, pnb)) {
+        // [2][pnb] behind the C <= 8 scalar records, 8-byte aligned
+        unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 7) & ~(uintptr_t)7);
+        unsigned long long* ent3 = ent + 2 * 1024;
+        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 6 * (size_t)pnb) * sizeof(unsigned long long), ctx->stream));
+        float tol2v = tol2;
+        int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
+        float* rho_v = d_rho;
+        void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &ent3, &scal, &tol2v, &maxit};
+#define SRPS_DCG(NVV) (ctx->albedo_one_sync ? (const void*)k_dcg_persistent<NVV, 512, true> : (const void*)k_dcg_persistent<NVV, 512, false>)
+        const void* fn = pNV == 2 ? SRPS_DCG(2) : pNV == 4 ? SRPS_DCG(4) : pNV == 8 ? SRPS_DCG(8) : SRPS_DCG(10);
+#undef SRPS_DCG
+        const int lrc = launch_persistent(ctx, fn, pnb, 512, args, 0);
+        if (lrc == SRPS_ERR_UNSUPPORTED) ctx->albedo_persistent = 0;     // fall through to the streaming form below
+        else {
+            SRPS_TRY(lrc);
+            // no host synchronisation here: the iteration counts are picked up from the pinned buffer the next time the
+            // host waits for the stream anyway (albedo_iters_collect)
+            SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->albedo_iters_pending = C;
+            return SRPS_OK;
+        }
+    }
+    if (vec) hipLaunchKernelGGL(k_dcg_init<4>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
+    else hipLaunchKernelGGL(k_dcg_init<1>, dim3(nb, C), dim3(256), 0, ctx->stream, d_rho, num, den, P, r, rr_part, nb, scal);
+    SRPS_LAUNCH_CHECK();
+    const int kmax = ctx->cg_max_iter + 1;         // "k <= max_iter" => up to max_iter+1 steps (dc.cu:252)
+    for (int k = 1; k <= kmax; ++k) {
+        if (vec) {
+            hipLaunchKernelGGL(k_dcg_a<4>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, P, rr_part, pw_part, nb, scal, tol2);
+            hipLaunchKernelGGL(k_dcg_b<4>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, d_rho, P, rr_part, pw_part, nb, scal, tol2);
+        } else {
+            hipLaunchKernelGGL(k_dcg_a<1>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, P, rr_part, pw_part, nb, scal, tol2);
+            hipLaunchKernelGGL(k_dcg_b<1>, dim3(nb, C), dim3(256), 0, ctx->stream, k, den, r, p, d_rho, P, rr_part, pw_part, nb, scal, tol2);
+        }
+        if ((k % 8) == 0 || k == kmax) {
+            SRPS_LAUNCH_CHECK();
+            SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+            SRPS_HIP(hipStreamSynchronize(ctx->stream));
+            bool any = false;
+            for (int c = 0; c < C; ++c) any |= (hs[c].active != 0) && (hs[c].iters == k);
+            if (!any) break;
+        }
+    }
+    SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = hs[c].iters;
+    return SRPS_OK;
+}
+
+}  // namespace srps

@@ -1,0 +1,581 @@
+// kernels_lighting.hip -- lighting estimation (devicecalls.cu:376-444): one sweep over I[n][c][p] for the Gram matrix and
+// A'I of every (image, channel) -- on the pipeline path fused with the photometric energy of the depth just solved -- and the
+// 4x4 solves.
+#include "srps_internal.h"
+#include "device_utils.h"
+
+namespace srps {
+
+// =============================================================================================
+// lighting (reference: devicecalls.cu:376-444)
+//   per channel c: A_c[p][k] = rho_c[p] N_k[p];  G_c = A_c' A_c (4x4, image independent);
+//   per image i:   ATb_ic = A_c' I_ic;  s_ic <- CG(G_c, warm start s_ic, ATb_ic - G_c s_ic)
+// Pass 1 streams I once and leaves per-block partial sums; pass 2 (one thread per (i,c)) adds
+// them in a fixed order and runs the reference's CG recurrence on the 4x4 system in registers.
+// =============================================================================================
+// With ENERGY the same sweep over I also evaluates the photometric energy of the depth that was just
+// solved (k_energy_partial's sum, with the lighting / albedo / dz the system was built from) and takes the
+// normals of that depth from z, zx, zy instead of reading N: the energy pass of outer iteration k and the
+// lighting pass of iteration k+1 read I once instead of twice.
+struct EnergyArgs {
+    const float *s, *xx, *yy, *dz, *z, *zx, *zy;
+    float fx, fy;
+    int img_offset;
+    float* part_e;
+};
+
+template <int V, int IB, bool ENERGY>
+__global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__ rho, const float* __restrict__ N,
+                                                       const float* __restrict__ I, int P, int n_img, int C, int chunk,
+                                                       float* __restrict__ part_atb, float* __restrict__ part_g,
+                                                       EnergyArgs ea) {
+    __shared__ float sm[4][IB * 4 + 10];
+    __shared__ float sme[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = blockIdx.x;
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        for (int b0 = 0; b0 < n_img; b0 += IB) {
+            float acc[IB][4];
+            float g[10];
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[ii][k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) g[t] = 0.f;
+            for (int q = p0 + tid * V; q < p1; q += 256 * V) {
+                const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
+                Vec<V> nk[4];
+                Vec<V> vxx, vyy, vz, vzx, vzy, vg;
+                if constexpr (ENERGY) {
+                    vxx = ldv<V>(ea.xx + q); vyy = ldv<V>(ea.yy + q);
+                    vz = ldv<V>(ea.z + q); vzx = ldv<V>(ea.zx + q); vzy = ldv<V>(ea.zy + q);
+                    const Vec<V> vdz = ldv<V>(ea.dz + q);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float nrm;
+                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e],
+                                           nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
+                        nk[3].v[e] = 1.f;
+                        vg.v[e] = r.v[e] / vdz.v[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+                }
+                float a[4][V];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a[k][e] = r.v[e] * nk[k].v[e];       // dc.cu:381
+                // All IB loads are issued back to back (no branch between them): images past the end of the
+                // batch re-read the last image (cache hits) and their sums are simply not stored.
+                Vec<V> iv[IB];
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(b0 + ii, n_img - 1) * C + c) * P + q);
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[ii][k]);
+                if constexpr (ENERGY) {
+#pragma unroll
+                    for (int ii = 0; ii < IB; ++ii) {
+                        if (b0 + ii < n_img) {                                   // wave-uniform
+                            const float* sv = ea.s + ((size_t)(ea.img_offset + b0 + ii) * C + c) * 4;
+                            const float s2 = sv[2], s3 = sv[3];
+                            const float fs0 = ea.fx * sv[0], fs1 = ea.fy * sv[1];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                const float a1 = vg.v[e] * (fs0 - vxx.v[e] * s2);
+                                const float a2 = vg.v[e] * (fs1 - vyy.v[e] * s2);
+                                const float a3 = vg.v[e] * s2;
+                                const float b = iv[ii].v[e] - r.v[e] * s3;
+                                const float res = a1 * vzx.v[e] + a2 * vzy.v[e] - a3 * vz.v[e] - b;
+                                e_acc = fmaf(res, res, e_acc);
+                            }
+                        }
+                    }
+                }
+                if (b0 == 0) {
+                    int t = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int l = k; l < 4; ++l) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                            ++t;
+                        }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = wave_sum(acc[ii][k]);
+                    if (lane == 0) sm[wv][ii * 4 + k] = v;
+                }
+            if (b0 == 0) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    const float v = wave_sum(g[t]);
+                    if (lane == 0) sm[wv][IB * 4 + t] = v;
+                }
+            }
+            __syncthreads();
+            if (tid < IB * 4) {
+                const int ii = tid >> 2, k = tid & 3;
+                if (b0 + ii < n_img)
+                    part_atb[(((size_t)blk * n_img + b0 + ii) * C + c) * 4 + k] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+            } else if (b0 == 0 && tid < IB * 4 + 10) {
+                part_g[((size_t)blk * C + c) * 10 + (tid - IB * 4)] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+            }
+            __syncthreads();
+        }
+    }
+    if constexpr (ENERGY) {
+        const float t = block_sum(e_acc, sme);
+        if (tid == 0) ea.part_e[blk] = t;
+    }
+}
+
+// The same sums with the images dealt to four BLOCKS per pixel range (image group g of every batch of 4*IBW images): the four
+// waves of a block read 4 KiB of consecutive pixels of each plane, with 20 accumulators per thread instead of 80 (the kernel
+// above holds 209 registers in its fused form, two waves per SIMD).  The four blocks of a pixel range are dispatched next to each other on the same XCD
+// (block id -> (range, group) below), so that part of the geometry re-reads hit the L2 (PMC: 1.42 GB fetched per sweep against
+// 1.16 GB touched; the sweep runs at 5.3 TB/s of fabric traffic).
+template <int V, int IBW, bool ENERGY>
+__global__ __launch_bounds__(256) void k_light_grouped(const float* __restrict__ rho, const float* __restrict__ N,
+                                                         const float* __restrict__ I, int P, int n_img, int C, int chunk,
+                                                         float* __restrict__ part_atb, float* __restrict__ part_g,
+                                                         EnergyArgs ea) {
+    __shared__ float sme[16];
+    __shared__ float smr[4][IBW * 4 + 10];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blocks b, b+8, ... share an XCD: the four image groups of a pixel range are 8 apart in dispatch order
+    const int xcd = blockIdx.x & 7, t8 = blockIdx.x >> 3;
+    const int grp = t8 & 3;
+    const int blk = (t8 >> 2) * 8 + xcd;                    // pixel range
+    if (blk * chunk >= P) { if (ENERGY && tid == 0) ea.part_e[blockIdx.x] = 0.f; return; }
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
+            const int ib = b0 + grp * IBW;                 // first image of this block (may be past the end: nothing stored)
+            const bool gram = (b0 == 0 && grp == 0);
+            float acc[IBW][4];
+            float g[10];
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[ii][k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) g[t] = 0.f;
+            for (int q = p0 + tid * V; q < p1; q += 256 * V) {
+                const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
+                Vec<V> nk[4];
+                Vec<V> vxx, vyy, vz, vzx, vzy, vg;
+                if constexpr (ENERGY) {
+                    vxx = ldv<V>(ea.xx + q); vyy = ldv<V>(ea.yy + q);
+                    vz = ldv<V>(ea.z + q); vzx = ldv<V>(ea.zx + q); vzy = ldv<V>(ea.zy + q);
+                    const Vec<V> vdz = ldv<V>(ea.dz + q);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float nrm;
+                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e],
+                                           nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
+                        nk[3].v[e] = 1.f;
+                        vg.v[e] = r.v[e] / vdz.v[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+                }
+                float a[4][V];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a[k][e] = r.v[e] * nk[k].v[e];       // dc.cu:381
+                Vec<V> iv[IBW];                                      // images past the end re-read the last one
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[ii][k]);
+                if constexpr (ENERGY) {
+                    // residual a1 zx + a2 zy - a3 z - (I - rho s3) of k_energy_partial, factored by the lighting vector:
+                    // (g fx zx) s0 + (g fy zy) s1 - g (xx zx + yy zy + z) s2 + rho s3 - I   (5 instead of 11 operations per image)
+                    float E[3][V];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        E[0][e] = vg.v[e] * (ea.fx * vzx.v[e]);
+                        E[1][e] = vg.v[e] * (ea.fy * vzy.v[e]);
+                        E[2][e] = -vg.v[e] * fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < IBW; ++ii) {
+                        if (ib + ii < n_img) {                                   // wave-uniform
+                            const float* sv = ea.s + ((size_t)(ea.img_offset + ib + ii) * C + c) * 4;
+                            const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                const float res = fmaf(E[0][e], s0, fmaf(E[1][e], s1, fmaf(E[2][e], s2, fmaf(r.v[e], s3, -iv[ii].v[e]))));
+                                e_acc = fmaf(res, res, e_acc);
+                            }
+                        }
+                    }
+                }
+                if (gram) {                                                      // wave-uniform
+                    int t = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int l = k; l < 4; ++l) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                            ++t;
+                        }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = wave_sum(acc[ii][k]);
+                    if (lane == 0) smr[wv][ii * 4 + k] = v;
+                }
+            if (gram) {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    const float v = wave_sum(g[t]);
+                    if (lane == 0) smr[wv][IBW * 4 + t] = v;
+                }
+            }
+            __syncthreads();
+            if (tid < IBW * 4) {
+                const int ii = tid >> 2, k = tid & 3;
+                if (ib + ii < n_img)
+                    part_atb[(((size_t)blk * n_img + ib + ii) * C + c) * 4 + k] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
+            } else if (gram && tid < IBW * 4 + 10) {
+                part_g[((size_t)blk * C + c) * 10 + (tid - IBW * 4)] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
+            }
+            __syncthreads();
+        }
+    }
+    if constexpr (ENERGY) {
+        const float t = block_sum(e_acc, sme);
+        if (tid == 0) ea.part_e[blockIdx.x] = t;
+    }
+}
+
+// The fused energy + lighting sweep with the channels in the INNER loop (NCH = C known at compile time): the six geometry
+// planes are loaded and the normal is formed once per pixel and image group instead of once per channel (k_light_grouped:
+// 12 reads of the geometry per pixel, about a third of them from HBM).  Same arithmetic, same sums, same bits as
+// k_light_grouped<V, IBW, true>; the Gram matrix of channel c is accumulated by image group c.
+template <int V, int IBW, int NCH>
+__global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict__ rho, const float* __restrict__ I, int P, int n_img,
+                                                          int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
+                                                          EnergyArgs ea) {
+    constexpr int C = NCH;
+    __shared__ float sme[16];
+    __shared__ float smr[4][NCH * IBW * 4 + 10];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, t8 = blockIdx.x >> 3;
+    const int grp = t8 & 3;
+    const int blk = (t8 >> 2) * 8 + xcd;                    // pixel range
+    if (blk * chunk >= P) { if (tid == 0) ea.part_e[blockIdx.x] = 0.f; return; }
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
+    for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
+        const int ib = b0 + grp * IBW;                     // first image of this block (may be past the end: nothing stored)
+        const int gram_c = (b0 == 0 && grp < NCH) ? grp : -1;      // the channel whose Gram matrix this block accumulates
+        float acc[NCH][IBW][4];
+        float g[10];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c][ii][k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) g[t] = 0.f;
+        for (int q = p0 + tid * V; q < p1; q += 256 * V) {
+            Vec<V> nk[3], T[3];
+            const Vec<V> vdz = ldv<V>(ea.dz + q);
+            {
+                const Vec<V> vxx = ldv<V>(ea.xx + q), vyy = ldv<V>(ea.yy + q);
+                const Vec<V> vz = ldv<V>(ea.z + q), vzx = ldv<V>(ea.zx + q), vzy = ldv<V>(ea.zy + q);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float nrm;
+                    perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
+                    T[0].v[e] = ea.fx * vzx.v[e];
+                    T[1].v[e] = ea.fy * vzy.v[e];
+                    T[2].v[e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
+                float a[4][V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    a[0][e] = r.v[e] * nk[0].v[e]; a[1][e] = r.v[e] * nk[1].v[e]; a[2][e] = r.v[e] * nk[2].v[e];       // dc.cu:381
+                    a[3][e] = r.v[e] * 1.f;
+                }
+                Vec<V> iv[IBW];                                      // images past the end re-read the last one
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[c][ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[c][ii][k]);
+                float E[3][V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float vg = r.v[e] / vdz.v[e];
+                    E[0][e] = vg * T[0].v[e];
+                    E[1][e] = vg * T[1].v[e];
+                    E[2][e] = -vg * T[2].v[e];
+                }
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii) {
+                    if (ib + ii < n_img) {                                   // wave-uniform
+                        const float* sv = ea.s + ((size_t)(ea.img_offset + ib + ii) * C + c) * 4;
+                        const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float res = fmaf(E[0][e], s0, fmaf(E[1][e], s1, fmaf(E[2][e], s2, fmaf(r.v[e], s3, -iv[ii].v[e]))));
+                            e_acc = fmaf(res, res, e_acc);
+                        }
+                    }
+                }
+                if (c == gram_c) {                                           // wave-uniform
+                    int t = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int l = k; l < 4; ++l) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                            ++t;
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = wave_sum(acc[c][ii][k]);
+                    if (lane == 0) smr[wv][(c * IBW + ii) * 4 + k] = v;
+                }
+        if (gram_c >= 0) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float v = wave_sum(g[t]);
+                if (lane == 0) smr[wv][NCH * IBW * 4 + t] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < NCH * IBW * 4) {
+            const int c = tid / (IBW * 4), ii = (tid / 4) % IBW, k = tid & 3;
+            if (ib + ii < n_img)
+                part_atb[(((size_t)blk * n_img + ib + ii) * C + c) * 4 + k] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
+        } else if (gram_c >= 0 && tid < NCH * IBW * 4 + 10) {
+            part_g[((size_t)blk * C + gram_c) * 10 + (tid - NCH * IBW * 4)] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
+        }
+        __syncthreads();
+    }
+    const float t = block_sum(e_acc, sme);
+    if (tid == 0) ea.part_e[blockIdx.x] = t;
+}
+
+// one wave per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
+// The 64 lanes add the per-block partial sums (fixed order, double), lane 0 runs the 4x4 CG.
+__global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
+                              int n_local, int C, int n_total, int img_offset, int zero_nonlocal,
+                              float* __restrict__ s, int* __restrict__ iters_max, float tol, int max_iter) {
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (t >= n_total * C) return;
+    const int i = t / C, c = t - i * C;
+    const int li = i - img_offset;
+    float* sv = s + (size_t)t * 4;
+    if (li < 0 || li >= n_local) {
+        if (zero_nonlocal && lane < 4) sv[lane] = 0.f;
+        return;
+    }
+    double Gd[10], bd[4];
+    for (int u = 0; u < 10; ++u) Gd[u] = 0.0;
+    for (int k = 0; k < 4; ++k) bd[k] = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        for (int u = 0; u < 10; ++u) Gd[u] += (double)part_g[((size_t)b * C + c) * 10 + u];
+        for (int k = 0; k < 4; ++k) bd[k] += (double)part_atb[(((size_t)b * n_local + li) * C + c) * 4 + k];
+    }
+    for (int u = 0; u < 10; ++u) Gd[u] = wave_sum(Gd[u]);
+    for (int k = 0; k < 4; ++k) bd[k] = wave_sum(bd[k]);
+    if (lane != 0) return;
+    float A[4][4];
+    {
+        int u = 0;
+        for (int k = 0; k < 4; ++k)
+            for (int l = k; l < 4; ++l) { A[k][l] = (float)Gd[u]; A[l][k] = A[k][l]; ++u; }    // sgemm dc.cu:422
+    }
+    float x[4], r[4], p[4], w[4];
+    for (int k = 0; k < 4; ++k) x[k] = sv[k];
+    for (int k = 0; k < 4; ++k) {                                                          // sgemv dc.cu:423-424
+        float acc = (float)bd[k];
+        for (int l = 0; l < 4; ++l) acc -= A[k][l] * x[l];
+        r[k] = acc;
+    }
+    // cuda_based_conjugate_gradient on the 4x4 system, dc.cu:251-275
+    float r1 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+    float r0 = 0.f;
+    int k = 0;
+    while (r1 > tol * tol && k <= max_iter) {
+        ++k;
+        if (k == 1) {
+            for (int u = 0; u < 4; ++u) p[u] = r[u];
+        } else {
+            const float beta = r1 / r0;
+            for (int u = 0; u < 4; ++u) p[u] = beta * p[u];
+            for (int u = 0; u < 4; ++u) p[u] = p[u] + r[u];
+        }
+        for (int u = 0; u < 4; ++u) w[u] = A[u][0] * p[0] + A[u][1] * p[1] + A[u][2] * p[2] + A[u][3] * p[3];
+        const float dot = p[0] * w[0] + p[1] * w[1] + p[2] * w[2] + p[3] * w[3];
+        const float alpha = r1 / dot;
+        for (int u = 0; u < 4; ++u) x[u] = x[u] + alpha * p[u];
+        for (int u = 0; u < 4; ++u) r[u] = r[u] - alpha * w[u];
+        r0 = r1;
+        r1 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+    }
+    for (int u = 0; u < 4; ++u) sv[u] = x[u];
+    atomicMax(iters_max, k);
+}
+
+struct LightPlan {
+    int V, IB, chunk, nblk;
+    int n_epart;               // energy partial sums the fused sweep leaves (one per launched block)
+    float *part_atb, *part_g;
+    int* d_it;
+};
+static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightPlan& L, bool fused = false) {
+    // images per register batch: the block re-reads rho and N once per batch, so one batch is best
+    L.IB = 4;
+    for (int cand : {4, 8, 12, 16, 20}) { L.IB = cand; if (n_local <= cand) break; }      // n_local > 20: batches of 20
+    // the fused sweep holds 7 more planes per pixel: 2 pixels per thread keep it at 2 waves per SIMD
+    // (334 us against 504 us at 2048^2, 20 images); alone the lighting sweep is faster with 4 (250 / 268 us)
+    L.V = vec ? ((fused && !ctx->light_grouped) ? 2 : 4) : 1;
+    if (ctx->light_grouped && L.V == 4) {
+        // one round of blocks: the sweep keeps 3 (fused, 135 registers) or 5 (96 registers) blocks per CU resident; with
+        // 1024 blocks the last third of the kernel ran at a third of the occupancy
+        const int target = (ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * (fused ? 3 : 5)) / 4;      // pixel ranges
+        const int gran = 256 * L.V;                        // a block covers 256 V pixels per iteration
+        L.chunk = std::max(gran, cdiv(cdiv(P, target), gran) * gran);
+    } else {
+        const int chunk = cdiv(P, 1024);
+        L.chunk = std::max(256 * L.V, cdiv(chunk, 256 * L.V) * 256 * L.V);
+    }
+    L.nblk = cdiv(P, L.chunk);
+    L.n_epart = (ctx->light_grouped && L.V == 4) ? cdiv(L.nblk, 8) * 32 : L.nblk;
+    const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
+    SRPS_TRY(ensure(ctx->ws_light, (n_atb + n_g) * sizeof(float) + 64));
+    L.part_atb = (float*)ctx->ws_light.p;
+    L.part_g = L.part_atb + n_atb;
+    L.d_it = (int*)(L.part_g + n_g);
+    return SRPS_OK;
+}
+template <bool ENERGY>
+static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* d_rho, const float* d_N, const float* d_I,
+                                int P, int n_local, int C, const EnergyArgs& ea) {
+    if (ctx->light_grouped && L.V == 4) {
+        const int ibw = std::min(5, cdiv(n_local, 4));
+        const int nb4 = cdiv(L.nblk, 8) * 8 * 4;            // four image groups per pixel range, ranges in sets of 8 (one per XCD)
+        if (ENERGY && ctx->light_channel_inner && (C == 1 || C == 3)) {
+#define SRPS_LCI(BB, CC) hipLaunchKernelGGL((k_light_fused_ci<4, BB, CC>), dim3(nb4), dim3(256), 0, ctx->stream, d_rho, d_I, P, n_local, L.chunk, L.part_atb, L.part_g, ea)
+            if (C == 3) { switch (ibw) { case 1: SRPS_LCI(1, 3); break; case 2: SRPS_LCI(2, 3); break; case 3: SRPS_LCI(3, 3); break; case 4: SRPS_LCI(4, 3); break; default: SRPS_LCI(5, 3); } }
+            else { switch (ibw) { case 1: SRPS_LCI(1, 1); break; case 2: SRPS_LCI(2, 1); break; case 3: SRPS_LCI(3, 1); break; case 4: SRPS_LCI(4, 1); break; default: SRPS_LCI(5, 1); } }
+#undef SRPS_LCI
+            SRPS_LAUNCH_CHECK();
+            return SRPS_OK;
+        }
+#define SRPS_LGR(BB) hipLaunchKernelGGL((k_light_grouped<4, BB, ENERGY>), dim3(nb4), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, L.chunk, L.part_atb, L.part_g, ea)
+        switch (ibw) { case 1: SRPS_LGR(1); break; case 2: SRPS_LGR(2); break; case 3: SRPS_LGR(3); break; case 4: SRPS_LGR(4); break; default: SRPS_LGR(5); }
+#undef SRPS_LGR
+        SRPS_LAUNCH_CHECK();
+        return SRPS_OK;
+    }
+#define SRPS_LIGHT(VV, BB) hipLaunchKernelGGL((k_light_partial<VV, BB, ENERGY>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, L.chunk, L.part_atb, L.part_g, ea)
+    if (L.V == 4) { if constexpr (!ENERGY) switch (L.IB) { case 4: SRPS_LIGHT(4, 4); break; case 8: SRPS_LIGHT(4, 8); break; case 12: SRPS_LIGHT(4, 12); break; case 16: SRPS_LIGHT(4, 16); break; default: SRPS_LIGHT(4, 20); } }
+    else if (L.V == 2) { if constexpr (ENERGY) switch (L.IB) { case 4: SRPS_LIGHT(2, 4); break; case 8: SRPS_LIGHT(2, 8); break; case 12: SRPS_LIGHT(2, 12); break; case 16: SRPS_LIGHT(2, 16); break; default: SRPS_LIGHT(2, 20); } }
+    else { switch (L.IB) { case 4: SRPS_LIGHT(1, 4); break; case 8: SRPS_LIGHT(1, 8); break; case 12: SRPS_LIGHT(1, 12); break; case 16: SRPS_LIGHT(1, 16); break; default: SRPS_LIGHT(1, 20); } }
+#undef SRPS_LIGHT
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
+// use_cache: the partial sums left by energy_light_fused for exactly these arrays are still in ws_light
+int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
+             int n_local, int C, int n_total, int img_offset, bool zero_nonlocal, bool use_cache) {
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_N | (uintptr_t)d_I) % 16 == 0);
+    LightPlan L;
+    const bool cached = use_cache && ctx->light_cache_valid && ctx->light_cache_normals;
+    ctx->light_cache_valid = false;
+    if (cached) {
+        L = LightPlan{ctx->light_cache_V, 0, 0, ctx->light_cache_nblk, 0, nullptr, nullptr, nullptr};
+        const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
+        L.part_atb = (float*)ctx->ws_light.p;
+        L.part_g = L.part_atb + n_atb;
+        L.d_it = (int*)(L.part_g + n_g);
+    } else {
+        SRPS_TRY(light_plan(ctx, vec, P, n_local, C, L));
+    }
+    SRPS_HIP(hipMemsetAsync(L.d_it, 0, sizeof(int), ctx->stream));
+    if (n_local > 0 && !cached) SRPS_TRY(light_partial_launch<false>(ctx, L, d_rho, d_N, d_I, P, n_local, C, EnergyArgs{}));
+    const int nt = n_total * C;
+    hipLaunchKernelGGL(k_light_solve, dim3(nt), dim3(64), 0, ctx->stream, L.part_atb, L.part_g, L.nblk, n_local, C,
+                       n_total, img_offset, zero_nonlocal ? 1 : 0, d_s, L.d_it, ctx->cg_tol, ctx->cg_max_iter);
+    SRPS_LAUNCH_CHECK();
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 8, L.d_it, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return SRPS_OK;
+}
+
+// Photometric energy of the depth just solved (k_energy_partial's quantity) and, in the same sweep over I, the
+// lighting partial sums of the next outer iteration (normals of the new depth computed in registers). The sums
+// stay in ws_light; lighting(..., use_cache) consumes them.
+int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
+                       const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
+                       float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out) {
+    Grid& G = ctx->grid;
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy |
+                                       (uintptr_t)d_dz | (uintptr_t)d_z | (uintptr_t)d_zx | (uintptr_t)d_zy) % 16 == 0);
+    LightPlan L;
+    SRPS_TRY(light_plan(ctx, vec, P, n_local, C, L, /*fused=*/true));
+    EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part};
+    SRPS_TRY(light_partial_launch<true>(ctx, L, d_rho, nullptr, d_I, P, n_local, C, ea));
+    SRPS_TRY(launch_final_sum(ctx->stream, G.d_misc_part, L.n_epart, d_out));
+    ctx->light_cache_valid = true;
+    ctx->light_cache_normals = false;
+    ctx->light_cache_V = L.V;
+    ctx->light_cache_nblk = L.nblk;
+    return SRPS_OK;
+}
+
+}  // namespace srps

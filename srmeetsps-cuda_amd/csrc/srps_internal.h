@@ -171,6 +171,7 @@ int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask,
 int launch_meshgrid_compact(hipStream_t st, const int* d_imask, int P, int h, float cx, float cy, float* xx, float* yy);
 int launch_meshgrid_full(hipStream_t st, int w, int h, float K02, float K12, float* xx, float* yy);
 int launch_mean_channels(hipStream_t st, const float* d_data, int h, int w, int nc, float* mean, uint8_t* flag);
+int launch_final_sum(hipStream_t st, const float* part, int n, float* out);      // out[0] = sum(part[0..n)), fixed order, double
 int launch_normals(hipStream_t st, const float* z, const float* zx, const float* zy, const float* xx,
                    const float* yy, int P, float fx, float fy, float* N, float* dz);
 int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
