@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Development aid: the default path (persistent kernels, fused sweeps, one wait per step) against the plain path (one kernel per
+half step, separate sweeps) over whole alternating loops on random scenes.  python tools/compare_paths.py [n_cases]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("srmeetsps-cuda_amd"); pkg.load()
+plain = {"cg_resident": 0, "albedo_persistent": 0, "fuse_energy_lighting": 0, "light_grouped": 0}
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+worst = 0.0
+for case in range(n_cases):
+    sf = int(rng.choice([1, 2, 4]))
+    h = int(rng.integers(6, 160)) * 4; w = int(rng.integers(6, 160)) * 4
+    n_img = int(rng.integers(2, 24)); n_ch = int(rng.choice([1, 3]))
+    kind = str(rng.choice(["full", "ellipse", "ragged"]))
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=int(rng.integers(1 << 30)), n_ch=n_ch, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = []
+    for opts in ({}, plain):
+        ctx = pkg.Context(device_id=0)
+        for k, v in opts.items(): ctx.set_option(k, v)
+        ctx.setup(dh)
+        en = pkg.alternating_loop(ctx, None, max_outer=3)
+        out.append((en, ctx.get("z"), ctx.get("rho"), ctx.get("s")))
+        ctx.close()
+    rm = float(np.sqrt(np.mean((out[0][1] - out[1][1]) ** 2)))
+    re = max(abs(a - b) / abs(b) for a, b in zip(out[0][0], out[1][0]))
+    rr = float(np.abs(out[0][2] - out[1][2]).max())
+    worst = max(worst, rm)
+    print(f"{h:4d}x{w:<4d} sf{sf} n{n_img:2d} c{n_ch} {kind:8s} passes {len(out[0][0])}/{len(out[1][0])}  depth rmse {rm:.2e}  energy rel {re:.1e}  albedo max {rr:.1e}", flush=True)
+    assert len(out[0][0]) == len(out[1][0]) and rm < 1e-4 and re < 2e-3, "paths disagree"
+print("worst depth rmse", worst)
