@@ -12,45 +12,63 @@ namespace srps {
 //   (the diagonal A'A and A'b of dc.cu:395-406);  then the reference's global CG on the
 //   diagonal system from the warm start rho_c (dc.cu:540), or its fixed point num/den.
 // =============================================================================================
-template <int V>
+// SUMS: the same sweep also leaves, per channel, the three image sums the depth right-hand side is made of,
+//   SA = sum_i (fx s_i0) I_i,  SA' = sum_i (fy s_i1) I_i,  SB = sum_i s_i2 I_i        (ssum[c][3][P]):
+//   q = sum_{c,i} g tau_i (I_i - rho s_i3), tau_i = (fx s_i0 - xx s_i2, fy s_i1 - yy s_i2, -s_i2)      (dc.cu:588-610)
+//     = sum_c g [ (SA - xx SB, SA' - yy SB, -SB) - rho (CA - xx CB, CA' - yy CB, -CB) ],  C. = the same sums of s_i3,
+// so that the depth assembly after the albedo step needs no second pass over I (k_depth_from_sums).
+template <int V, bool SUMS>
 __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__ s, const float* __restrict__ N,
                                                        const float* __restrict__ I, int P, int n_local, int C,
-                                                       int s_img_offset, float* __restrict__ num, float* __restrict__ den) {
+                                                       int s_img_offset, float* __restrict__ num, float* __restrict__ den,
+                                                       float fx, float fy, float* __restrict__ ssum) {
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
     if (q >= P) return;
     Vec<V> nk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
     for (int c = 0; c < C; ++c) {
-        Vec<V> nu, de;
+        Vec<V> nu, de, sa, sap, sb;
 #pragma unroll
-        for (int e = 0; e < V; ++e) { nu.v[e] = 0.f; de.v[e] = 0.f; }
+        for (int e = 0; e < V; ++e) { nu.v[e] = 0.f; de.v[e] = 0.f; sa.v[e] = 0.f; sap.v[e] = 0.f; sb.v[e] = 0.f; }
 #pragma unroll 4
         for (int i = 0; i < n_local; ++i) {
             const float* sv = s + ((size_t)(s_img_offset + i) * C + c) * 4;      // uniform -> scalar loads
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+            const float fs0 = fx * s0, fs1 = fy * s1;
             const Vec<V> iv = ldv<V>(I + ((size_t)i * C + c) * P + q);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float sh = nk[0].v[e] * s0 + nk[1].v[e] * s1 + nk[2].v[e] * s2 + nk[3].v[e] * s3;
                 nu.v[e] = fmaf(sh, iv.v[e], nu.v[e]);
                 de.v[e] = fmaf(sh, sh, de.v[e]);
+                if (SUMS) {
+                    sa.v[e] = fmaf(fs0, iv.v[e], sa.v[e]);
+                    sap.v[e] = fmaf(fs1, iv.v[e], sap.v[e]);
+                    sb.v[e] = fmaf(s2, iv.v[e], sb.v[e]);
+                }
             }
         }
         stv<V>(num + (size_t)c * P + q, nu);
         stv<V>(den + (size_t)c * P + q, de);
+        if (SUMS) {
+            stv<V>(ssum + ((size_t)c * 3 + 0) * P + q, sa);
+            stv<V>(ssum + ((size_t)c * 3 + 1) * P + q, sap);
+            stv<V>(ssum + ((size_t)c * 3 + 2) * P + q, sb);
+        }
     }
 }
 
+// ssum != null: also the image sums of the depth right-hand side (fx, fy needed)
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
-                  int C, int s_img_offset, float* d_numden) {
+                  int C, int s_img_offset, float* d_numden, float fx, float fy, float* d_ssum) {
     float* num = d_numden;
     float* den = d_numden + (size_t)C * P;
-    const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_numden) % 16 == 0);
-    if (vec)
-        hipLaunchKernelGGL((k_albedo_numden<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den);
-    else
-        hipLaunchKernelGGL((k_albedo_numden<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den);
+    const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_numden | (uintptr_t)d_ssum) % 16 == 0);
+#define SRPS_NUMDEN(VV, SS, NB) hipLaunchKernelGGL((k_albedo_numden<VV, SS>), dim3(NB), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum)
+    if (vec) { if (d_ssum) SRPS_NUMDEN(4, true, cdiv(P, 1024)); else SRPS_NUMDEN(4, false, cdiv(P, 1024)); }
+    else { if (d_ssum) SRPS_NUMDEN(1, true, cdiv(P, 256)); else SRPS_NUMDEN(1, false, cdiv(P, 256)); }
+#undef SRPS_NUMDEN
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
 }

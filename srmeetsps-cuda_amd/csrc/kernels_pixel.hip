@@ -211,6 +211,90 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
     }
 }
 
+// The same assembly without the pass over I: the image sums SA, SA', SB of every channel were left by the albedo sweep
+// (k_albedo_numden<., true>), qc[c] = (CA, CA', CB) are the corresponding sums of s_i3 over this rank's images.
+template <int V>
+__global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict__ s, const float* __restrict__ rho,
+                                                         const float* __restrict__ ssum, const float* __restrict__ qc,
+                                                         const float* __restrict__ xx, const float* __restrict__ yy,
+                                                         const float* __restrict__ dz, float fx, float fy, int P, int C, int n_total,
+                                                         const int* __restrict__ gofp, size_t plane,
+                                                         float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp) {
+    const int q = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (q >= P) return;
+    const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
+    float m[6][V], qq[3][V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) m[t][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) qq[t][e] = 0.f;
+    }
+    for (int c = 0; c < C; ++c) {
+        const Vec<V> vr = ldv<V>(rho + (size_t)c * P + q);
+        const Vec<V> sa = ldv<V>(ssum + ((size_t)c * 3 + 0) * P + q), sap = ldv<V>(ssum + ((size_t)c * 3 + 1) * P + q),
+                     sb = ldv<V>(ssum + ((size_t)c * 3 + 2) * P + q);
+        const float ca = qc[c * 4 + 0], cap = qc[c * 4 + 1], cb = qc[c * 4 + 2];
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = vr.v[e] / vdz.v[e];
+        if (Gp) {                                                            // g_c^2 for the tensor-recompute operator
+#pragma unroll
+            for (int e = 0; e < V; ++e) Gp[(size_t)c * plane + gofp[q + e]] = g[e] * g[e];
+        }
+        if (M) {                                                             // stored tensor (no image data), as in k_depth_assemble
+            for (int i = 0; i < n_total; ++i) {
+                const float* sv = s + ((size_t)i * C + c) * 4;
+                const float s0 = sv[0], s1 = sv[1], s2 = sv[2];
+                const float fs0 = fx * s0, fs1 = fy * s1;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float v0 = g[e] * (fs0 - vxx.v[e] * s2);
+                    const float v1 = g[e] * (fs1 - vyy.v[e] * s2);
+                    const float v2 = -(g[e] * s2);
+                    m[0][e] = fmaf(v0, v0, m[0][e]);
+                    m[1][e] = fmaf(v0, v1, m[1][e]);
+                    m[2][e] = fmaf(v0, v2, m[2][e]);
+                    m[3][e] = fmaf(v1, v1, m[3][e]);
+                    m[4][e] = fmaf(v1, v2, m[4][e]);
+                    m[5][e] = fmaf(v2, v2, m[5][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float t0 = fmaf(-vxx.v[e], sb.v[e], sa.v[e]), t1 = fmaf(-vyy.v[e], sb.v[e], sap.v[e]), t2 = -sb.v[e];
+            const float u0 = fmaf(-vxx.v[e], cb, ca), u1 = fmaf(-vyy.v[e], cb, cap), u2 = -cb;
+            qq[0][e] = fmaf(g[e], fmaf(-vr.v[e], u0, t0), qq[0][e]);
+            qq[1][e] = fmaf(g[e], fmaf(-vr.v[e], u1, t1), qq[1][e]);
+            qq[2][e] = fmaf(g[e], fmaf(-vr.v[e], u2, t2), qq[2][e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int go = gofp[q + e];
+        if (M) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) Q[(size_t)t * plane + go] = qq[t][e];
+    }
+}
+
+// qc[c] = (sum_i fx s_i0 s_i3, sum_i fy s_i1 s_i3, sum_i s_i2 s_i3, 0) over the images [img_offset, img_offset + n_local), in double
+__global__ void k_q_consts(const float* __restrict__ s, int n_local, int img_offset, int C, float fx, float fy, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double ca = 0, cap = 0, cb = 0;
+    for (int li = 0; li < n_local; ++li) {
+        const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
+        ca += (double)(fx * sv[0]) * sv[3]; cap += (double)(fy * sv[1]) * sv[3]; cb += (double)sv[2] * sv[3];
+    }
+    out[c * 4 + 0] = (float)ca; out[c * 4 + 1] = (float)cap; out[c * 4 + 2] = (float)cb; out[c * 4 + 3] = 0.f;
+}
+
 // Per-channel constants of the tensor-recompute form.  With a_i = fx s_i0, a'_i = fy s_i1, b_i = s_i2
 // (image i, channel c) and sums S.. over the images:
 //   sum_i t_i t_i' ,  t_i = (a_i - xx b_i, a'_i - yy b_i, -b_i)
@@ -234,7 +318,7 @@ __global__ void k_tensor_consts(const float* __restrict__ s, int n_total, int C,
 
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset, float cx, float cy) {
+                   int n_total, int img_offset, float cx, float cy, const float* d_ssum) {
     Grid& G = ctx->grid;
     // tensor-recompute form needs the principal point (xx = j - cx, yy = i - cy are rebuilt in the kernel)
     const bool rec = ctx->tensor_recompute && (C == 1 || C == 3) && cx == cx && cy == cy;
@@ -257,6 +341,20 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
     float* Mp = (rec && use_march(ctx) && !ctx->keep_stored_tensor) ? nullptr : G.d_M;
     G.M_valid = Mp != nullptr;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy | (uintptr_t)d_dz) % 16 == 0);
+    if (d_ssum) {
+        // the albedo sweep of this pass left the image sums: no second pass over I
+        float* qc = G.d_tconsts + 64;                      // [8][4] behind the 8 x 8 tensor constants
+        hipLaunchKernelGGL(k_q_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_local, img_offset, C, fx, fy, qc);
+        if (vec && ((uintptr_t)d_ssum % 16 == 0))
+            hipLaunchKernelGGL((k_depth_from_sums<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
+                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp);
+        else
+            hipLaunchKernelGGL((k_depth_from_sums<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
+                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp);
+        SRPS_LAUNCH_CHECK();
+        ctx->tensor_valid = true;
+        return SRPS_OK;
+    }
     if (vec)
         hipLaunchKernelGGL((k_depth_assemble<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
                            fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, Mp, G.d_q, Gp);

@@ -141,7 +141,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     march_plan(G, ctx->march_tj);
     const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
     SRPS_TRY(dalloc(&G.d_pw_part, n_pw)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
-    SRPS_TRY(dalloc(&G.d_scal, 1)); SRPS_TRY(dalloc(&G.d_tconsts, 64));
+    SRPS_TRY(dalloc(&G.d_scal, 1)); SRPS_TRY(dalloc(&G.d_tconsts, 128));      // [8][8] tensor constants + [8][4] right-hand-side constants
     SRPS_HIP(hipMemset(G.d_pw_part, 0, n_pw * sizeof(float))); SRPS_HIP(hipMemset(G.d_rr_part, 0, 2 * (size_t)G.nb_update * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_scal, 0, sizeof(CgScalars)));
     G.bound = true;
@@ -221,6 +221,7 @@ int srps_destroy(srps_ctx* ctx) {
     grid_release(ctx->grid);
     if (ctx->ws_light.p) (void)hipFree(ctx->ws_light.p);
     if (ctx->ws_resident.p) (void)hipFree(ctx->ws_resident.p);
+    if (ctx->ws_ssum.p) (void)hipFree(ctx->ws_ssum.p);
     if (ctx->ws_albedo.p) (void)hipFree(ctx->ws_albedo.p);
     if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
     if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
@@ -278,6 +279,9 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "light_grouped")) {
         ctx->light_grouped = value ? 1 : 0;
         ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "assemble_from_sums")) {
+        ctx->assemble_from_sums = value ? 1 : 0;
+        ctx->ssum_valid = false;
     } else if (!strcmp(name, "albedo_one_sync")) {
         ctx->albedo_one_sync = value ? 1 : 0;
     } else if (!strcmp(name, "albedo_persistent")) {
@@ -429,6 +433,7 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     CTX_CHECK(ctx);
     SRPS_REQUIRE(pr != nullptr, SRPS_ERR_INVALID, "setup: problem is NULL");
     ctx->light_cache_valid = false;
+    ctx->ssum_valid = false;
     ctx->grad_current = false;
     SRPS_REQUIRE(pr->mask && pr->K && pr->zs_lr && pr->z_full, SRPS_ERR_INVALID, "setup: mask, K, zs_lr and z_full are required");
     SRPS_REQUIRE(pr->n_channels > 0 && pr->n_channels <= 8 && pr->n_images >= 0 && pr->n_images_total > 0, SRPS_ERR_INVALID, "setup: bad image counts");
@@ -474,6 +479,7 @@ int srps_upload_image(srps_ctx* ctx, int li, const float* host_image) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(host_image && li >= 0 && li < ctx->N_local, SRPS_ERR_INVALID, "upload_image: bad arguments");
     ctx->light_cache_valid = false;
+    ctx->ssum_valid = false;
     Grid& G = ctx->grid;
     const size_t hw = (size_t)G.h * G.w, n = hw * ctx->C;
     SRPS_TRY(ensure(ctx->ws_stage, n * sizeof(float)));
@@ -495,6 +501,7 @@ int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, in
 
 int srps_lighting_local(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    ctx->ssum_valid = false;             // s changes
     return lighting(ctx, ctx->s, ctx->rho, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
                     ctx->N_local != ctx->N_total, /*use_cache=*/true);
 }
@@ -506,7 +513,16 @@ int srps_lighting(srps_ctx* ctx) {
 
 int srps_albedo_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
-    return albedo_numden(ctx, ctx->s, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->albedo_ex);
+    float* ssum = nullptr;
+    ctx->ssum_valid = false;
+    if (ctx->assemble_from_sums && ctx->N_local > 0) {      // this sweep over I also leaves the image sums of the depth right-hand side
+        SRPS_TRY(ensure(ctx->ws_ssum, (size_t)3 * ctx->C * ctx->grid.P * sizeof(float)));
+        ssum = (float*)ctx->ws_ssum.p;
+    }
+    SRPS_TRY(albedo_numden(ctx, ctx->s, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->albedo_ex,
+                           ctx->fx, ctx->fy, ssum));
+    ctx->ssum_valid = ssum != nullptr;
+    return SRPS_OK;
 }
 int srps_albedo_finish(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -522,8 +538,9 @@ int srps_albedo(srps_ctx* ctx) {
 
 int srps_depth_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
     return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
-                          ctx->N_total, ctx->img_offset, ctx->cx, ctx->cy);
+                          ctx->N_total, ctx->img_offset, ctx->cx, ctx->cy, ssum);
 }
 int srps_depth_solve(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -583,7 +600,7 @@ int srps_exchange(srps_ctx* ctx, const char* which, void** d_ptr, size_t* n_floa
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(which && d_ptr && n_floats, SRPS_ERR_INVALID, "exchange: null argument");
     Grid& G = ctx->grid;
-    if (!strcmp(which, "s")) { *d_ptr = ctx->s; *n_floats = (size_t)ctx->N_total * ctx->C * 4; }
+    if (!strcmp(which, "s")) { *d_ptr = ctx->s; *n_floats = (size_t)ctx->N_total * ctx->C * 4; ctx->ssum_valid = false; }
     else if (!strcmp(which, "albedo")) { *d_ptr = ctx->albedo_ex; *n_floats = 2 * (size_t)ctx->C * G.P; }
     else if (!strcmp(which, "depth")) { *d_ptr = G.d_q; *n_floats = 3 * G.plane; }
     else if (!strcmp(which, "energy")) { *d_ptr = ctx->energy_ex + 1; *n_floats = 1; }
@@ -655,6 +672,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     SRPS_TRY(lookup(ctx, name, &p, &len));
     SRPS_REQUIRE(n == len, SRPS_ERR_INVALID, "set('%s'): buffer holds %zu floats, array has %zu", name, n, len);
     ctx->light_cache_valid = false;
+    ctx->ssum_valid = false;
     ctx->grad_current = false;
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
@@ -667,6 +685,7 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
     SRPS_TRY(lookup(ctx, name, &p, &len));
     *d_ptr = p; *n_floats = len;
     ctx->light_cache_valid = false;      // the caller may write through the pointer
+    ctx->ssum_valid = false;
     ctx->grad_current = false;
     return SRPS_OK;
 }

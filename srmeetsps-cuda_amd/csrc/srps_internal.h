@@ -132,6 +132,10 @@ struct srps_ctx {
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;
     bool light_cache_valid = false;
+    // image sums of the depth right-hand side left by the albedo sweep of this pass (assemble_from_sums)
+    int assemble_from_sums = 1;
+    srps::DevBuf ws_ssum;                 // [C][3][P]
+    bool ssum_valid = false;              // they belong to the current s and I
     bool plane_holds_z = false;           // the grid plane d_x holds the current z (left there by the last solve)
     bool grad_current = false;            // zx, zy (and the grid copy of z) belong to the current z: srps_normals need not redo them
     bool light_cache_normals = false;     // srps_normals ran on the depth the sums were taken from (Nrm is current)
@@ -180,12 +184,12 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
                        const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
                        float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out);
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
-                  int C, int s_img_offset, float* d_numden);
+                  int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr);
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
 void albedo_iters_collect(srps_ctx* ctx);
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset, float cx, float cy);
+                   int n_total, int img_offset, float cx, float cy, const float* d_ssum = nullptr);
 int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I,
                                const float* d_xx, const float* d_yy, const float* d_dz, const float* d_z,
                                const float* d_zx, const float* d_zy, float fx, float fy, int P, int n_local,

@@ -349,6 +349,34 @@ def test_fused_energy_and_lighting_sweep_equals_separate_passes(pkg, kind, sf, h
     assert rmse(res[1][3], res[0][3]) < 2e-5
 
 
+@pytest.mark.parametrize("kind,sf,h,w,n,n_ch", [("ragged", 2, 96, 72, 5, 3), ("full", 4, 64, 48, 23, 3), ("ellipse", 1, 50, 46, 2, 1), ("ragged", 1, 57, 33, 4, 2)])
+def test_depth_assembly_from_the_sums_of_the_albedo_sweep(pkg, kind, sf, h, w, n, n_ch):
+    """the albedo sweep over I also leaves SA = sum_i fx s_i0 I_i, SA' = sum_i fy s_i1 I_i, SB = sum_i s_i2 I_i per channel;
+    the depth assembly then forms q = sum_c g [(SA - xx SB, SA' - yy SB, -SB) - rho (CA - xx CB, CA' - yy CB, -CB)] without a second
+    pass over I: same right-hand side planes as the assembly that streams I (rounding), same solve"""
+    sc = pkg.synth.make_scene(h, w, sf, n, seed=31, n_ch=n_ch, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for sums in (0, 1):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("assemble_from_sums", sums)
+        ctx.setup(dh)
+        ctx.lighting(); ctx.albedo()
+        ctx.depth_partial()
+        q = ctx.exchange("depth").cpu().numpy().copy()
+        ctx.depth_solve(); ctx.energy_partial(); e = ctx.energy_finish()
+        out[sums] = (q, ctx.get("z"), e)
+        # a second assembly after the lighting was overwritten must not use stale sums
+        if sums:
+            ctx.set("s", (ctx.get("s") * 1.5).astype(f32))
+            ctx.depth_partial()
+            q2 = ctx.exchange("depth").cpu().numpy()
+            assert rel(q2, q) > 1e-2
+        ctx.close()
+    assert rel(out[1][0], out[0][0]) < 1e-5
+    assert rmse(out[1][1], out[0][1]) < 1e-5 and abs(out[1][2] - out[0][2]) <= 1e-4 * abs(out[0][2])
+
+
 def test_operator_level_depth_with_principal_point_hint(gpu_ctx, oracle, pkg):
     """srps_depth_estimation (the reference's signature: xx, yy as arrays) with and without the optional
     srps_set_principal_point hint that switches it to the tensor-recompute operator"""
