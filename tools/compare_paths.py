@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("srmeetsps-cuda_amd"); pkg.load()
-plain = {"cg_resident": 0, "albedo_persistent": 0, "fuse_energy_lighting": 0, "light_grouped": 0}
+plain = {"cg_resident": 0, "albedo_persistent": 0, "fuse_energy_lighting": 0, "light_grouped": 0, "assemble_from_sums": 0}
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 worst = 0.0
