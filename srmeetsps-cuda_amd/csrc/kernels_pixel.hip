@@ -283,27 +283,24 @@ __global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict
     }
 }
 
-// qc[c] = (sum_i fx s_i0 s_i3, sum_i fy s_i1 s_i3, sum_i s_i2 s_i3, 0) over the images [img_offset, img_offset + n_local), in double
-__global__ void k_q_consts(const float* __restrict__ s, int n_local, int img_offset, int C, float fx, float fy, float* __restrict__ out) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    double ca = 0, cap = 0, cb = 0;
-    for (int li = 0; li < n_local; ++li) {
-        const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
-        ca += (double)(fx * sv[0]) * sv[3]; cap += (double)(fy * sv[1]) * sv[3]; cb += (double)sv[2] * sv[3];
-    }
-    out[c * 4 + 0] = (float)ca; out[c * 4 + 1] = (float)cap; out[c * 4 + 2] = (float)cb; out[c * 4 + 3] = 0.f;
-}
-
 // Per-channel constants of the tensor-recompute form.  With a_i = fx s_i0, a'_i = fy s_i1, b_i = s_i2
 // (image i, channel c) and sums S.. over the images:
 //   sum_i t_i t_i' ,  t_i = (a_i - xx b_i, a'_i - yy b_i, -b_i)
 //     = [[Sbb dx^2 + R00, Sbb dx dy + R01, Sbb dx], [., Sbb dy^2 + R11, Sbb dy], [., ., Sbb]]
 //   dx = xx - Sab/Sbb, dy = yy - Sa'b/Sbb, R00 = Saa - Sab^2/Sbb, R01 = Saa' - Sab Sa'b/Sbb, R11 = Sa'a' - Sa'b^2/Sbb
 // (completed squares: every term is non-negative, no cancellation).  Evaluated in double.
-__global__ void k_tensor_consts(const float* __restrict__ s, int n_total, int C, float fx, float fy, float* __restrict__ out) {
+__global__ void k_tensor_consts(const float* __restrict__ s, int n_total, int C, float fx, float fy, float* __restrict__ out,
+                                int n_local, int img_offset, float* __restrict__ qc /* [C][4], may be null */) {
     const int c = threadIdx.x;
     if (c >= C) return;
+    if (qc) {      // (sum_i fx s_i0 s_i3, sum_i fy s_i1 s_i3, sum_i s_i2 s_i3, 0) over this rank's images: right-hand side from sums
+        double ca = 0, cap = 0, cb = 0;
+        for (int li = 0; li < n_local; ++li) {
+            const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
+            ca += (double)(fx * sv[0]) * sv[3]; cap += (double)(fy * sv[1]) * sv[3]; cb += (double)sv[2] * sv[3];
+        }
+        qc[c * 4 + 0] = (float)ca; qc[c * 4 + 1] = (float)cap; qc[c * 4 + 2] = (float)cb; qc[c * 4 + 3] = 0.f;
+    }
     double Saa = 0, Sab = 0, Sbb = 0, Saap = 0, Sapap = 0, Sapb = 0;
     for (int i = 0; i < n_total; ++i) {
         const float* sv = s + ((size_t)i * C + c) * 4;
@@ -332,7 +329,8 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
             G.G_planes = C;
         }
         Gp = G.d_G;
-        hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts);
+        hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset,
+                           d_ssum ? G.d_tconsts + 64 : (float*)nullptr);
         G.tensor_channels = C; G.cx = cx; G.cy = cy;
     } else {
         G.tensor_channels = 0;
@@ -344,7 +342,7 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
     if (d_ssum) {
         // the albedo sweep of this pass left the image sums: no second pass over I
         float* qc = G.d_tconsts + 64;                      // [8][4] behind the 8 x 8 tensor constants
-        hipLaunchKernelGGL(k_q_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_local, img_offset, C, fx, fy, qc);
+        if (!rec) hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset, qc);
         if (vec && ((uintptr_t)d_ssum % 16 == 0))
             hipLaunchKernelGGL((k_depth_from_sums<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
                                fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp);
