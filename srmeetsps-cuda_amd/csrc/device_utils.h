@@ -139,48 +139,66 @@ __device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsi
     return grid_sum_collect(ent, gen, sm);
 }
 
-// Three sums in one exchange (ent3: [2][3][blocks]); partial sums are float per thread and double from the wave upwards,
-// a block publishes them rounded to float, the collected totals are returned in double.
-__device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen) {
-    const int tid = threadIdx.x, nw = (int)blockDim.x >> 6, nb = gridDim.x;
-    __shared__ double sd[2][3][16];
+// Three sums in one exchange. A block publishes ONE 16-byte granule {generation, v0, v1, v2} (partial sums float per
+// thread, double from the wave upwards, rounded to float), written by a single global_store_dwordx4 and read by a single
+// global_load_dwordx4 (agent scope, sc1), so the three values and their tag arrive together: the collecting wave needs one
+// round trip when all blocks have published -- with three 8-byte granules per block it needed three.
+// ent3: [2][blocks rounded up to 256] granules, 16-byte aligned, zeroed before the launch; readable up to the rounded size.
+typedef unsigned srps_v4u __attribute__((ext_vector_type(4)));
+template <int NW = 0>      // NW: waves per block when known at compile time (the cross-wave sum is then one LDS round trip)
+__device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen, unsigned long long* st = nullptr) {
+    const int tid = threadIdx.x, nw = NW ? NW : (int)blockDim.x >> 6, nb = gridDim.x;
+    __shared__ double sd[2][16][4];                        // per wave: three totals (+ pad)
     const double t0 = wave_total((double)v0), t1 = wave_total((double)v1), t2 = wave_total((double)v2);
-    if ((tid & 63) == 0) { sd[gen & 1u][0][tid >> 6] = t0; sd[gen & 1u][1][tid >> 6] = t1; sd[gen & 1u][2][tid >> 6] = t2; }
+    if ((tid & 63) == 0) { double* d = sd[gen & 1u][tid >> 6]; d[0] = t0; d[1] = t1; d[2] = t2; }
     __syncthreads();
-    if (tid < 3) {
-        double tot = 0.0;
-        for (int i = 0; i < nw; ++i) tot += sd[gen & 1u][tid][i];
-        __hip_atomic_store(&ent3[((size_t)(gen & 1u) * 3 + tid) * nb + blockIdx.x],
-                           ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint((float)tot), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        double tot[3] = {0.0, 0.0, 0.0};
+        if (NW) {
+#pragma unroll
+            for (int i = 0; i < (NW ? NW : 1); ++i) { const double* d = sd[gen & 1u][i]; tot[0] += d[0]; tot[1] += d[1]; tot[2] += d[2]; }
+        } else {
+            for (int i = 0; i < nw; ++i) { const double* d = sd[gen & 1u][i]; tot[0] += d[0]; tot[1] += d[1]; tot[2] += d[2]; }
+        }
+        const srps_v4u g = {gen, __float_as_uint((float)tot[0]), __float_as_uint((float)tot[1]), __float_as_uint((float)tot[2])};
+        const int nbr = (nb + 255) & ~255;
+        const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * 16;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(g) : "memory");
+        if (st) st[0] = __builtin_amdgcn_s_memrealtime();
     }
 }
-__device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsigned gen, double& o0, double& o1, double& o2) {
+__device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsigned gen, double& o0, double& o1, double& o2, unsigned long long* st = nullptr) {
     const int nb = gridDim.x, tid = threadIdx.x, lane = tid & 63;
     __shared__ double res3[2][3];
     if (tid < 64) {                                        // one polling wave per block
         double acc[3] = {0.0, 0.0, 0.0};
+        const int nbr = (nb + 255) & ~255;
+        const char* slot = reinterpret_cast<const char*>(ent3) + (size_t)(gen & 1u) * nbr * 16;
+        for (int base = 0; base < nb; base += 256) {
+            // four consecutive granules per lane, all requested before the first is looked at
+            const char* src = slot + (size_t)(base + 4 * lane) * 16;
+            srps_v4u w[4];
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                         "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                         "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(src) : "memory");
+            if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const unsigned long long* slot = ent3 + ((size_t)(gen & 1u) * 3 + v) * nb;
-            for (int base = 0; base < nb; base += 256) {
-                unsigned long long w[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = base + 4 * lane + i;
-                    w[i] = (idx < nb) ? __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)gen << 32);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = base + 4 * lane + i;
-                    while ((unsigned)(w[i] >> 32) != gen) {
+            for (int i = 0; i < 4; ++i) {
+                if (base + 4 * lane + i < nb) {
+                    while (w[i].x != gen) {
                         __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
-                        w[i] = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w[i]) : "v"(src + 16 * i) : "memory");
                     }
-                    acc[v] += (double)__uint_as_float((unsigned)w[i]);
+                    acc[0] += (double)__uint_as_float(w[i].y);
+                    acc[1] += (double)__uint_as_float(w[i].z);
+                    acc[2] += (double)__uint_as_float(w[i].w);
                 }
             }
         }
+        if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
         const double t0 = wave_total(acc[0]), t1 = wave_total(acc[1]), t2 = wave_total(acc[2]);
         if (lane == 0) { res3[gen & 1u][0] = t0; res3[gen & 1u][1] = t1; res3[gen & 1u][2] = t2; }
     }

@@ -198,7 +198,7 @@ template <int NV, int BT, bool ONE>
 __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, const float* __restrict__ num,
                                                          const float* __restrict__ den, int P, int C,
                                                          unsigned long long* ent /* [2][gridDim.x], zeroed */,
-                                                         unsigned long long* ent3 /* [2][3][gridDim.x], zeroed */,
+                                                         unsigned long long* ent3 /* [2][256] 16-byte granules, zeroed */,
                                                          DcgScal* __restrict__ scal, float tol2, int max_iter) {
     __shared__ float sm[40];
     const int nb = gridDim.x, tid = threadIdx.x;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
                 for (int e = 0; e < 4; ++e) { p[j].e[e] = r[j].e[e]; a_rdr = fmaf(r[j].e[e], d[j].e[e] * r[j].e[e], a_rdr); }      // k = 1: p = r
             double s_rr, s_pw, s_x;
             ++gen;
-            grid_sum3_publish(acc, a_rdr, 0.f, ent3, gen);
+            grid_sum3_publish<BT / 64>(acc, a_rdr, 0.f, ent3, gen);
             grid_sum3_collect(ent3, gen, s_rr, s_pw, s_x);
             r1 = (float)s_rr;
             double pw = s_pw;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
                     }
                 double s_rdr, s_rdp;
                 ++gen;
-                grid_sum3_publish(a_rr, a_rdr, a_rdp, ent3, gen);
+                grid_sum3_publish<BT / 64>(a_rr, a_rdr, a_rdp, ent3, gen);
                 grid_sum3_collect(ent3, gen, s_rr, s_rdr, s_rdp);
                 r0 = r1;
                 r1 = (float)s_rr;
@@ -374,10 +374,10 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     DcgScal* hs = (DcgScal*)(ctx->h_pinned + 16);
     int pNV = 0, pnb = 0;
     if (dcg_persistent_plan(ctx, P, vec, pNV, pnb)) {
-        // [2][pnb] behind the C <= 8 scalar records, 8-byte aligned
-        unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 7) & ~(uintptr_t)7);
+        // [2][pnb] behind the C <= 8 scalar records, 16-byte aligned (ent3 holds 16-byte granules, [2][256])
+        unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 15) & ~(uintptr_t)15);
         unsigned long long* ent3 = ent + 2 * 1024;
-        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 6 * (size_t)pnb) * sizeof(unsigned long long), ctx->stream));
+        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 2 * 2 * (size_t)((pnb + 255) & ~255)) * sizeof(unsigned long long), ctx->stream));
         float tol2v = tol2;
         int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
         float* rho_v = d_rho;

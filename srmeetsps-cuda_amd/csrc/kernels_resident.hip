@@ -97,7 +97,7 @@ struct ResidentArgs {
     float* x;                  // [plane] in/out
     const float* r;            // [plane] right-hand side b (the kernel forms the residual b - A_ x0 itself)
     unsigned long long* ent;   // [2][tiles]          reduction granules, zeroed before the launch
-    unsigned long long* ent3;  // [2][3][tiles]       the same for the three-value reduction of the one-sync form
+    unsigned long long* ent3;  // [2][256] 16-byte granules: the three-value reduction of the one-sync form
     unsigned long long* halo;  // [tiles][2][HALO_N]  edge granules, zeroed before the launch
     CgScalars* scal;
     int Hs, Ws;
@@ -116,25 +116,20 @@ struct TensorConsts {
     float kS[NC], kX[NC], kY[NC], kR00[NC], kR01[NC], kR11[NC];
 };
 
-// (u, v, w) = M (gx, gy, xv) of one pixel; M = sum_c g_c Q_c(dx, dy)
-template <int NC, bool NEED_U, bool NEED_V, bool NEED_W>
-__device__ __forceinline__ void uvw_pixel(const TensorConsts<NC>& K, const float (&g)[NC], const float (&dxc)[NC],
-                                          const float (&q00)[NC], const float (&q02)[NC], const float (&sdy)[NC],
-                                          const float (&q11)[NC], float gx, float gy, float xv, float& U, float& V, float& W) {
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < NC; ++ch) {
-        if (NEED_U) m0 = fmaf(g[ch], q00[ch], m0);
-        if (NEED_U || NEED_V) m1 = fmaf(g[ch], fmaf(dxc[ch], sdy[ch], K.kR01[ch]), m1);
-        if (NEED_U || NEED_W) m2 = fmaf(g[ch], q02[ch], m2);
-        if (NEED_V) m3 = fmaf(g[ch], q11[ch], m3);
-        if (NEED_V || NEED_W) m4 = fmaf(g[ch], sdy[ch], m4);
-        if (NEED_W) m5 = fmaf(g[ch], K.kS[ch], m5);
-    }
-    if (NEED_U) U = m0 * gx + m1 * gy + m2 * xv;
-    if (NEED_V) V = m1 * gx + m3 * gy + m4 * xv;
-    if (NEED_W) W = m2 * gx + m4 * gy + m5 * xv;
-}
+#ifdef SRPS_STAMPS
+// Development aid (make EXTRA=-DSRPS_STAMPS, then tools/resident_stamps.py): wall-clock stamps (s_memrealtime, 100 MHz)
+// taken by thread 0 of every block at the phase boundaries of every CG step, [step][block][16]; stamps 8..10 come from
+// inside the three-value reduction.  Costs ~0.7 us per step; never part of the shipped build.
+__device__ unsigned long long g_stamps[128 * 256 * 16];
+#define SRPS_STAMP(ID) do { if (tid == 0 && k < 128) g_stamps[((size_t)k * 256 + blockIdx.x) * 16 + (ID)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SRPS_STAMP(ID) do { } while (0)
+#endif
+#ifdef SRPS_STAMPS
+#define SRPS_STAMP_PTR ((k < 128) ? &g_stamps[((size_t)k * 256 + blockIdx.x) * 16 + 8] : nullptr)
+#else
+#define SRPS_STAMP_PTR nullptr
+#endif
 
 template <int SF, int NC, bool ONE_SYNC>
 __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
@@ -169,6 +164,45 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         const float* k8 = a.consts + ch * 8;
         K.kS[ch] = k8[0]; K.kX[ch] = k8[1]; K.kY[ch] = k8[2]; K.kR00[ch] = k8[3]; K.kR01[ch] = k8[4]; K.kR11[ch] = k8[5];
     }
+
+    // Factored form used by the column body: M = E P E', E = [[1,0,-x],[0,1,-y],[0,0,-1]] with (x, y) measured from the
+    // mean (xm, ym) of the channels' vertices, P = sum_c g_c T_c, T_c the constant 3 x 3 moment matrix of channel c about
+    // that point: T00 = R00 + S ex^2, T01 = R01 + S ex ey, T11 = R11 + S ey^2, T02 = S ex, T12 = S ey, T22 = S
+    // (ex, ey = vertex of the channel minus the mean). No per-column / per-row terms are needed.
+    float xm = 0.f, ym = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) { xm += K.kX[ch]; ym += K.kY[ch]; }
+    xm *= 1.f / NC; ym *= 1.f / NC;
+    float T00[NC], T01[NC], T02[NC], T11[NC], T12[NC], T22[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+        const float ex = K.kX[ch] - xm, ey = K.kY[ch] - ym;
+        T22[ch] = K.kS[ch]; T02[ch] = K.kS[ch] * ex; T12[ch] = K.kS[ch] * ey;
+        T00[ch] = fmaf(T02[ch], ex, K.kR00[ch]); T01[ch] = fmaf(T02[ch], ey, K.kR01[ch]); T11[ch] = fmaf(T12[ch], ey, K.kR11[ch]);
+        // uniform, but computed by the vector unit: moved to scalar registers (as VGPR pairs they cost 30 registers)
+        T00[ch] = readlane_f(T00[ch], 0); T01[ch] = readlane_f(T01[ch], 0); T02[ch] = readlane_f(T02[ch], 0);
+        T11[ch] = readlane_f(T11[ch], 0); T12[ch] = readlane_f(T12[ch], 0);
+    }
+    const float xoff = readlane_f(a.cx + xm, 0), yoff = readlane_f(a.cy + ym, 0);
+    // (u, v) = first two components of M (gx, gy, xv) at one pixel with coordinates (xs, ys) from (xoff, yoff)
+    auto uv_pixel = [&](auto need_u, const float (&g)[NC], float xs, float ys, float gx, float gy, float xv) -> float {
+        constexpr bool NU = decltype(need_u)::value;
+        float Pa = 0.f, P01 = 0.f, P02 = 0.f, P12 = 0.f, P22 = 0.f;      // Pa = P00 (u) or P11 (v)
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            Pa = fmaf(g[ch], NU ? T00[ch] : T11[ch], Pa);
+            P01 = fmaf(g[ch], T01[ch], P01);
+            P02 = fmaf(g[ch], T02[ch], P02);
+            P12 = fmaf(g[ch], T12[ch], P12);
+            P22 = fmaf(g[ch], T22[ch], P22);
+        }
+        const float t2 = -(gx * xs + (gy * ys + xv));
+        const float Y2 = P02 * gx + (P12 * gy + P22 * t2);
+        if (NU) return (Pa * gx + (P01 * gy + P02 * t2)) - Y2 * xs;
+        return (P01 * gx + (Pa * gy + P12 * t2)) - Y2 * ys;
+    };
+    auto xs_of = [&](int gcol) { return (float)(a.j_lo + gcol) - xoff; };
+    auto ys_of = [&](int grow) { return (float)(a.i_lo + grow) - yoff; };
 
     // ---- own pixels -------------------------------------------------------------------------------------
     const int grow0 = br * TR + 4 * lane;                  // grid row of element 0
@@ -252,25 +286,6 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     __syncthreads();
     const bool any_bx = sflag[0] != 0;
 
-    // row-dependent tensor terms of the own rows:  dy = yy - y*,  S dy,  S dy^2 + R11   (recomputed per use: registers)
-    auto row_terms = [&](int grow, float (&sdy)[NC], float (&q11)[NC]) {
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            const float dy = ((float)(a.i_lo + grow) - a.cy) - K.kY[ch];
-            sdy[ch] = K.kS[ch] * dy;
-            q11[ch] = (K.kS[ch] * dy) * dy + K.kR11[ch];
-        }
-    };
-    auto col_terms = [&](int gcol, float (&dxc)[NC], float (&q00)[NC], float (&q02)[NC]) {
-        const float xxv = (float)(a.j_lo + gcol) - a.cx;
-#pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            dxc[ch] = xxv - K.kX[ch];
-            q02[ch] = K.kS[ch] * dxc[ch];
-            q00[ch] = q02[ch] * dxc[ch] + K.kR00[ch];
-        }
-    };
-
     // the plane sizes of the bench shapes stay far below the 4 GiB a descriptor can address
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
     unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
@@ -287,6 +302,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     bool pass0 = true;
     while (pass0 || (r1 > a.tol2 && k < a.max_steps)) {
         if (!pass0) ++k;
+        SRPS_STAMP(0);
         const bool first = pass0 || k == 1;               // p is taken as it is (x, or r), not updated
         const float beta = first ? 0.f : r1 / r0;         // dc.cu:262
         // An opaque zero added to every coordinate: without it the compiler hoists the (step-invariant) tensor terms
@@ -307,6 +323,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         ex2[tid] = make_float4(p[CPT - 1].e[0], p[CPT - 1].e[1], p[CPT - 1].e[2], p[CPT - 1].e[3]);
         __syncthreads();
 
+        SRPS_STAMP(1);
         // ---- omega = A_ p ------------------------------------------------------------------------------------
 #pragma unroll
         for (int c = 0; c < CPT; ++c) w[c] = zero4();
@@ -325,10 +342,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         for (int c = 0; c < CPT; ++c) {
             const F4 grc = gnext;
             if (c + 1 < CPT) gnext = as_f4(__builtin_amdgcn_raw_buffer_load_b128(g_rsrc, rowLb, colb + (c + 1) * hsb, 0));
-            float dxc[NC], q00[NC], q02[NC];
             int ozc = 0;
-            asm volatile("" : "+s"(ozc));                  // per column: keeps the column's tensor terms from being formed early
-            col_terms(gcol0 + c + ozc, dxc, q00, q02);
+            asm volatile("" : "+s"(ozc));                  // per column: keeps the column's terms from being formed early
+            const float xs = (float)(a.j_lo + gcol0 + c + ozc) - xoff;
             F4 g0v, g1v;
             if (GL == 2) {
                 const float4 t0 = lg[(0 * CPT + c) * NT + tid + oz], t1 = lg[(1 * CPT + c) * NT + tid + oz];
@@ -363,22 +379,19 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int e0 = 2 * h, e1 = 2 * h + 1;
-                const v2f yyv = {(float)(a.i_lo + grow0 + e0 + ozc) - a.cy, (float)(a.i_lo + grow0 + e1 + ozc) - a.cy};
-                v2f m0 = {0.f, 0.f}, m1 = m0, m2 = m0, m3 = m0, m4 = m0, m5 = m0;
+                const v2f ys = {(float)(a.i_lo + grow0 + e0 + ozc) - yoff, (float)(a.i_lo + grow0 + e1 + ozc) - yoff};
+                v2f P00 = {0.f, 0.f}, P01 = P00, P02 = P00, P11 = P00, P12 = P00, P22 = P00;
 #pragma unroll
                 for (int ch = 0; ch < NC; ++ch) {
                     v2f g;
                     if (NC == 3) g = (ch == 0) ? (v2f){g0v.e[e0], g0v.e[e1]} : (ch == 1) ? (v2f){g1v.e[e0], g1v.e[e1]} : (v2f){grc.e[e0], grc.e[e1]};
                     else g = (v2f){grc.e[e0], grc.e[e1]};
-                    const v2f dy = yyv - K.kY[ch];
-                    const v2f sdy = K.kS[ch] * dy;
-                    const v2f q11 = sdy * dy + K.kR11[ch];
-                    m0 = g * q00[ch] + m0;
-                    m1 = g * (dxc[ch] * sdy + K.kR01[ch]) + m1;
-                    m2 = g * q02[ch] + m2;
-                    m3 = g * q11 + m3;
-                    m4 = g * sdy + m4;
-                    m5 = g * K.kS[ch] + m5;
+                    P00 = g * T00[ch] + P00;
+                    P01 = g * T01[ch] + P01;
+                    P02 = g * T02[ch] + P02;
+                    P11 = g * T11[ch] + P11;
+                    P12 = g * T12[ch] + P12;
+                    P22 = g * T22[ch] + P22;
                 }
                 const v2f xv = {xc.e[e0], xc.e[e1]};
                 const v2f up = {(h == 0) ? x_up : xc.e[1], (h == 0) ? xc.e[0] : xc.e[2]};
@@ -389,9 +402,13 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 const v2i mfy = {SRPS_MSK(B_FY, e0, FL), SRPS_MSK(B_FY, e1, FL)}, mby = {SRPS_MSK(B_BY, e0, FL), SRPS_MSK(B_BY, e1, FL)};
                 const v2f gx = andm2(xrv - xv, mfx) + andm2(xv - xlv, mbx);
                 const v2f gy = andm2(dn - xv, mfy) + andm2(xv - up, mby);
-                const v2f U = m0 * gx + m1 * gy + m2 * xv;
-                const v2f V = m1 * gx + m3 * gy + m4 * xv;
-                const v2f W = m2 * gx + m4 * gy + m5 * xv;
+                const v2f t2 = -(gx * xs + (gy * ys + xv));             // E'(gx, gy, x)
+                const v2f Y0 = P02 * t2 + (P00 * gx + P01 * gy);        // the t2 term last: shortest dependent chain
+                const v2f Y1 = P12 * t2 + (P01 * gx + P11 * gy);
+                const v2f Y2 = P22 * t2 + (P02 * gx + P12 * gy);
+                const v2f U = Y0 - Y2 * xs;
+                const v2f V = Y1 - Y2 * ys;
+                const v2f W = -Y2;
                 const v2f fxU = andm2(U, mfx), bxU = andm2(U, mbx);
                 const v2f fyV = andm2(V, mfy), byV = andm2(V, mby);
                 const v2f own = W + (bxU - fxU) + (byV - fyV);        // A'(u, v, w) at the pixel itself
@@ -431,6 +448,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float t = S[c].e[e] + S[c + 1].e[e]; S[c].e[e] = S[c + 1].e[e] = t; }
         }
+        SRPS_STAMP(2);
         // ring rows: the pixels above row 0 (they act on row 0 when they are forward in y) and below row 255 (on row 255
         // when backward in y). Only lane 0 / lane 63 own the rows they act on, so instead of every lane repeating the
         // work per column, lanes 0..7 take the top ring pixel of columns 0..7 and lanes 8..15 the bottom one; the row-0 /
@@ -447,16 +465,14 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             const int cc = CPT * wave + j;
             const int ir = bot ? ring_rowB(cc) : ring_rowT(cc);
             const unsigned f = hfl[ir];
-            float dxc[NC], q00[NC], q02[NC], sdy[NC], q11[NC], g[NC];
-            col_terms(gcol0 + j + oz, dxc, q00, q02);
-            row_terms((bot ? br * TR + TR : br * TR - 1) + oz, sdy, q11);
+            float g[NC];
+            const float xs = xs_of(gcol0 + j + oz), ys = ys_of((bot ? br * TR + TR : br * TR - 1) + oz);
 #pragma unroll
             for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + ir];
             const float xv = hp[ir];
             const float gx = if_bit_rt(hp[ir + 1] - xv, f, B_FX) + if_bit_rt(xv - hp[ir - 1], f, B_BX);
             const float gy = bot ? (xv - pown) : (pown - xv);     // bottom: backward in y; top: forward in y
-            float U, V, W;
-            uvw_pixel<NC, false, true, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+            const float V = uv_pixel(std::false_type{}, g, xs, ys, gx, gy, xv);
             const float cv = if_bit_rt(V, f, bot ? B_BY : B_FY);
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
@@ -467,43 +483,40 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         }
         // ring columns: the pixels left of column 0 (forward in x) and right of column 63 (backward in x)
         if (wave == 0) {
-            float dxc[NC], q00[NC], q02[NC];
-            col_terms(bc * TC - 1 + oz, dxc, q00, q02);
+            const float xs = xs_of(bc * TC - 1 + oz);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int il = ring_colL(4 * lane + e);
                 const unsigned f = hfl[il];
-                float sdy[NC], q11[NC], g[NC];
-                row_terms(grow0 + e + oz, sdy, q11);
+                float g[NC];
+                const float ys = ys_of(grow0 + e + oz);
 #pragma unroll
                 for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + il];
                 const float xv = hp[il];
                 const float gx = p[0].e[e] - xv;                       // used only if the ring pixel is forward in x
                 const float gy = if_bit_rt(hp[il + 1] - xv, f, B_FY) + if_bit_rt(xv - hp[il - 1], f, B_BY);
-                float U, V, W;
-                uvw_pixel<NC, true, false, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+                const float U = uv_pixel(std::true_type{}, g, xs, ys, gx, gy, xv);
                 w[0].e[e] += if_bit_rt(U, f, B_FX);
             }
         }
         if (any_bx && wave == NWV - 1) {
-            float dxc[NC], q00[NC], q02[NC];
-            col_terms(bc * TC + TC + oz, dxc, q00, q02);
+            const float xs = xs_of(bc * TC + TC + oz);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int irr = ring_colR(4 * lane + e);
                 const unsigned f = hfl[irr];
-                float sdy[NC], q11[NC], g[NC];
-                row_terms(grow0 + e + oz, sdy, q11);
+                float g[NC];
+                const float ys = ys_of(grow0 + e + oz);
 #pragma unroll
                 for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + irr];
                 const float xv = hp[irr];
                 const float gx = xv - p[CPT - 1].e[e];                 // backward in x
                 const float gy = if_bit_rt(hp[irr + 1] - xv, f, B_FY) + if_bit_rt(xv - hp[irr - 1], f, B_BY);
-                float U, V, W;
-                uvw_pixel<NC, true, false, false>(K, g, dxc, q00, q02, sdy, q11, gx, gy, xv, U, V, W);
+                const float U = uv_pixel(std::true_type{}, g, xs, ys, gx, gy, xv);
                 w[CPT - 1].e[e] -= if_bit_rt(U, f, B_BX);
             }
         }
+        SRPS_STAMP(3);
         // u across the wave boundaries
         __syncthreads();                                   // every wave has read the p columns in ex / ex2
         ex[tid] = make_float4(u3.e[0], u3.e[1], u3.e[2], u3.e[3]);
@@ -579,7 +592,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             // not summed again: |r - alpha omega|^2 = r.r - 2 alpha r.omega + alpha^2 omega.omega, and the three products on
             // the right are reduced together with p.omega (float per thread, double from the wave upwards).  Guard: when
             // that difference cancels more than two digits the direct sum is taken (one more wait, rare).
+            SRPS_STAMP(4);
             publish_edges(w);
+            SRPS_STAMP(11);
             float wr[RPT];
             if (pass0) {
                 red = 0.f;
@@ -600,11 +615,13 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 for (int q = 0; q < RPT; ++q) rh[q] -= wr[q];
             } else {
                 ++gen;
-                grid_sum3_publish(red, red_rw, red_ww, a.ent3, gen);
+                grid_sum3_publish<NWV>(red, red_rw, red_ww, a.ent3, gen, SRPS_STAMP_PTR);
                 request_ring();
+                SRPS_STAMP(5);
                 double pw, rw, ww;
                 if (a.debug & 1) { pw = 1e30; rw = 0.0; ww = 0.0; }
-                else grid_sum3_collect(a.ent3, gen, pw, rw, ww);
+                else grid_sum3_collect(a.ent3, gen, pw, rw, ww, SRPS_STAMP_PTR);
+                SRPS_STAMP(6);
                 alpha = r1 / (float)pw;                    // dc.cu:269
                 red = 0.f;
 #pragma unroll
@@ -615,7 +632,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                         r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
                         red = fmaf(r[c].e[e], r[c].e[e], red);
                     }
+                SRPS_STAMP(12);
                 await_ring(wr);
+                SRPS_STAMP(13);
 #pragma unroll
                 for (int q = 0; q < RPT; ++q) rh[q] = fmaf(-alpha, wr[q], rh[q]);
                 r0 = r1;
@@ -675,6 +694,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                     if (ridx[q] >= 0 && hsrc[q] != nullptr) rh[q] = rv[q];
             }
         }
+        SRPS_STAMP(7);
         pass0 = false;
     }
     // ---- results ---------------------------------------------------------------------------------------------
@@ -697,6 +717,12 @@ size_t resident_lds_bytes(int NC) {
 
 }  // namespace
 
+#ifdef SRPS_STAMPS
+extern "C" int srps_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif
+
 bool resident_supported(const srps_ctx* ctx) {
     const Grid& G = ctx->grid;
     if (!ctx->cg_resident || !use_march(ctx)) return false;
@@ -712,15 +738,17 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     Grid& G = ctx->grid;
     const int nc = march_recompute_channels(ctx);
     const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc;
-    const size_t need = (size_t)tiles * (2 + 6 + 2 * HALO_N) * sizeof(unsigned long long);
+    // ent [2][tiles] | ent3 [2][tiles rounded up to 256] 16-byte granules | edge granules [tiles][2][HALO_N]
+    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * 2;
+    const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
     SRPS_TRY(ensure(ctx->ws_resident, need));
     SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));
     ResidentArgs a;
     memset(&a, 0, sizeof(a));
     a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.r = G.d_r;
     a.ent = (unsigned long long*)ctx->ws_resident.p;
-    a.ent3 = a.ent + (size_t)tiles * 2;
-    a.halo = a.ent3 + (size_t)tiles * 6;
+    a.ent3 = a.ent + ent_n;
+    a.halo = a.ent3 + ent3_n;
     a.scal = G.d_scal;
     a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = nbr; a.nbc = nbc;
     a.lambda = ctx->lambda;
