@@ -143,8 +143,13 @@ __device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsi
 // thread, double from the wave upwards, rounded to float), written by a single global_store_dwordx4 and read by a single
 // global_load_dwordx4 (agent scope, sc1), so the three values and their tag arrive together: the collecting wave needs one
 // round trip when all blocks have published -- with three 8-byte granules per block it needed three.
-// ent3: [2][blocks rounded up to 256] granules, 16-byte aligned, zeroed before the launch; readable up to the rounded size.
+// ent3: [2][blocks rounded up to 256] granules SRPS_G3_STRIDE bytes apart, 16-byte aligned, zeroed before the launch.
 typedef unsigned srps_v4u __attribute__((ext_vector_type(4)));
+#ifndef SRPS_G3_STRIDE
+#define SRPS_G3_STRIDE 256       // bytes between the granules of consecutive blocks: every block polls all of them at the same
+                                 // time, and packed into 4 KB they queue on a few memory channels (16: 11.75, 64: 11.5, 256 and
+                                 // 1024: 11.45 us per CG step at 2048 x 2048)
+#endif
 template <int NW = 0>      // NW: waves per block when known at compile time (the cross-wave sum is then one LDS round trip)
 __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen, unsigned long long* st = nullptr) {
     const int tid = threadIdx.x, nw = NW ? NW : (int)blockDim.x >> 6, nb = gridDim.x;
@@ -162,7 +167,7 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
         }
         const srps_v4u g = {gen, __float_as_uint((float)tot[0]), __float_as_uint((float)tot[1]), __float_as_uint((float)tot[2])};
         const int nbr = (nb + 255) & ~255;
-        const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * 16;
+        const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(g) : "memory");
         if (st) st[0] = __builtin_amdgcn_s_memrealtime();
     }
@@ -173,24 +178,25 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
     if (tid < 64) {                                        // one polling wave per block
         double acc[3] = {0.0, 0.0, 0.0};
         const int nbr = (nb + 255) & ~255;
-        const char* slot = reinterpret_cast<const char*>(ent3) + (size_t)(gen & 1u) * nbr * 16;
+        const char* slot = reinterpret_cast<const char*>(ent3) + (size_t)(gen & 1u) * nbr * SRPS_G3_STRIDE;
         for (int base = 0; base < nb; base += 256) {
-            // four consecutive granules per lane, all requested before the first is looked at
-            const char* src = slot + (size_t)(base + 4 * lane) * 16;
+            // lane l takes granules l, l + 64, l + 128, l + 192 of this group, all requested before the first is looked at
+            const char* src = slot + (size_t)(base + lane) * SRPS_G3_STRIDE;
+            const char *s1 = src + 64 * SRPS_G3_STRIDE, *s2 = src + 128 * SRPS_G3_STRIDE, *s3 = src + 192 * SRPS_G3_STRIDE;
             srps_v4u w[4];
             asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                         "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
-                         "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                         "global_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\t"
+                         "global_load_dwordx4 %3, %7, off sc1\n\t"
                          "s_waitcnt vmcnt(0)"
-                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(src) : "memory");
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(src), "v"(s1), "v"(s2), "v"(s3) : "memory");
             if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (base + 4 * lane + i < nb) {
+                if (base + lane + 64 * i < nb) {
                     while (w[i].x != gen) {
                         __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w[i]) : "v"(src + 16 * i) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w[i]) : "v"(src + (size_t)64 * i * SRPS_G3_STRIDE) : "memory");
                     }
                     acc[0] += (double)__uint_as_float(w[i].y);
                     acc[1] += (double)__uint_as_float(w[i].z);

@@ -362,7 +362,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     ctx->albedo_iters_pending = 0;
     const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
     const size_t nv = (size_t)C * P;
-    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + (2 + 6) * 1024 * sizeof(unsigned long long) + 256;
+    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + 2 * 1024 * sizeof(unsigned long long) + 2 * 1024 * SRPS_G3_STRIDE + 256;
     SRPS_TRY(ensure(ctx->ws_albedo, bytes));
     float* r = (float*)ctx->ws_albedo.p;
     float* p = r + nv;
@@ -377,7 +377,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
         // [2][pnb] behind the C <= 8 scalar records, 16-byte aligned (ent3 holds 16-byte granules, [2][256])
         unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 15) & ~(uintptr_t)15);
         unsigned long long* ent3 = ent + 2 * 1024;
-        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 2 * 2 * (size_t)((pnb + 255) & ~255)) * sizeof(unsigned long long), ctx->stream));
+        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 2 * (SRPS_G3_STRIDE / 8) * (size_t)((pnb + 255) & ~255)) * sizeof(unsigned long long), ctx->stream));
         float tol2v = tol2;
         int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
         float* rho_v = d_rho;

@@ -739,7 +739,7 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const int nc = march_recompute_channels(ctx);
     const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc;
     // ent [2][tiles] | ent3 [2][tiles rounded up to 256] 16-byte granules | edge granules [tiles][2][HALO_N]
-    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * 2;
+    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
     const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
     SRPS_TRY(ensure(ctx->ws_resident, need));
     SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));

@@ -40,6 +40,8 @@ def seg(a, b, name):
 if t[:, :, 8].any():
     seg(4, 11, "edges published (4->11)")
     seg(11, 8, "sums: totals+barrier+store (11->8)")
+    if t[:, :, 14].any():
+        seg(11, 14, "  wave totals (11->14)"); seg(14, 15, "  LDS + barrier (14->15)"); seg(15, 8, "  thread-0 sum + store (15->8)")
     seg(8, 5, "ring requested (8->5)")
     seg(5, 9, "first poll round returned (5->9)")
     seg(9, 10, "retries (9->10)")
