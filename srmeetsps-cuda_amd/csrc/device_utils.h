@@ -140,7 +140,7 @@ __device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsi
 }
 
 // Three sums in one exchange. A block publishes ONE 16-byte granule {generation, v0, v1, v2} (partial sums float per
-// thread, double from the wave upwards, rounded to float), written by a single global_store_dwordx4 and read by a single
+// thread and per wave, double across the waves, rounded to float), written by a single global_store_dwordx4 and read by a single
 // global_load_dwordx4 (agent scope, sc1), so the three values and their tag arrive together: the collecting wave needs one
 // round trip when all blocks have published -- with three 8-byte granules per block it needed three.
 // ent3: [2][blocks rounded up to 256] granules SRPS_G3_STRIDE bytes apart, 16-byte aligned, zeroed before the launch.
@@ -154,7 +154,7 @@ template <int NW = 0>      // NW: waves per block when known at compile time (th
 __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen, unsigned long long* st = nullptr) {
     const int tid = threadIdx.x, nw = NW ? NW : (int)blockDim.x >> 6, nb = gridDim.x;
     __shared__ double sd[2][16][4];                        // per wave: three totals (+ pad)
-    const double t0 = wave_total((double)v0), t1 = wave_total((double)v1), t2 = wave_total((double)v2);
+    const double t0 = (double)wave_total(v0), t1 = (double)wave_total(v1), t2 = (double)wave_total(v2);
     if ((tid & 63) == 0) { double* d = sd[gen & 1u][tid >> 6]; d[0] = t0; d[1] = t1; d[2] = t2; }
     __syncthreads();
     if (tid == 0) {
