@@ -86,11 +86,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # Dry-run hook for a one-GPU box (tests/test_gpu_distributed.py::test_bench_two_ranks_on_one_gpu): all ranks share device 0 and
+    # the process group is gloo, because RCCL refuses two ranks on one device.  Never set on a multi-GPU node.
+    shared_gpu = os.environ.get("SRPS_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("srmeetsps-cuda_amd")
     pkg.load()                                       # no fallback: raises when the extension is missing
@@ -140,7 +148,8 @@ def main():
         "config": {"workload": f"synthetic full-mask HR grid {H}x{W}, sf {args.sf}, {args.images} images/GPU x {world} GPU, 3 channels",
                    "hr_grid": [H, W], "sf": args.sf, "images_per_gpu": args.images, "images_total": n_total,
                    "unknowns": dims["npix"], "cg_steps_per_solve": 101,
-                   "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, replicated CG"},
+                   "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, replicated CG"
+                                   + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},
         "energies": energies,
     }
     if rank == 0:

@@ -85,3 +85,31 @@ def test_rccl_backend_accepts_the_exchange_buffers(tmp_path, pkg):
     np.testing.assert_array_equal(r["energies"], np.array(e1))
     np.testing.assert_array_equal(r["z"], one.z())
     ctx.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), dry run: both
+    ranks share device 0 over gloo (SRPS_BENCH_SHARED_GPU).  A small grid, so that the persistent kernels of the two
+    processes fit on the device side by side.  Checks the contract line and that sharding 2 x 3 images changes nothing."""
+    import json
+    import subprocess
+    env = dict(os.environ, SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--size", "256", "--sf", "2", "--no-cpu-baseline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "3"] + common
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE line
+    two = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in two, key
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["config"]["images_total"] == 6 and two["value"] > 0
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--images", "6"] + common, env=env,
+                         capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    np.testing.assert_allclose(two["energies"], ref["energies"], rtol=1e-4)       # same job, images sharded 3 + 3
+    assert two["total_solve_outer_iterations"] == ref["total_solve_outer_iterations"]
