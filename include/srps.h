@@ -72,6 +72,8 @@ int srps_synchronize(srps_ctx* ctx);
  * "assemble_from_sums" (0|1: depth right-hand side from image sums left by the albedo sweep; no second pass over I),
  * "albedo_one_sync" (0|1: persistent albedo CG with one grid-wide wait per step),
  * "cg_one_sync" (0|1: resident CG with one grid-wide wait per step),
+ * "cg_resident_tile" (0|256|512: tile shape of the resident CG by its threads per block; 0 = 256 x 32 tiles wherever the
+ *  device has a CU for each of them, else 256 x 64),
  * "cg_resident_debug" (timing experiments only: wrong results) */
 int srps_set_option(srps_ctx* ctx, const char* name, int value);
 /* reads an option back; also "cg_resident_active" (1 when the bound grid fits one tile per CU and the depth CG

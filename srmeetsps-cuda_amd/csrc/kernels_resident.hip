@@ -29,11 +29,20 @@ namespace srps {
 
 namespace {
 
-constexpr int TR = 256, TC = 64;               // tile rows, columns
-constexpr int NT = 512, NWV = NT / 64;          // threads, waves per block
-constexpr int CPT = TC / NWV;                  // columns per thread (8)
-constexpr int RING_COL = 264;                  // ring column: rows -4..259 (row r at index r + 4, float4-aligned)
-constexpr int RING_ROW = 72;                   // ring row: columns -4..67
+// Two tile shapes are built from this source (kernels_resident_n256.hip includes it with SRPS_RES_NT = 256): 256 x 64 with
+// 512 threads (two waves per SIMD) for grids that need up to one tile per CU at that size, and 256 x 32 with 256 threads
+// (one wave per SIMD, half the arithmetic per CU and step) for smaller grids, which would otherwise leave most CUs idle.
+#ifndef SRPS_RES_NT
+#define SRPS_RES_NT 512
+#endif
+#define SRPS_RES_CAT2(a, b) a##b
+#define SRPS_RES_CAT(a, b) SRPS_RES_CAT2(a, b)
+#define SRPS_RES_NAME(base) SRPS_RES_CAT(base##_n, SRPS_RES_NT)
+constexpr int NT = SRPS_RES_NT, NWV = NT / 64;  // threads, waves per block
+constexpr int CPT = 8;                         // columns per thread
+constexpr int TR = 256, TC = CPT * NWV;        // tile rows, columns (64 or 32)
+constexpr int RING_COL = TR + 8;               // ring column: rows -4..259 (row r at index r + 4, float4-aligned)
+constexpr int RING_ROW = TC + 8;               // ring row: columns -4..TC+3
 constexpr int RING = 2 * RING_COL + 2 * RING_ROW;
 constexpr int HALO_N = 2 * TR + 2 * TC;        // granules a block publishes per step: first/last column, first/last row
 constexpr int B_FX = 1, B_BX = 2, B_FY = 3, B_BY = 4, B_KB = 5;
@@ -227,9 +236,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     }
 
     // ---- ring ---------------------------------------------------------------------------------------------
-    // ring pixels: 0..257 left column (rows -1..256), 258..515 right column, 516..581 top row (columns -1..64),
-    // 582..647 bottom row; thread t looks after ring pixels t and t + NT
-    constexpr int NRING = 648, RPT = (NRING + NT - 1) / NT;
+    // ring pixels: 0..257 left column (rows -1..256), 258..515 right column, then the top row (columns -1..TC) and the
+    // bottom row; thread t looks after ring pixels t, t + NT, ...
+    constexpr int RC_N = TR + 2, RR_N = TC + 2, NRING = 2 * RC_N + 2 * RR_N, RPT = (NRING + NT - 1) / NT;
     int ridx[RPT];                                         // index into the ring arrays, -1: none
     const unsigned long long* hsrc[RPT];                   // granule of the ring pixel in its owner's edge arrays (slot 0)
     float rh[RPT];                                         // r on the ring pixel
@@ -244,10 +253,10 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         ridx[q] = -1; hsrc[q] = nullptr; rh[q] = 0.f;
         if (i >= NRING) continue;
         int kind, u;
-        if (i < 258) { kind = 0; u = i - 1; }
-        else if (i < 516) { kind = 1; u = i - 258 - 1; }
-        else if (i < 582) { kind = 2; u = i - 516 - 1; }
-        else { kind = 3; u = i - 582 - 1; }
+        if (i < RC_N) { kind = 0; u = i - 1; }
+        else if (i < 2 * RC_N) { kind = 1; u = i - RC_N - 1; }
+        else if (i < 2 * RC_N + RR_N) { kind = 2; u = i - 2 * RC_N - 1; }
+        else { kind = 3; u = i - 2 * RC_N - RR_N - 1; }
         const int pr = (kind == 0 || kind == 1) ? u : (kind == 2 ? -1 : TR);
         const int pc = (kind == 0) ? -1 : (kind == 1) ? TC : u;
         ridx[q] = (kind == 0) ? ring_colL(u) : (kind == 1) ? ring_colR(u) : (kind == 2) ? ring_rowT(u) : ring_rowB(u);
@@ -720,13 +729,13 @@ size_t resident_lds_bytes(int NC) {
 
 }  // namespace
 
-#ifdef SRPS_STAMPS
+#if defined(SRPS_STAMPS) && SRPS_RES_NT == 512
 extern "C" int srps_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
 #endif
 
-bool resident_supported(const srps_ctx* ctx) {
+bool SRPS_RES_NAME(resident_supported)(const srps_ctx* ctx) {
     const Grid& G = ctx->grid;
     if (!ctx->cg_resident || !use_march(ctx)) return false;
     const int nc = march_recompute_channels(ctx);
@@ -737,7 +746,7 @@ bool resident_supported(const srps_ctx* ctx) {
 }
 
 // the residual b - A_ x0 (devicecalls.cu:758) and the whole CG of devicecalls.cu:252-275: G.d_r holds b, G.d_x holds x0
-int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
+int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     Grid& G = ctx->grid;
     const int nc = march_recompute_channels(ctx);
     const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc;
@@ -770,5 +779,18 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     void* args[] = {&a};
     return launch_persistent(ctx, fn, tiles, NT, args, lds);      // SRPS_ERR_UNSUPPORTED: the caller falls back to the streaming kernels
 }
+
+#if SRPS_RES_NT == 512
+// the smaller tile wherever it fits on the device (more CUs at work), cg_resident_tile = 256 | 512 forces one shape
+bool resident_supported(const srps_ctx* ctx) {
+    if (ctx->cg_resident_tile == 512) return resident_supported_n512(ctx);
+    if (ctx->cg_resident_tile == 256) return resident_supported_n256(ctx);
+    return resident_supported_n256(ctx) || resident_supported_n512(ctx);
+}
+int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
+    const bool small = ctx->cg_resident_tile == 256 || (ctx->cg_resident_tile != 512 && resident_supported_n256(ctx));
+    return small ? resident_cg_n256(ctx, max_steps, fixed_steps) : resident_cg_n512(ctx, max_steps, fixed_steps);
+}
+#endif
 
 }  // namespace srps

@@ -128,6 +128,7 @@ struct srps_ctx {
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
+    int cg_resident_tile = 0;        // 0: the smallest tile shape that fits the device, 256 | 512: threads per block of the forced shape
     int albedo_one_sync = 1;         // persistent albedo CG: p.(D p) of the next direction predicted from three products summed with r.r
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;
@@ -201,6 +202,10 @@ int contexts_on_device(int device);      // live srps contexts of this process o
 int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes);
 bool resident_supported(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
+bool resident_supported_n512(const srps_ctx* ctx);       // the two tile shapes (kernels_resident.hip, kernels_resident_n256.hip)
+bool resident_supported_n256(const srps_ctx* ctx);
+int resident_cg_n512(srps_ctx* ctx, int max_steps, bool fixed_steps);
+int resident_cg_n256(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
 int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact);
 int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy, float* d_compact = nullptr);      // also gathers the plane when d_compact is given

@@ -151,10 +151,12 @@ def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
 
 @pytest.mark.parametrize("h,w,sf,n_ch,kind", [(40, 32, 2, 3, "ragged"), (300, 200, 1, 3, "ragged"), (520, 136, 4, 1, "ellipse"),
                                                (257, 65, 1, 3, "full"), (1024, 640, 4, 3, "ellipse"), (768, 1280, 2, 3, "ragged")])
-def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind):
+@pytest.mark.parametrize("tile", [256, 512])
+def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind, tile):
     """the depth CG as one persistent launch (state in registers + LDS, grid-wide sums and tile edges through
     generation-tagged granules) against the kernel-per-half-step form: one tile / many tiles, tiles cut by the
-    grid border, ragged masks (backward differences, incomplete KT blocks), 1 and 3 channels, sf 1, 2, 4;
+    grid border, ragged masks (backward differences, incomplete KT blocks), 1 and 3 channels, sf 1, 2, 4, both tile
+    shapes (256 x 32 with 256 threads, 256 x 64 with 512 threads);
     101 truncated steps amplify rounding differences, hence the tolerance; two resident runs are bit-identical"""
     sc = pkg.synth.make_scene(h, w, sf, 3, seed=h + w, n_ch=n_ch, mask_kind=kind)
     dh = pkg.DataHandler.from_scene(sc)
@@ -162,9 +164,11 @@ def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind):
     for res in (0, 1, 1):
         ctx = pkg.Context(device_id=0)
         ctx.set_option("cg_resident", res)
+        ctx.set_option("cg_resident_tile", tile)
         ctx.setup(dh)
         ctx.lighting(); ctx.albedo()
         e = ctx.depth()
+        assert ctx.get_option("cg_resident_active") == res
         out.setdefault(res, []).append((e, ctx.get("z"), ctx.last_cg_iterations()["depth"]))
         ctx.close()
     (e0, z0, i0), = out[0]
