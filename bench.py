@@ -163,10 +163,12 @@ def main():
                                    "frac": loop_bytes / (1e3 * us_iter) / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_iteration": loop_bytes}
         traffic = None
+        valu = None
         resident = bool(ctx.get_option("cg_resident_active"))
         try:     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             traffic = tj.get(f"{H}x{W}_sf{args.sf}", {}).get("resident" if resident else "apply")
+            valu = tj.get(f"{H}x{W}_sf{args.sf}", {}).get("resident_valu") if resident else None
         except Exception:
             pass
         if resident:
@@ -182,6 +184,10 @@ def main():
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "avg_launch_us": launch_us, "steps_per_launch": 101,
                                "algorithmic_bytes_per_launch": bytes_launch,
+                               # what really binds this kernel (committed SQ counters): VALU issue, then one fabric round trip per step
+                               "binding": "valu issue + one grid-wide reduction (fabric round trip) per step; HBM ~4 % utilised",
+                               "valu": (dict(valu, measured_us_per_step=launch_us / 101.0,
+                                             issue_floor_frac=valu["issue_floor_us_per_step_at_2.4GHz"] / (launch_us / 101.0)) if valu else None),
                                "note": "state resident in registers/LDS; the launch also forms the initial residual b - A x (one more operator pass, not counted in the bytes); frac > 1 means faster than any kernel that streams the CG vectors from HBM could be"}
         else:
             # Per-kernel duration: events around the whole 101-step loop give the time per step (kernel boundaries
