@@ -1,18 +1,19 @@
 // kernels_resident.hip -- the truncated depth CG (devicecalls.cu:229-279 on A_ = KT'KT + lambda A'A) as ONE
 // persistent launch whose state lives on the chip.
 //
-// One block of 512 threads per CU owns a tile of 256 rows x 64 columns of the grid; thread (wave w, lane l)
+// One block of 512 threads per CU owns a tile of 256 rows x 64 columns of the grid (a second shape, 256 threads and
+// 256 x 32, is built from this source for smaller grids: see SRPS_RES_NT below); thread (wave w, lane l)
 // owns rows 4l..4l+3 of columns 8w..8w+7 and keeps p, r, x and omega of its 32 pixels in registers (two waves
 // per SIMD, 256 registers each) for all 101 steps; two of the three g planes sit in LDS (128 KiB), the third is
 // re-read every step through the XCD's L2 (2 MB per XCD, it stays there).  2048 x 2048 is exactly 256 tiles.
 // Per step nothing else moves:
-//   * the two dot products are grid-wide sums (device_utils.h grid_sum: 8-byte {generation, value} granules,
-//     no read-modify-write atomics);
-//   * a tile needs r on the one-pixel ring around it: every block publishes the r of its four edges as
-//     generation-tagged granules after the update and keeps its own copy of p on the ring (same recurrence,
-//     same bits as the owner);
+//   * the dot products are grid-wide sums (device_utils.h grid_sum / grid_sum3: generation-tagged granules of 8 or 16
+//     bytes, no read-modify-write atomics); the default form (ONE_SYNC) needs one such sum per step;
+//   * a tile needs r on the one-pixel ring around it: every block publishes the values of its four edges as
+//     generation-tagged granules (r after the update, or omega before alpha is known in the one-wait form) and
+//     keeps its own copy of p on the ring (same recurrence, same bits as the owner);
 //   * inside a block, columns cross waves through two 8 KiB LDS buffers and rows cross lanes through DPP.
-// The operator is the one of kernels_march.hip (same per-pixel formulas, tensor rebuilt from g_c); the
+// The operator is the one of kernels_march.hip; the tensor is applied in factored form (M = E P E', see below) and the
 // contributions of the neighbours are added in a different order, so results agree to rounding.
 // Grids that need more than one tile per CU fall back to the streaming kernels (kernels_march.hip).
 //
