@@ -184,25 +184,30 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
             const char* src = slot + (size_t)(base + lane) * SRPS_G3_STRIDE;
             const char *s1 = src + 64 * SRPS_G3_STRIDE, *s2 = src + 128 * SRPS_G3_STRIDE, *s3 = src + 192 * SRPS_G3_STRIDE;
             srps_v4u w[4];
-            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                         "global_load_dwordx4 %1, %5, off sc1\n\t"
-                         "global_load_dwordx4 %2, %6, off sc1\n\t"
-                         "global_load_dwordx4 %3, %7, off sc1\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(src), "v"(s1), "v"(s2), "v"(s3) : "memory");
-            if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (base + lane + 64 * i < nb) {
-                    while (w[i].x != gen) {
-                        __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w[i]) : "v"(src + (size_t)64 * i * SRPS_G3_STRIDE) : "memory");
-                    }
-                    acc[0] += (double)__uint_as_float(w[i].y);
-                    acc[1] += (double)__uint_as_float(w[i].z);
-                    acc[2] += (double)__uint_as_float(w[i].w);
-                }
+            // every round asks for all four again: a lane whose granules arrive in a different order than it looks at them
+            // would otherwise pay one more round trip per granule
+            const unsigned want0 = (base + lane < nb) ? gen : 0u, want1 = (base + lane + 64 < nb) ? gen : 0u;
+            const unsigned want2 = (base + lane + 128 < nb) ? gen : 0u, want3 = (base + lane + 192 < nb) ? gen : 0u;
+            bool first = true;
+            for (;;) {
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                             "global_load_dwordx4 %1, %5, off sc1\n\t"
+                             "global_load_dwordx4 %2, %6, off sc1\n\t"
+                             "global_load_dwordx4 %3, %7, off sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(src), "v"(s1), "v"(s2), "v"(s3) : "memory");
+                if (first && st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+                first = false;
+                // out-of-range granules are never written (tag 0): they are not waited for
+                const bool ok = (want0 == 0u || w[0].x == gen) && (want1 == 0u || w[1].x == gen) && (want2 == 0u || w[2].x == gen) &&
+                                (want3 == 0u || w[3].x == gen);
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
             }
+            if (want0) { acc[0] += (double)__uint_as_float(w[0].y); acc[1] += (double)__uint_as_float(w[0].z); acc[2] += (double)__uint_as_float(w[0].w); }
+            if (want1) { acc[0] += (double)__uint_as_float(w[1].y); acc[1] += (double)__uint_as_float(w[1].z); acc[2] += (double)__uint_as_float(w[1].w); }
+            if (want2) { acc[0] += (double)__uint_as_float(w[2].y); acc[1] += (double)__uint_as_float(w[2].z); acc[2] += (double)__uint_as_float(w[2].w); }
+            if (want3) { acc[0] += (double)__uint_as_float(w[3].y); acc[1] += (double)__uint_as_float(w[3].z); acc[2] += (double)__uint_as_float(w[3].w); }
         }
         if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
         const double t0 = wave_total(acc[0]), t1 = wave_total(acc[1]), t2 = wave_total(acc[2]);
