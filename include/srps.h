@@ -71,6 +71,7 @@ int srps_synchronize(srps_ctx* ctx);
  * "light_blocks" (0 = automatic), "coop_launch" (0 plain | 1 hipLaunchCooperativeKernel | 2 cooperative only when the process has several contexts on the device),
  * "assemble_from_sums" (0|1: depth right-hand side from image sums left by the albedo sweep; no second pass over I),
  * "albedo_one_sync" (0|1: persistent albedo CG with one grid-wide wait per step),
+ * "albedo_channels_together" (0|1: persistent albedo CG of 3 channels on masks up to 1 M pixels: the channels share the grid-wide waits),
  * "cg_one_sync" (0|1: resident CG with one grid-wide wait per step),
  * "cg_resident_tile" (0|256|512: tile shape of the resident CG by its threads per block; 0 = 256 x 32 tiles wherever the
  *  device has a CU for each of them, else 256 x 64),

@@ -219,6 +219,101 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
     o0 = res3[gen & 1u][0]; o1 = res3[gen & 1u][1]; o2 = res3[gen & 1u][2];
 }
 
+// The same exchange for three independent triples at once (the three colour channels of the albedo CG advance in lockstep):
+// one granule per block and triple, ent9: [2][3][blocks rounded up to 256] granules SRPS_G3_STRIDE apart; all twelve
+// granules of a lane are requested before the first is looked at, so the collect is still one round trip.  Per triple the
+// arithmetic (float per thread and wave, double across waves and blocks, fixed order) is that of grid_sum3.
+template <int NW>
+__device__ __forceinline__ void grid_sum9_publish(const float (&v)[3][3], unsigned long long* ent9, unsigned gen) {
+    const int tid = threadIdx.x, nb = gridDim.x;
+    __shared__ double sd9[2][NW][3][4];
+    double t[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[c][k] = (double)wave_total(v[c][k]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sd9[gen & 1u][tid >> 6][c][k] = t[c][k];
+    }
+    __syncthreads();
+    if (tid < 3) {                                         // thread c publishes the granule of triple c
+        double tot[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { const double* d = sd9[gen & 1u][i][tid]; tot[0] += d[0]; tot[1] += d[1]; tot[2] += d[2]; }
+        const srps_v4u g = {gen, __float_as_uint((float)tot[0]), __float_as_uint((float)tot[1]), __float_as_uint((float)tot[2])};
+        const int nbr = (nb + 255) & ~255;
+        const char* dst = reinterpret_cast<const char*>(ent9) + (((size_t)(gen & 1u) * 3 + tid) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(g) : "memory");
+    }
+}
+__device__ __forceinline__ void grid_sum9_collect(unsigned long long* ent9, unsigned gen, double (&o)[3][3]) {
+    const int nb = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ double res9[2][3][4];
+    if (tid < 64) {
+        double acc[3][3] = {};
+        const int nbr = (nb + 255) & ~255;
+        const char* slot = reinterpret_cast<const char*>(ent9) + (size_t)(gen & 1u) * 3 * nbr * SRPS_G3_STRIDE;
+        const size_t cstep = (size_t)nbr * SRPS_G3_STRIDE;
+        for (int base = 0; base < nb; base += 256) {
+            const char* a0 = slot + (size_t)(base + lane) * SRPS_G3_STRIDE;
+            const char *a1 = a0 + 64 * SRPS_G3_STRIDE, *a2 = a0 + 128 * SRPS_G3_STRIDE, *a3 = a0 + 192 * SRPS_G3_STRIDE;
+            const bool want[4] = {base + lane < nb, base + lane + 64 < nb, base + lane + 128 < nb, base + lane + 192 < nb};
+            srps_v4u w[3][4];
+            for (;;) {
+                asm volatile("global_load_dwordx4 %0, %12, off sc1\n\t"
+                             "global_load_dwordx4 %1, %13, off sc1\n\t"
+                             "global_load_dwordx4 %2, %14, off sc1\n\t"
+                             "global_load_dwordx4 %3, %15, off sc1\n\t"
+                             "global_load_dwordx4 %4, %16, off sc1\n\t"
+                             "global_load_dwordx4 %5, %17, off sc1\n\t"
+                             "global_load_dwordx4 %6, %18, off sc1\n\t"
+                             "global_load_dwordx4 %7, %19, off sc1\n\t"
+                             "global_load_dwordx4 %8, %20, off sc1\n\t"
+                             "global_load_dwordx4 %9, %21, off sc1\n\t"
+                             "global_load_dwordx4 %10, %22, off sc1\n\t"
+                             "global_load_dwordx4 %11, %23, off sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[0][2]), "=&v"(w[0][3]), "=&v"(w[1][0]), "=&v"(w[1][1]), "=&v"(w[1][2]),
+                               "=&v"(w[1][3]), "=&v"(w[2][0]), "=&v"(w[2][1]), "=&v"(w[2][2]), "=&v"(w[2][3])
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a0 + cstep), "v"(a1 + cstep), "v"(a2 + cstep), "v"(a3 + cstep),
+                               "v"(a0 + 2 * cstep), "v"(a1 + 2 * cstep), "v"(a2 + 2 * cstep), "v"(a3 + 2 * cstep)
+                             : "memory");
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ok = ok && (!want[i] || w[c][i].x == gen);
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (want[i]) {
+                        acc[c][0] += (double)__uint_as_float(w[c][i].y);
+                        acc[c][1] += (double)__uint_as_float(w[c][i].z);
+                        acc[c][2] += (double)__uint_as_float(w[c][i].w);
+                    }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double t = wave_total(acc[c][k]);
+                if (lane == 0) res9[gen & 1u][c][k] = t;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[c][k] = res9[gen & 1u][c][k];
+}
+
 // p = beta p + r the way the reference's CG does it: Sscal (dc.cu:263) then Saxpy (dc.cu:264), two roundings
 __device__ __forceinline__ float scal_then_axpy(float beta, float p, float r) {
 #pragma clang fp contract(off)

@@ -324,6 +324,122 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
     }
 }
 
+// The three colour channels advanced together (C == 3, masks that leave room for 3 x 4 arrays in the register file):
+// the channels are independent solves, so their steps can share the grid-wide wait -- one exchange of three granules
+// per block and step instead of one per channel and step; a solve then waits as often as its slowest channel iterates
+// (11 - 15 times) instead of the sum over the channels.  Per channel the arithmetic, the order of every sum and the stop
+// test are those of k_dcg_persistent<NV, BT, true>: same bits.
+template <int NV, int BT>
+__global__ __launch_bounds__(BT) void k_dcg_persistent3(float* __restrict__ rho, const float* __restrict__ num,
+                                                          const float* __restrict__ den, int P,
+                                                          unsigned long long* ent /* [2][gridDim.x], zeroed */,
+                                                          unsigned long long* ent9 /* [2][3][256] 16-byte granules, zeroed */,
+                                                          DcgScal* __restrict__ scal, float tol2, int max_iter) {
+    __shared__ float sm[40];
+    const int nb = gridDim.x, tid = threadIdx.x;
+    unsigned gen = 0, gen1 = 0;        // generations of the nine-value and of the single-value exchange
+    F4 x[3][NV], r[3][NV], p[3][NV], d[3][NV];
+    float part[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t base = (size_t)c * P;
+        float acc = 0.f, a_rdr = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * BT + tid) * 4;
+            if (q < (size_t)P) {
+                const Vec<4> vn = ldv<4>(num + base + q), vd = ldv<4>(den + base + q), vx = ldv<4>(rho + base + q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[c][j].e[e] = vx.v[e]; d[c][j].e[e] = vd.v[e];
+                    r[c][j].e[e] = vn.v[e] - vd.v[e] * vx.v[e];                   // dc.cu:404-405
+                    acc = fmaf(r[c][j].e[e], r[c][j].e[e], acc);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[c][j].e[e] = 0.f; d[c][j].e[e] = 0.f; r[c][j].e[e] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { p[c][j].e[e] = r[c][j].e[e]; a_rdr = fmaf(r[c][j].e[e], d[c][j].e[e] * r[c][j].e[e], a_rdr); }   // k = 1: p = r
+        part[c][0] = acc; part[c][1] = a_rdr; part[c][2] = 0.f;
+    }
+    double tot[3][3];
+    ++gen;
+    grid_sum9_publish<BT / 64>(part, ent9, gen);
+    grid_sum9_collect(ent9, gen, tot);
+    float r1[3], r0[3] = {0.f, 0.f, 0.f};
+    double pw[3];
+    int k[3] = {0, 0, 0};
+    bool act[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r1[c] = (float)tot[c][0]; pw[c] = tot[c][1]; act[c] = r1[c] > tol2 && k[c] <= max_iter; }
+    while (act[0] || act[1] || act[2]) {                                          // dc.cu:252, per channel
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            part[c][0] = 0.f; part[c][1] = 0.f; part[c][2] = 0.f;
+            if (act[c]) {
+                ++k[c];
+                const float alpha = r1[c] / (float)pw[c];
+                float a_rr = 0.f, a_rdr = 0.f, a_rdp = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float w = d[c][j].e[e] * p[c][j].e[e];
+                        x[c][j].e[e] = fmaf(alpha, p[c][j].e[e], x[c][j].e[e]);
+                        r[c][j].e[e] = fmaf(-alpha, w, r[c][j].e[e]);
+                        a_rr = fmaf(r[c][j].e[e], r[c][j].e[e], a_rr);
+                        a_rdr = fmaf(r[c][j].e[e], d[c][j].e[e] * r[c][j].e[e], a_rdr);
+                        a_rdp = fmaf(r[c][j].e[e], w, a_rdp);
+                    }
+                part[c][0] = a_rr; part[c][1] = a_rdr; part[c][2] = a_rdp;
+            }
+        }
+        ++gen;
+        grid_sum9_publish<BT / 64>(part, ent9, gen);
+        grid_sum9_collect(ent9, gen, tot);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (act[c]) {
+                r0[c] = r1[c];
+                r1[c] = (float)tot[c][0];
+                const float beta = r1[c] / r0[c];
+                const double t_sq = tot[c][1] + (double)beta * (double)beta * pw[c];      // >= |2 beta r.Dp| (Cauchy-Schwarz)
+                pw[c] = t_sq + 2.0 * (double)beta * tot[c][2];
+                float a_pdp = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p[c][j].e[e] = scal_then_axpy(beta, p[c][j].e[e], r[c][j].e[e]);
+                        a_pdp = fmaf(p[c][j].e[e], d[c][j].e[e] * p[c][j].e[e], a_pdp);
+                    }
+                // the same guard as in the one-channel form; every block holds the same numbers, so the decision is uniform
+                if (!(pw[c] > 1e-2 * t_sq) && r1[c] > tol2) pw[c] = (double)grid_sum(a_pdp, ent, ++gen1, sm);
+                act[c] = r1[c] > tol2 && k[c] <= max_iter;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t base = (size_t)c * P;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const size_t q = ((size_t)(j * nb + blockIdx.x) * BT + tid) * 4;
+            if (q < (size_t)P) {
+                Vec<4> vx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vx.v[e] = x[c][j].e[e];
+                stv<4>(rho + base + q, vx);
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) { scal[c].r0 = r0[c]; scal[c].iters = k[c]; scal[c].active = (r1[c] > tol2) ? 1 : 0; }
+    }
+}
+
 // 0 when the persistent form cannot be used (mask too large for the register file, unaligned arrays)
 // blocks of 512 threads (8 waves: cheaper block barriers in the grid-wide sums than 16 waves) with 2, 4 or 8 float4 per
 // thread and array; 10 float4 (160 of 256 registers) for masks up to 5.2 M pixels
@@ -362,7 +478,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     ctx->albedo_iters_pending = 0;
     const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
     const size_t nv = (size_t)C * P;
-    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + 2 * 1024 * sizeof(unsigned long long) + 2 * 1024 * SRPS_G3_STRIDE + 256;
+    const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + 2 * 1024 * sizeof(unsigned long long) + 3 * 2 * 1024 * SRPS_G3_STRIDE + 256;
     SRPS_TRY(ensure(ctx->ws_albedo, bytes));
     float* r = (float*)ctx->ws_albedo.p;
     float* p = r + nv;
@@ -377,7 +493,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
         // [2][pnb] behind the C <= 8 scalar records, 16-byte aligned (ent3 holds 16-byte granules, [2][256])
         unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 15) & ~(uintptr_t)15);
         unsigned long long* ent3 = ent + 2 * 1024;
-        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 2 * (SRPS_G3_STRIDE / 8) * (size_t)((pnb + 255) & ~255)) * sizeof(unsigned long long), ctx->stream));
+        SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 3 * 2 * (SRPS_G3_STRIDE / 8) * (size_t)((pnb + 255) & ~255)) * sizeof(unsigned long long), ctx->stream));
         float tol2v = tol2;
         int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
         float* rho_v = d_rho;
@@ -385,7 +501,11 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
 #define SRPS_DCG(NVV) (ctx->albedo_one_sync ? (const void*)k_dcg_persistent<NVV, 512, true> : (const void*)k_dcg_persistent<NVV, 512, false>)
         const void* fn = pNV == 2 ? SRPS_DCG(2) : pNV == 4 ? SRPS_DCG(4) : pNV == 8 ? SRPS_DCG(8) : SRPS_DCG(10);
 #undef SRPS_DCG
-        const int lrc = launch_persistent(ctx, fn, pnb, 512, args, 0);
+        // three channels of a mask that leaves room for them in the register file: one launch, shared waits
+        const bool together = C == 3 && ctx->albedo_one_sync && ctx->albedo_channels_together && pNV <= 2;
+        void* args3[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &ent, &ent3, &scal, &tol2v, &maxit};
+        if (together) fn = (const void*)k_dcg_persistent3<2, 512>;
+        const int lrc = launch_persistent(ctx, fn, pnb, 512, together ? args3 : args, 0);
         if (lrc == SRPS_ERR_UNSUPPORTED) ctx->albedo_persistent = 0;     // fall through to the streaming form below
         else {
             SRPS_TRY(lrc);

@@ -285,6 +285,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "cg_resident_tile")) {
         SRPS_REQUIRE(value == 0 || value == 256 || value == 512, SRPS_ERR_INVALID, "cg_resident_tile: 0, 256 or 512");
         ctx->cg_resident_tile = value;
+    } else if (!strcmp(name, "albedo_channels_together")) {
+        ctx->albedo_channels_together = value ? 1 : 0;
     } else if (!strcmp(name, "albedo_one_sync")) {
         ctx->albedo_one_sync = value ? 1 : 0;
     } else if (!strcmp(name, "albedo_persistent")) {

@@ -129,6 +129,7 @@ struct srps_ctx {
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
     int cg_resident_tile = 0;        // 0: the smallest tile shape that fits the device, 256 | 512: threads per block of the forced shape
+    int albedo_channels_together = 1;   // persistent albedo CG, 3 channels, small masks: the channels share the grid-wide waits
     int albedo_one_sync = 1;         // persistent albedo CG: p.(D p) of the next direction predicted from three products summed with r.r
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;

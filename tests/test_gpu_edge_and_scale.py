@@ -124,6 +124,31 @@ def test_scalar_paths_when_pixel_count_is_not_a_multiple_of_four(pkg, oracle):
     assert z.size % 4 != 0
 
 
+@pytest.mark.parametrize("h,w,sf,kind", [(40, 32, 2, "ragged"), (600, 700, 4, "ellipse"), (960, 1280, 2, "ragged"), (1024, 1024, 4, "full")])
+def test_albedo_channels_sharing_the_waits_equal_channel_after_channel(pkg, h, w, sf, kind):
+    """persistent albedo CG with the three channels advancing in lockstep (one exchange of three granules per block and
+    step) against the same kernel run channel after channel: per channel the arithmetic and the order of every sum are
+    the same, so iteration counts and albedo are bit-identical"""
+    sc = pkg.synth.make_scene(h, w, sf, 4, seed=h + 11, n_ch=3, mask_kind=kind)
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    ctx.lighting()
+    rho0 = ctx.get("rho")
+    out = {}
+    for together in (0, 1, 1):
+        ctx.set_option("albedo_channels_together", together)
+        ctx.set("rho", rho0)
+        ctx.albedo()
+        out.setdefault(together, []).append((ctx.get("rho"), ctx.last_cg_iterations()["albedo"][:3]))
+    ctx.close()
+    (rho_a, it_a), = out[0]
+    (rho_b, it_b), (rho_c, it_c) = out[1]
+    assert all(k > 1 for k in it_b), it_b
+    assert list(it_a) == list(it_b) == list(it_c)
+    np.testing.assert_array_equal(rho_b, rho_c)
+    np.testing.assert_array_equal(rho_a, rho_b)
+
+
 @pytest.mark.parametrize("h,w,sf,n_ch", [(40, 32, 2, 3), (600, 700, 4, 3), (1024, 1536, 4, 2), (2304, 2200, 4, 1)])
 def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
     """the albedo CG that keeps x, r, p and the diagonal in registers for the whole solve (one cooperative
