@@ -303,10 +303,6 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
     unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
     float r1 = 0.f, r0 = 0.f, alpha = 0.f, r1_anchor = 0.f;
-    // Code-generation note (hipcc 7.2): these two otherwise unused values and the store of n_direct at the end change the
-    // register allocation of the loop below; without them the same arithmetic runs 1.4 us per step slower (14.6 instead of
-    // 13.2 us at 2048^2, bit-identical results).  Measured, not understood; re-measure when the compiler changes.
-    int since_anchor = 0, n_direct = 0;
     int k = 0;
     // Pass 0 forms the residual r = b - A_ x0 (devicecalls.cu:758) with the same operator code: p := x, then r -= omega.
     // The CG steps k = 1.. follow (dc.cu:252: while r1 > tol^2 and k <= max_iter, max_steps = max_iter + 1).
@@ -718,7 +714,6 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     if (blockIdx.x == 0 && tid == 0) {
         a.scal->r0 = r0; a.scal->r1_last = r1; a.scal->iters = k; a.scal->active = (r1 > a.tol2) ? 1 : 0;
         a.scal->alpha = 0.f;                               // nothing pending: x is final
-        a.scal->pad[0] = n_direct + since_anchor;          // see the code-generation note above
     }
     (void)ntile;
 }
