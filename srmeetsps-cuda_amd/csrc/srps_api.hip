@@ -320,6 +320,9 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
     else if (!strcmp(name, "cg_one_sync")) *value = ctx->cg_one_sync;
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
+    else if (!strcmp(name, "cg_resident_tile")) *value = ctx->cg_resident_tile;
+    else if (!strcmp(name, "albedo_channels_together")) *value = ctx->albedo_channels_together;
+    else if (!strcmp(name, "albedo_one_sync")) *value = ctx->albedo_one_sync;
     else if (!strcmp(name, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(name, "cg_resident_active")) *value = (ctx->grid.bound && resident_supported(ctx)) ? 1 : 0;
     else SRPS_REQUIRE(false, SRPS_ERR_INVALID, "get_option: unknown option '%s'", name);

@@ -288,3 +288,12 @@ def test_full_size_solve_is_deterministic_and_decreases_the_energy(big, pkg):
     assert ctx.last_cg_iterations()["depth"] == 101
     sel = sc.mask == 1
     assert rmse(runs[0][1], sc.z_true[sel]) < rmse(sc.z_init[sel], sc.z_true[sel])          # closer to the ground truth than the initial depth
+
+
+def test_tile_shape_option_rejects_other_values(pkg):
+    ctx = pkg.Context(device_id=0)
+    with pytest.raises(Exception):
+        ctx.set_option("cg_resident_tile", 128)
+    ctx.set_option("cg_resident_tile", 256); assert ctx.get_option("cg_resident_tile") == 256
+    ctx.set_option("cg_resident_tile", 0)
+    ctx.close()
