@@ -476,6 +476,22 @@ struct LightPlan {
     float *part_atb, *part_g;
     int* d_it;
 };
+// resident blocks per CU of the channel-inner fused sweep (register-bound), asked from the runtime once per variant
+static int fused_ci_blocks_per_cu(int ibw, int C) {
+    static int cache[6][4] = {};
+    int& v = cache[ibw][C];
+    if (v == 0) {
+        const void* fn = nullptr;
+#define SRPS_LCI_PTR(BB, CC) fn = (const void*)k_light_fused_ci<4, BB, CC>
+        if (C == 3) { switch (ibw) { case 1: SRPS_LCI_PTR(1, 3); break; case 2: SRPS_LCI_PTR(2, 3); break; case 3: SRPS_LCI_PTR(3, 3); break; case 4: SRPS_LCI_PTR(4, 3); break; default: SRPS_LCI_PTR(5, 3); } }
+        else { switch (ibw) { case 1: SRPS_LCI_PTR(1, 1); break; case 2: SRPS_LCI_PTR(2, 1); break; case 3: SRPS_LCI_PTR(3, 1); break; case 4: SRPS_LCI_PTR(4, 1); break; default: SRPS_LCI_PTR(5, 1); } }
+#undef SRPS_LCI_PTR
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        v = std::min(nb, 8);
+    }
+    return v;
+}
 static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightPlan& L, bool fused = false) {
     // images per register batch: the block re-reads rho and N once per batch, so one batch is best
     L.IB = 4;
@@ -486,7 +502,11 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     if (ctx->light_grouped && L.V == 4) {
         // one round of blocks: the sweep keeps 3 (fused, 135 registers) or 5 (96 registers) blocks per CU resident; with
         // 1024 blocks the last third of the kernel ran at a third of the occupancy
-        const int target = (ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * (fused ? 3 : 5)) / 4;      // pixel ranges
+        // (the channel-inner fused kernel needs ~250 registers: 2 blocks per CU; 768 blocks were 1.5 rounds, the last half of
+        // the kernel at half the occupancy: 60 us of a 2 ms pass)
+        int per_cu = fused ? 3 : 5;
+        if (fused && ctx->light_channel_inner && (C == 1 || C == 3)) per_cu = fused_ci_blocks_per_cu(std::min(5, cdiv(n_local, 4)), C);
+        const int target = (ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * per_cu) / 4;      // pixel ranges
         const int gran = 256 * L.V;                        // a block covers 256 V pixels per iteration
         L.chunk = std::max(gran, cdiv(cdiv(P, target), gran) * gran);
     } else {
