@@ -484,14 +484,15 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     float* p = r + nv;
     float* rr_part = p + nv;                    // [C][2][nb]
     float* pw_part = rr_part + (size_t)C * 2 * nb;
-    DcgScal* scal = (DcgScal*)(pw_part + (size_t)C * nb);
+    DcgScal* scal = (DcgScal*)(ctx->d_report + 16);             // [8] records, part of the context's report record
+    float* after_parts = pw_part + (size_t)C * nb;
     const float tol2 = ctx->cg_tol * ctx->cg_tol;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_numden | (uintptr_t)r) % 16 == 0);
     DcgScal* hs = (DcgScal*)(ctx->h_pinned + 16);
     int pNV = 0, pnb = 0;
     if (dcg_persistent_plan(ctx, P, vec, pNV, pnb)) {
         // [2][pnb] behind the C <= 8 scalar records, 16-byte aligned (ent3 holds 16-byte granules, [2][256])
-        unsigned long long* ent = (unsigned long long*)(((uintptr_t)(scal + 8) + 15) & ~(uintptr_t)15);
+        unsigned long long* ent = (unsigned long long*)(((uintptr_t)after_parts + 15) & ~(uintptr_t)15);
         unsigned long long* ent3 = ent + 2 * 1024;
         SRPS_HIP(hipMemsetAsync(ent, 0, (2 * 1024 + 3 * 2 * (SRPS_G3_STRIDE / 8) * (size_t)((pnb + 255) & ~255)) * sizeof(unsigned long long), ctx->stream));
         float tol2v = tol2;
@@ -511,7 +512,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
             SRPS_TRY(lrc);
             // no host synchronisation here: the iteration counts are picked up from the pinned buffer the next time the
             // host waits for the stream anyway (albedo_iters_collect)
-            SRPS_HIP(hipMemcpyAsync(hs, scal, C * sizeof(DcgScal), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->report_pending = true;
             ctx->albedo_iters_pending = C;
             return SRPS_OK;
         }

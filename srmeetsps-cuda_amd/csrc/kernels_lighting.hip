@@ -519,7 +519,7 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     SRPS_TRY(ensure(ctx->ws_light, (n_atb + n_g) * sizeof(float) + 64));
     L.part_atb = (float*)ctx->ws_light.p;
     L.part_g = L.part_atb + n_atb;
-    L.d_it = (int*)(L.part_g + n_g);
+    L.d_it = (int*)(ctx->d_report + 8);
     return SRPS_OK;
 }
 template <bool ENERGY>
@@ -560,10 +560,10 @@ int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, co
     ctx->light_cache_valid = false;
     if (cached) {
         L = LightPlan{ctx->light_cache_V, 0, 0, ctx->light_cache_nblk, 0, nullptr, nullptr, nullptr};
-        const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
+        const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4;
         L.part_atb = (float*)ctx->ws_light.p;
         L.part_g = L.part_atb + n_atb;
-        L.d_it = (int*)(L.part_g + n_g);
+        L.d_it = (int*)(ctx->d_report + 8);
     } else {
         SRPS_TRY(light_plan(ctx, vec, P, n_local, C, L));
     }
@@ -573,7 +573,7 @@ int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, co
     hipLaunchKernelGGL(k_light_solve, dim3(nt), dim3(64), 0, ctx->stream, L.part_atb, L.part_g, L.nblk, n_local, C,
                        n_total, img_offset, zero_nonlocal ? 1 : 0, d_s, L.d_it, ctx->cg_tol, ctx->cg_max_iter);
     SRPS_LAUNCH_CHECK();
-    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 8, L.d_it, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->report_pending = true;          // d_it is part of the report record
     return SRPS_OK;
 }
 

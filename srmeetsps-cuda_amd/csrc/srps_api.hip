@@ -47,13 +47,13 @@ static void dfree(T*& p) {
 static void grid_release(Grid& G) {
     dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index);
     dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_save);
-    dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); dfree(G.d_scal);
+    dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); G.d_scal = nullptr;      // d_scal lives in the context's report record
     G.bound = false;
 }
 
 static void state_release(srps_ctx* c) {
     dfree(c->s); dfree(c->rho); dfree(c->z); dfree(c->Nrm); dfree(c->dz); dfree(c->zx); dfree(c->zy);
-    dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); dfree(c->energy_ex);
+    dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
 }
 
@@ -141,7 +141,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     march_plan(G, ctx->march_tj);
     const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
     SRPS_TRY(dalloc(&G.d_pw_part, n_pw)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
-    SRPS_TRY(dalloc(&G.d_scal, 1)); SRPS_TRY(dalloc(&G.d_tconsts, 128));      // [8][8] tensor constants + [8][4] right-hand-side constants
+    G.d_scal = (CgScalars*)(ctx->d_report + 64); SRPS_TRY(dalloc(&G.d_tconsts, 128));      // [8][8] tensor constants + [8][4] right-hand-side constants
     SRPS_HIP(hipMemset(G.d_pw_part, 0, n_pw * sizeof(float))); SRPS_HIP(hipMemset(G.d_rr_part, 0, 2 * (size_t)G.nb_update * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_scal, 0, sizeof(CgScalars)));
     G.bound = true;
@@ -155,7 +155,14 @@ static int depth_solve_impl(srps_ctx* ctx, const float* d_z0s, float* d_z, float
     SRPS_TRY(grid_rhs(ctx, d_z0s));                               // dc.cu:743-745
     SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:758-759 (residual; k <= max_iter => 101 steps)
     SRPS_TRY(grid_gradient(ctx, G.d_x, d_zx, d_zy, d_z));         // the new z in the compact layout, and Dx z, Dy z (energy + normals)
-    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned + 64, G.d_scal, sizeof(CgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->report_pending = true;          // the CG scalars are fetched with the rest of the report record
+    return SRPS_OK;
+}
+
+// one copy for all the scalars of a pass (energy terms, iteration counts); the caller synchronises the stream
+static int report_fetch(srps_ctx* ctx) {
+    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_report, 80 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->report_pending = false;
     return SRPS_OK;
 }
 
@@ -207,6 +214,9 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     e = hipHostMalloc((void**)&c->h_pinned, 256 * sizeof(float));
     if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
     memset(c->h_pinned, 0, 256 * sizeof(float));
+    e = hipMalloc((void**)&c->d_report, 256 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(c->d_report, 0, 256 * sizeof(float));
+    if (e != hipSuccess) { (void)hipHostFree(c->h_pinned); (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     if (device_id < 64) g_live_contexts[device_id].fetch_add(1);
     *out = c;
     return SRPS_OK;
@@ -226,6 +236,7 @@ int srps_destroy(srps_ctx* ctx) {
     if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
     if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->d_report) (void)hipFree(ctx->d_report);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SRPS_OK;
@@ -416,6 +427,7 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
     SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
     SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
     SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
+    SRPS_TRY(report_fetch(ctx));          // first: the two energy terms of this call overwrite the record's
     SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, e2, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     albedo_iters_collect(ctx);
@@ -457,7 +469,7 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     SRPS_TRY(dalloc(&ctx->Nrm, 4 * (size_t)P)); SRPS_TRY(dalloc(&ctx->dz, P)); SRPS_TRY(dalloc(&ctx->zx, P)); SRPS_TRY(dalloc(&ctx->zy, P));
     SRPS_TRY(dalloc(&ctx->xx, P)); SRPS_TRY(dalloc(&ctx->yy, P)); SRPS_TRY(dalloc(&ctx->z0s, std::max(G.Ps, 1)));
     SRPS_TRY(dalloc(&ctx->I, (size_t)std::max(NL, 1) * C * P));
-    SRPS_TRY(dalloc(&ctx->albedo_ex, 2 * (size_t)C * P)); SRPS_TRY(dalloc(&ctx->energy_ex, 4));
+    SRPS_TRY(dalloc(&ctx->albedo_ex, 2 * (size_t)C * P)); ctx->energy_ex = ctx->d_report;
     ctx->have_state = true;
     // lighting init s = (0,0,-1,0)  SRPS.cu:209-217
     std::vector<float> s0((size_t)NT * C * 4, 0.f);
@@ -575,7 +587,7 @@ int srps_energy_partial(srps_ctx* ctx) {
 int srps_energy_finish(srps_ctx* ctx, float* energy) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(energy != nullptr, SRPS_ERR_INVALID, "energy_finish: energy is NULL");
-    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->energy_ex, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_TRY(report_fetch(ctx));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     albedo_iters_collect(ctx);
     *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];
@@ -699,9 +711,12 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
 }
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters, int* lighting_iters_max) {
     CTX_CHECK(ctx);
-    if (ctx->albedo_iters_pending > 0) {
+    if (ctx->albedo_iters_pending > 0 || ctx->report_pending) {
+        SRPS_TRY(report_fetch(ctx));
         SRPS_HIP(hipStreamSynchronize(ctx->stream));
         albedo_iters_collect(ctx);
+        ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 64))->iters;
+        ctx->last_light_iters = *(int*)(ctx->h_pinned + 8);
     }
     if (depth_iters) *depth_iters = ctx->last_depth_iters;
     if (albedo_iters) for (int c = 0; c < 8; ++c) albedo_iters[c] = ctx->last_albedo_iters[c];

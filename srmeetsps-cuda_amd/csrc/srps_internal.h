@@ -100,6 +100,10 @@ struct srps_ctx {
     // grow-only workspaces for the per-pixel phases
     srps::DevBuf ws_light, ws_albedo, ws_stage, ws_misc;
     float* h_pinned = nullptr;       // 256 floats of pinned host memory for scalar read-back
+    // The scalars the host reads back after a pass live in ONE device record with the layout of h_pinned -- [0..3] energy terms,
+    // [8] lighting iterations, [16..47] albedo CG records, [64..71] depth CG scalars -- so that one copy fetches them all.
+    float* d_report = nullptr;       // 256 floats
+    bool report_pending = false;     // the device record is newer than h_pinned
     // pipeline state (srps_setup); reference layouts
     bool have_state = false;
     int C = 0, N_local = 0, N_total = 0, img_offset = 0;
