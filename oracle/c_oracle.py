@@ -64,6 +64,13 @@ def mf_apply(st: Structure, M, x, lam=1.0):
     return y
 
 
+def gradient(st: Structure, x):
+    """zx = Dx x, zy = Dy x (rows of make_gradient, SRPS.cu:29-47)"""
+    x = np.ascontiguousarray(x, f32); gx = np.empty(st.P, f32); gy = np.empty(st.P, f32)
+    _L.oc_gradient(st.P, _i(st.nb), _f(x), _f(gx), _f(gy))
+    return gx, gy
+
+
 def rhs(st: Structure, q, z0s, lam=1.0):
     out = np.empty(st.P, f32); z0s = np.ascontiguousarray(z0s, f32)
     _L.oc_rhs(st.P, st.sf, _i(st.nb), _i(st.blk), _f(q), _f(z0s), C.c_float(lam), _f(out))

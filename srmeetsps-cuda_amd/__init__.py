@@ -7,4 +7,10 @@ The directory name contains a hyphen (it is fixed by the project layout); import
 from ._lib import SRPSError, build, load, declared_symbols, LIB_PATH  # noqa: F401
 from .api import (Context, DataHandler, Preferences, SRPS, alternating_loop, shard_range)  # noqa: F401
 from . import synth  # noqa: F401
+
+
+def last_error() -> str:
+    """text of the calling thread's last failure or fallback notice (srps_last_error)"""
+    return load().srps_last_error().decode(errors="replace")
+
 from . import host  # noqa: F401

@@ -84,6 +84,53 @@ __device__ __forceinline__ double wave_total(double v) {
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
+// ---- bounded waits of the persistent kernels ---------------------------------------------------------------
+// A kernel whose blocks wait for each other hangs forever when one of its blocks never becomes resident (a co-tenant
+// process holds the CU, a CU mask, the occupancy API admitting one block more than the hardware).  Every wait below is
+// therefore bounded: the kernel computes ONE deadline at its start (s_memrealtime, 100 MHz, plus the budget the host
+// passes: option "spin_budget_ms"), a waiting wave looks at the clock every 64th failed poll, and once the deadline has
+// passed the wait gives up: it marks the block dead (an LDS flag every thread reads at the end of the kernel: a dead block
+// stores no results), records in the status words which wait failed and how many blocks had arrived, and returns NaN --
+// the CG loops end on a NaN r.r by themselves.  A dead block publishes nothing further, so its neighbours time out in
+// turn and the whole launch ends within about two budgets.  The host finds the abort flag in the report record and
+// repeats the solve with the streaming kernels (srps_api.hip: persistent_recover).
+// The deadline, the status pointer and the dead flag live in LDS (a fixed address: no registers are held for them in
+// kernels that have none to spare); only failed polls ever look at them.
+struct SpinState {
+    unsigned long long deadline;   // s_memrealtime value after which a failed poll gives up
+    int* status;                   // [3] abort flags | blocks that had arrived at the failing wait | its generation
+    int bit;                       // this kernel's bit in the abort flags (1 depth CG, 2 albedo CG)
+    int dead;                      // some wait of this block gave up
+};
+__device__ __forceinline__ SpinState* spin_state() {
+    __shared__ SpinState st;
+    return &st;
+}
+// called by every thread at the start of a persistent kernel; a barrier must follow before the first wait
+__device__ __forceinline__ void spin_guard_init(unsigned long long budget_ticks, int* status, int bit) {
+    if (threadIdx.x == 0) {
+        SpinState* st = spin_state();
+        st->deadline = __builtin_amdgcn_s_memrealtime() + budget_ticks;
+        st->status = status; st->bit = bit; st->dead = 0;
+    }
+}
+__device__ __forceinline__ bool spin_deadline_passed() { return __builtin_amdgcn_s_memrealtime() > spin_state()->deadline; }
+__device__ __forceinline__ bool spin_expired(unsigned& polls) {
+    if ((++polls & 63u) != 0u) return false;
+    return spin_deadline_passed();
+}
+__device__ __forceinline__ void spin_give_up(int arrived, unsigned gen) {
+    SpinState* st = spin_state();
+    st->dead = 1;
+    int* status = st->status;
+    if (__hip_atomic_fetch_or(status, st->bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { status[1] = arrived; status[2] = (int)gen; }
+}
+// after the last barrier-separated wait of the kernel: true when some wait of this block gave up (block-uniform)
+__device__ __forceinline__ bool spin_block_dead() {
+    __syncthreads();
+    return spin_state()->dead != 0;
+}
+
 // ---- grid-wide sum of a persistent (cooperative) launch: blocks of up to 1024 threads (a multiple of 64) ----
 // No read-modify-write atomics (256 device-scope atomics on one address serialise in the fabric: the library's grid
 // barrier costs 33 us on 256 CUs).  Every block publishes {generation, partial sum} as one 64-bit device-scope store;
@@ -111,6 +158,8 @@ __device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsig
     float* res = sm + 32 + (gen & 1u);                     // behind the two sets of wave partials
     if (tid < 64) {                                        // one polling wave per block: pollers cost fabric bandwidth
         double a = 0.0;
+        unsigned polls = 0;
+        bool gave_up = false;
         for (int base = 0; base < nb; base += 256) {
             unsigned long long w[4];
 #pragma unroll
@@ -121,14 +170,20 @@ __device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsig
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = base + 4 * lane + i;
-                while ((unsigned)(w[i] >> 32) != gen) {
+                while (!gave_up && (unsigned)(w[i] >> 32) != gen) {
+                    if (spin_expired(polls)) { gave_up = true; break; }
                     __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
                     w[i] = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 a += (double)__uint_as_float((unsigned)w[i]);
             }
         }
-        const float tot = (float)wave_total(a);
+        float tot = (float)wave_total(a);
+        const unsigned long long missing = __builtin_amdgcn_ballot_w64(gave_up);
+        if (missing != 0ull) {                             // wave-uniform: some lane's granule never came
+            tot = __builtin_nanf("");
+            if (lane == 0) spin_give_up(nb - (int)__builtin_popcountll(missing), gen);
+        }
         if (lane == 0) *res = tot;
     }
     __syncthreads();
@@ -204,6 +259,14 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
                 const bool ok = (want0 == 0u || w[0].x == gen) && (want1 == 0u || w[1].x == gen) && (want2 == 0u || w[2].x == gen) &&
                                 (want3 == 0u || w[3].x == gen);
                 if (ok) break;
+                if (spin_deadline_passed()) {          // the clock is read by the scalar unit; only lanes still waiting get here
+                    const int n_missing = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want0 != 0u && w[0].x != gen)) +
+                                          (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want1 != 0u && w[1].x != gen)) +
+                                          (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want2 != 0u && w[2].x != gen)) +
+                                          (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want3 != 0u && w[3].x != gen));
+                    spin_give_up(nb - n_missing, gen);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
             }
             if (want0) { acc[0] += (double)__uint_as_float(w[0].y); acc[1] += (double)__uint_as_float(w[0].z); acc[2] += (double)__uint_as_float(w[0].w); }
@@ -217,6 +280,7 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
     }
     __syncthreads();
     o0 = res3[gen & 1u][0]; o1 = res3[gen & 1u][1]; o2 = res3[gen & 1u][2];
+    if (spin_state()->dead) o0 = o1 = o2 = (double)__builtin_nanf("");      // a wait gave up: the CG loops end on a NaN
 }
 
 // The same exchange for three independent triples at once (the three colour channels of the albedo CG advance in lockstep):
@@ -254,6 +318,8 @@ __device__ __forceinline__ void grid_sum9_collect(unsigned long long* ent9, unsi
     __shared__ double res9[2][3][4];
     if (tid < 64) {
         double acc[3][3] = {};
+        unsigned polls = 0;
+        int missing = 0;
         const int nbr = (nb + 255) & ~255;
         const char* slot = reinterpret_cast<const char*>(ent9) + (size_t)(gen & 1u) * 3 * nbr * SRPS_G3_STRIDE;
         const size_t cstep = (size_t)nbr * SRPS_G3_STRIDE;
@@ -287,6 +353,11 @@ __device__ __forceinline__ void grid_sum9_collect(unsigned long long* ent9, unsi
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ok = ok && (!want[i] || w[c][i].x == gen);
                 if (ok) break;
+                if (spin_expired(polls)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) missing += (int)(want[i] && (w[0][i].x != gen || w[1][i].x != gen || w[2][i].x != gen));
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
             }
 #pragma unroll
@@ -299,11 +370,16 @@ __device__ __forceinline__ void grid_sum9_collect(unsigned long long* ent9, unsi
                         acc[c][2] += (double)__uint_as_float(w[c][i].w);
                     }
         }
+        const bool gave_up = __builtin_amdgcn_ballot_w64(missing != 0) != 0ull;      // wave-uniform
+        if (gave_up) {
+            const int n_missing = (int)wave_total((float)missing);
+            if (lane == 0) spin_give_up(nb - n_missing, gen);
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double t = wave_total(acc[c][k]);
+                const double t = gave_up ? (double)__builtin_nanf("") : wave_total(acc[c][k]);
                 if (lane == 0) res9[gen & 1u][c][k] = t;
             }
     }

@@ -199,10 +199,13 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
                                                          const float* __restrict__ den, int P, int C,
                                                          unsigned long long* ent /* [2][gridDim.x], zeroed */,
                                                          unsigned long long* ent3 /* [2][256] 16-byte granules, zeroed */,
-                                                         DcgScal* __restrict__ scal, float tol2, int max_iter) {
+                                                         DcgScal* __restrict__ scal, float tol2, int max_iter,
+                                                         int* status /* CgScalars::abort_flags.. */, unsigned long long spin_ticks) {
     __shared__ float sm[40];
     const int nb = gridDim.x, tid = threadIdx.x;
     unsigned gen = 0;                  // generations start at 1: the entries are zeroed before the launch
+    spin_guard_init(spin_ticks, status, ABORT_ALBEDO);      // bounded waits: device_utils.h
+    __syncthreads();
     for (int c = 0; c < C; ++c) {
         const size_t base = (size_t)c * P;
         F4 x[NV], r[NV], p[NV], d[NV];
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent(float* __restrict__ rho, 
             r1 = grid_sum(acc, ent, ++gen, sm);
         }
         }
+        if (spin_block_dead()) break;          // a wait gave up: this channel (and the ones after it) keep their albedo
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const size_t q = ((size_t)(j * nb + blockIdx.x) * BT + tid) * 4;
@@ -334,10 +338,13 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent3(float* __restrict__ rho,
                                                           const float* __restrict__ den, int P,
                                                           unsigned long long* ent /* [2][gridDim.x], zeroed */,
                                                           unsigned long long* ent9 /* [2][3][256] 16-byte granules, zeroed */,
-                                                          DcgScal* __restrict__ scal, float tol2, int max_iter) {
+                                                          DcgScal* __restrict__ scal, float tol2, int max_iter,
+                                                          int* status /* CgScalars::abort_flags.. */, unsigned long long spin_ticks) {
     __shared__ float sm[40];
     const int nb = gridDim.x, tid = threadIdx.x;
     unsigned gen = 0, gen1 = 0;        // generations of the nine-value and of the single-value exchange
+    spin_guard_init(spin_ticks, status, ABORT_ALBEDO);      // bounded waits: device_utils.h
+    __syncthreads();
     F4 x[3][NV], r[3][NV], p[3][NV], d[3][NV];
     float part[3][3];
 #pragma unroll
@@ -423,6 +430,7 @@ __global__ __launch_bounds__(BT) void k_dcg_persistent3(float* __restrict__ rho,
             }
         }
     }
+    if (spin_block_dead()) return;             // a wait gave up: the albedo stays as it was
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const size_t base = (size_t)c * P;
@@ -498,13 +506,15 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
         float tol2v = tol2;
         int maxit = ctx->cg_max_iter, Pv = P, Cv = C;
         float* rho_v = d_rho;
-        void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &ent3, &scal, &tol2v, &maxit};
+        int* status = (int*)(ctx->d_report + 64) + 5;                         // CgScalars::abort_flags of the report record
+        unsigned long long spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;
+        void* args[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &Cv, &ent, &ent3, &scal, &tol2v, &maxit, &status, &spin_ticks};
 #define SRPS_DCG(NVV) (ctx->albedo_one_sync ? (const void*)k_dcg_persistent<NVV, 512, true> : (const void*)k_dcg_persistent<NVV, 512, false>)
         const void* fn = pNV == 2 ? SRPS_DCG(2) : pNV == 4 ? SRPS_DCG(4) : pNV == 8 ? SRPS_DCG(8) : SRPS_DCG(10);
 #undef SRPS_DCG
         // three channels of a mask that leaves room for them in the register file: one launch, shared waits
         const bool together = C == 3 && ctx->albedo_one_sync && ctx->albedo_channels_together && pNV <= 2;
-        void* args3[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &ent, &ent3, &scal, &tol2v, &maxit};
+        void* args3[] = {&rho_v, (void*)&num, (void*)&den, &Pv, &ent, &ent3, &scal, &tol2v, &maxit, &status, &spin_ticks};
         if (together) fn = (const void*)k_dcg_persistent3<2, 512>;
         const int lrc = launch_persistent(ctx, fn, pnb, 512, together ? args3 : args, 0);
         if (lrc == SRPS_ERR_UNSUPPORTED) ctx->albedo_persistent = 0;     // fall through to the streaming form below

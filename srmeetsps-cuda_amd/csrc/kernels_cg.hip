@@ -393,13 +393,17 @@ static ApplyArgs base_args(srps_ctx* ctx) {
     return a;
 }
 
-// A kernel with grid-wide sums deadlocks unless all its blocks are resident together.  The occupancy query gives the
+// A kernel with grid-wide sums makes no progress unless all its blocks are resident together.  The occupancy query gives the
 // blocks one CU takes; blocks <= CUs x that number is checked here.  Two persistent kernels launched at the same time on
-// one device could still interleave their blocks and wait for each other forever: hipLaunchCooperativeKernel sends such
-// kernels through one queue per device and rules that out, at the price of 13 us of queue time before and after the
-// kernel.  Default (coop_launch = 2): the cooperative launch only while this process has more than one live context on the
-// device, a plain launch (same residency) otherwise.  SRPS_ERR_UNSUPPORTED: does not fit, the caller streams instead.
+// one device could still interleave their blocks and wait for each other: hipLaunchCooperativeKernel sends such kernels
+// through one queue per device and rules that out, at the price of 13 us of queue time before and after the kernel.
+// Default (coop_launch = 1): the cooperative launch; option "exclusive_device" = 1 (coop_launch = 0) selects the plain launch
+// (same residency) for a device that nothing else uses.  Neither launch can see other processes, CU masks or a hardware that
+// admits one block fewer than the API reports -- which is why every wait inside the kernels is bounded (device_utils.h
+// SpinGuard): such a launch ends with an abort flag within the spin budget and the host repeats the phase with the streaming
+// kernels.  SRPS_ERR_UNSUPPORTED: does not fit, the caller streams instead.
 int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes) {
+    ctx->persistent_inflight = 1;
     int per_cu = 0;
     const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds_bytes);
     if (oe != hipSuccess || per_cu < 1 || (long)blocks > (long)per_cu * ctx->num_cus) {

@@ -118,6 +118,7 @@ struct ResidentArgs {
     float cx, cy;
     int i_lo, j_lo;
     int debug;                 // timing experiments only: 1 = no grid-wide sums, no ring polls (wrong results)
+    unsigned long long spin_ticks;   // budget of the whole launch in s_memrealtime ticks (10 ns): waits give up after it
 };
 
 // per-channel constants of the tensor-recompute form (uniform)
@@ -158,6 +159,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int ntile = a.nbr * a.nbc;
+    // every wait below is bounded by one deadline (device_utils.h): a block that never becomes resident ends the launch
+    // with an abort flag instead of hanging it; the first grid-wide sum (pass 0) doubles as the census of resident blocks
+    spin_guard_init(a.spin_ticks, &a.scal->abort_flags, ABORT_DEPTH);
     // XCD-aware tile order: the blocks of one XCD (b, b+8, ...) get a contiguous range of tiles
     int tile = blockIdx.x;
     {
@@ -588,6 +592,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 if (ridx[q] >= 0 && hsrc[q] != nullptr && !(a.debug & 1)) {
                     const unsigned long long* s = hsrc[q] + (size_t)(hgen & 1u) * HALO_N;
                     while ((unsigned)(hv[q] >> 32) != hgen) {
+                        // the clock is read by the scalar unit (no counter register); uniform for the lanes still waiting
+                        if (spin_deadline_passed()) { spin_give_up(-1, hgen); break; }
                         __builtin_amdgcn_s_sleep(1);
                         hv[q] = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -707,7 +713,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         pass0 = false;
     }
     // ---- results ---------------------------------------------------------------------------------------------
-    if (act) {
+    // a block one of whose waits gave up stores nothing: x keeps the iterate the launch started from
+    const bool dead = spin_block_dead();
+    if (act && !dead) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) st4(a.x + (size_t)(gcol0 + c + PAD) * Hs + srow0, x[c]);
     }
@@ -765,6 +773,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.max_steps = max_steps;
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     a.debug = ctx->cg_resident_debug;
+    a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;      // s_memrealtime: 100 MHz
     const void* fn = nullptr;
 #define SRPS_RES(SFV, NCV) fn = ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true> : (const void*)k_cg_resident<SFV, NCV, false>
     if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else if (G.sf == 2) SRPS_RES(2, 3); else SRPS_RES(4, 3); }

@@ -166,6 +166,37 @@ static int report_fetch(srps_ctx* ctx) {
     return SRPS_OK;
 }
 
+// After the report record has been fetched and the stream waited for: did a persistent launch give up a wait
+// (device_utils.h SpinGuard)?  Returns the ABORT_* bits, switches the kernels concerned off for this context (the phases
+// fall back to the streaming kernels), clears the device flags and leaves the reason in srps_last_error().
+static int persistent_aborts(srps_ctx* ctx, int* flags_out) {
+    *flags_out = 0;
+    const CgScalars* hs = (const CgScalars*)(ctx->h_pinned + 64);
+    const int flags = hs->abort_flags;
+    ctx->persistent_inflight = 0;
+    if (!flags) return SRPS_OK;
+    ++ctx->persistent_fallbacks;
+    if (flags & ABORT_DEPTH) ctx->cg_resident = 0;
+    if (flags & ABORT_ALBEDO) ctx->albedo_persistent = 0;
+    set_error("persistent %s%s%s kernel gave up a grid-wide wait after %d ms (wait %d: %d blocks had arrived) -- the device is shared or "
+              "admits fewer resident blocks than the occupancy query reports; this context now uses the streaming kernels",
+              (flags & ABORT_DEPTH) ? "depth-CG" : "", (flags & ABORT_DEPTH) && (flags & ABORT_ALBEDO) ? " and " : "",
+              (flags & ABORT_ALBEDO) ? "albedo-CG" : "", ctx->spin_budget_ms, hs->abort_gen, hs->abort_arrived);
+    SRPS_HIP(hipMemsetAsync(&((CgScalars*)(ctx->d_report + 64))->abort_flags, 0, 3 * sizeof(int), ctx->stream));
+    ((CgScalars*)(ctx->h_pinned + 64))->abort_flags = 0;
+    *flags_out = flags;
+    return SRPS_OK;
+}
+// the same with its own fetch + wait, for the calls that cannot defer the check to the end of the pass
+static int persistent_sync_check(srps_ctx* ctx, int* flags_out) {
+    *flags_out = 0;
+    if (!ctx->persistent_inflight) return SRPS_OK;
+    SRPS_TRY(report_fetch(ctx));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    albedo_iters_collect(ctx);
+    return persistent_aborts(ctx, flags_out);
+}
+
 }  // namespace srps
 
 using namespace srps;
@@ -274,6 +305,12 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "coop_launch")) {
         SRPS_REQUIRE(value >= 0 && value <= 2, SRPS_ERR_INVALID, "coop_launch: 0 (plain), 1 (cooperative) or 2 (cooperative when the device is shared)");
         ctx->coop_launch = value;
+    } else if (!strcmp(name, "exclusive_device")) {
+        // the caller states that no other process or context uses the device: plain launches of the persistent kernels
+        ctx->coop_launch = value ? 0 : 1;
+    } else if (!strcmp(name, "spin_budget_ms")) {
+        SRPS_REQUIRE(value >= 1 && value <= 600000, SRPS_ERR_INVALID, "spin_budget_ms: 1 .. 600000");
+        ctx->spin_budget_ms = value;
     } else if (!strcmp(name, "cg_one_sync")) {
         ctx->cg_one_sync = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident")) {
@@ -335,6 +372,10 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "albedo_channels_together")) *value = ctx->albedo_channels_together;
     else if (!strcmp(name, "albedo_one_sync")) *value = ctx->albedo_one_sync;
     else if (!strcmp(name, "num_cus")) *value = ctx->num_cus;
+    else if (!strcmp(name, "coop_launch")) *value = ctx->coop_launch;
+    else if (!strcmp(name, "exclusive_device")) *value = ctx->coop_launch == 0 ? 1 : 0;
+    else if (!strcmp(name, "spin_budget_ms")) *value = ctx->spin_budget_ms;
+    else if (!strcmp(name, "persistent_fallbacks")) *value = ctx->persistent_fallbacks;
     else if (!strcmp(name, "cg_resident_active")) *value = (ctx->grid.bound && resident_supported(ctx)) ? 1 : 0;
     else SRPS_REQUIRE(false, SRPS_ERR_INVALID, "get_option: unknown option '%s'", name);
     return SRPS_OK;
@@ -383,7 +424,11 @@ int srps_albedo_estimation(srps_ctx* ctx, const float* d_s, float* d_rho, const 
     SRPS_TRY(ensure(ctx->ws_misc, 2 * (size_t)nchannels * npix * sizeof(float) + 64));
     float* numden = (float*)ctx->ws_misc.p;
     SRPS_TRY(albedo_numden(ctx, d_s, d_N, d_I, npix, nimages, nchannels, 0, numden));
-    return albedo_finish(ctx, d_rho, numden, npix, nchannels);
+    SRPS_TRY(albedo_finish(ctx, d_rho, numden, npix, nchannels));
+    int aborted = 0;
+    SRPS_TRY(persistent_sync_check(ctx, &aborted));           // waits only when the persistent kernel was launched
+    if (aborted & ABORT_ALBEDO) SRPS_TRY(albedo_finish(ctx, d_rho, numden, npix, nchannels));      // streaming form now
+    return SRPS_OK;
 }
 
 int srps_bind_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
@@ -424,13 +469,18 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
     SRPS_TRY(depth_assemble(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, K00, K11, npix, nimages, nchannels, nimages, 0,
                             ctx->op_pp_set ? ctx->op_cx : NAN, ctx->op_pp_set ? ctx->op_cy : NAN));
     ctx->plane_holds_z = false;
-    SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
-    SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
-    SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
-    SRPS_TRY(report_fetch(ctx));          // first: the two energy terms of this call overwrite the record's
-    SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, e2, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    albedo_iters_collect(ctx);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
+        SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
+        SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
+        SRPS_TRY(report_fetch(ctx));          // first: the two energy terms of this call overwrite the record's
+        SRPS_HIP(hipMemcpyAsync(ctx->h_pinned, e2, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        SRPS_HIP(hipStreamSynchronize(ctx->stream));
+        albedo_iters_collect(ctx);
+        int aborted = 0;
+        SRPS_TRY(persistent_aborts(ctx, &aborted));
+        if (!(aborted & ABORT_DEPTH)) break;          // else: d_z is untouched (a dead block stores nothing), solve again by streaming
+    }
     *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];               // dc.cu:785
     ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 64))->iters;
     (void)G;
@@ -547,7 +597,13 @@ int srps_albedo_partial(srps_ctx* ctx) {
 int srps_albedo_finish(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     ctx->light_cache_valid = false;      // rho changes
-    return albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C);
+    SRPS_TRY(albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C));
+    if (ctx->N_local != ctx->N_total) {  // a shard cannot repeat the pass on its own later (srps_energy_finish): look now
+        int aborted = 0;
+        SRPS_TRY(persistent_sync_check(ctx, &aborted));
+        if (aborted & ABORT_ALBEDO) SRPS_TRY(albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C));
+    }
+    return SRPS_OK;
 }
 int srps_albedo(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -570,6 +626,12 @@ int srps_depth_solve(srps_ctx* ctx) {
     ctx->grad_current = false;
     ctx->plane_holds_z = false;
     SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy, plane_current));
+    if (ctx->N_local != ctx->N_total) {  // see srps_albedo_finish
+        int aborted = 0;
+        SRPS_TRY(persistent_sync_check(ctx, &aborted));
+        // a dead block stores nothing: the plane still holds the iterate the launch started from
+        if (aborted & ABORT_DEPTH) SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy, true));
+    }
     ctx->grad_current = true;            // depth_solve_impl leaves Dx z, Dy z of the new z in zx, zy
     ctx->plane_holds_z = true;           // ... and z itself on the grid plane
     return SRPS_OK;
@@ -590,6 +652,20 @@ int srps_energy_finish(srps_ctx* ctx, float* energy) {
     SRPS_TRY(report_fetch(ctx));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     albedo_iters_collect(ctx);
+    // The one place a pass waits for the device: were the persistent kernels of this pass served?  If not (nothing was stored by
+    // them), the part of the pass that followed is repeated with the streaming kernels -- on one GPU only: a shard has looked
+    // already (srps_albedo_finish, srps_depth_solve), its energy term went through the all-reduce.
+    int aborted = 0;
+    SRPS_TRY(persistent_aborts(ctx, &aborted));
+    if (aborted && ctx->N_local == ctx->N_total) {
+        if (aborted & ABORT_ALBEDO) { SRPS_TRY(srps_albedo_finish(ctx)); SRPS_TRY(srps_depth_partial(ctx)); }
+        SRPS_TRY(srps_depth_solve(ctx));
+        SRPS_TRY(srps_energy_partial(ctx));
+        SRPS_TRY(srps_normals(ctx));
+        SRPS_TRY(report_fetch(ctx));
+        SRPS_HIP(hipStreamSynchronize(ctx->stream));
+        albedo_iters_collect(ctx);
+    }
     *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];
     ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 64))->iters;
     ctx->last_light_iters = *(int*)(ctx->h_pinned + 8);
@@ -794,6 +870,10 @@ int srps_bench_cg(srps_ctx* ctx, int solves, int iters, double* seconds, double*
     SRPS_HIP(hipMemcpyAsync(G.d_x, G.d_save, G.plane * sizeof(float), hipMemcpyDeviceToDevice, st));
     SRPS_HIP(hipStreamSynchronize(st));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    int aborted = 0;
+    ctx->persistent_inflight |= ABORT_DEPTH;
+    SRPS_TRY(persistent_sync_check(ctx, &aborted));
+    SRPS_REQUIRE(!aborted, SRPS_ERR_HIP, "bench_cg: %s", srps_last_error());      // a timing of an aborted launch is worthless
     return SRPS_OK;
 }
 

@@ -32,8 +32,12 @@ struct CgScalars {
     int iters;       // steps executed    (dc.cu:254)
     int active;      // 1 while r1 > tol^2
     float alpha;     // step length of the last update kernel; x += alpha p is applied by the NEXT operator launch
-    int pad[3];
+    // status words of the persistent kernels (device_utils.h SpinGuard): a wait that outlived the spin budget
+    int abort_flags;    // bit 0: depth CG (k_cg_resident), bit 1: albedo CG (k_dcg_persistent*); 0 = every wait completed
+    int abort_arrived;  // blocks whose granule had arrived at the first wait that gave up
+    int abort_gen;      // generation (wait number) of that wait: 1 = not all blocks became resident
 };
+enum { ABORT_DEPTH = 1, ABORT_ALBEDO = 2 };
 
 struct Grid {
     bool bound = false;
@@ -124,10 +128,16 @@ struct srps_ctx {
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
     int light_channel_inner = 1;     // fused energy + lighting sweep with the channels in the inner loop (C in {1, 3})
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
-    int coop_launch = 2;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (one cooperative queue per
-                                     // device: two such kernels of this process cannot interleave their blocks and wait for each
-                                     // other forever; +13 us of queue time before and after), 0 = plain launch behind the same
-                                     // occupancy check, 2 = plain while this is the only live context of the process on its device
+    int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue
+                                     // per device: two such kernels of this process cannot interleave their blocks and wait for each
+                                     // other; +13 us of queue time before and after), 0 = plain launch behind the same occupancy
+                                     // check -- the caller states that the device is exclusive to this context (option
+                                     // "exclusive_device"), 2 = plain while this is the only live context of the process on its device.
+                                     // Whatever the launch, every wait inside the kernels is bounded (spin_budget_ms).
+    int spin_budget_ms = 200;        // a persistent launch whose waits are not all served within this time aborts (device_utils.h
+                                     // SpinGuard); the host then repeats the phase with the streaming kernels
+    int persistent_fallbacks = 0;    // aborted persistent launches so far (option "persistent_fallbacks", read-only)
+    int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at
     int cg_one_sync = 1;             // resident CG: r.r from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per step)
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;

@@ -1,0 +1,180 @@
+"""GPU parity at BASELINE.json's sizes against the C oracle (oracle/srps_oracle.c, OpenMP: it finishes a 2048 x 2048
+depth step in seconds on the GPU box's host cores):
+
+  * 2048 x 2048, sf 4 -- the metric's grid: the kernel the bench times (k_cg_resident, 256 tiles of 256 x 64, every CU),
+    with one and with two grid-wide waits per CG step, against the streaming kernels and against the oracle's
+    assembled-CSR CG (the reference's formulation, devicecalls.cu:229-279, 743-759);
+  * 1024 x 1024, sf 4, 20 images (BASELINE.json configs[2]): one whole alternating pass against the oracle;
+  * 4096 x 4096, sf 2 (configs[4]'s grid): the streaming kernels (the grid needs more tiles than the chip has CUs)
+    against the oracle's matrix-free CG, plus the operator properties.
+
+Tolerances: depth RMSE < 1e-4 against the oracle (north_star), < 2e-5 between two of our own kernel paths.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def coracle():
+    import c_oracle
+    return c_oracle
+
+
+def _lr_compact(sc, st, v_lr):
+    """masked LR vector in the order of KT's rows (SRPS.cu:237-239): block b -> LR linear index of its first pixel"""
+    if st.Ps == 0:
+        return np.zeros(0, f32)
+    first = st.imask[st.blk_pix.reshape(st.Ps, -1)[:, 0]]
+    j, i = first // sc.h, first % sc.h
+    return np.ascontiguousarray(np.asarray(v_lr, f32)[(j // sc.sf) * (sc.h // sc.sf) + (i // sc.sf)])
+
+
+def _oracle_start(sc, oracle, coracle):
+    """SRPS.cu:151-270 with the C oracle's structure: compaction, initial values, first normals"""
+    st = coracle.Structure(sc.h, sc.w, sc.sf, sc.mask)
+    I = np.ascontiguousarray(sc.I[:, :, st.imask])
+    z = np.ascontiguousarray(sc.z_init[st.imask])
+    K = np.asarray(sc.K, f32)
+    xx = ((st.imask // sc.h).astype(f32) - K[6]).astype(f32)
+    yy = ((st.imask % sc.h).astype(f32) - K[7]).astype(f32)
+    zx, zy = coracle.gradient(st, z)
+    N, dz = oracle.normal_init(z, zx, zy, xx, yy, K[0], K[4])
+    return st, dict(I=I, z=z, xx=xx, yy=yy, N=N, dz=dz, z0s=_lr_compact(sc, st, sc.zs_lr), fx=float(K[0]), fy=float(K[4]))
+
+
+def _depth_three_ways(pkg, sc, variants):
+    """the state after lighting + albedo, and z / energy / iterations of one depth phase per variant (a dict of options)"""
+    dh = pkg.DataHandler.from_scene(sc)
+    out, state = {}, None
+    for name, opts in variants.items():
+        ctx = pkg.Context(device_id=0)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.setup(dh)
+        ctx.lighting(); ctx.albedo()
+        if state is None:
+            state = {k: ctx.get(k) for k in ("s", "rho", "dz", "z", "xx", "yy", "z0s")}
+        e = ctx.depth()
+        out[name] = dict(e=e, z=ctx.get("z"), it=ctx.last_cg_iterations()["depth"], resident=ctx.get_option("cg_resident_active"))
+        ctx.close()
+    return state, out
+
+
+def test_metric_size_depth_phase_resident_streaming_and_oracle(pkg, oracle, coracle):
+    """2048 x 2048, sf 4, 4 images, 3 channels, full mask: exactly the launch the bench times"""
+    sc = pkg.synth.make_scene(2048, 2048, 4, 4, seed=1237, mask_kind="full")
+    variants = {"resident_one_wait": dict(cg_resident=1, cg_resident_tile=512, cg_one_sync=1),
+                "resident_two_waits": dict(cg_resident=1, cg_resident_tile=512, cg_one_sync=0),
+                "streaming": dict(cg_resident=0)}
+    state, out = _depth_three_ways(pkg, sc, variants)
+    assert out["resident_one_wait"]["resident"] == 1 and out["resident_two_waits"]["resident"] == 1 and out["streaming"]["resident"] == 0
+    assert all(o["it"] == 101 for o in out.values()), {k: o["it"] for k, o in out.items()}
+    # the oracle's depth step from the same state (assembled CSR + the reference's CG)
+    st = coracle.Structure(sc.h, sc.w, sc.sf, sc.mask)
+    P = st.P
+    assert P == 2048 * 2048
+    I = np.ascontiguousarray(sc.I[:, :, st.imask])
+    z_ref = state["z"].copy()
+    e_ref, it_ref = coracle.depth_estimation(st, state["s"].reshape(-1, 3, 4), state["rho"].reshape(3, P), I, state["xx"], state["yy"],
+                                             state["dz"], state["z0s"], z_ref, float(sc.K[0]), float(sc.K[4]), assembled=True)
+    assert it_ref == 101
+    z_mf = state["z"].copy()
+    e_mf, _ = coracle.depth_estimation(st, state["s"].reshape(-1, 3, 4), state["rho"].reshape(3, P), I, state["xx"], state["yy"],
+                                       state["dz"], state["z0s"], z_mf, float(sc.K[0]), float(sc.K[4]), assembled=False)
+    report = {k: (rmse(o["z"], z_ref), rmse(o["z"], z_mf), o["e"]) for k, o in out.items()}
+    print("2048^2 depth phase: RMSE vs assembled oracle, vs matrix-free oracle, energy:", report, "oracle energies", e_ref, e_mf,
+          "oracle assembled vs matrix-free", rmse(z_ref, z_mf))
+    for k, o in out.items():
+        assert rmse(o["z"], z_ref) < 1e-4, report
+        assert abs(o["e"] - e_ref) <= 1e-3 * abs(e_ref), report
+    # our own paths among each other: the drift of the predicted r.r at full size, and resident against streaming
+    assert rmse(out["resident_one_wait"]["z"], out["resident_two_waits"]["z"]) < 2e-5, report
+    assert rmse(out["resident_one_wait"]["z"], out["streaming"]["z"]) < 2e-5, report
+    assert rmse(out["resident_two_waits"]["z"], out["streaming"]["z"]) < 2e-5, report
+
+
+def test_config3_whole_pass_against_the_oracle(pkg, oracle, coracle):
+    """1024 x 1024, sf 4, 20 images (BASELINE.json configs[2]): lighting -> albedo -> depth -> normals, default options,
+    against numpy (lighting dc.cu:376-444, albedo dc.cu:395-406 + 513-548 on the diagonal system) and C (depth)"""
+    sc = pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full")
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    en = pkg.alternating_loop(ctx, None, max_outer=1)
+    z = ctx.get("z"); rho = ctx.get("rho").reshape(3, -1); s = ctx.get("s").reshape(-1, 3, 4); Nrm = ctx.get("N").reshape(4, -1)
+    iters = ctx.last_cg_iterations()
+    assert ctx.get_option("cg_resident_active") == 1
+    ctx.close()
+    st, o = _oracle_start(sc, oracle, coracle)
+    P = st.P
+    s_ref = np.zeros((20, 3, 4), f32); s_ref[:, :, 2] = -1
+    rho_ref = np.full((3, P), 0.5, f32)
+    oracle.lighting_estimation(s_ref, rho_ref, o["N"], o["I"])
+    num, den = oracle.albedo_numden(s_ref, o["N"], o["I"])
+    alb_it = []
+    oracle.albedo_solve_numden(rho_ref, num, den, alb_it)
+    z_ref = o["z"].copy()
+    e_ref, it_ref = coracle.depth_estimation(st, s_ref, rho_ref, o["I"], o["xx"], o["yy"], o["dz"], o["z0s"], z_ref, o["fx"], o["fy"], assembled=True)
+    # normals (dc.cu:171-223) of the depth the GPU solved: N = (fx zx, fy zy, ...) / |.| multiplies depth differences by the
+    # focal length (1229 here), so they are compared on the same z rather than through the two solves
+    zx, zy = coracle.gradient(st, z)
+    N_ref, _ = oracle.normal_init(z, zx, zy, o["xx"], o["yy"], o["fx"], o["fy"])
+    print("1024^2 pass: depth RMSE", rmse(z, z_ref), "albedo max", np.abs(rho - rho_ref).max(), "energy", en[0], e_ref, "albedo CG", iters["albedo"][:3], alb_it)
+    assert iters["depth"] == it_ref == 101
+    assert all(abs(a - b) <= 2 for a, b in zip(iters["albedo"][:3], alb_it))
+    assert rmse(z, z_ref) < 1e-4
+    assert np.abs(rho - rho_ref).max() < 1e-4
+    assert abs(en[0] - e_ref) <= 1e-2 * abs(e_ref)            # first pass: see DESIGN.md section 6
+    # lighting through the shading it predicts (the first pass's 4 x 4 systems have a flat direction)
+    A = (rho_ref[:, None, :] * o["N"][None, :, :]).astype(np.float64)                 # [c][4][P]
+    for c in range(3):
+        d = (s[:, c, :] - s_ref[:, c, :]).astype(np.float64) @ A[c]
+        r = s_ref[:, c, :].astype(np.float64) @ A[c]
+        assert np.linalg.norm(d) / np.linalg.norm(r) < 1e-4
+    assert np.abs(Nrm - N_ref).max() < 2e-5
+
+
+def test_largest_grid_streaming_kernels_against_the_oracle(pkg, oracle, coracle):
+    """4096 x 4096, sf 2 (BASELINE.json configs[4]'s grid; 2 images keep the host side of the test small): 4 x the tiles
+    the chip has CUs, so the depth CG streams its vectors; against the oracle's matrix-free CG, and the operator is
+    symmetric, positive and linear at this size"""
+    import torch
+    sc = pkg.synth.make_scene(4096, 4096, 2, 2, seed=1238, mask_kind="full")
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    ctx.lighting(); ctx.albedo()
+    state = {k: ctx.get(k) for k in ("s", "rho", "dz", "z", "xx", "yy", "z0s")}
+    e = ctx.depth()
+    assert ctx.get_option("cg_resident_active") == 0
+    assert ctx.last_cg_iterations()["depth"] == 101
+    z = ctx.get("z")
+    P = ctx.dims()["npix"]
+    assert P == 4096 * 4096
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(P, device="cuda", generator=g); y = torch.randn(P, device="cuda", generator=g)
+    Ax = torch.empty_like(x); Ay = torch.empty_like(x); Az = torch.empty_like(x)
+    ctx.depth_operator_apply(x, P, Ax); ctx.depth_operator_apply(y, P, Ay)
+    ctx.depth_operator_apply(0.5 * x - 2.0 * y, P, Az)
+    ctx.synchronize()
+    xAx = torch.dot(x.double(), Ax.double()).item()
+    assert xAx > 0
+    assert abs(torch.dot(x.double(), Ay.double()).item() - torch.dot(y.double(), Ax.double()).item()) / xAx < 1e-5
+    lin = 0.5 * Ax - 2.0 * Ay
+    assert (torch.linalg.norm((Az - lin).double()) / torch.linalg.norm(lin.double())).item() < 1e-5
+    ctx.close()
+    del x, y, Ax, Ay, Az, lin
+    st = coracle.Structure(sc.h, sc.w, sc.sf, sc.mask)
+    I = np.ascontiguousarray(sc.I[:, :, st.imask])
+    z_ref = state["z"].copy()
+    e_ref, it_ref = coracle.depth_estimation(st, state["s"].reshape(-1, 3, 4), state["rho"].reshape(3, P), I, state["xx"], state["yy"],
+                                             state["dz"], state["z0s"], z_ref, float(sc.K[0]), float(sc.K[4]), assembled=False)
+    print("4096^2 depth phase: RMSE vs oracle", rmse(z, z_ref), "energy", e, e_ref)
+    assert it_ref == 101
+    assert rmse(z, z_ref) < 1e-4
+    assert abs(e - e_ref) <= 1e-3 * abs(e_ref)
