@@ -159,9 +159,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int ntile = a.nbr * a.nbc;
-    // every wait below is bounded by one deadline (device_utils.h): a block that never becomes resident ends the launch
-    // with an abort flag instead of hanging it; the first grid-wide sum (pass 0) doubles as the census of resident blocks
-    spin_guard_init(a.spin_ticks, &a.scal->abort_flags, ABORT_DEPTH);
+
     // XCD-aware tile order: the blocks of one XCD (b, b+8, ...) get a contiguous range of tiles
     int tile = blockIdx.x;
     {
@@ -251,6 +249,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     for (int t = tid; t < RING; t += NT) { hp[t] = 0.f; hfl[t] = 0u; }
     for (int t = tid; t < NC * RING; t += NT) hg[t] = 0.f;
     if (tid < 4) sflag[tid] = 0;
+    // every wait below is bounded by one deadline (device_utils.h): a block that never becomes resident ends the launch
+    // with an abort flag instead of hanging it; the first grid-wide sum (pass 0) doubles as the census of resident blocks
+    spin_guard_init(a.spin_ticks, &a.scal->abort_flags, ABORT_DEPTH);      // here, not at the top: 44 bytes of scratch less
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {

@@ -38,7 +38,7 @@ def _prepared_context(pkg, dh, budget_ms):
     ctx = pkg.Context(device_id=0)
     ctx.set_option("spin_budget_ms", budget_ms)
     ctx.setup(dh)
-    ctx.lighting(); ctx.albedo()
+    ctx.lighting(); ctx.albedo(); ctx.depth_partial()      # the assembly decides which operator kernels apply
     ctx.synchronize()
     assert ctx.get_option("cg_resident_active") == 1 and ctx.get_option("persistent_fallbacks") == 0
     return ctx
