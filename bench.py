@@ -67,6 +67,76 @@ def cpu_baseline(sc, pkg, budget_s=20.0):
             "sample": f"{iters} CG steps of the matrix-free 2048^2 system (numpy/scipy restatement, 1 thread)"}
 
 
+FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X peak fp32 vector rate, /opt/skills/guides/MI355X_MICROARCH.md (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz)
+# useful flops of one CG step per unknown in the executed (tensor-recompute, one-wait) form -- DESIGN.md section 4:
+# P = sum_c g_c T_c 36, gradients 2, E'(.) 4, P(.) 15, E(.) 4, scatter 4, KT'KT + lambda 3, three dot products 6,
+# p = beta p + r 2, x += alpha p and r -= alpha omega 4, r.r 2
+FLOPS_PER_UNKNOWN_STEP = 82
+FLOPS_PER_UNKNOWN_RESIDUAL_PASS = 71
+
+
+def _profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
+    """isolated inner loop (srps_bench_cg: HIP events on the launch stream) and the roofline of its dominant kernel"""
+    out = {}
+    b = ctx.bench_cg(solves=solves, iters=101)
+    us_iter = 1e6 * b["seconds"] / b["iterations"]
+    out["cg_only_it_per_s"] = b["iterations"] / b["seconds"]
+    out["cg_only_us_per_iteration"] = us_iter
+    loop_bytes = b["apply_bytes"] + b["update_bytes"]
+    P = ctx.dims()["npix"]
+    resident = bool(ctx.get_option("cg_resident_active"))
+    assert resident == resident_expected or not resident_expected, "the resident CG kernel was expected to run"
+    tj = _profile("r02_traffic.json") or _profile("r01_traffic.json") or {}
+    key = f"{H}x{W}_sf{sf}"
+    if resident:
+        # ONE launch runs the residual pass and all 101 steps with the CG state in registers + LDS (kernels_resident.hip).
+        # HBM is not what bounds it (the state never leaves the chip): the binding resource is the vector ALU.  `achieved` =
+        # useful flops of the launch / its duration against the fp32 vector peak; `issue` prices the instruction stream the
+        # compiler actually emitted (tools/isa_loop_report.py) with the measured issue cost per instruction class
+        # (tools/valu_issue_bench.hip: 2.3 clocks full rate, 4.5 packed fp32 / v_bfe / DPP, two waves per SIMD).
+        launch_us = 1e6 * b["seconds"] / (b["iterations"] / 101)
+        flops = float(P) * (101 * FLOPS_PER_UNKNOWN_STEP + FLOPS_PER_UNKNOWN_RESIDUAL_PASS)
+        ach = flops / (launch_us * 1e6)                     # TFLOP/s
+        isa = _profile("r02_resident_isa.json")
+        issue = None
+        if isa and key in isa:
+            clk = isa[key]["valu_issue_clocks_per_wave_step"] * isa[key]["waves_per_simd"]
+            floor_us = clk / (isa[key]["GHz"] * 1e3)
+            issue = {"valu_issue_clocks_per_simd_step": clk, "issue_floor_us_per_step": floor_us,
+                     "measured_us_per_step": launch_us / 101.0, "issue_frac": floor_us / (launch_us / 101.0), "source": isa[key]["source"]}
+        out["roofline"] = {"bound": "valu", "kernel": "k_cg_resident: residual pass + the whole truncated CG (101 steps) in one persistent launch",
+                           "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
+                           "traffic": (tj.get(key) or {}).get("resident"), "avg_launch_us": launch_us, "steps_per_launch": 101,
+                           "flops_per_launch": flops, "flops_per_unknown_and_step": FLOPS_PER_UNKNOWN_STEP, "issue": issue,
+                           # what a CG that streams its vectors would have to move for the same work, as a bandwidth -- NOT a roofline fraction
+                           "hbm_equivalent": {"algorithmic_bytes_per_launch": loop_bytes * 101, "GBs": loop_bytes * 101 / (1e3 * launch_us),
+                                              "x_hbm_peak": loop_bytes * 101 / (1e3 * launch_us) / HBM_PEAK_GBS}}
+    else:
+        out["cg_loop_roofline"] = {"bound": "hbm", "achieved": loop_bytes / (1e3 * us_iter), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": loop_bytes / (1e3 * us_iter) / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": loop_bytes,
+                                   "kernels_per_step": 2 if b["update_bytes"] > 0 else 1}
+        # events around the whole 101-step loop give the time per step; an event after EVERY launch (apply_us, update_us) adds
+        # ~3 us to each kernel, so it is used only to split the step between the kernels
+        share = b["apply_us"] / (b["apply_us"] + b["update_us"]) if b["update_us"] > 0 else 1.0
+        apply_us = us_iter * share
+        ach = b["apply_bytes"] / (1e3 * apply_us)
+        out["roofline"] = {"bound": "hbm", "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial dot products, deferred x / r updates)",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": (tj.get(key) or {}).get("apply"), "avg_launch_us": apply_us,
+                           "algorithmic_bytes_per_launch": b["apply_bytes"]}
+        if b["update_us"] > 0:
+            out["roofline"]["update_kernel_us"] = us_iter - apply_us
+            out["roofline"]["update_kernel_GBs"] = b["update_bytes"] / (1e3 * (us_iter - apply_us))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +147,7 @@ def main():
     ap.add_argument("--images", type=int, default=20, help="images per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-total-solve", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the streaming-CG legs (2048^2 streaming, 4096^2 sf 2)")
     ap.add_argument("--apply-mode", type=int, default=0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="srps_set_option before setup (A/B runs)")
     args = ap.parse_args()
@@ -112,6 +183,9 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    # the bench box is exclusive to this job (one rank per GPU), said explicitly: plain launches of the persistent kernels
+    if not shared_gpu:
+        ctx.set_option("exclusive_device", 1)
     if args.apply_mode:
         ctx.set_option("apply_mode", args.apply_mode)
     for kv in args.option:
@@ -153,55 +227,32 @@ def main():
         "energies": energies,
     }
     if rank == 0:
-        # isolated inner loop + per-kernel HIP-event timings (same stream as the launches)
-        b = ctx.bench_cg(solves=10, iters=101)
-        us_iter = 1e6 * b["seconds"] / b["iterations"]
-        out["cg_only_it_per_s"] = b["iterations"] / b["seconds"]
-        out["cg_only_us_per_iteration"] = us_iter
-        loop_bytes = b["apply_bytes"] + b["update_bytes"]
-        out["cg_loop_roofline"] = {"bound": "hbm", "achieved": loop_bytes / (1e3 * us_iter), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": loop_bytes / (1e3 * us_iter) / HBM_PEAK_GBS,
-                                   "algorithmic_bytes_per_iteration": loop_bytes}
-        traffic = None
-        valu = None
-        resident = bool(ctx.get_option("cg_resident_active"))
-        try:     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = tj.get(f"{H}x{W}_sf{args.sf}", {}).get("resident" if resident else "apply")
-            valu = tj.get(f"{H}x{W}_sf{args.sf}", {}).get("resident_valu") if resident else None
-        except Exception:
-            pass
-        if resident:
-            # ONE launch runs all 101 steps with the CG state in registers + LDS (kernels_resident.hip).  `achieved` is,
-            # as for the streaming kernels, the ALGORITHMIC bytes of the CG loop (49 B per unknown and step: what a
-            # kernel-per-half-step CG has to move) over the measured launch time; the state never leaves the chip, so
-            # this can exceed the HBM peak -- `traffic` (PMC) is what really crossed the fabric.
-            launch_us = 1e6 * b["seconds"] / (b["iterations"] / 101)
-            bytes_launch = loop_bytes * 101
-            ach = bytes_launch / (1e3 * launch_us)
-            out["roofline"] = {"bound": "hbm", "kernel": "k_cg_resident: the whole truncated CG (101 steps of p = beta p + r, omega = A_ p, "
-                                                         "x += alpha p, r -= alpha omega, two grid-wide dot products) in one persistent launch",
-                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic, "avg_launch_us": launch_us, "steps_per_launch": 101,
-                               "algorithmic_bytes_per_launch": bytes_launch,
-                               # what really binds this kernel (committed SQ counters): VALU issue, then one fabric round trip per step
-                               "binding": "valu issue + one grid-wide reduction (fabric round trip) per step; HBM ~4 % utilised",
-                               "valu": (dict(valu, measured_us_per_step=launch_us / 101.0,
-                                             issue_floor_frac=valu["issue_floor_us_per_step_at_2.4GHz"] / (launch_us / 101.0)) if valu else None),
-                               "note": "state resident in registers/LDS; the launch also forms the initial residual b - A x (one more operator pass, not counted in the bytes); frac > 1 means faster than any kernel that streams the CG vectors from HBM could be"}
-        else:
-            # Per-kernel duration: events around the whole 101-step loop give the time per step (kernel boundaries
-            # overlap there); an event after EVERY launch (b["apply_us"], b["update_us"]) adds ~3 us of event /
-            # boundary cost to each kernel, so it is used only to split the step time between the two kernels.
-            share = b["apply_us"] / (b["apply_us"] + b["update_us"])
-            apply_us = us_iter * share
-            ach = b["apply_bytes"] / (1e3 * apply_us)
-            out["roofline"] = {"bound": "hbm", "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial p.omega)",
-                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic, "avg_launch_us": apply_us, "avg_launch_us_event_bracketed": b["apply_us"],
-                               "algorithmic_bytes_per_launch": b["apply_bytes"],
-                               "update_kernel_us": us_iter - apply_us,
-                               "update_kernel_GBs": b["update_bytes"] / (1e3 * (us_iter - apply_us))}
+        out.update(cg_legs(pkg, ctx, H, W, args.sf, resident_expected=True))
+        if not args.no_legs and world == 1:
+            # the two HBM-bound legs of north_star, driver-timed with the headline: the streaming CG on the metric's grid
+            # (">= 60 % of the HBM roofline on the CG SpMV + axpy loop at 2048 x 2048") and on the largest single-GPU grid
+            # of BASELINE.json's configs (4096 x 4096, sf 2: four times the tiles the chip has CUs)
+            legs = {}
+            c2 = pkg.Context(device_id=local_rank)
+            c2.set_stream(stream.cuda_stream)
+            c2.set_option("cg_resident", 0)
+            c2.set_option("exclusive_device", 1)
+            c2.setup(dh)
+            pkg.alternating_loop(c2, None, max_outer=1)
+            legs["streaming_2048"] = dict(cg_legs(pkg, c2, H, W, args.sf, resident_expected=False, solves=5),
+                                          workload=f"depth CG of the headline workload with the streaming kernels (cg_resident=0), {H}x{W}, sf {args.sf}")
+            c2.close()
+            sc4 = pkg.synth.make_scene(4096, 4096, 2, 2, seed=1234 + 5, mask_kind="full")
+            c4 = pkg.Context(device_id=local_rank)
+            c4.set_stream(stream.cuda_stream)
+            c4.set_option("exclusive_device", 1)
+            c4.setup(pkg.DataHandler.from_scene(sc4))
+            pkg.alternating_loop(c4, None, max_outer=1)
+            legs["largest_grid_4096_sf2"] = dict(cg_legs(pkg, c4, 4096, 4096, 2, resident_expected=False, solves=3),
+                                                 workload="depth CG on a synthetic full-mask 4096x4096 HR grid, sf 2 (16.8 M unknowns; 2 images: the CG does not depend on their number)")
+            c4.close()
+            del sc4
+            out["legs"] = legs
     if rank == 0:
         # measured device-copy ceiling: 1 GiB device-to-device copy, read + write bytes over the event time
         try:
@@ -219,16 +270,23 @@ def main():
             out["device_copy_GBs"] = None
             out["device_copy_error"] = str(exc)
     if not args.no_total_solve:
-        # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up
-        ctx.setup(dh)
+        # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up; reported with and without srps_setup
+        # (= SRPS.cu:100-270: the upload of the images from host memory, compaction, first normals)
         if dist: dist.barrier()
         torch.cuda.synchronize()
+        t_setup0 = time.perf_counter()
+        ctx.setup(dh)
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
         t0 = time.perf_counter()
         en = pkg.alternating_loop(ctx, ar)
         torch.cuda.synchronize()
-        ts = time.perf_counter() - t0
+        t1 = time.perf_counter()
         if rank == 0:
-            out["total_solve_s"] = ts
+            out["total_solve_s"] = t1 - t0
+            out["total_solve_with_setup_s"] = t1 - t_setup0
+            out["setup_s"] = t0 - t_setup0
+            out["setup_host_bytes"] = int(dh.I.nbytes)
             out["total_solve_outer_iterations"] = len(en)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -75,10 +75,16 @@ int srps_synchronize(srps_ctx* ctx);
  * "cg_one_sync" (0|1: resident CG with one grid-wide wait per step),
  * "cg_resident_tile" (0|256|512: tile shape of the resident CG by its threads per block; 0 = 256 x 32 tiles wherever the
  *  device has a CU for each of them, else 256 x 64),
- * "cg_resident_debug" (timing experiments only: wrong results) */
+ * "cg_resident_debug" (timing experiments only: wrong results),
+ * "cg_resident_rect" (0|1: tiles wholly inside the mask run the resident CG's body without structure bits),
+ * "cg_fused_step" (0|1: streaming depth CG with the whole step in one launch instead of operator + update kernel),
+ * "exclusive_device" (0|1: the caller states that nothing else uses the device: plain instead of cooperative launches of the
+ *  persistent kernels), "spin_budget_ms" (a persistent launch whose grid-wide waits are not served within this time aborts and the
+ *  phase is repeated by the streaming kernels; default 200), "phase_timing", "roctx" (see srps_get_timings) */
 int srps_set_option(srps_ctx* ctx, const char* name, int value);
 /* reads an option back; also "cg_resident_active" (1 when the bound grid fits one tile per CU and the depth CG
- * therefore runs as the persistent on-chip kernel) and "num_cus" */
+ * therefore runs as the persistent on-chip kernel), "num_cus", "persistent_fallbacks" (persistent launches that gave up a wait
+ * so far), "cg_resident_rect_tiles_256" / "_512" (tiles of the bound grid that qualify for the body without structure bits) */
 int srps_get_option(srps_ctx* ctx, const char* name, int* value);
 
 /* ---- generic sparse operators (device pointers) -------------------------------------------*/
@@ -206,6 +212,17 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n);
  * that keeps the pointer and writes through it later must call this again (or srps_set) before the next phase. */
 int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats);
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters /*[8]*/, int* lighting_iters_max);
+
+/* ---- tracing ------------------------------------------------------------------------------
+ * replaces: the host Timer around every phase of the loop (Utilities.h:194-222, SRPS.cu:277-295), which needs a device
+ * synchronisation per phase.  With option "phase_timing" = 1 every pipeline phase records a pair of HIP events on the
+ * context's stream (no synchronisation); srps_get_timings waits for the stream and returns the milliseconds of the phases
+ * run since the previous call (summed per phase; -1 for a phase that did not run).  With option "roctx" = 1 (default: the
+ * environment variable SRPS_ROCTX) the same spans are roctx ranges, visible in rocprofv3 --marker-trace. */
+enum { SRPS_PHASE_LIGHTING = 0, SRPS_PHASE_ALBEDO_SWEEP, SRPS_PHASE_ALBEDO_SOLVE, SRPS_PHASE_DEPTH_ASSEMBLY, SRPS_PHASE_DEPTH_SOLVE,
+       SRPS_PHASE_ENERGY, SRPS_PHASE_NORMALS, SRPS_N_PHASES };
+int srps_get_timings(srps_ctx* ctx, float* ms /* [SRPS_N_PHASES] */);
+const char* srps_phase_name(int phase);
 
 /* ---- measurement --------------------------------------------------------------------------
  * Runs `solves` depth-CG solves of exactly `iters_per_solve` steps on the current system

@@ -123,6 +123,8 @@ def load():
         "srps_last_cg_iterations": (i, [vp, ip, ip, ip]),
         "srps_bench_cg": (i, [vp, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "srps_cg_bytes": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "srps_get_timings": (i, [vp, fp]),
+        "srps_phase_name": (C.c_char_p, [i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export it

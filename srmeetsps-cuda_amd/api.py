@@ -272,6 +272,14 @@ class Context:
         check(self.lib.srps_last_cg_iterations(self.h, C.byref(d), a, C.byref(l)))
         return {"depth": d.value, "albedo": list(a), "lighting_max": l.value}
 
+    def timings(self) -> dict:
+        """milliseconds per pipeline phase since the last call (option "phase_timing" must be on); replaces the host Timer of
+        SRPS.cu:277-295 -- HIP events on the stream, no synchronisation per phase"""
+        n = 7
+        ms = (C.c_float * n)()
+        check(self.lib.srps_get_timings(self.h, ms))
+        return {self.lib.srps_phase_name(k).decode(): ms[k] for k in range(n) if ms[k] >= 0}
+
     def bench_cg(self, solves: int, iters: int = 101) -> dict:
         s = C.c_double(0); a = C.c_double(0); u = C.c_double(0)
         check(self.lib.srps_bench_cg(self.h, solves, iters, C.byref(s), C.byref(a), C.byref(u)))

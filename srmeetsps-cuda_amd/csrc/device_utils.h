@@ -49,6 +49,41 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
 }
 
+// four partial-sum arrays [4][n] at once (one pair of barriers): the same pattern and the same bits per array as sum_partials
+__device__ __forceinline__ void sum_partials4(const float* __restrict__ part, int n, double (&out)[4], double (*sm_d)[4] /* [4][4] */) {
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < n; i += 256) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += (double)part[(size_t)v * n + i];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = wave_sum(acc[v]);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sm_d[v][tid >> 6] = acc[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out[v] = ((sm_d[v][0] + sm_d[v][1]) + sm_d[v][2]) + sm_d[v][3];
+}
+// block sums of four values of a 256-thread block: results in sm[0..3] (sm holds 4 + 16 floats), valid after the call
+__device__ __forceinline__ void block_sum4(const float (&v)[4], float* sm) {
+    const int tid = threadIdx.x;
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = wave_sum(v[i]);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm[4 + i * 4 + (tid >> 6)] = t[i];
+    }
+    __syncthreads();
+    if (tid < 4) sm[tid] = ((sm[4 + tid * 4] + sm[4 + tid * 4 + 1]) + sm[4 + tid * 4 + 2]) + sm[4 + tid * 4 + 3];
+    __syncthreads();
+}
+
 // ---- wave totals through DPP (no LDS traffic; ds_bpermute-based shuffles cost ~150 cycles each) -------------
 // Fixed order: four row_shr steps leave each row's total in its lane 15, row_bcast:15 / row_bcast:31 carry them
 // to lane 63, v_readlane broadcasts.  Invalid source lanes read 0.

@@ -368,6 +368,29 @@ __global__ __launch_bounds__(256) void k_cg_flush_x(float* __restrict__ x, const
     }
 }
 
+// the x update still pending after the last executed step K of the one-launch protocol: alpha_K = r_{K-1}.r_{K-1} / p_K.omega_K from
+// the sums launch K left (dc.cu:269-270)
+__global__ __launch_bounds__(256) void k_cg_flush_x2(float* __restrict__ x, const float* __restrict__ p0, const float* __restrict__ p1,
+                                                     size_t n4, const float* __restrict__ part4, int n_part, CgScalars* __restrict__ scal) {
+    __shared__ double smd4[4][4];
+    const int it = scal->iters;
+    if (it < 1) return;
+    double s4[4];
+    sum_partials4(part4 + (size_t)(it & 1) * 4 * n_part, n_part, s4, smd4);
+    const float alpha = (float)s4[3] / (float)s4[0];
+    const float4* p4 = reinterpret_cast<const float4*>((it & 1) ? p1 : p0);
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < n4; t += (size_t)gridDim.x * 256) {
+        const float4 pv = p4[t];
+        float4 xv = x4[t];
+        xv.x = fmaf(alpha, pv.x, xv.x); xv.y = fmaf(alpha, pv.y, xv.y); xv.z = fmaf(alpha, pv.z, xv.z); xv.w = fmaf(alpha, pv.w, xv.w);
+        x4[t] = xv;
+    }
+}
+__global__ void k_cg_reset2(CgScalars* scal) {
+    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = 0.f; scal->iters = 0; scal->active = 1; scal->alpha = 0.f; }
+}
+
 __global__ void k_cg_reset(CgScalars* scal, float* rr0, int n_rr, const float* first) {
     // rr_part[0][0] = r.r of the initial residual, the rest zero
     for (int t = threadIdx.x; t < n_rr; t += blockDim.x) rr0[t] = (t == 0) ? first[0] : 0.f;
@@ -423,6 +446,8 @@ int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, vo
     return SRPS_OK;
 }
 
+bool cg_fused_step(const srps_ctx* ctx) { return ctx->cg_fused_step && use_march(ctx); }
+
 bool use_march(const srps_ctx* ctx) {
     if (ctx->apply_mode == SRPS_APPLY_SIMPLE) return false;
     return march_supported(ctx);
@@ -460,6 +485,11 @@ int grid_residual(srps_ctx* ctx) {
         hipLaunchKernelGGL((k_apply_simple<1>), dim3(G.nb_apply), dim3(64, 4), 0, ctx->stream, a);
         SRPS_LAUNCH_CHECK();
     }
+    if (cg_fused_step(ctx)) {                      // the first step sums the residual's partials itself
+        hipLaunchKernelGGL(k_cg_reset2, dim3(1), dim3(64), 0, ctx->stream, G.d_scal);
+        SRPS_LAUNCH_CHECK();
+        return SRPS_OK;
+    }
     float* first = G.d_misc_part + 4000;
     hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, ctx->stream, G.d_pw_part, apply_blocks(ctx), first);
     hipLaunchKernelGGL(k_cg_reset, dim3(1), dim3(256), 0, ctx->stream, G.d_scal, G.d_rr_part, G.nb_update, first);
@@ -469,6 +499,7 @@ int grid_residual(srps_ctx* ctx) {
 
 int cg_launch_apply(srps_ctx* ctx, int k) {
     Grid& G = ctx->grid;
+    if (cg_fused_step(ctx)) return march_cg_step(ctx, k);
     if (use_march(ctx)) return march_cg_apply(ctx, k);
     ApplyArgs a = base_args(ctx);
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
@@ -482,6 +513,7 @@ int cg_launch_apply(srps_ctx* ctx, int k) {
 
 int cg_launch_update(srps_ctx* ctx, int k) {
     Grid& G = ctx->grid;
+    if (cg_fused_step(ctx)) return SRPS_OK;       // nothing left to do: the next launch applies this step's updates
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
     const float tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
     if (use_march(ctx)) {      // fused protocol: the operator kernel applies x += alpha p
@@ -499,6 +531,11 @@ int cg_launch_update(srps_ctx* ctx, int k) {
 int cg_flush_x(srps_ctx* ctx) {
     Grid& G = ctx->grid;
     if (!use_march(ctx)) return SRPS_OK;       // classic protocol: k_cg_update already moved x
+    if (cg_fused_step(ctx)) {
+        hipLaunchKernelGGL(k_cg_flush_x2, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x, G.d_p, G.d_p + G.plane, G.used / 4, G.d_part4, G.n_part4, G.d_scal);
+        SRPS_LAUNCH_CHECK();
+        return SRPS_OK;
+    }
     hipLaunchKernelGGL(k_cg_flush_x, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x, G.d_p, G.d_p + G.plane, G.used / 4, G.d_scal);
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;

@@ -47,6 +47,12 @@ struct MarchArgs {
     const float* consts;   // [NC][8]: Sbb, x*, y*, R00, R01, R11, 0, 0
     float cx, cy;
     int i_lo, j_lo;
+    // MODE 3 (the whole CG step in one launch): omega of the previous step, and four partial sums per block --
+    // p.omega, r.omega, omega.omega, r.r -- of the previous launch (in) and of this one (out), [4][n_part]
+    const float* w_prev;
+    const float* part4_in;
+    float* part4_out;
+    int n_part;
 };
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v) {      // lane i <- lane i-1 ; lane 0 <- 0
@@ -94,15 +100,47 @@ __device__ __forceinline__ void st4(float* __restrict__ p, const F4& a) {
 }
 __device__ __forceinline__ F4 zero4() { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0.f; return r; }
 
+// MODE 0: out = A_ xin.  MODE 1: r -= A_ xin, partial r.r (residual, dc.cu:758).  MODE 2: p = beta p + r, out = A_ p, partial
+// p.out, x += alpha_prev p_prev (the update kernel k_cg_update_r follows).  MODE 3: the whole CG step k in ONE launch --
+// the updates of step k-1 that wait for its alpha are applied while the vectors stream through anyway:
+//     alpha_{k-1} = r_{k-2}.r_{k-2} / p_{k-1}.omega_{k-1}                    (sums of the previous launch, dc.cu:269)
+//     r_{k-1} = r_{k-2} - alpha_{k-1} omega_{k-1},  x_{k-1} = x_{k-2} + alpha_{k-1} p_{k-1}      (dc.cu:270-272)
+//     beta_k = r_{k-1}.r_{k-1} / r_{k-2}.r_{k-2},  p_k = beta_k p_{k-1} + r_{k-1},  omega_k = A_ p_k     (dc.cu:262-268)
+// r_{k-1}.r_{k-1} is needed for beta_k before r_{k-1} has been summed: it is taken as r.r - 2 alpha r.omega + alpha^2 omega.omega
+// from the previous launch's sums (the same identity as in the resident kernel).  The DIRECT sum of r_{k-1}.r_{k-1} is formed by
+// this launch and is what the next launch uses for alpha_k and as the denominator of beta_{k+1}: every predicted value is
+// anchored on a direct sum one step old, the prediction error does not accumulate.  45 B per unknown instead of 37 + 12, one
+// launch per step instead of two.
 template <int SF, int MODE, int NC>
-__global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
+__global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
     const int TJ = a.tj;                      // strip width: even, multiple of SF (runtime, the loop is unrolled by two)
     constexpr int NT = (NC > 0) ? NC : 6;     // planes streamed for the tensor: NC (recompute) or 6 (stored M)
     constexpr int L = (SF == 4) ? 3 : 2;      // look-ahead columns of the x window
     constexpr int NX = L + 2;                 // window holds x[c-1 .. c+L]
     __shared__ float sm[16];
     __shared__ double smd[4];
+    __shared__ double smd4[4][4];
+    __shared__ float sm4[4 + 4 * 4];
     float beta = 0.f;
+    float alpha_prev3 = 0.f;
+    if (MODE == 3) {
+        if (!a.scal->active) return;                                   // an earlier launch found r.r <= tol^2 (dc.cu:252)
+        double s4[4];
+        sum_partials4(a.part4_in, a.n_part, s4, smd4);
+        float r1;
+        const float r1_direct = (float)s4[3];                          // r_{k-2}.r_{k-2} (k == 1: of the initial residual)
+        if (a.k == 1) r1 = r1_direct;
+        else {
+            alpha_prev3 = r1_direct / (float)s4[0];                    // dc.cu:269
+            r1 = (float)((double)r1_direct - 2.0 * (double)alpha_prev3 * s4[1] + (double)alpha_prev3 * (double)alpha_prev3 * s4[2]);
+            beta = r1 / r1_direct;                                     // dc.cu:262
+        }
+        if (!(r1 > a.tol2)) {                                          // converged: dc.cu:252.  The pending x update is k_cg_flush_x2's
+            if (blockIdx.x == 0 && threadIdx.x == 0) a.scal->active = 0;
+            return;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal->iters = a.k; a.scal->r0 = r1_direct; a.scal->r1_last = r1; a.scal->alpha = alpha_prev3; }
+    }
     if (MODE == 2) {
         const float r1 = (float)sum_partials(a.rr_part, a.n_rr, smd);
         if (!(r1 > a.tol2)) return;                                   // converged: dc.cu:252
@@ -112,7 +150,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
     }
     // x_k = x_{k-1} + alpha_k p_k (dc.cu:270) of the PREVIOUS step is applied by this launch, which streams
     // p_k anyway; the update kernel then only touches r and omega (12 B/unknown instead of 24)
-    const float alpha_prev = (MODE == 2 && a.k != 1) ? a.scal->alpha : 0.f;
+    const float alpha_prev = (MODE == 3) ? alpha_prev3 : (MODE == 2 && a.k != 1) ? a.scal->alpha : 0.f;
     // XCD-aware block order: blocks are dealt round-robin over the 8 XCDs; give every XCD a
     // contiguous range of work items (neighbouring strips share halo columns through its L2)
     int bid = blockIdx.x;
@@ -122,7 +160,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane(bid * 4 + wave);      // wave-uniform: keeps the column loop scalar
-    float red = 0.f;
+    float red = 0.f, red_rw = 0.f, red_ww = 0.f, red_rr = 0.f;
     const int strip = (item < a.n_items) ? item / a.n_seg : 0;
     // D = +1: the wave marches left to right over its strip, D = -1: right to left.  Odd strips march
     // backwards ("snake"): two neighbouring strips then reach their shared halo columns at the same time
@@ -149,39 +187,49 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
             F4 T[NT];
             unsigned fl;
             F4 r, p;
-            F4 xo, po;         // MODE 2: x and the previous p of the column this step outputs
+            F4 xo, po;         // MODE 2, 3: x and the previous p of the column this step outputs
+            F4 wp;             // MODE 3: omega of the previous step (column c + D*L)
         };
         auto issue = [&](Raw& w, int c) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) w.T[t] = ld4(tens + (size_t)t * pl + (size_t)(c + D) * Hs + rowL);
             w.fl = *reinterpret_cast<const unsigned*>(a.flags + (size_t)(c + D) * Hs + rowL);
             const size_t off = (size_t)(c + D * L) * Hs + rowL;
-            if (MODE != 2) { w.r = ld4(a.xin + off); }
+            if (MODE < 2) { w.r = ld4(a.xin + off); }
             else {
                 w.r = ld4(a.r + off); w.p = ld4(a.p_in + off);
                 const size_t oo = (size_t)c * Hs + rowL;               // the column step c outputs
                 w.xo = ld4(a.x + oo); w.po = ld4(a.p_in + oo);
+                if (MODE == 3) w.wp = (a.k != 1) ? ld4(a.w_prev + off) : zero4();      // step 1 has no update pending (uniform)
             }
         };
-        auto convert = [&](const Raw& w) -> F4 {               // x of the loaded column (CG: p_new = beta p + r)
-            if (MODE != 2) return w.r;
+        auto convert = [&](const Raw& w, F4& rnew) -> F4 {     // x of the loaded column (CG: p_new = beta p + r)
+            if (MODE < 2) return w.r;
             F4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o.e[e] = mul_then_add(beta, w.p.e[e], w.r.e[e]);
+            for (int e = 0; e < 4; ++e) {
+                rnew.e[e] = (MODE == 3) ? fmaf(-alpha_prev, w.wp.e[e], w.r.e[e]) : w.r.e[e];      // Saxpy dc.cu:272, deferred
+                o.e[e] = mul_then_add(beta, w.p.e[e], rnew.e[e]);
+            }
             return o;
         };
-        auto load_x = [&](int col) -> F4 {                     // prologue only (waited immediately)
+        auto load_x = [&](int col, F4& rnew) -> F4 {           // prologue only (waited immediately)
             const size_t off = (size_t)col * Hs + rowL;
-            if (MODE != 2) return ld4(a.xin + off);
+            if (MODE < 2) return ld4(a.xin + off);
             const F4 rv = ld4(a.r + off);
             const F4 pv = ld4(a.p_in + off);
+            const F4 wv = (MODE == 3 && a.k != 1) ? ld4(a.w_prev + off) : zero4();
             F4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o.e[e] = mul_then_add(beta, pv.e[e], rv.e[e]);
+            for (int e = 0; e < 4; ++e) {
+                rnew.e[e] = (MODE == 3) ? fmaf(-alpha_prev, wv.e[e], rv.e[e]) : rv.e[e];
+                o.e[e] = mul_then_add(beta, pv.e[e], rnew.e[e]);
+            }
             return o;
         };
 
         F4 X[NX];                      // X[k] = x at column c + D*(k-1): [previous, current, next, next+1, ...] in march order
+        F4 R[MODE == 3 ? NX - 1 : 1];  // MODE 3: the updated residual of the columns X[1..NX-1] (stored and summed when a column is output)
         F4 Uprev = zero4(), U0 = zero4(), V0 = zero4(), W0 = zero4();
         unsigned FLm1 = 0u, FL0 = 0u;
         // tensor-recompute mode: M = sum_c g_c Q_c with
@@ -207,7 +255,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         const int c_first = (D > 0) ? c0 - 2 : c0 + TJ + 1;      // two priming steps before the strip
         const int c_final = (D > 0) ? c0 + TJ - 1 : c0;          // last output column
 #pragma unroll
-        for (int k = 1; k + 1 < NX; ++k) X[k] = load_x(c_first + D * (k - 1));
+        for (int k = 1; k + 1 < NX; ++k) X[k] = load_x(c_first + D * (k - 1), R[MODE == 3 ? k - 1 : 0]);
         X[NX - 1] = zero4();
         // Software pipeline: the loads of step c+1 are issued before the arithmetic of step c, into two
         // alternating buffer sets (the loop is unrolled by two, so no in-flight register is ever copied).
@@ -219,7 +267,7 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         auto step = [&](const int m, const Raw& cur, Raw& nxt) {      // m = march index: -2, -1 prime, 0..TJ-1 output
             const int c = c_first + D * (m + 2);
             issue(nxt, (D > 0) ? min(c + 1, c_final) : max(c - 1, c_final));
-            X[NX - 1] = convert(cur);             // x of column c+D*L
+            X[NX - 1] = convert(cur, R[MODE == 3 ? NX - 2 : 0]);             // x of column c+D*L
             const unsigned FL1 = cur.fl;          // structure bytes of the next column (c+D)
             const F4* Mc = cur.T;                 // tensor data of the next column
             // ---- (u,v,w) of column c+1 ----------------------------------------------------------
@@ -358,6 +406,14 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
                     } else {
                         st4(a.p_out + off, X[1]);
                         st4(a.out + off, acc);
+                        if (MODE == 3) {
+                            if (a.k != 1) st4(a.r + off, R[0]);       // uniform; step 1: r is unchanged
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float rv = R[0].e[e];
+                                red_rw = fmaf(rv, acc.e[e], red_rw); red_ww = fmaf(acc.e[e], acc.e[e], red_ww); red_rr = fmaf(rv, rv, red_rr);
+                            }
+                        }
                         if (a.k != 1) {                                   // uniform
                             F4 xn;
 #pragma unroll
@@ -374,6 +430,10 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
             FLm1 = FL0; FL0 = FL1;
 #pragma unroll
             for (int k = 0; k + 1 < NX; ++k) X[k] = X[k + 1];
+            if (MODE == 3) {
+#pragma unroll
+                for (int k = 0; k + 2 < NX; ++k) R[MODE == 3 ? k : 0] = R[MODE == 3 ? k + 1 : 0];
+            }
         };
         for (int m = -2; m < TJ; m += 2) {
             step(m, bufA, bufB);
@@ -384,7 +444,11 @@ __global__ __launch_bounds__(256) void k_apply_march(MarchArgs a) {
         if (a.snake && (strip & 1)) body(std::integral_constant<int, -1>{});
         else body(std::integral_constant<int, 1>{});
     }
-    if (MODE != 0) {
+    if (MODE == 3) {
+        float v4[4] = {red, red_rw, red_ww, red_rr};
+        block_sum4(v4, sm4);
+        if (threadIdx.x < 4) a.part4_out[(size_t)threadIdx.x * a.n_part + blockIdx.x] = sm4[threadIdx.x];
+    } else if (MODE != 0) {
         const float t = block_sum(red, sm);
         if (threadIdx.x == 0) a.part_out[blockIdx.x] = t;
     }
@@ -480,9 +544,27 @@ int march_residual(srps_ctx* ctx) {
     Grid& G = ctx->grid;
     MarchArgs a = march_base(ctx);
     a.xin = G.d_x; a.r = G.d_r;
+    if (cg_fused_step(ctx)) a.part_out = G.d_part4 + 3 * (size_t)G.n_part4;      // r.r of the initial residual: slot 3 of the sums [0]
     SRPS_TRY(launch_march<1>(ctx, a));
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
+}
+
+// one launch per CG step (MODE 3); the residual launch has left r.r of the initial residual in slot 3 of the partial sums [0]
+int march_cg_step(srps_ctx* ctx, int k) {
+    Grid& G = ctx->grid;
+    MarchArgs a = march_base(ctx);
+    float* pbuf[2] = {G.d_p, G.d_p + G.plane};
+    float* wbuf[2] = {G.d_w, G.d_w2};
+    a.p_in = (k == 1) ? G.d_r : pbuf[(k + 1) & 1];       // step 1: p = r
+    a.p_out = pbuf[k & 1]; a.r = G.d_r; a.x = G.d_x;
+    a.out = wbuf[k & 1]; a.w_prev = wbuf[(k + 1) & 1];
+    a.n_part = G.n_part4;
+    a.part4_in = G.d_part4 + (size_t)((k + 1) & 1) * 4 * G.n_part4;
+    a.part4_out = G.d_part4 + (size_t)(k & 1) * 4 * G.n_part4;
+    a.k = k;
+    a.tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
+    return launch_march<3>(ctx, a);
 }
 
 int march_cg_apply(srps_ctx* ctx, int k) {

@@ -82,6 +82,8 @@ __device__ __forceinline__ int msk(unsigned flword) {
     return m;
 }
 __device__ __forceinline__ float andm(float v, int m) { return __int_as_float(__float_as_int(v) & m); }
+// a where the mask is all ones, b where it is zero: v_bfi_b32 on three vector registers
+__device__ __forceinline__ float selm(int m, float a, float b) { return __int_as_float((m & __float_as_int(a)) | (~m & __float_as_int(b))); }
 #define SRPS_MSK(B, e, FL) ((e) == 0 ? msk<(B)>(FL) : (e) == 1 ? msk<(B) + 8>(FL) : (e) == 2 ? msk<(B) + 16>(FL) : msk<(B) + 24>(FL))
 __device__ __forceinline__ float if_bit_rt(float v, unsigned flword, int bit) {
     return ((flword >> bit) & 1u) ? v : 0.f;
@@ -90,6 +92,11 @@ __device__ __forceinline__ float if_bit_rt(float v, unsigned flword, int bit) {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }      // v_pk_fma_f32
+__device__ __forceinline__ v2f mul2(v2f a, v2f b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
 __device__ __forceinline__ v2f andm2(v2f v, v2i m) { return __builtin_bit_cast(v2f, __builtin_bit_cast(v2i, v) & m); }
 __device__ __forceinline__ F4 as_f4(v4i v) {
     F4 r; r.e[0] = __int_as_float(v.x); r.e[1] = __int_as_float(v.y); r.e[2] = __int_as_float(v.z); r.e[3] = __int_as_float(v.w);
@@ -119,6 +126,7 @@ struct ResidentArgs {
     int i_lo, j_lo;
     int debug;                 // timing experiments only: 1 = no grid-wide sums, no ring polls (wrong results)
     unsigned long long spin_ticks;   // budget of the whole launch in s_memrealtime ticks (10 ns): waits give up after it
+    const uint8_t* tile_cls;   // [tiles] TILE_* bits per tile (host: classify_tiles), nullptr: every tile takes the general body
 };
 
 // per-channel constants of the tensor-recompute form (uniform)
@@ -142,8 +150,15 @@ __device__ unsigned long long g_stamps[128 * 256 * 16];
 #define SRPS_STAMP_PTR nullptr
 #endif
 
-template <int SF, int NC, bool ONE_SYNC>
-__global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
+// RECT: the body for a tile that lies wholly inside the mask and whose ring sides are each wholly masked or wholly empty
+// (TILE_RECT; every tile of a full-frame mask, every tile in the interior of an object).  All its pixels are forward
+// differences inside complete KT blocks, except -- when the ring below / to the right is empty (TILE_BOTTOM_EMPTY /
+// TILE_RIGHT_EMPTY: the tile touches the mask's last row / column) -- the backward differences of row 255 / of the last
+// column (SRPS.cu:35-38, 43-46).  No structure bits are decoded: the two edge cases are selects on loop-invariant lane
+// masks.  The arithmetic per pixel is that of the general body (the masked-out terms there are additions of 0), so the two
+// bodies agree bit for bit up to the sign of zeros.
+template <int SF, int NC, bool ONE_SYNC, bool RECT>
+__device__ __forceinline__ void resident_body(const ResidentArgs& a, const int tile, const unsigned cls) {
     extern __shared__ float4 lds4[];
     // LDS map: [NC==3: g0, g1 as float4 [CPT][NT]] | ex, ex2 (float4 [NT]) | ring (floats): hp, hg[NC], hfl
     constexpr int GL = (NC == 3) ? 2 : 0;                 // g planes kept in LDS
@@ -159,13 +174,6 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int ntile = a.nbr * a.nbc;
-
-    // XCD-aware tile order: the blocks of one XCD (b, b+8, ...) get a contiguous range of tiles
-    int tile = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = tile & 7, kk = tile >> 3;
-        tile = xcd * q + min(xcd, rem) + kk;
-    }
     const int bc = tile / a.nbr, br = tile - bc * a.nbr;          // consecutive tiles are vertical neighbours
     const int Hs = a.Hs;
     const size_t pl = a.plane;
@@ -195,6 +203,12 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         T00[ch] = readlane_f(T00[ch], 0); T01[ch] = readlane_f(T01[ch], 0); T02[ch] = readlane_f(T02[ch], 0);
         T11[ch] = readlane_f(T11[ch], 0); T12[ch] = readlane_f(T12[ch], 0);
     }
+    // the constants of a channel as three pairs {T00, T01}, {T02, T11}, {T12, T22} for the packed column body
+    v2f TP[NC][3];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+        TP[ch][0] = (v2f){T00[ch], T01[ch]}; TP[ch][1] = (v2f){T02[ch], readlane_f(T11[ch], 0)}; TP[ch][2] = (v2f){readlane_f(T12[ch], 0), readlane_f(T22[ch], 0)};
+    }
     const float xoff = readlane_f(a.cx + xm, 0), yoff = readlane_f(a.cy + ym, 0);
     // (u, v) = first two components of M (gx, gy, xv) at one pixel with coordinates (xs, ys) from (xoff, yoff)
     auto uv_pixel = [&](auto need_u, const float (&g)[NC], float xs, float ys, float gx, float gy, float xv) -> float {
@@ -208,10 +222,12 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             P12 = fmaf(g[ch], T12[ch], P12);
             P22 = fmaf(g[ch], T22[ch], P22);
         }
-        const float t2 = -(gx * xs + (gy * ys + xv));
-        const float Y2 = P02 * gx + (P12 * gy + P22 * t2);
-        if (NU) return (Pa * gx + (P01 * gy + P02 * t2)) - Y2 * xs;
-        return (P01 * gx + (Pa * gy + P12 * t2)) - Y2 * ys;
+        // every multiply-add spelled out: which products the compiler fuses must not depend on the surrounding code (the two
+        // bodies, RECT and general, have to produce the same bits)
+        const float t2 = -fmaf(gx, xs, fmaf(gy, ys, xv));
+        const float Y2 = fmaf(P02, gx, fmaf(P12, gy, P22 * t2));
+        if (NU) return fmaf(-Y2, xs, fmaf(Pa, gx, fmaf(P01, gy, P02 * t2)));
+        return fmaf(-Y2, ys, fmaf(P01, gx, fmaf(Pa, gy, P12 * t2)));
     };
     auto xs_of = [&](int gcol) { return (float)(a.j_lo + gcol) - xoff; };
     auto ys_of = [&](int grow) { return (float)(a.i_lo + grow) - yoff; };
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         const size_t off = (size_t)(gcol0 + c + PAD) * Hs + rowL;
         r[c] = ld4(a.r + off);
         x[c] = ld4(a.x + off);
-        fl[c] = *reinterpret_cast<const unsigned*>(a.flags + off);
+        fl[c] = RECT ? 0u : *reinterpret_cast<const unsigned*>(a.flags + off);
 #pragma unroll
         for (int t = 0; t < GL; ++t) lg[(t * CPT + c) * NT + tid] = *reinterpret_cast<const float4*>(a.G + (size_t)t * pl + off);
         p[c] = zero4(); w[c] = zero4();
@@ -242,8 +258,13 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     // ring pixels: 0..257 left column (rows -1..256), 258..515 right column, then the top row (columns -1..TC) and the
     // bottom row; thread t looks after ring pixels t, t + NT, ...
     constexpr int RC_N = TR + 2, RR_N = TC + 2, NRING = 2 * RC_N + 2 * RR_N, RPT = (NRING + NT - 1) / NT;
-    int ridx[RPT];                                         // index into the ring arrays, -1: none
-    const unsigned long long* hsrc[RPT];                   // granule of the ring pixel in its owner's edge arrays (slot 0)
+    // Ring pixel number i sits at index i + 3 / + 9 / + 15 / + 21 of the ring arrays (left column, right column, top row, bottom
+    // row: ring_colL .. ring_rowB): the index is recomputed where it is needed -- kept per thread it was spilled to scratch and
+    // reloaded (a memory round trip) at the top of every CG step.
+    static_assert(RING_COL - RC_N == 6 && RING_ROW - RR_N == 6, "ring layout");
+    auto ring_index = [](int i) -> int { return i + (i < RC_N ? 3 : i < 2 * RC_N ? 9 : i < 2 * RC_N + RR_N ? 15 : 21); };
+    int hoff[RPT];                                         // granule of the ring pixel in its owner's edge arrays (slot 0), as an
+                                                           // offset from a.halo (one register instead of a pointer's two); -1: none
     float rh[RPT];                                         // r on the ring pixel
     unsigned rflags = 0u;                                  // union of the ring pixels' structure bytes
     for (int t = tid; t < RING; t += NT) { hp[t] = 0.f; hfl[t] = 0u; }
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const int i = tid + q * NT;
-        ridx[q] = -1; hsrc[q] = nullptr; rh[q] = 0.f;
+        hoff[q] = -1; rh[q] = 0.f;
         if (i >= NRING) continue;
         int kind, u;
         if (i < RC_N) { kind = 0; u = i - 1; }
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         else { kind = 3; u = i - 2 * RC_N - RR_N - 1; }
         const int pr = (kind == 0 || kind == 1) ? u : (kind == 2 ? -1 : TR);
         const int pc = (kind == 0) ? -1 : (kind == 1) ? TC : u;
-        ridx[q] = (kind == 0) ? ring_colL(u) : (kind == 1) ? ring_colR(u) : (kind == 2) ? ring_rowT(u) : ring_rowB(u);
+        const int ridx = (kind == 0) ? ring_colL(u) : (kind == 1) ? ring_colR(u) : (kind == 2) ? ring_rowT(u) : ring_rowB(u);      // == ring_index(i)
         const int dbr = pr < 0 ? -1 : (pr >= TR ? 1 : 0), dbc = pc < 0 ? -1 : (pc >= TC ? 1 : 0);
         const int nbr_ = br + dbr, nbc_ = bc + dbc;
         const int lr = pr - TR * dbr, lc = pc - TC * dbc;      // coordinates inside the owning tile
@@ -276,18 +297,18 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             else if (lc == TC - 1) gi = TR + lr;                // last column
             else if (lr == 0) gi = 2 * TR + lc;                 // first row
             else gi = 2 * TR + TC + lc;                         // last row
-            hsrc[q] = a.halo + (size_t)nt * 2 * HALO_N + gi;
+            hoff[q] = nt * 2 * HALO_N + gi;
         }
         const int srow = br * TR + pr + PAD, scol = bc * TC + pc + PAD;
         if (srow >= 0 && srow < Hs && scol >= 0 && scol < a.Ws) {
             const size_t rstor = (size_t)scol * Hs + srow;
-            if (ONE_SYNC) { rh[q] = a.r[rstor]; hp[ridx[q]] = a.x[rstor]; }      // r (= b) and p (= x) on the ring for pass 0
+            if (ONE_SYNC) { rh[q] = a.r[rstor]; hp[ridx] = a.x[rstor]; }      // r (= b) and p (= x) on the ring for pass 0
             else rh[q] = a.x[rstor];                        // the residual pass applies the operator to x
             const unsigned f = a.flags[rstor];
-            hfl[ridx[q]] = f;
+            hfl[ridx] = f;
             rflags |= f;
 #pragma unroll
-            for (int ch = 0; ch < NC; ++ch) hg[ch * RING + ridx[q]] = a.G[(size_t)ch * pl + rstor];
+            for (int ch = 0; ch < NC; ++ch) hg[ch * RING + ridx] = a.G[(size_t)ch * pl + rstor];
         }
     }
     // structure summary of the block: is there any backward difference in x (own pixels or ring) / in y
@@ -302,7 +323,18 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         if (by) sflag[1] = 1;
     }
     __syncthreads();
-    const bool any_bx = sflag[0] != 0;
+    const bool any_bx = RECT ? false : sflag[0] != 0;      // a RECT tile has no backward difference on its ring
+    // RECT: the lanes / the wave that hold the mask's last row / last column (loop-invariant lane masks in scalar registers)
+    const bool bot63 = RECT && (cls & TILE_BOTTOM_EMPTY) != 0u && lane == 63;
+    const bool rightw = RECT && (cls & TILE_RIGHT_EMPTY) != 0u && wave == NWV - 1;
+    // The lane masks of the selects inside the CG loop live in VECTOR registers (all ones / zero), and so do the scalars of the
+    // element-wise updates (alpha, beta, lambda): an instruction that reads a scalar register -- v_cndmask_b32 with its mask in a
+    // register pair, v_fmac_f32 with a scalar factor -- takes 4.5 - 5 clocks of the SIMD, the same instruction on vector
+    // registers 2.3 (tools/valu_issue_bench.hip), and scalar registers are what this kernel has fewest of.
+    int m_l0 = (lane == 0) ? -1 : 0, m_l63 = (lane == 63) ? -1 : 0, m_bot = bot63 ? -1 : 0, m_right = rightw ? -1 : 0;
+    asm volatile("" : "+v"(m_l0), "+v"(m_l63), "+v"(m_bot), "+v"(m_right));
+    float lambda_v = a.lambda, inv_sf4_v = a.inv_sf4;
+    asm volatile("" : "+v"(lambda_v), "+v"(inv_sf4_v));
 
     // the plane sizes of the bench shapes stay far below the 4 GiB a descriptor can address
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
@@ -318,7 +350,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         if (!pass0) ++k;
         SRPS_STAMP(0);
         const bool first = pass0 || k == 1;               // p is taken as it is (x, or r), not updated
-        const float beta = first ? 0.f : r1 / r0;         // dc.cu:262
+        float beta = first ? 0.f : r1 / r0;               // dc.cu:262
+        asm volatile("" : "+v"(beta));                     // a vector register: see the lane masks above
         // An opaque zero added to every coordinate: without it the compiler hoists the (step-invariant) tensor terms
         // and the LDS reads of g out of the CG loop and keeps ~100 more values per thread alive than there are registers.
         int oz = 0;
@@ -328,11 +361,14 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p[c].e[e] = (k == 1) ? r[c].e[e] : scal_then_axpy(beta, p[c].e[e], r[c].e[e]);
+                for (int e = 0; e < 4; ++e) p[c].e[e] = scal_then_axpy(beta, p[c].e[e], r[c].e[e]);      // k == 1: beta = 0, p = 0 p + r = r (dc.cu:258)
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q)
-            if (ridx[q] >= 0 && !(ONE_SYNC && pass0)) hp[ridx[q]] = first ? rh[q] : scal_then_axpy(beta, hp[ridx[q]], rh[q]);
+            if (tid + q * NT < NRING && !(ONE_SYNC && pass0)) {
+                const int ri = ring_index(tid + q * NT);
+                hp[ri] = first ? rh[q] : scal_then_axpy(beta, hp[ri], rh[q]);
+            }
         ex[tid] = make_float4(p[0].e[0], p[0].e[1], p[0].e[2], p[0].e[3]);
         ex2[tid] = make_float4(p[CPT - 1].e[0], p[CPT - 1].e[1], p[CPT - 1].e[2], p[CPT - 1].e[3]);
         __syncthreads();
@@ -361,7 +397,12 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             const float xs = (float)(a.j_lo + gcol0 + c + ozc) - xoff;
             F4 g0v, g1v;
             if (GL == 2) {
-                const float4 t0 = lg[(0 * CPT + c) * NT + tid + oz], t1 = lg[(1 * CPT + c) * NT + tid + oz];
+                // The thread index goes through an opaque copy made inside the column: otherwise the sixteen addresses (invariant:
+                // tid * 16 + a constant) are formed before the CG loop, cannot all stay in registers, and every column starts
+                // with a scratch reload -- a memory round trip -- of its address.
+                int tidc = tid;
+                asm volatile("" : "+v"(tidc));
+                const float4 t0 = lg[(0 * CPT + c) * NT + tidc], t1 = lg[(1 * CPT + c) * NT + tidc];
                 g0v.e[0] = t0.x; g0v.e[1] = t0.y; g0v.e[2] = t0.z; g0v.e[3] = t0.w;
                 g1v.e[0] = t1.x; g1v.e[1] = t1.y; g1v.e[2] = t1.z; g1v.e[3] = t1.w;
             }
@@ -383,8 +424,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             {   // no branches inside the column body: a branch splits the block and the compiler then sinks half of the
                 // column's arithmetic (and everything it reads) below the loop
                 const float rt = hp[ring_rowT(CPT * wave + c)], rb = hp[ring_rowB(CPT * wave + c)];
-                x_up = (lane == 0) ? rt : x_up;
-                x_dn = (lane == 63) ? rb : x_dn;
+                x_up = selm(m_l0, rt, x_up);
+                x_dn = selm(m_l63, rb, x_dn);
             }
             unsigned FL = fl[c];
             asm volatile("" : "+v"(FL));             // opaque: the 16 masks per column derived from it are not worth 16 registers
@@ -394,51 +435,92 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             for (int h = 0; h < 2; ++h) {
                 const int e0 = 2 * h, e1 = 2 * h + 1;
                 const v2f ys = (h == 0) ? ys01 : ys23;
-                v2f P00 = {0.f, 0.f}, P01 = P00, P02 = P00, P11 = P00, P12 = P00, P22 = P00;
+                // P = sum_c g_c T_c.  The scalar operand of a packed instruction is a register PAIR; written in C the compiler keeps
+                // every constant twice (36 scalar registers for 18 constants -- and then spills them to vector-register lanes,
+                // reloading them with v_readlane for every column).  In assembly one pair carries two constants and op_sel picks
+                // the half both rows multiply with.  Same instruction, same rounding (the first channel as a product: g T + 0).
+                v2f P00, P01, P02, P11, P12, P22;
 #pragma unroll
                 for (int ch = 0; ch < NC; ++ch) {
                     v2f g;
                     if (NC == 3) g = (ch == 0) ? (v2f){g0v.e[e0], g0v.e[e1]} : (ch == 1) ? (v2f){g1v.e[e0], g1v.e[e1]} : (v2f){grc.e[e0], grc.e[e1]};
                     else g = (v2f){grc.e[e0], grc.e[e1]};
-                    P00 = g * T00[ch] + P00;
-                    P01 = g * T01[ch] + P01;
-                    P02 = g * T02[ch] + P02;
-                    P11 = g * T11[ch] + P11;
-                    P12 = g * T12[ch] + P12;
-                    P22 = g * T22[ch] + P22;
+                    if (ch == 0) {
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(P00) : "v"(g), "s"(TP[ch][0]));
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(P01) : "v"(g), "s"(TP[ch][0]));
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(P02) : "v"(g), "s"(TP[ch][1]));
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(P11) : "v"(g), "s"(TP[ch][1]));
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(P12) : "v"(g), "s"(TP[ch][2]));
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(P22) : "v"(g), "s"(TP[ch][2]));
+                    } else {
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(P00) : "v"(g), "s"(TP[ch][0]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(P01) : "v"(g), "s"(TP[ch][0]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(P02) : "v"(g), "s"(TP[ch][1]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(P11) : "v"(g), "s"(TP[ch][1]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(P12) : "v"(g), "s"(TP[ch][2]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(P22) : "v"(g), "s"(TP[ch][2]));
+                    }
                 }
                 const v2f xv = {xc.e[e0], xc.e[e1]};
                 const v2f up = {(h == 0) ? x_up : xc.e[1], (h == 0) ? xc.e[0] : xc.e[2]};
                 const v2f dn = {(h == 0) ? xc.e[1] : xc.e[3], (h == 0) ? xc.e[2] : x_dn};
                 const v2f xrv = {xr.e[e0], xr.e[e1]}, xlv = {xl.e[e0], xl.e[e1]};
                 // forward / backward are exclusive (SRPS.cu:39-46, 31-38)
-                const v2i mfx = {SRPS_MSK(B_FX, e0, FL), SRPS_MSK(B_FX, e1, FL)}, mbx = {SRPS_MSK(B_BX, e0, FL), SRPS_MSK(B_BX, e1, FL)};
-                const v2i mfy = {SRPS_MSK(B_FY, e0, FL), SRPS_MSK(B_FY, e1, FL)}, mby = {SRPS_MSK(B_BY, e0, FL), SRPS_MSK(B_BY, e1, FL)};
-                const v2f gx = andm2(xrv - xv, mfx) + andm2(xv - xlv, mbx);
-                const v2f gy = andm2(dn - xv, mfy) + andm2(xv - up, mby);
-                const v2f t2 = -(gx * xs + (gy * ys + xv));             // E'(gx, gy, x)
-                const v2f Y0 = P02 * t2 + (P00 * gx + P01 * gy);        // the t2 term last: shortest dependent chain
-                const v2f Y1 = P12 * t2 + (P01 * gx + P11 * gy);
-                const v2f Y2 = P22 * t2 + (P02 * gx + P12 * gy);
-                const v2f U = Y0 - Y2 * xs;
-                const v2f V = Y1 - Y2 * ys;
+                v2i mfx, mbx, mfy, mby;
+                v2f gx, gy;
+                if constexpr (RECT) {
+                    gx = xrv - xv;
+                    if (c == CPT - 1) {                        // the mask's last column: backward (the wave is uniform)
+                        const v2f gb = xv - xlv;
+                        gx.x = selm(m_right, gb.x, gx.x); gx.y = selm(m_right, gb.y, gx.y);
+                    }
+                    gy = dn - xv;
+                    if (h == 1) gy.y = selm(m_bot, gy.x, gy.y);      // the mask's last row: backward = the forward difference of the row above
+                } else {
+                    mfx = (v2i){SRPS_MSK(B_FX, e0, FL), SRPS_MSK(B_FX, e1, FL)}; mbx = (v2i){SRPS_MSK(B_BX, e0, FL), SRPS_MSK(B_BX, e1, FL)};
+                    mfy = (v2i){SRPS_MSK(B_FY, e0, FL), SRPS_MSK(B_FY, e1, FL)}; mby = (v2i){SRPS_MSK(B_BY, e0, FL), SRPS_MSK(B_BY, e1, FL)};
+                    gx = andm2(xrv - xv, mfx) + andm2(xv - xlv, mbx);
+                    gy = andm2(dn - xv, mfy) + andm2(xv - up, mby);
+                }
+                // every multiply-add spelled out (see uv_pixel)
+                const v2f xs2 = {xs, xs};
+                const v2f t2 = -fma2(gx, xs2, fma2(gy, ys, xv));         // E'(gx, gy, x)
+                const v2f Y0 = fma2(P02, t2, fma2(P00, gx, mul2(P01, gy)));      // the t2 term last: shortest dependent chain
+                const v2f Y1 = fma2(P12, t2, fma2(P01, gx, mul2(P11, gy)));
+                const v2f Y2 = fma2(P22, t2, fma2(P02, gx, mul2(P12, gy)));
+                const v2f U = fma2(-Y2, xs2, Y0);
+                const v2f V = fma2(-Y2, ys, Y1);
                 const v2f W = -Y2;
-                const v2f fxU = andm2(U, mfx), bxU = andm2(U, mbx);
-                const v2f fyV = andm2(V, mfy), byV = andm2(V, mby);
+                v2f fxU, bxU, fyV, byV;
+                if constexpr (RECT) {
+                    const v2f zero = {0.f, 0.f};
+                    // u and v as values of their own, as in the general body (whose bit masks see them): without this the compiler
+                    // fuses the multiply-adds that make them into the sums below (aggressive FMA fusion) and rounds differently
+                    v2f Uo = U, Vo = V;
+                    asm("" : "+v"(Uo), "+v"(Vo));
+                    fxU = Uo; bxU = zero; fyV = Vo; byV = zero;
+                    if (c == CPT - 1) { fxU.x = andm(Uo.x, ~m_right); fxU.y = andm(Uo.y, ~m_right); bxU.x = andm(Uo.x, m_right); bxU.y = andm(Uo.y, m_right); }
+                    if (h == 1) { fyV.y = andm(Vo.y, ~m_bot); byV.y = andm(Vo.y, m_bot); }
+                } else {
+                    fxU = andm2(U, mfx); bxU = andm2(U, mbx);
+                    fyV = andm2(V, mfy); byV = andm2(V, mby);
+                }
                 const v2f own = W + (bxU - fxU) + (byV - fyV);        // A'(u, v, w) at the pixel itself
                 w[c].e[e0] += own.x; w[c].e[e1] += own.y;
                 if (c < CPT - 1) { w[c < CPT - 1 ? c + 1 : CPT - 1].e[e0] += fxU.x; w[c < CPT - 1 ? c + 1 : CPT - 1].e[e1] += fxU.y; }      // Dx': +u right of a forward pixel
                 else { u3.e[e0] = fxU.x; u3.e[e1] = fxU.y; }
-                if (c > 0) { w[c > 0 ? c - 1 : 0].e[e0] -= bxU.x; w[c > 0 ? c - 1 : 0].e[e1] -= bxU.y; }                                  //      -u left of a backward pixel
-                else { u0.e[e0] = bxU.x; u0.e[e1] = bxU.y; }
+                if (!RECT || c == CPT - 1) {
+                    if (c > 0) { w[c > 0 ? c - 1 : 0].e[e0] -= bxU.x; w[c > 0 ? c - 1 : 0].e[e1] -= bxU.y; }                              //      -u left of a backward pixel
+                    else { u0.e[e0] = bxU.x; u0.e[e1] = bxU.y; }
+                }
                 // Dy': +v below a forward pixel, -v above a backward pixel
                 w[c].e[e1] += fyV.x;
                 if (h == 0) w[c].e[2] += fyV.y; else send_dn = fyV.y;
-                w[c].e[e0] -= byV.y;
-                if (h == 1) w[c].e[1] -= byV.x; else send_up = byV.x;
+                if (!RECT || h == 1) w[c].e[e0] -= byV.y;
+                if (!RECT) { if (h == 1) w[c].e[1] -= byV.x; else send_up = byV.x; }
             }
             w[c].e[0] += dpp_from_prev_lane(send_dn);
-            w[c].e[3] -= dpp_from_next_lane(send_up);
+            if (!RECT) w[c].e[3] -= dpp_from_next_lane(send_up);
             // block sums of KT'KT
             if (SF == 1) S[c] = xc;
             else if (SF == 2) {
@@ -491,8 +573,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 const float tt = readlane_f(cv, c), tb = readlane_f(cv, CPT + c);
-                w[c].e[0] += (lane == 0) ? tt : 0.f;
-                w[c].e[3] -= (lane == 63) ? tb : 0.f;
+                w[c].e[0] += andm(tt, m_l0);
+                w[c].e[3] -= andm(tb, m_l63);
             }
         }
         // ring columns: the pixels left of column 0 (forward in x) and right of column 63 (backward in x)
@@ -553,8 +635,9 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         for (int c = 0; c < CPT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float s = ((SF == 4) ? ksum[c / 4] : S[c].e[e]) * a.inv_sf4;
-                w[c].e[e] = w[c].e[e] * a.lambda + andm(s, SRPS_MSK(B_KB, e, flk[c]));
+                float s = ((SF == 4) ? ksum[c / 4] : S[c].e[e]) * inv_sf4_v;
+                if (RECT) asm("" : "+v"(s));               // a value of its own, as behind the general body's mask (see u, v above)
+                w[c].e[e] = w[c].e[e] * lambda_v + (RECT ? s : andm(s, SRPS_MSK(B_KB, e, flk[c])));
                 red = fmaf(p[c].e[e], w[c].e[e], red);
                 if (ONE_SYNC) { red_rw = fmaf(r[c].e[e], w[c].e[e], red_rw); red_ww = fmaf(w[c].e[e], w[c].e[e], red_ww); }
             }
@@ -583,15 +666,15 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         auto request_ring = [&]() {
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
-                hv[q] = (ridx[q] >= 0 && hsrc[q] != nullptr && !(a.debug & 1))
-                            ? __hip_atomic_load(hsrc[q] + (size_t)(hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                hv[q] = (hoff[q] >= 0 && !(a.debug & 1))
+                            ? __hip_atomic_load(a.halo + hoff[q] + (hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         };
         auto await_ring = [&](float (&val)[RPT]) {
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 val[q] = 0.f;
-                if (ridx[q] >= 0 && hsrc[q] != nullptr && !(a.debug & 1)) {
-                    const unsigned long long* s = hsrc[q] + (size_t)(hgen & 1u) * HALO_N;
+                if (hoff[q] >= 0 && !(a.debug & 1)) {
+                    const unsigned long long* s = a.halo + hoff[q] + (hgen & 1u) * HALO_N;
                     while ((unsigned)(hv[q] >> 32) != hgen) {
                         // the clock is read by the scalar unit (no counter register); uniform for the lanes still waiting
                         if (spin_deadline_passed()) { spin_give_up(-1, hgen); break; }
@@ -639,6 +722,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 else grid_sum3_collect(a.ent3, gen, pw, rw, ww, SRPS_STAMP_PTR);
                 SRPS_STAMP(6);
                 alpha = r1 / (float)pw;                    // dc.cu:269
+                asm volatile("" : "+v"(alpha));
                 red = 0.f;
 #pragma unroll
                 for (int c = 0; c < CPT; ++c)
@@ -682,6 +766,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
             } else {
                 const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
                 alpha = r1 / dot;                              // dc.cu:269
+                asm volatile("" : "+v"(alpha));
                 // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
                 red = 0.f;
 #pragma unroll
@@ -707,7 +792,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
                 await_ring(rv);
 #pragma unroll
                 for (int q = 0; q < RPT; ++q)
-                    if (ridx[q] >= 0 && hsrc[q] != nullptr) rh[q] = rv[q];
+                    if (hoff[q] >= 0) rh[q] = rv[q];
             }
         }
         SRPS_STAMP(7);
@@ -725,6 +810,21 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         a.scal->alpha = 0.f;                               // nothing pending: x is final
     }
     (void)ntile;
+}
+
+// One launch for all tiles: the block looks up the class of its tile and takes the body made for it.  The choice is made
+// once, outside the CG loop (two whole copies of the loop): every tile does the same number of grid-wide waits either way.
+template <int SF, int NC, bool ONE_SYNC>
+__global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
+    // XCD-aware tile order: the blocks of one XCD (b, b+8, ...) get a contiguous range of tiles
+    int tile = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = tile & 7, kk = tile >> 3;
+        tile = xcd * q + min(xcd, rem) + kk;
+    }
+    const unsigned cls = a.tile_cls ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.tile_cls[tile]) : 0u;
+    if (cls & TILE_RECT) resident_body<SF, NC, ONE_SYNC, true>(a, tile, cls);
+    else resident_body<SF, NC, ONE_SYNC, false>(a, tile, cls);
 }
 
 size_t resident_lds_bytes(int NC) {
@@ -775,6 +875,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     a.debug = ctx->cg_resident_debug;
     a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;      // s_memrealtime: 100 MHz
+    a.tile_cls = ctx->cg_resident_rect ? (NT == 512 ? G.d_tile_cls[1] : G.d_tile_cls[0]) : nullptr;
     const void* fn = nullptr;
 #define SRPS_RES(SFV, NCV) fn = ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true> : (const void*)k_cg_resident<SFV, NCV, false>
     if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else if (G.sf == 2) SRPS_RES(2, 3); else SRPS_RES(4, 3); }

@@ -4,6 +4,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
+#include <dlfcn.h>
 #include "srps_internal.h"
 
 namespace srps {
@@ -31,6 +33,43 @@ int ensure(DevBuf& b, size_t bytes) {
     return SRPS_OK;
 }
 
+// ---- tracing: roctx resolved at run time (no link dependency), HIP events per phase --------------------------------------
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+static roctx_push_t g_roctx_push = nullptr;
+static roctx_pop_t g_roctx_pop = nullptr;
+static bool roctx_resolve() {
+    static int state = 0;      // 0 not tried, 1 found, -1 absent
+    if (state == 0) {
+        state = -1;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+            g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+            if (g_roctx_push && g_roctx_pop) { state = 1; break; }
+        }
+    }
+    return state == 1;
+}
+static const char* const kPhaseNames[SRPS_N_PHASES] = {"srps:lighting", "srps:albedo_sweep", "srps:albedo_solve", "srps:depth_assembly",
+                                                       "srps:depth_solve", "srps:energy", "srps:normals"};
+PhaseSpan::PhaseSpan(srps_ctx* ctx, int ph) : c(ctx), phase(ph) {
+    if (c->roctx && roctx_resolve()) g_roctx_push(kPhaseNames[phase]);
+    if (c->phase_timing) {
+        if (!c->ev_created) {
+            for (int i = 0; i < SRPS_N_PHASES; ++i) { (void)hipEventCreate(&c->ev_begin[i]); (void)hipEventCreate(&c->ev_end[i]); }
+            c->ev_created = true;
+        }
+        // a phase that runs twice between two srps_get_timings calls keeps its first begin and its last end
+        if (!(c->ev_mask & (1u << phase))) (void)hipEventRecord(c->ev_begin[phase], c->stream);
+    }
+}
+PhaseSpan::~PhaseSpan() {
+    if (c->phase_timing && c->ev_created) { (void)hipEventRecord(c->ev_end[phase], c->stream); c->ev_mask |= 1u << phase; }
+    if (c->roctx && g_roctx_pop) g_roctx_pop();
+}
+
 template <typename T>
 static int dalloc(T** p, size_t n) {
     *p = nullptr;
@@ -45,8 +84,8 @@ static void dfree(T*& p) {
 }
 
 static void grid_release(Grid& G) {
-    dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index);
-    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_save);
+    dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index); dfree(G.d_tile_cls[0]); dfree(G.d_tile_cls[1]);
+    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_w2); dfree(G.d_part4); dfree(G.d_save);
     dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); G.d_scal = nullptr;      // d_scal lives in the context's report record
     G.bound = false;
 }
@@ -55,6 +94,39 @@ static void state_release(srps_ctx* c) {
     dfree(c->s); dfree(c->rho); dfree(c->z); dfree(c->Nrm); dfree(c->dz); dfree(c->zx); dfree(c->zy);
     dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
+}
+
+// Classes of the resident CG's tiles (kernels_resident.hip, tile = 256 rows x tc columns, tile index = column of tiles *
+// tiles per column + row of tiles): TILE_RECT when every pixel of the tile is masked and inside a complete KT block and the
+// ring row below / ring column to the right is either wholly masked (with no backward difference pointing into the tile) or
+// wholly empty -- then the only backward differences of the tile are those of its last row / last column, which the RECT
+// body handles without structure bits.
+static std::vector<uint8_t> classify_tiles(const Grid& G, const std::vector<uint8_t>& flags, int tc, int* n_rect) {
+    const int TRr = 256, nbr = cdiv(G.Hg, TRr), nbc = cdiv(G.Wg, tc);
+    auto F = [&](int r, int c) -> uint8_t {
+        const int sr = r + PAD, sc = c + PAD;
+        if (sr < 0 || sr >= G.Hs || sc < 0 || sc >= G.Ws) return 0;
+        return flags[(size_t)sc * G.Hs + sr];
+    };
+    std::vector<uint8_t> cls((size_t)nbr * nbc, 0);
+    *n_rect = 0;
+    for (int bc = 0; bc < nbc; ++bc)
+        for (int br = 0; br < nbr; ++br) {
+            const int r0 = br * TRr, c0 = bc * tc;
+            bool rect = r0 + TRr <= G.Hg && c0 + tc <= G.Wg;
+            for (int c = c0; c < c0 + tc && rect; ++c)
+                for (int r = r0; r < r0 + TRr; ++r)
+                    if ((F(r, c) & (F_MASK | F_KB)) != (F_MASK | F_KB)) { rect = false; break; }
+            if (!rect) continue;
+            int nb = 0, nr = 0;
+            bool bad = false;
+            for (int c = c0; c < c0 + tc; ++c) { const uint8_t f = F(r0 + TRr, c); nb += (f & F_MASK) ? 1 : 0; bad |= (f & F_BY) != 0; }
+            for (int r = r0; r < r0 + TRr; ++r) { const uint8_t f = F(r, c0 + tc); nr += (f & F_MASK) ? 1 : 0; bad |= (f & F_BX) != 0; }
+            if (bad || (nb != 0 && nb != tc) || (nr != 0 && nr != TRr)) continue;
+            cls[(size_t)bc * nbr + br] = (uint8_t)(TILE_RECT | (nb == 0 ? TILE_BOTTOM_EMPTY : 0) | (nr == 0 ? TILE_RIGHT_EMPTY : 0));
+            ++*n_rect;
+        }
+    return cls;
 }
 
 // Host construction of the grid structure: what SRPS.cu:151-203 expresses as index lists and the
@@ -128,9 +200,16 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     SRPS_HIP(hipMemcpy(G.d_imask, G.imask.data(), G.P * sizeof(int), hipMemcpyHostToDevice));
     SRPS_HIP(hipMemcpy(G.d_flags, flags.data(), G.plane, hipMemcpyHostToDevice));
     SRPS_HIP(hipMemcpy(G.d_lr_index, lr_index.data(), lr_index.size() * sizeof(int), hipMemcpyHostToDevice));
+    for (int shape = 0; shape < 2; ++shape) {                    // [0] 256 x 32 tiles, [1] 256 x 64 tiles
+        const std::vector<uint8_t> cls = classify_tiles(G, flags, shape ? 64 : 32, &G.n_rect_tiles[shape]);
+        G.n_tiles[shape] = (int)cls.size();
+        SRPS_TRY(dalloc(&G.d_tile_cls[shape], cls.size()));
+        SRPS_HIP(hipMemcpy(G.d_tile_cls[shape], cls.data(), cls.size(), hipMemcpyHostToDevice));
+    }
     SRPS_TRY(dalloc(&G.d_M, 6 * G.plane)); SRPS_TRY(dalloc(&G.d_q, 3 * G.plane));
     SRPS_TRY(dalloc(&G.d_x, G.plane)); SRPS_TRY(dalloc(&G.d_r, G.plane)); SRPS_TRY(dalloc(&G.d_p, 2 * G.plane));
-    SRPS_TRY(dalloc(&G.d_w, G.plane)); SRPS_TRY(dalloc(&G.d_save, G.plane));
+    SRPS_TRY(dalloc(&G.d_w, G.plane)); SRPS_TRY(dalloc(&G.d_w2, G.plane)); SRPS_TRY(dalloc(&G.d_save, G.plane));
+    SRPS_HIP(hipMemset(G.d_w2, 0, G.plane * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_M, 0, 6 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_q, 0, 3 * G.plane * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_x, 0, G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_r, 0, G.plane * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_p, 0, 2 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_w, 0, G.plane * sizeof(float)));
@@ -139,6 +218,9 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     G.used = (size_t)G.Hs * (G.Wg + 2 * PAD);      // the CG vectors are zero (and stay zero) beyond the used columns
     G.nb_update = std::max(1, std::min(cdiv((long long)G.used / 4, 256 * 4), 1024));
     march_plan(G, ctx->march_tj);
+    G.n_part4 = std::max(4096, march_blocks(G) + 8);      // any strip width the options allow stays below this (see march_strip)
+    SRPS_TRY(dalloc(&G.d_part4, 2 * 4 * (size_t)G.n_part4));
+    SRPS_HIP(hipMemset(G.d_part4, 0, 2 * 4 * (size_t)G.n_part4 * sizeof(float)));
     const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
     SRPS_TRY(dalloc(&G.d_pw_part, n_pw)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
     G.d_scal = (CgScalars*)(ctx->d_report + 64); SRPS_TRY(dalloc(&G.d_tconsts, 128));      // [8][8] tensor constants + [8][4] right-hand-side constants
@@ -249,6 +331,7 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     if (e == hipSuccess) e = hipMemset(c->d_report, 0, 256 * sizeof(float));
     if (e != hipSuccess) { (void)hipHostFree(c->h_pinned); (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     if (device_id < 64) g_live_contexts[device_id].fetch_add(1);
+    if (const char* e = getenv("SRPS_ROCTX")) c->roctx = atoi(e) != 0;
     *out = c;
     return SRPS_OK;
 }
@@ -266,6 +349,8 @@ int srps_destroy(srps_ctx* ctx) {
     if (ctx->ws_albedo.p) (void)hipFree(ctx->ws_albedo.p);
     if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
     if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
+    if (ctx->ev_created)
+        for (int i = 0; i < SRPS_N_PHASES; ++i) { (void)hipEventDestroy(ctx->ev_begin[i]); (void)hipEventDestroy(ctx->ev_end[i]); }
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_report) (void)hipFree(ctx->d_report);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -313,8 +398,17 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->spin_budget_ms = value;
     } else if (!strcmp(name, "cg_one_sync")) {
         ctx->cg_one_sync = value ? 1 : 0;
+    } else if (!strcmp(name, "cg_fused_step")) {
+        ctx->cg_fused_step = value ? 1 : 0;
+    } else if (!strcmp(name, "phase_timing")) {
+        ctx->phase_timing = value ? 1 : 0;
+        ctx->ev_mask = 0;
+    } else if (!strcmp(name, "roctx")) {
+        ctx->roctx = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident")) {
         ctx->cg_resident = value ? 1 : 0;
+    } else if (!strcmp(name, "cg_resident_rect")) {
+        ctx->cg_resident_rect = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident_debug")) {
         ctx->cg_resident_debug = value;
     } else if (!strcmp(name, "light_blocks")) {
@@ -343,8 +437,16 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->keep_stored_tensor = value ? 1 : 0;
     } else if (!strcmp(name, "march_strip")) {
         SRPS_REQUIRE(value == 0 || (value >= 4 && value <= 512 && value % 4 == 0), SRPS_ERR_INVALID, "march_strip: 0 (automatic) or a multiple of 4 in [4, 512]");
+        if (ctx->grid.bound) {
+            // the partial-sum buffers were sized at bind time (build_grid): refuse a strip width whose block count exceeds them
+            srps::Grid trial = ctx->grid;
+            march_plan(trial, value);
+            SRPS_REQUIRE(march_blocks(trial) + 8 <= std::max(4096, ctx->grid.n_part4), SRPS_ERR_INVALID,
+                         "march_strip: %d-column strips need %d blocks, more than the %d partial sums allocated for the bound grid (set the option before srps_bind_grid / srps_setup)",
+                         value, march_blocks(trial), ctx->grid.n_part4);
+            march_plan(ctx->grid, value);
+        }
         ctx->march_tj = value;
-        if (ctx->grid.bound) march_plan(ctx->grid, value);
     } else if (!strcmp(name, "cg_max_iter")) {
         SRPS_REQUIRE(value >= 0, SRPS_ERR_INVALID, "cg_max_iter: bad value %d", value);
         ctx->cg_max_iter = value;
@@ -366,7 +468,13 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "fuse_energy_lighting")) *value = ctx->fuse_energy_lighting;
     else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
+    else if (!strcmp(name, "cg_fused_step")) *value = ctx->cg_fused_step;
+    else if (!strcmp(name, "phase_timing")) *value = ctx->phase_timing;
+    else if (!strcmp(name, "roctx")) *value = ctx->roctx;
     else if (!strcmp(name, "cg_one_sync")) *value = ctx->cg_one_sync;
+    else if (!strcmp(name, "cg_resident_rect")) *value = ctx->cg_resident_rect;
+    else if (!strcmp(name, "cg_resident_rect_tiles_256")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[0] : 0;      // of the 256 x 32 tiling
+    else if (!strcmp(name, "cg_resident_rect_tiles_512")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[1] : 0;      // of the 256 x 64 tiling
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
     else if (!strcmp(name, "cg_resident_tile")) *value = ctx->cg_resident_tile;
     else if (!strcmp(name, "albedo_channels_together")) *value = ctx->albedo_channels_together;
@@ -571,6 +679,7 @@ int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, in
 
 int srps_lighting_local(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_LIGHTING);
     ctx->ssum_valid = false;             // s changes
     return lighting(ctx, ctx->s, ctx->rho, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
                     ctx->N_local != ctx->N_total, /*use_cache=*/true);
@@ -583,6 +692,7 @@ int srps_lighting(srps_ctx* ctx) {
 
 int srps_albedo_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SWEEP);
     float* ssum = nullptr;
     ctx->ssum_valid = false;
     if (ctx->assemble_from_sums && ctx->N_local > 0) {      // this sweep over I also leaves the image sums of the depth right-hand side
@@ -596,6 +706,7 @@ int srps_albedo_partial(srps_ctx* ctx) {
 }
 int srps_albedo_finish(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SOLVE);
     ctx->light_cache_valid = false;      // rho changes
     SRPS_TRY(albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C));
     if (ctx->N_local != ctx->N_total) {  // a shard cannot repeat the pass on its own later (srps_energy_finish): look now
@@ -614,12 +725,14 @@ int srps_albedo(srps_ctx* ctx) {
 
 int srps_depth_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
     const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
     return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
                           ctx->N_total, ctx->img_offset, ctx->cx, ctx->cy, ssum);
 }
 int srps_depth_solve(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_DEPTH_SOLVE);
     SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
     ctx->light_cache_valid = false;      // z changes
     const bool plane_current = ctx->grad_current && ctx->plane_holds_z;      // nothing wrote z or the plane since the last solve
@@ -638,6 +751,7 @@ int srps_depth_solve(srps_ctx* ctx) {
 }
 int srps_energy_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_ENERGY);
     SRPS_TRY(grid_energy_t1(ctx, ctx->z0s, ctx->energy_ex));
     // the sweep over I that evaluates the energy also leaves the lighting sums of the next outer iteration
     if (ctx->fuse_energy_lighting && ctx->N_local > 0)
@@ -682,6 +796,7 @@ int srps_depth(srps_ctx* ctx, float* energy) {
 
 int srps_normals(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_NORMALS);
     Grid& G = ctx->grid;
     if (!ctx->grad_current) {
         SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));
@@ -800,6 +915,22 @@ int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters, 
     return SRPS_OK;
 }
 
+// ---- tracing --------------------------------------------------------------------------------
+const char* srps_phase_name(int phase) { return (phase >= 0 && phase < SRPS_N_PHASES) ? kPhaseNames[phase] + 5 : ""; }
+
+int srps_get_timings(srps_ctx* ctx, float* ms) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(ms != nullptr, SRPS_ERR_INVALID, "get_timings: ms is NULL");
+    SRPS_REQUIRE(ctx->phase_timing, SRPS_ERR_STATE, "get_timings: option phase_timing is off");
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < SRPS_N_PHASES; ++i) {
+        ms[i] = -1.f;
+        if (ctx->ev_mask & (1u << i)) SRPS_HIP(hipEventElapsedTime(&ms[i], ctx->ev_begin[i], ctx->ev_end[i]));
+    }
+    ctx->ev_mask = 0;
+    return SRPS_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------
 int srps_cg_bytes(srps_ctx* ctx, double* apply_bytes, double* update_bytes) {
     CTX_CHECK(ctx); GRID_CHECK(ctx);
@@ -811,8 +942,10 @@ int srps_cg_bytes(srps_ctx* ctx, double* apply_bytes, double* update_bytes) {
     // marching operator also carries the deferred x update (x read + write, +8); its update kernel then
     // reads r, w and writes r (12) instead of reading x, r, p, w and writing x, r (24)
     const bool fused = use_march(ctx);
-    if (apply_bytes) *apply_bytes = ((nc > 0 ? 17.0 + 4.0 * nc : 41.0) + (fused ? 8.0 : 0.0)) * P;
-    if (update_bytes) *update_bytes = (fused ? 12.0 : 24.0) * P;
+    // one-launch step: the operator launch also reads omega of the previous step and reads + writes r (+8), no update kernel
+    const bool one = cg_fused_step(ctx);
+    if (apply_bytes) *apply_bytes = ((nc > 0 ? 17.0 + 4.0 * nc : 41.0) + (fused ? 8.0 : 0.0) + (one ? 8.0 : 0.0)) * P;
+    if (update_bytes) *update_bytes = one ? 0.0 : (fused ? 12.0 : 24.0) * P;
     return SRPS_OK;
 }
 

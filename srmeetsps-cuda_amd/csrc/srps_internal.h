@@ -38,6 +38,8 @@ struct CgScalars {
     int abort_gen;      // generation (wait number) of that wait: 1 = not all blocks became resident
 };
 enum { ABORT_DEPTH = 1, ABORT_ALBEDO = 2 };
+// class of a tile of the resident CG (kernels_resident.hip: resident_body<.., RECT>), per tile shape, set by build_grid
+enum : uint8_t { TILE_RECT = 1, TILE_BOTTOM_EMPTY = 2, TILE_RIGHT_EMPTY = 4 };
 
 struct Grid {
     bool bound = false;
@@ -53,6 +55,8 @@ struct Grid {
     int* d_imask = nullptr;       // [P]   HR linear index of compact pixel p (SRPS.cu:157-162)
     uint8_t* d_flags = nullptr;   // [plane]
     int* d_lr_index = nullptr;    // [Hl*Wl] compact LR index of the block, -1 if not fully masked
+    uint8_t* d_tile_cls[2] = {nullptr, nullptr};   // TILE_* bits of the resident CG's tiles: [0] 256 x 32, [1] 256 x 64
+    int n_tiles[2] = {0, 0}, n_rect_tiles[2] = {0, 0};
     // depth workspace (grid layout)
     float* d_M = nullptr;         // [6][plane]  photometric tensor, SoA
     float* d_q = nullptr;         // [3][plane]  (exchange buffer for the sharded depth phase)
@@ -66,6 +70,9 @@ struct Grid {
     float* d_r = nullptr;         // [plane] rhs, then residual
     float* d_p = nullptr;         // [2][plane] search direction, double-buffered by step parity
     float* d_w = nullptr;         // [plane] omega = A p
+    float* d_w2 = nullptr;        // [plane] second omega plane of the one-launch CG step (omega of the previous step is read while the new one is written)
+    float* d_part4 = nullptr;     // [2][4][n_part4] partial sums of the one-launch CG step (p.omega, r.omega, omega.omega, r.r per block)
+    int n_part4 = 0;
     float* d_save = nullptr;      // [plane] bench: copy of x
     // reductions
     float* d_pw_part = nullptr;   // [nb_apply]
@@ -139,10 +146,12 @@ struct srps_ctx {
     int persistent_fallbacks = 0;    // aborted persistent launches so far (option "persistent_fallbacks", read-only)
     int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at
     int cg_one_sync = 1;             // resident CG: r.r from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per step)
+    int cg_fused_step = 1;           // streaming depth CG: the whole step in one launch (kernels_march.hip MODE 3) instead of operator + update
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
     int cg_resident_tile = 0;        // 0: the smallest tile shape that fits the device, 256 | 512: threads per block of the forced shape
+    int cg_resident_rect = 1;        // tiles inside the mask take the body without structure bits (0: every tile the general body)
     int albedo_channels_together = 1;   // persistent albedo CG, 3 channels, small masks: the channels share the grid-wide waits
     int albedo_one_sync = 1;         // persistent albedo CG: p.(D p) of the next direction predicted from three products summed with r.r
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
@@ -156,9 +165,22 @@ struct srps_ctx {
     bool grad_current = false;            // zx, zy (and the grid copy of z) belong to the current z: srps_normals need not redo them
     bool light_cache_normals = false;     // srps_normals ran on the depth the sums were taken from (Nrm is current)
     int light_cache_V = 0, light_cache_nblk = 0;
+    // tracing: per-phase HIP events on the context's stream (option "phase_timing") and roctx ranges (option "roctx")
+    int phase_timing = 0, roctx = 0;
+    hipEvent_t ev_begin[SRPS_N_PHASES] = {}, ev_end[SRPS_N_PHASES] = {};
+    unsigned ev_mask = 0;            // phases whose pair of events has been recorded since the last srps_get_timings
+    bool ev_created = false;
 };
 
 namespace srps {
+
+// phase spans for tracing: an RAII guard at the top of every pipeline phase
+struct PhaseSpan {
+    srps_ctx* c;
+    int phase;
+    PhaseSpan(srps_ctx* ctx, int ph);
+    ~PhaseSpan();
+};
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
@@ -241,6 +263,8 @@ int march_blocks(const Grid& G);
 int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
 int march_residual(srps_ctx* ctx);
 int march_cg_apply(srps_ctx* ctx, int k);
+int march_cg_step(srps_ctx* ctx, int k);
+bool cg_fused_step(const srps_ctx* ctx);      // the streaming CG runs one launch per step
 int cg_flush_x(srps_ctx* ctx);
 int march_recompute_channels(const srps_ctx* ctx);
 

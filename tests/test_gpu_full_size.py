@@ -72,9 +72,14 @@ def test_metric_size_depth_phase_resident_streaming_and_oracle(pkg, oracle, cora
     sc = pkg.synth.make_scene(2048, 2048, 4, 4, seed=1237, mask_kind="full")
     variants = {"resident_one_wait": dict(cg_resident=1, cg_resident_tile=512, cg_one_sync=1),
                 "resident_two_waits": dict(cg_resident=1, cg_resident_tile=512, cg_one_sync=0),
+                "resident_general_body": dict(cg_resident=1, cg_resident_tile=512, cg_one_sync=1, cg_resident_rect=0),
                 "streaming": dict(cg_resident=0)}
     state, out = _depth_three_ways(pkg, sc, variants)
     assert out["resident_one_wait"]["resident"] == 1 and out["resident_two_waits"]["resident"] == 1 and out["streaming"]["resident"] == 0
+    # every tile of the full frame takes the body without structure bits (resident_body<.., RECT>); it performs the general
+    # body's operations minus additions of zero: identical depth
+    np.testing.assert_array_equal(out["resident_one_wait"]["z"], out["resident_general_body"]["z"])
+    assert out["resident_one_wait"]["e"] == out["resident_general_body"]["e"]
     assert all(o["it"] == 101 for o in out.values()), {k: o["it"] for k, o in out.items()}
     # the oracle's depth step from the same state (assembled CSR + the reference's CG)
     st = coracle.Structure(sc.h, sc.w, sc.sf, sc.mask)

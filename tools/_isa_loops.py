@@ -1,0 +1,31 @@
+"""Loop finder shared by the ISA report tools."""
+
+def find_main_loops(body, lo=3000, hi=8000):
+    """the CG loops of a kernel body: backward branches spanning lo..hi lines, one per disjoint region (latest start, furthest end)"""
+    import re
+    labels = {}
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+    loops = set()
+    for i, l in enumerate(body):
+        m = re.search(r"\b(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(2) in labels and labels[m.group(2)] < i and lo <= i - labels[m.group(2)] <= hi:
+            a0 = labels[m.group(2)]
+            if not any(t.strip().startswith("s_endpgm") for t in body[a0:i]):      # a span with an exit in it is not a loop body
+                loops.add((a0, i))
+    groups = []
+    for a, b in sorted(loops):
+        for g in groups:
+            if not (b < g[0][0] or a > max(e for _, e in g)):
+                g.append((a, b)); break
+        else:
+            groups.append([(a, b)])
+    out = []
+    for g in groups:
+        # loops that share the CG loop's back edge region: take the common innermost start among the long ones
+        a = max(s for s, e in g if e - s >= 0.9 * max(e2 - s2 for s2, e2 in g))
+        b = max(e for s, e in g if s == a)
+        out.append((a, b))
+    return out

@@ -36,7 +36,7 @@ def main():
                     f"-I{os.path.dirname(os.path.abspath(src))}", "-S", "--cuda-device-only", src, "-o", asm] + extra, check=True, stderr=subprocess.DEVNULL)
     lines = open(asm).read().split("\n")
     start = next(i for i, l in enumerate(lines) if pat in l and l.endswith(":") or (pat in l and re.match(r"^_Z\S+:", l)))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end + 1]
     labels = {}
     for i, l in enumerate(body):

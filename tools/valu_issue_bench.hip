@@ -21,9 +21,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define REP8(X) X X X X X X X X
 
-enum { K_FMA = 0, K_PK_FMA, K_PK_MUL, K_PK_ADD, K_ADD, K_BFE, K_AND, K_DPP_MOV, K_FMA_DPP_MIX, K_COUNT };
+enum { K_FMA = 0, K_PK_FMA, K_PK_MUL, K_PK_ADD, K_ADD, K_BFE, K_AND, K_DPP_MOV, K_FMA_DPP_MIX, K_READLANE, K_CNDMASK_SGPR, K_FMAC_SGPR, K_PK_FMA_SGPR, K_CNDMASK_VCC, K_ADD_SGPR, K_FMA_LITERAL, K_COUNT };
 static const char* kNames[K_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_add_f32", "v_bfe_i32",
-                                      "v_and_b32", "v_mov_b32_dpp(wave_shr:1)", "v_pk_fma_f32+v_bfe_i32 (1:1)"};
+                                      "v_and_b32", "v_mov_b32_dpp(wave_shr:1)", "v_pk_fma_f32+v_bfe_i32 (1:1)", "v_readlane_b32 (SGPR spill reload)",
+                                      "v_cndmask_b32 (mask in an SGPR pair)", "v_fmac_f32 (one SGPR operand)",
+                                      "v_pk_fma_f32 (one SGPR-pair operand)", "v_cndmask_b32 (mask in vcc)", "v_add_f32 (one SGPR operand)",
+                                      "v_fma_f32 (one literal constant)"};
 
 template <int KIND>
 __global__ void k_issue(float* out, int iters, float seed) {
@@ -68,6 +71,45 @@ __global__ void k_issue(float* out, int iters, float seed) {
                               "v_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
                               "v_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n")
                          : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if (KIND == K_READLANE) {
+            int s0, s1, s2, s3, s4, s5, s6, s7;
+            asm volatile(REP8("v_readlane_b32 %0, %8, 1\n v_readlane_b32 %1, %9, 2\n v_readlane_b32 %2, %10, 3\n v_readlane_b32 %3, %11, 4\n"
+                              "v_readlane_b32 %4, %12, 5\n v_readlane_b32 %5, %13, 6\n v_readlane_b32 %6, %14, 7\n v_readlane_b32 %7, %15, 8\n")
+                         : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7)
+                         : "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(i4), "v"(i5), "v"(i6), "v"(i7));
+            i0 += s0 & 1; i1 += s1 & 1; i2 += s2 & 1; i3 += s3 & 1; i4 += s4 & 1; i5 += s5 & 1; i6 += s6 & 1; i7 += s7 & 1;      // 8 more (full-rate) instructions per 64
+        } else if (KIND == K_CNDMASK_SGPR) {
+            const unsigned long long m = 0x5555555555555555ull + (unsigned long long)it;
+            asm volatile(REP8("v_cndmask_b32 %0, %0, %8, %9\n v_cndmask_b32 %1, %1, %8, %9\n v_cndmask_b32 %2, %2, %8, %9\n v_cndmask_b32 %3, %3, %8, %9\n"
+                              "v_cndmask_b32 %4, %4, %8, %9\n v_cndmask_b32 %5, %5, %8, %9\n v_cndmask_b32 %6, %6, %8, %9\n v_cndmask_b32 %7, %7, %8, %9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y), "s"(m));
+        } else if (KIND == K_FMAC_SGPR) {
+            float sc = x;
+            asm volatile("" : "+s"(sc));
+            asm volatile(REP8("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                              "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sc), "v"(y));
+        } else if (KIND == K_PK_FMA_SGPR) {
+            v2f sc = xx;
+            asm volatile("" : "+s"(sc));
+            asm volatile(REP8("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                              "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(sc), "v"(yy));
+        } else if (KIND == K_CNDMASK_VCC) {
+            asm volatile("s_mov_b64 vcc, 0x55555555\n"
+                         REP8("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                              "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y) : "vcc");
+        } else if (KIND == K_ADD_SGPR) {
+            float sc = y;
+            asm volatile("" : "+s"(sc));
+            asm volatile(REP8("v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"
+                              "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sc));
+        } else if (KIND == K_FMA_LITERAL) {
+            asm volatile(REP8("v_fmac_f32 %0, 0x3a83126f, %8\n v_fmac_f32 %1, 0x3a83126f, %8\n v_fmac_f32 %2, 0x3a83126f, %8\n v_fmac_f32 %3, 0x3a83126f, %8\n"
+                              "v_fmac_f32 %4, 0x3a83126f, %8\n v_fmac_f32 %5, 0x3a83126f, %8\n v_fmac_f32 %6, 0x3a83126f, %8\n v_fmac_f32 %7, 0x3a83126f, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
         } else {      // the resident kernel's mix: packed arithmetic interleaved with mask formation
             asm volatile(REP8("v_pk_fma_f32 %0, %0, %8, %9\n v_bfe_i32 %4, %4, 3, 29\n v_pk_fma_f32 %1, %1, %8, %9\n v_bfe_i32 %5, %5, 3, 29\n"
                               "v_pk_fma_f32 %2, %2, %8, %9\n v_bfe_i32 %6, %6, 3, 29\n v_pk_fma_f32 %3, %3, %8, %9\n v_bfe_i32 %7, %7, 3, 29\n")
@@ -119,7 +161,8 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&d_out, (size_t)cus * 1024 * sizeof(float)));
     if (run<K_FMA>(cus, ghz, d_out) || run<K_PK_FMA>(cus, ghz, d_out) || run<K_PK_MUL>(cus, ghz, d_out) || run<K_PK_ADD>(cus, ghz, d_out) ||
         run<K_ADD>(cus, ghz, d_out) || run<K_BFE>(cus, ghz, d_out) || run<K_AND>(cus, ghz, d_out) || run<K_DPP_MOV>(cus, ghz, d_out) ||
-        run<K_FMA_DPP_MIX>(cus, ghz, d_out))
+        run<K_FMA_DPP_MIX>(cus, ghz, d_out) || run<K_READLANE>(cus, ghz, d_out) || run<K_CNDMASK_SGPR>(cus, ghz, d_out) || run<K_FMAC_SGPR>(cus, ghz, d_out) ||
+        run<K_PK_FMA_SGPR>(cus, ghz, d_out) || run<K_CNDMASK_VCC>(cus, ghz, d_out) || run<K_ADD_SGPR>(cus, ghz, d_out) || run<K_FMA_LITERAL>(cus, ghz, d_out))
         return 1;
     (void)hipFree(d_out);
     return 0;
