@@ -141,13 +141,27 @@ int srps_bind_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask);
  * tensor is streamed.  Reset by srps_bind_grid. */
 int srps_set_principal_point(srps_ctx* ctx, float K02, float K12);
 /* replaces: cuda_based_depth_estimation (devicecalls.cuh:36, devicecalls.cu:550-786).
- * The nine CSR arguments of the reference (Dx, Dy, KT) are implied by srps_bind_grid.
+ * The nine CSR arguments of the reference (Dx, Dy, KT) are implied by srps_bind_grid (srps_depth_estimation_csr below
+ * takes them).  d_N is accepted for the reference's argument order and not read (N3 == 1 enters through s3, devicecalls.cu:573).
  * d_z [npix] is updated in place (101 CG steps from the warm start); *energy receives
  * ||KT z - z0s||^2 + lambda * ||A z - B||^2 (devicecalls.cu:762-785). Synchronises. */
 int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_N,
                           const float* d_I, const float* d_xx, const float* d_yy, const float* d_dz,
                           const float* d_z0s, float* d_z, float K00, float K11,
                           int npix, int nimages, int nchannels, float* energy);
+/* The same call with the reference's argument list (devicecalls.cuh:36; call site SRPS.cu:293), for a caller that keeps
+ * building Dx, Dy, KT as CSR matrices: d_s, d_rho, d_N, d_I, d_xx, d_yy, d_dz, the three matrices as (row_ptr, col_ind, val,
+ * n_rows, n_cols, nnz) each, d_z0s, d_z, K00, K11, npix, nimages, nchannels -- the float the reference returns comes back
+ * through *energy.  The matrices are not used for the arithmetic (the operator is applied matrix-free from the bound mask):
+ * they are CHECKED, row by row, against the structure srps_bind_grid derived -- SRPS_ERR_INVALID names the matrix that
+ * does not describe the bound mask -- and the call is forwarded to srps_depth_estimation.  d_N is accepted and unused in
+ * both calls: the linearised system takes N3 == 1 and dz, never N (devicecalls.cu:573). */
+int srps_depth_estimation_csr(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_N, const float* d_I,
+                              const float* d_xx, const float* d_yy, const float* d_dz,
+                              const int* d_Dx_row_ptr, const int* d_Dx_col_ind, const float* d_Dx_val, int n_rows_Dx, int n_cols_Dx, int nnz_Dx,
+                              const int* d_Dy_row_ptr, const int* d_Dy_col_ind, const float* d_Dy_val, int n_rows_Dy, int n_cols_Dy, int nnz_Dy,
+                              const int* d_KT_row_ptr, const int* d_KT_col_ind, const float* d_KT_val, int n_rows_KT, int n_cols_KT, int nnz_KT,
+                              const float* d_z0s, float* d_z, float K00, float K11, int npix, int nimages, int nchannels, float* energy);
 /* zx = Dx z, zy = Dy z on the bound grid.
  * replaces: the two cuda_based_sparsemat_densevec_mul calls at SRPS.cu:264-265 / 310-311. */
 int srps_gradient(srps_ctx* ctx, const float* d_z, int npix, float* d_zx, float* d_zy);
@@ -192,7 +206,7 @@ int srps_normals(srps_ctx* ctx);                     /* SRPS.cu:310-315 */
 int srps_lighting_local(srps_ctx* ctx);              /* s of the local images; other rows zeroed */
 int srps_albedo_partial(srps_ctx* ctx);              /* [2][C][P] num, den                        */
 int srps_albedo_finish(srps_ctx* ctx);
-int srps_depth_partial(srps_ctx* ctx);               /* q planes on the grid [3][Hs*Ws]           */
+int srps_depth_partial(srps_ctx* ctx);               /* q [3][P] (compact; one GPU: on the grid)  */
 int srps_depth_solve(srps_ctx* ctx);                 /* rhs, residual, 101 CG steps               */
 int srps_energy_partial(srps_ctx* ctx);              /* [2] floats: t1 (replicated), t2 (partial) */
 int srps_energy_finish(srps_ctx* ctx, float* energy);

@@ -98,6 +98,7 @@ def load():
         "srps_albedo_estimation": (i, [vp, p, p, p, p, i, i, i]),
         "srps_bind_grid": (i, [vp, i, i, i, fp]),
         "srps_depth_estimation": (i, [vp, p, p, p, p, p, p, p, p, p, f, f, i, i, i, fp]),
+        "srps_depth_estimation_csr": (i, [vp, p, p, p, p, p, p, p, p, p, p, i, i, i, p, p, p, i, i, i, p, p, p, i, i, i, p, p, f, f, i, i, i, fp]),
         "srps_gradient": (i, [vp, p, i, p, p]),
         "srps_set_principal_point": (i, [vp, f, f]),
         "srps_depth_operator_apply": (i, [vp, p, i, p]),

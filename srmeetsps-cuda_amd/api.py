@@ -188,6 +188,16 @@ class Context:
                                              nchannels, C.byref(e)))
         return e.value
 
+    def depth_estimation_csr(self, d_s, d_rho, d_N, d_I, d_xx, d_yy, d_dz, Dx, Dy, KT, d_z0s, d_z, K00, K11, npix, nimages, nchannels) -> float:
+        """the reference's argument list (devicecalls.cuh:36): Dx, Dy, KT = (d_row_ptr, d_col_ind, d_val, n_rows, n_cols, nnz)"""
+        e = C.c_float(0)
+        mats = []
+        for M in (Dx, Dy, KT):
+            mats += [_ptr(M[0]), _ptr(M[1]), _ptr(M[2]), int(M[3]), int(M[4]), int(M[5])]
+        check(self.lib.srps_depth_estimation_csr(self.h, _ptr(d_s), _ptr(d_rho), _ptr(d_N), _ptr(d_I), _ptr(d_xx), _ptr(d_yy), _ptr(d_dz),
+                                                 *mats, _ptr(d_z0s), _ptr(d_z), float(K00), float(K11), npix, nimages, nchannels, C.byref(e)))
+        return e.value
+
     def set_principal_point(self, K02, K12):
         check(self.lib.srps_set_principal_point(self.h, float(K02), float(K12)))
 

@@ -43,6 +43,76 @@ int csr_spmv(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n_
     return SRPS_OK;
 }
 
+// ---- do caller-built Dx / Dy / KT (the CSR arguments of cuda_based_depth_estimation, devicecalls.cuh:36) describe the bound mask? ----
+// One thread per row.  A gradient row of pixel p must be empty (isolated pixel), or hold the pair (+1 at the forward
+// neighbour, -1 at p) / (+1 at p, -1 at the backward neighbour) that make_gradient writes (SRPS.cu:29-47), in either
+// order; a KT row must hold the sf*sf pixels of its block with value 1/sf^2 (SRPS.cu:176-190).  err: bit 0 Dx, 1 Dy, 2 KT.
+__global__ void k_check_gradient_csr(const int* __restrict__ rp, const int* __restrict__ ci, const float* __restrict__ v, int P,
+                                     const int* __restrict__ gofp, const uint8_t* __restrict__ flags, int step /* Hs for Dx, 1 for Dy */,
+                                     unsigned fwd_bit, unsigned bwd_bit, int err_bit, int* __restrict__ err) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int g = gofp[p];
+        const unsigned f = flags[g];
+        const int t0 = rp[p], n = rp[p + 1] - t0;
+        bool ok;
+        if (!(f & (fwd_bit | bwd_bit))) ok = (n == 0);
+        else {
+            const bool fwd = (f & fwd_bit) != 0u;
+            const int g_other = fwd ? g + step : g - step;
+            const float v_self = fwd ? -1.f : 1.f;
+            ok = (n == 2);
+            bool seen_self = false, seen_other = false;
+            for (int t = t0; ok && t < t0 + 2; ++t) {
+                const int c = ci[t];
+                if (c < 0 || c >= P) { ok = false; break; }
+                if (c == p) { ok = (v[t] == v_self) && !seen_self; seen_self = true; }
+                else { ok = (gofp[c] == g_other) && (v[t] == -v_self) && !seen_other; seen_other = true; }
+            }
+            ok = ok && seen_self && seen_other;
+        }
+        if (!ok) atomicOr(err, err_bit);
+    }
+}
+__global__ void k_check_kt_csr(const int* __restrict__ rp, const int* __restrict__ ci, const float* __restrict__ v, int Ps, int P,
+                               const int* __restrict__ gofp, const int* __restrict__ lr_index, int Hs, int Hl, int sf, int* __restrict__ err) {
+    const float val = 1.0f / (float)(sf * sf);                 // SRPS.cu:188
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < Ps; b += gridDim.x * blockDim.x) {
+        const int t0 = rp[b], n = rp[b + 1] - t0;
+        bool ok = (n == sf * sf);
+        unsigned long long seen = 0ull;                        // one bit per pixel of the block (sf <= 8)
+        for (int t = t0; ok && t < t0 + n; ++t) {
+            const int c = ci[t];
+            if (c < 0 || c >= P || v[t] != val) { ok = false; break; }
+            const int g = gofp[c];
+            const int gj = g / Hs - PAD, gi = g - (gj + PAD) * Hs - PAD;
+            if (lr_index[(gj / sf) * Hl + gi / sf] != b) { ok = false; break; }
+            const unsigned long long bit = 1ull << ((gj % sf) * sf + gi % sf);
+            ok = !(seen & bit);
+            seen |= bit;
+        }
+        if (!ok) atomicOr(err, 4);
+    }
+}
+
+// returns the error bits through *h_err (synchronises)
+int csr_matches_grid(srps_ctx* ctx, const int* dx_rp, const int* dx_ci, const float* dx_v, const int* dy_rp, const int* dy_ci, const float* dy_v,
+                     const int* kt_rp, const int* kt_ci, const float* kt_v, int* h_err) {
+    Grid& G = ctx->grid;
+    SRPS_TRY(ensure(ctx->ws_misc, 64));
+    int* d_err = (int*)ctx->ws_misc.p;
+    SRPS_HIP(hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
+    const int nb = std::max(1, std::min(cdiv(G.P, 256), 4096));
+    hipLaunchKernelGGL(k_check_gradient_csr, dim3(nb), dim3(256), 0, ctx->stream, dx_rp, dx_ci, dx_v, G.P, G.d_gofp, G.d_flags, G.Hs, (unsigned)F_FX, (unsigned)F_BX, 1, d_err);
+    hipLaunchKernelGGL(k_check_gradient_csr, dim3(nb), dim3(256), 0, ctx->stream, dy_rp, dy_ci, dy_v, G.P, G.d_gofp, G.d_flags, 1, (unsigned)F_FY, (unsigned)F_BY, 2, d_err);
+    if (G.Ps > 0)
+        hipLaunchKernelGGL(k_check_kt_csr, dim3(std::max(1, std::min(cdiv(G.Ps, 256), 4096))), dim3(256), 0, ctx->stream, kt_rp, kt_ci, kt_v, G.Ps, G.P,
+                           G.d_gofp, G.d_lr_index, G.Hs, G.Hl, G.sf, d_err);
+    SRPS_LAUNCH_CHECK();
+    SRPS_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    return SRPS_OK;
+}
+
 // ---- CG on a CSR matrix, device-resident scalars, same step structure as kernels_cg.hip ------
 struct CsrCgScal {
     float r0;

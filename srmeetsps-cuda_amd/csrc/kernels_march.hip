@@ -29,7 +29,8 @@ struct MarchArgs {
     const float* xin;      // MODE 0/1
     const float* p_in;     // MODE 2
     float* p_out;          // MODE 2
-    float* r;              // MODE 1 (in/out), MODE 2 (in)
+    float* r;              // MODE 1 (in/out), MODE 2 (in), MODE 3 (in: the residual before the pending update)
+    float* r_out;          // MODE 3: the updated residual goes to the OTHER plane (neighbouring strips still read the old one as halo)
     float* out;            // MODE 0/2
     float* x;              // MODE 2: the iterate; x += alpha_prev * p_in is applied here (deferred from the last update)
     const float* rr_part;
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
                         st4(a.p_out + off, X[1]);
                         st4(a.out + off, acc);
                         if (MODE == 3) {
-                            if (a.k != 1) st4(a.r + off, R[0]);       // uniform; step 1: r is unchanged
+                            st4(a.r_out + off, R[0]);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float rv = R[0].e[e];
@@ -556,8 +557,9 @@ int march_cg_step(srps_ctx* ctx, int k) {
     MarchArgs a = march_base(ctx);
     float* pbuf[2] = {G.d_p, G.d_p + G.plane};
     float* wbuf[2] = {G.d_w, G.d_w2};
-    a.p_in = (k == 1) ? G.d_r : pbuf[(k + 1) & 1];       // step 1: p = r
-    a.p_out = pbuf[k & 1]; a.r = G.d_r; a.x = G.d_x;
+    float* rbuf[2] = {G.d_r, G.d_r2};                     // like p: updated while neighbouring strips read the old values as halo
+    a.p_in = (k == 1) ? rbuf[0] : pbuf[(k + 1) & 1];
+    a.p_out = pbuf[k & 1]; a.r = rbuf[(k + 1) & 1]; a.r_out = rbuf[k & 1]; a.x = G.d_x;
     a.out = wbuf[k & 1]; a.w_prev = wbuf[(k + 1) & 1];
     a.n_part = G.n_part4;
     a.part4_in = G.d_part4 + (size_t)((k + 1) & 1) * 4 * G.n_part4;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
                                                         const float* __restrict__ yy, const float* __restrict__ dz,
                                                         float fx, float fy, int P, int n_local, int C, int n_total,
                                                         int img_offset, const int* __restrict__ gofp, size_t plane,
-                                                        float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp) {
+                                                        float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp, float* __restrict__ Qc /* compact [3][P] or null */) {
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
     if (q >= P) return;
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
             for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) Q[(size_t)t * plane + go] = qq[t][e];
+        for (int t = 0; t < 3; ++t) {
+            if (Qc) Qc[(size_t)t * P + q + e] = qq[t][e];      // sharded: compact [3][P] exchange buffer (scattered after the all-reduce)
+            else Q[(size_t)t * plane + go] = qq[t][e];
+        }
     }
 }
 
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict
                                                          const float* __restrict__ xx, const float* __restrict__ yy,
                                                          const float* __restrict__ dz, float fx, float fy, int P, int C, int n_total,
                                                          const int* __restrict__ gofp, size_t plane,
-                                                         float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp) {
+                                                         float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp, float* __restrict__ Qc /* compact [3][P] or null */) {
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
     if (q >= P) return;
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
@@ -279,7 +282,10 @@ __global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict
             for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) Q[(size_t)t * plane + go] = qq[t][e];
+        for (int t = 0; t < 3; ++t) {
+            if (Qc) Qc[(size_t)t * P + q + e] = qq[t][e];      // sharded: compact [3][P] exchange buffer (scattered after the all-reduce)
+            else Q[(size_t)t * plane + go] = qq[t][e];
+        }
     }
 }
 
@@ -313,9 +319,24 @@ __global__ void k_tensor_consts(const float* __restrict__ s, int n_total, int C,
     o[0] = (float)Sbb; o[1] = (float)xs; o[2] = (float)ys; o[3] = (float)fmax(R00, 0.0); o[4] = (float)R01; o[5] = (float)fmax(R11, 0.0); o[6] = 0.f; o[7] = 0.f;
 }
 
+// q of the sharded depth phase, summed over the ranks in its compact [3][P] exchange buffer, onto the grid planes the solve reads
+__global__ void k_scatter3(const float* __restrict__ compact, const int* __restrict__ gofp, int P, size_t plane, float* __restrict__ planes) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int g = gofp[p];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) planes[(size_t)t * plane + g] = compact[(size_t)t * P + p];
+    }
+}
+int depth_q_scatter(srps_ctx* ctx, const float* d_q_compact) {
+    Grid& G = ctx->grid;
+    hipLaunchKernelGGL(k_scatter3, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_q_compact, G.d_gofp, G.P, G.plane, G.d_q);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset, float cx, float cy, const float* d_ssum) {
+                   int n_total, int img_offset, float cx, float cy, const float* d_ssum, float* d_q_compact) {
     Grid& G = ctx->grid;
     // tensor-recompute form needs the principal point (xx = j - cx, yy = i - cy are rebuilt in the kernel)
     const bool rec = ctx->tensor_recompute && (C == 1 || C == 3) && cx == cx && cy == cy;
@@ -345,20 +366,20 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
         if (!rec) hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset, qc);
         if (vec && ((uintptr_t)d_ssum % 16 == 0))
             hipLaunchKernelGGL((k_depth_from_sums<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
-                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp);
+                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact);
         else
             hipLaunchKernelGGL((k_depth_from_sums<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
-                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp);
+                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact);
         SRPS_LAUNCH_CHECK();
         ctx->tensor_valid = true;
         return SRPS_OK;
     }
     if (vec)
         hipLaunchKernelGGL((k_depth_assemble<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
-                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, Mp, G.d_q, Gp);
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact);
     else
         hipLaunchKernelGGL((k_depth_assemble<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_I, d_xx, d_yy, d_dz,
-                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, Mp, G.d_q, Gp);
+                           fx, fy, P, n_local, C, n_total, img_offset, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact);
     SRPS_LAUNCH_CHECK();
     ctx->tensor_valid = true;
     return SRPS_OK;

@@ -85,14 +85,14 @@ static void dfree(T*& p) {
 
 static void grid_release(Grid& G) {
     dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index); dfree(G.d_tile_cls[0]); dfree(G.d_tile_cls[1]);
-    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_w2); dfree(G.d_part4); dfree(G.d_save);
+    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_w2); dfree(G.d_r2); dfree(G.d_part4); dfree(G.d_save);
     dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); G.d_scal = nullptr;      // d_scal lives in the context's report record
     G.bound = false;
 }
 
 static void state_release(srps_ctx* c) {
     dfree(c->s); dfree(c->rho); dfree(c->z); dfree(c->Nrm); dfree(c->dz); dfree(c->zx); dfree(c->zy);
-    dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); c->energy_ex = nullptr;      // energy_ex lives in the report record
+    dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); dfree(c->q_ex); c->q_in_exchange = false; c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
 }
 
@@ -210,6 +210,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     SRPS_TRY(dalloc(&G.d_x, G.plane)); SRPS_TRY(dalloc(&G.d_r, G.plane)); SRPS_TRY(dalloc(&G.d_p, 2 * G.plane));
     SRPS_TRY(dalloc(&G.d_w, G.plane)); SRPS_TRY(dalloc(&G.d_w2, G.plane)); SRPS_TRY(dalloc(&G.d_save, G.plane));
     SRPS_HIP(hipMemset(G.d_w2, 0, G.plane * sizeof(float)));
+    SRPS_TRY(dalloc(&G.d_r2, G.plane)); SRPS_HIP(hipMemset(G.d_r2, 0, G.plane * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_M, 0, 6 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_q, 0, 3 * G.plane * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_x, 0, G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_r, 0, G.plane * sizeof(float)));
     SRPS_HIP(hipMemset(G.d_p, 0, 2 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_w, 0, G.plane * sizeof(float)));
@@ -348,6 +349,7 @@ int srps_destroy(srps_ctx* ctx) {
     if (ctx->ws_ssum.p) (void)hipFree(ctx->ws_ssum.p);
     if (ctx->ws_albedo.p) (void)hipFree(ctx->ws_albedo.p);
     if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
+    if (ctx->ws_stage2.p) (void)hipFree(ctx->ws_stage2.p);
     if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
     if (ctx->ev_created)
         for (int i = 0; i < SRPS_N_PHASES; ++i) { (void)hipEventDestroy(ctx->ev_begin[i]); (void)hipEventDestroy(ctx->ev_end[i]); }
@@ -400,6 +402,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->cg_one_sync = value ? 1 : 0;
     } else if (!strcmp(name, "cg_fused_step")) {
         ctx->cg_fused_step = value ? 1 : 0;
+    } else if (!strcmp(name, "pin_uploads")) {
+        ctx->pin_uploads = value ? 1 : 0;
     } else if (!strcmp(name, "phase_timing")) {
         ctx->phase_timing = value ? 1 : 0;
         ctx->ev_mask = 0;
@@ -470,6 +474,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
     else if (!strcmp(name, "cg_fused_step")) *value = ctx->cg_fused_step;
     else if (!strcmp(name, "phase_timing")) *value = ctx->phase_timing;
+    else if (!strcmp(name, "pin_uploads")) *value = ctx->pin_uploads;
     else if (!strcmp(name, "roctx")) *value = ctx->roctx;
     else if (!strcmp(name, "cg_one_sync")) *value = ctx->cg_one_sync;
     else if (!strcmp(name, "cg_resident_rect")) *value = ctx->cg_resident_rect;
@@ -595,6 +600,29 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
     return SRPS_OK;
 }
 
+int srps_depth_estimation_csr(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_N, const float* d_I,
+                              const float* d_xx, const float* d_yy, const float* d_dz,
+                              const int* d_Dx_row_ptr, const int* d_Dx_col_ind, const float* d_Dx_val, int n_rows_Dx, int n_cols_Dx, int nnz_Dx,
+                              const int* d_Dy_row_ptr, const int* d_Dy_col_ind, const float* d_Dy_val, int n_rows_Dy, int n_cols_Dy, int nnz_Dy,
+                              const int* d_KT_row_ptr, const int* d_KT_col_ind, const float* d_KT_val, int n_rows_KT, int n_cols_KT, int nnz_KT,
+                              const float* d_z0s, float* d_z, float K00, float K11, int npix, int nimages, int nchannels, float* energy) {
+    CTX_CHECK(ctx); GRID_CHECK(ctx);
+    const Grid& G = ctx->grid;
+    SRPS_REQUIRE(d_Dx_row_ptr && d_Dx_col_ind && d_Dx_val && d_Dy_row_ptr && d_Dy_col_ind && d_Dy_val, SRPS_ERR_INVALID, "depth_estimation_csr: null gradient matrix");
+    SRPS_REQUIRE(G.Ps == 0 || (d_KT_row_ptr && d_KT_col_ind && d_KT_val), SRPS_ERR_INVALID, "depth_estimation_csr: null KT matrix");
+    SRPS_REQUIRE(npix == G.P && n_rows_Dx == G.P && n_cols_Dx == G.P && n_rows_Dy == G.P && n_cols_Dy == G.P, SRPS_ERR_INVALID,
+                 "depth_estimation_csr: Dx / Dy must be %d x %d (the bound mask), got %d x %d and %d x %d", G.P, G.P, n_rows_Dx, n_cols_Dx, n_rows_Dy, n_cols_Dy);
+    SRPS_REQUIRE(n_rows_KT == G.Ps && n_cols_KT == G.P && nnz_KT == G.Ps * G.sf * G.sf, SRPS_ERR_INVALID,
+                 "depth_estimation_csr: KT must be %d x %d with %d entries (complete %d x %d blocks of the bound mask), got %d x %d with %d", G.Ps, G.P,
+                 G.Ps * G.sf * G.sf, G.sf, G.sf, n_rows_KT, n_cols_KT, nnz_KT);
+    SRPS_REQUIRE(nnz_Dx >= 0 && nnz_Dy >= 0, SRPS_ERR_INVALID, "depth_estimation_csr: negative nnz");
+    int err = 0;
+    SRPS_TRY(csr_matches_grid(ctx, d_Dx_row_ptr, d_Dx_col_ind, d_Dx_val, d_Dy_row_ptr, d_Dy_col_ind, d_Dy_val, d_KT_row_ptr, d_KT_col_ind, d_KT_val, &err));
+    SRPS_REQUIRE(err == 0, SRPS_ERR_INVALID, "depth_estimation_csr: %s%s%s not the matrix make_gradient / the KT filter build from the bound mask (SRPS.cu:23-71, 170-193)",
+                 (err & 1) ? "Dx " : "", (err & 2) ? "Dy " : "", (err & 4) ? "KT " : "");
+    return srps_depth_estimation(ctx, d_s, d_rho, d_N, d_I, d_xx, d_yy, d_dz, d_z0s, d_z, K00, K11, npix, nimages, nchannels, energy);
+}
+
 int srps_depth_operator_apply(srps_ctx* ctx, const float* d_x, int npix, float* d_y) {
     CTX_CHECK(ctx); GRID_CHECK(ctx);
     SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_operator_apply: no tensor assembled yet");
@@ -617,8 +645,14 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     SRPS_REQUIRE(pr->n_channels > 0 && pr->n_channels <= 8 && pr->n_images >= 0 && pr->n_images_total > 0, SRPS_ERR_INVALID, "setup: bad image counts");
     SRPS_REQUIRE(pr->image_offset >= 0 && pr->image_offset + pr->n_images <= pr->n_images_total, SRPS_ERR_INVALID, "setup: shard [%d,%d) outside [0,%d)", pr->image_offset, pr->image_offset + pr->n_images, pr->n_images_total);
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    // SRPS_SETUP_TIMING=1: where the set-up time goes (stderr), for the set-up inclusive solve time of bench.py
+    const bool tm = getenv("SRPS_SETUP_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t_all = now(), t0 = now();
     state_release(ctx);
     SRPS_TRY(build_grid(ctx, pr->h, pr->w, pr->sf, pr->mask));
+    if (tm) { fprintf(stderr, "srps_setup: grid structure (host) + workspace %.1f ms\n", ms_since(t0)); t0 = now(); }
     Grid& G = ctx->grid;
     const int P = G.P, C = pr->n_channels, NL = pr->n_images, NT = pr->n_images_total;
     ctx->C = C; ctx->N_local = NL; ctx->N_total = NT; ctx->img_offset = pr->image_offset;
@@ -628,6 +662,7 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     SRPS_TRY(dalloc(&ctx->xx, P)); SRPS_TRY(dalloc(&ctx->yy, P)); SRPS_TRY(dalloc(&ctx->z0s, std::max(G.Ps, 1)));
     SRPS_TRY(dalloc(&ctx->I, (size_t)std::max(NL, 1) * C * P));
     SRPS_TRY(dalloc(&ctx->albedo_ex, 2 * (size_t)C * P)); ctx->energy_ex = ctx->d_report;
+    if (NL != NT) SRPS_TRY(dalloc(&ctx->q_ex, 3 * (size_t)P));      // a shard exchanges q compactly (3 P floats, not 3 padded planes)
     ctx->have_state = true;
     // lighting init s = (0,0,-1,0)  SRPS.cu:209-217
     std::vector<float> s0((size_t)NT * C * 4, 0.f);
@@ -644,12 +679,41 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
         SRPS_HIP(hipMemcpy(ctx->z, zt.data(), (size_t)P * sizeof(float), hipMemcpyHostToDevice));
     }
     SRPS_TRY(launch_meshgrid_compact(ctx->stream, G.d_imask, P, G.h, ctx->cx, ctx->cy, ctx->xx, ctx->yy));
-    if (pr->I) {
-        const size_t per = (size_t)C * G.h * G.w;
-        for (int n = 0; n < NL; ++n) SRPS_TRY(srps_upload_image(ctx, n, pr->I + (size_t)n * per));
+    if (tm) { fprintf(stderr, "srps_setup: state allocation + initial values %.1f ms\n", ms_since(t0)); t0 = now(); }
+    if (pr->I && NL > 0) {
+        // The images are the one large transfer of a solve (1.0 GB at the metric's configuration).  From pageable memory the
+        // runtime stages every copy through its own pinned chunks (about 19 GB/s measured); the caller's array is therefore
+        // pinned in place for the duration of the upload (hipHostRegister: the copies then run as plain DMA), and the per-image
+        // copies alternate between two staging buffers so that the host never waits for a gather kernel.
+        const size_t per = (size_t)C * G.h * G.w, bytes = (size_t)NL * per * sizeof(float);
+        const bool pinned = ctx->pin_uploads && bytes >= ((size_t)8 << 20) &&
+                            hipHostRegister((void*)pr->I, bytes, hipHostRegisterDefault) == hipSuccess;
+        if (!pinned) (void)hipGetLastError();
+        SRPS_TRY(ensure(ctx->ws_stage, per * sizeof(float)));
+        SRPS_TRY(ensure(ctx->ws_stage2, per * sizeof(float)));
+        hipEvent_t freed[2] = {nullptr, nullptr};
+        int rc = SRPS_OK;
+        for (int b = 0; b < 2 && rc == SRPS_OK; ++b)
+            if (hipEventCreateWithFlags(&freed[b], hipEventDisableTiming) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
+        for (int n = 0; n < NL && rc == SRPS_OK; ++n) {
+            const int b = n & 1;
+            float* stage = (float*)(b ? ctx->ws_stage2.p : ctx->ws_stage.p);
+            hipError_t e = (n >= 2) ? hipEventSynchronize(freed[b]) : hipSuccess;      // the gather that read this buffer two images ago
+            if (e == hipSuccess) e = hipMemcpyAsync(stage, pr->I + (size_t)n * per, per * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { rc = hip_fail(e, "image upload", __FILE__, __LINE__); break; }
+            rc = launch_gather_image(ctx->stream, stage, G.d_imask, G.P, C, (size_t)G.h * G.w, ctx->I + (size_t)n * C * G.P);
+            if (rc == SRPS_OK && hipEventRecord(freed[b], ctx->stream) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        for (int b = 0; b < 2; ++b) if (freed[b]) (void)hipEventDestroy(freed[b]);
+        if (tm) { fprintf(stderr, "srps_setup: %d images, %.2f GB uploaded and compacted %.1f ms (%s)\n", NL, bytes * 1e-9, ms_since(t0), pinned ? "pinned in place" : "pageable"); t0 = now(); }
+        if (pinned) (void)hipHostUnregister((void*)pr->I);
+        if (tm) { fprintf(stderr, "srps_setup: unpin %.1f ms\n", ms_since(t0)); t0 = now(); }
+        SRPS_TRY(rc);
     }
     SRPS_TRY(srps_normals(ctx));                                                            // SRPS.cu:264-270
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    if (tm) fprintf(stderr, "srps_setup: total %.1f ms\n", ms_since(t_all));
     return SRPS_OK;
 }
 
@@ -727,13 +791,15 @@ int srps_depth_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
     const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
+    ctx->q_in_exchange = ctx->q_ex != nullptr;
     return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
-                          ctx->N_total, ctx->img_offset, ctx->cx, ctx->cy, ssum);
+                          ctx->N_total, ctx->img_offset, ctx->cx, ctx->cy, ssum, ctx->q_ex);
 }
 int srps_depth_solve(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_DEPTH_SOLVE);
     SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
+    if (ctx->q_in_exchange) { SRPS_TRY(depth_q_scatter(ctx, ctx->q_ex)); ctx->q_in_exchange = false; }      // the all-reduced q of a shard
     ctx->light_cache_valid = false;      // z changes
     const bool plane_current = ctx->grad_current && ctx->plane_holds_z;      // nothing wrote z or the plane since the last solve
     ctx->grad_current = false;
@@ -813,7 +879,10 @@ int srps_exchange(srps_ctx* ctx, const char* which, void** d_ptr, size_t* n_floa
     Grid& G = ctx->grid;
     if (!strcmp(which, "s")) { *d_ptr = ctx->s; *n_floats = (size_t)ctx->N_total * ctx->C * 4; ctx->ssum_valid = false; }
     else if (!strcmp(which, "albedo")) { *d_ptr = ctx->albedo_ex; *n_floats = 2 * (size_t)ctx->C * G.P; }
-    else if (!strcmp(which, "depth")) { *d_ptr = G.d_q; *n_floats = 3 * G.plane; }
+    else if (!strcmp(which, "depth")) {
+        if (ctx->q_ex) { *d_ptr = ctx->q_ex; *n_floats = 3 * (size_t)G.P; }       // compact: 3 P floats
+        else { *d_ptr = G.d_q; *n_floats = 3 * G.plane; }                          // one GPU: nothing to exchange, the grid planes themselves
+    }
     else if (!strcmp(which, "energy")) { *d_ptr = ctx->energy_ex + 1; *n_floats = 1; }
     else SRPS_REQUIRE(false, SRPS_ERR_INVALID, "exchange: unknown buffer '%s'", which);
     return SRPS_OK;

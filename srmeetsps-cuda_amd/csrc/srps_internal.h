@@ -68,6 +68,7 @@ struct Grid {
     float cx = 0.f, cy = 0.f;     // principal point used by the last assembly (xx = j - cx, yy = i - cy)
     float* d_x = nullptr;         // [plane] z on the grid
     float* d_r = nullptr;         // [plane] rhs, then residual
+    float* d_r2 = nullptr;        // [plane] second residual plane of the one-launch CG step
     float* d_p = nullptr;         // [2][plane] search direction, double-buffered by step parity
     float* d_w = nullptr;         // [plane] omega = A p
     float* d_w2 = nullptr;        // [plane] second omega plane of the one-launch CG step (omega of the previous step is read while the new one is written)
@@ -109,7 +110,8 @@ struct srps_ctx {
     float lambda = 1.0f;             // dc.cu:644
     srps::Grid grid;
     // grow-only workspaces for the per-pixel phases
-    srps::DevBuf ws_light, ws_albedo, ws_stage, ws_misc;
+    srps::DevBuf ws_light, ws_albedo, ws_stage, ws_stage2, ws_misc;
+    int pin_uploads = 1;             // srps_setup pins the caller's image array in place (hipHostRegister) while it uploads it
     float* h_pinned = nullptr;       // 256 floats of pinned host memory for scalar read-back
     // The scalars the host reads back after a pass live in ONE device record with the layout of h_pinned -- [0..3] energy terms,
     // [8] lighting iterations, [16..47] albedo CG records, [64..71] depth CG scalars -- so that one copy fetches them all.
@@ -124,6 +126,8 @@ struct srps_ctx {
     float *s = nullptr, *rho = nullptr, *z = nullptr, *Nrm = nullptr, *dz = nullptr;
     float *zx = nullptr, *zy = nullptr, *xx = nullptr, *yy = nullptr, *z0s = nullptr, *I = nullptr;
     float* albedo_ex = nullptr;      // [2][C][P]  num, den
+    float* q_ex = nullptr;           // [3][P] q of a shard in the compact layout: what travels in the all-reduce (allocated for shards only)
+    bool q_in_exchange = false;      // srps_depth_partial left q in q_ex: srps_depth_solve scatters it onto the grid planes first
     float* energy_ex = nullptr;      // [2]
     int last_depth_iters = 0, last_light_iters = 0;
     int last_albedo_iters[8] = {0};
@@ -227,7 +231,8 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
 void albedo_iters_collect(srps_ctx* ctx);
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset, float cx, float cy, const float* d_ssum = nullptr);
+                   int n_total, int img_offset, float cx, float cy, const float* d_ssum = nullptr, float* d_q_compact = nullptr);
+int depth_q_scatter(srps_ctx* ctx, const float* d_q_compact);
 int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I,
                                const float* d_xx, const float* d_yy, const float* d_dz, const float* d_z,
                                const float* d_zx, const float* d_zy, float fx, float fy, int P, int n_local,
@@ -271,6 +276,8 @@ int march_recompute_channels(const srps_ctx* ctx);
 // ---- generic CSR (kernels_csr.hip) --------------------------------------------------------
 int csr_spmv(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n_rows, int n_cols, int nnz,
              const float* x, int transpose, float* y);
+int csr_matches_grid(srps_ctx* ctx, const int* dx_rp, const int* dx_ci, const float* dx_v, const int* dy_rp, const int* dy_ci, const float* dy_v,
+                     const int* kt_rp, const int* kt_ci, const float* kt_v, int* h_err);
 int csr_cg(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n, int nnz, float* x, float* b, int* iters);
 
 }  // namespace srps

@@ -52,15 +52,21 @@ def _oracle_start(sc, oracle, coracle):
 def _depth_three_ways(pkg, sc, variants):
     """the state after lighting + albedo, and z / energy / iterations of one depth phase per variant (a dict of options)"""
     dh = pkg.DataHandler.from_scene(sc)
-    out, state = {}, None
+    # the state is read from a context of its own: handing out state arrays makes a context drop the image sums its albedo
+    # sweep left for the depth assembly (the caller might write through the pointer), and the assembly then takes its other,
+    # differently rounded route -- the variants below must all take the same one
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(dh)
+    ctx.lighting(); ctx.albedo()
+    state = {k: ctx.get(k) for k in ("s", "rho", "dz", "z", "xx", "yy", "z0s")}
+    ctx.close()
+    out = {}
     for name, opts in variants.items():
         ctx = pkg.Context(device_id=0)
         for k, v in opts.items():
             ctx.set_option(k, v)
         ctx.setup(dh)
         ctx.lighting(); ctx.albedo()
-        if state is None:
-            state = {k: ctx.get(k) for k in ("s", "rho", "dz", "z", "xx", "yy", "z0s")}
         e = ctx.depth()
         out[name] = dict(e=e, z=ctx.get("z"), it=ctx.last_cg_iterations()["depth"], resident=ctx.get_option("cg_resident_active"))
         ctx.close()

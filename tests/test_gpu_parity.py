@@ -207,6 +207,51 @@ def test_depth_phase(gpu_ctx, oracle, pkg, kind, sf, h, w, n):
     assert abs(e - e_ref) / abs(e_ref) < 1e-3 and abs(e - e64) / abs(e64) < 2e-2, (e, e_ref, e64)
 
 
+@pytest.mark.parametrize("kind,sf,h,w", [("ragged", 2, 48, 40), ("full", 4, 64, 48), ("ellipse", 1, 36, 44)])
+def test_depth_estimation_with_the_references_csr_arguments(gpu_ctx, oracle, pkg, kind, sf, h, w):
+    """srps_depth_estimation_csr = cuda_based_depth_estimation's 35-argument list (devicecalls.cuh:36, call site SRPS.cu:293):
+    Dx, Dy, KT built the reference's way (make_gradient / KT filter -> COO -> cuda_based_host_COO_to_device_CSR) are checked
+    against the bound mask and the call gives the same depth and energy as srps_depth_estimation; a matrix that does not
+    belong to the mask is refused with a message naming it"""
+    import torch
+    sc = pkg.synth.make_scene(h, w, sf, 4, seed=13, mask_kind=kind)
+    st, _ = _state(oracle, sc)
+    oracle.lighting_estimation(st.s, st.rho, st.N, st.I)
+    oracle.albedo_estimation(st.s, st.rho, st.N, st.I)
+    P, Ps = st.geo.npix, st.geo.npixs
+    gpu_ctx.bind_grid(h, w, sf, sc.mask)
+
+    def upload(M, shuffle_seed):
+        M = M.tocoo()
+        perm = np.random.default_rng(shuffle_seed).permutation(M.nnz)      # COO in arbitrary order, as push_back leaves it
+        rp = torch.empty(M.shape[0] + 1, dtype=torch.int32, device="cuda"); ci = torch.empty(max(M.nnz, 1), dtype=torch.int32, device="cuda")
+        vv = torch.empty(max(M.nnz, 1), device="cuda")
+        gpu_ctx.host_COO_to_device_CSR(M.row[perm], M.col[perm], M.data[perm].astype(f32), M.shape[0], M.shape[1], rp, ci, vv)
+        return (rp, ci, vv, M.shape[0], M.shape[1], M.nnz)
+    Dx, Dy, KT = upload(st.geo.Dx, 1), upload(st.geo.Dy, 2), upload(st.geo.KT, 3)
+    args = (_t(st.s), _t(st.rho), _t(st.N), _t(st.I), _t(st.xx), _t(st.yy), _t(st.dz))
+    z_a = _t(st.z); z_b = _t(st.z)
+    e_a = gpu_ctx.depth_estimation(*args, _t(st.z0s), z_a, st.fx, st.fy, P, sc.n_img, sc.n_ch)
+    e_b = gpu_ctx.depth_estimation_csr(*args, Dx, Dy, KT, _t(st.z0s), z_b, st.fx, st.fy, P, sc.n_img, sc.n_ch)
+    assert e_a == e_b
+    np.testing.assert_array_equal(z_a.cpu().numpy(), z_b.cpu().numpy())
+    # wrong matrices: Dy in place of Dx, a flipped sign, a KT weight that is not 1/sf^2, a wrong size
+    for bad, name in (((Dy, Dy, KT), "Dx"), ((Dx, Dx, KT), "Dy")):
+        with pytest.raises(pkg.SRPSError) as ei:
+            gpu_ctx.depth_estimation_csr(*args, *bad, _t(st.z0s), _t(st.z), st.fx, st.fy, P, sc.n_img, sc.n_ch)
+        assert name in str(ei.value)
+    v_bad = Dx[2].clone(); v_bad[0] = -v_bad[0]
+    with pytest.raises(pkg.SRPSError):
+        gpu_ctx.depth_estimation_csr(*args, (Dx[0], Dx[1], v_bad) + Dx[3:], Dy, KT, _t(st.z0s), _t(st.z), st.fx, st.fy, P, sc.n_img, sc.n_ch)
+    if Ps > 0:
+        k_bad = KT[2].clone(); k_bad[KT[5] // 2] *= 2.0
+        with pytest.raises(pkg.SRPSError) as ei:
+            gpu_ctx.depth_estimation_csr(*args, Dx, Dy, (KT[0], KT[1], k_bad) + KT[3:], _t(st.z0s), _t(st.z), st.fx, st.fy, P, sc.n_img, sc.n_ch)
+        assert "KT" in str(ei.value)
+    with pytest.raises(pkg.SRPSError):
+        gpu_ctx.depth_estimation_csr(*args, Dx[:3] + (P - 1, P, Dx[5]), Dy, KT, _t(st.z0s), _t(st.z), st.fx, st.fy, P, sc.n_img, sc.n_ch)
+
+
 @pytest.mark.parametrize("kind,sf,h,w,n", [("ragged", 2, 48, 40, 5), ("full", 4, 64, 48, 6)])
 def test_full_alternating_loop(gpu_ctx, oracle, pkg, kind, sf, h, w, n):
     """SRPS::execute end to end: same number of outer passes, energies and final z/rho/s"""
