@@ -34,9 +34,9 @@ def cpu_baseline(sc, pkg, budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
         import c_oracle
-        return c_oracle.bench_cpu_baseline(sc, budget_s)
-    except ImportError:
-        pass
+        return dict(c_oracle.bench_cpu_baseline(sc, budget_s), implementation="C/OpenMP (oracle/srps_oracle.c)")
+    except ImportError as exc:
+        print(f"bench.py: the C oracle is not built ({exc}); timing the numpy restatement on one thread instead", file=sys.stderr)
     import srps_oracle as O
     geo = O.build_geometry(sc.h, sc.w, sc.sf, sc.mask)
     P = geo.npix
@@ -63,7 +63,7 @@ def cpu_baseline(sc, pkg, budget_s=20.0):
         r0 = r1; r1 = float(r @ r); p = (r1 / r0) * p + r
         iters += 1
     dt = time.perf_counter() - t0
-    return {"value": iters / dt, "unit": "cg_iterations/s", "cores": 1, "kind": "port",
+    return {"value": iters / dt, "unit": "cg_iterations/s", "cores": 1, "kind": "port", "implementation": "numpy (oracle/libsrps_oracle.so was not built)",
             "sample": f"{iters} CG steps of the matrix-free 2048^2 system (numpy/scipy restatement, 1 thread)"}
 
 

@@ -506,7 +506,9 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
         // the kernel at half the occupancy: 60 us of a 2 ms pass)
         int per_cu = fused ? 3 : 5;
         if (fused && ctx->light_channel_inner && (C == 1 || C == 3)) per_cu = fused_ci_blocks_per_cu(std::min(5, cdiv(n_local, 4)), C);
-        const int target = (ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * per_cu) / 4;      // pixel ranges
+        // pixel ranges; at most 504 of them: the fused sweep leaves cdiv(ranges, 8) * 32 energy partials in the first 2048 floats
+        // of d_misc_part (the partials of the depth term start there)
+        const int target = std::max(1, std::min((ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * per_cu) / 4, 504));
         const int gran = 256 * L.V;                        // a block covers 256 V pixels per iteration
         L.chunk = std::max(gran, cdiv(cdiv(P, target), gran) * gran);
     } else {
@@ -515,6 +517,7 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     }
     L.nblk = cdiv(P, L.chunk);
     L.n_epart = (ctx->light_grouped && L.V == 4) ? cdiv(L.nblk, 8) * 32 : L.nblk;
+    SRPS_REQUIRE(L.n_epart <= 2048, SRPS_ERR_UNSUPPORTED, "lighting sweep: %d energy partial sums do not fit their buffer", L.n_epart);
     const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
     SRPS_TRY(ensure(ctx->ws_light, (n_atb + n_g) * sizeof(float) + 64));
     L.part_atb = (float*)ctx->ws_light.p;

@@ -812,9 +812,12 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
     (void)ntile;
 }
 
-// One launch for all tiles: the block looks up the class of its tile and takes the body made for it.  The choice is made
-// once, outside the CG loop (two whole copies of the loop): every tile does the same number of grid-wide waits either way.
-template <int SF, int NC, bool ONE_SYNC>
+// Two kernels, one per body.  A CG step lasts as long as its slowest tile (every step ends in a grid-wide wait), so the body
+// without structure bits only pays when EVERY tile of the grid qualifies for it -- a full-frame mask, or an object that covers
+// its whole bounding box -- and that is when the host launches the RECT kernel; any other grid runs the general kernel on all
+// its tiles.  (Both bodies in one kernel, chosen per block, made the general body 0.6 us per step slower: the two share one
+// register allocation.)
+template <int SF, int NC, bool ONE_SYNC, bool RECT>
 __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     // XCD-aware tile order: the blocks of one XCD (b, b+8, ...) get a contiguous range of tiles
     int tile = blockIdx.x;
@@ -822,9 +825,8 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = tile & 7, kk = tile >> 3;
         tile = xcd * q + min(xcd, rem) + kk;
     }
-    const unsigned cls = a.tile_cls ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.tile_cls[tile]) : 0u;
-    if (cls & TILE_RECT) resident_body<SF, NC, ONE_SYNC, true>(a, tile, cls);
-    else resident_body<SF, NC, ONE_SYNC, false>(a, tile, cls);
+    const unsigned cls = RECT ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.tile_cls[tile]) : 0u;
+    resident_body<SF, NC, ONE_SYNC, RECT>(a, tile, cls);
 }
 
 size_t resident_lds_bytes(int NC) {
@@ -875,9 +877,12 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     a.debug = ctx->cg_resident_debug;
     a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;      // s_memrealtime: 100 MHz
-    a.tile_cls = ctx->cg_resident_rect ? (NT == 512 ? G.d_tile_cls[1] : G.d_tile_cls[0]) : nullptr;
+    const int shape = NT == 512 ? 1 : 0;
+    const bool rect = ctx->cg_resident_rect && G.n_tiles[shape] == tiles && G.n_rect_tiles[shape] == tiles;      // every tile qualifies
+    a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr;
     const void* fn = nullptr;
-#define SRPS_RES(SFV, NCV) fn = ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true> : (const void*)k_cg_resident<SFV, NCV, false>
+#define SRPS_RES(SFV, NCV) fn = rect ? (ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true, true> : (const void*)k_cg_resident<SFV, NCV, false, true>) \
+                                    : (ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true, false> : (const void*)k_cg_resident<SFV, NCV, false, false>)
     if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else if (G.sf == 2) SRPS_RES(2, 3); else SRPS_RES(4, 3); }
     else { if (G.sf == 1) SRPS_RES(1, 1); else if (G.sf == 2) SRPS_RES(2, 1); else SRPS_RES(4, 1); }
 #undef SRPS_RES

@@ -110,13 +110,20 @@ static std::vector<uint8_t> classify_tiles(const Grid& G, const std::vector<uint
     };
     std::vector<uint8_t> cls((size_t)nbr * nbc, 0);
     *n_rect = 0;
+    const uint64_t need = 0x0101010101010101ull * (F_MASK | F_KB);
     for (int bc = 0; bc < nbc; ++bc)
         for (int br = 0; br < nbr; ++br) {
             const int r0 = br * TRr, c0 = bc * tc;
             bool rect = r0 + TRr <= G.Hg && c0 + tc <= G.Wg;
-            for (int c = c0; c < c0 + tc && rect; ++c)
-                for (int r = r0; r < r0 + TRr; ++r)
-                    if ((F(r, c) & (F_MASK | F_KB)) != (F_MASK | F_KB)) { rect = false; break; }
+            // the tile's 256 rows of a column are contiguous bytes (PAD + r0 is a multiple of 4): eight pixels per test
+            for (int c = c0; c < c0 + tc && rect; ++c) {
+                const uint8_t* col = flags.data() + (size_t)(c + PAD) * G.Hs + r0 + PAD;
+                for (int r = 0; r < TRr; r += 8) {
+                    uint64_t w8;
+                    memcpy(&w8, col + r, 8);
+                    if ((w8 & need) != need) { rect = false; break; }
+                }
+            }
             if (!rect) continue;
             int nb = 0, nr = 0;
             bool bad = false;
@@ -141,17 +148,29 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     SRPS_REQUIRE(hw < (size_t)1 << 31, SRPS_ERR_UNSUPPORTED, "bind_grid: h*w must fit int32");
     int imin = h, imax = -1, jmin = w, jmax = -1;
     G.imask.clear(); G.imasks.clear();
-    for (int j = 0; j < w; ++j)
+    G.imask.reserve(hw);
+    // the mask as bytes with a one-pixel empty border: the neighbour tests below need no bounds checks (this set-up is host
+    // time inside every solve: 4 M pixels at the metric's size)
+    const size_t hb = (size_t)h + 2;
+    std::vector<uint8_t> mb(hb * ((size_t)w + 2), 0);
+    for (int j = 0; j < w; ++j) {
+        const float* mc = mask + (size_t)j * h;
+        uint8_t* bcol = mb.data() + (size_t)(j + 1) * hb + 1;
+        int lo = h, hi = -1;
         for (int i = 0; i < h; ++i) {
-            const float m = mask[(size_t)j * h + i];
+            const float m = mc[i];
             // the reference indexes with mask != 0 (SRPS.cu:158) but compacts with mask == 1
             // (devicecalls.cuh:19-24): anything but {0,1} silently corrupts it; we refuse.
             SRPS_REQUIRE(m == 0.f || m == 1.f, SRPS_ERR_INVALID, "bind_grid: mask must be {0,1}, found %g at (%d,%d)", (double)m, i, j);
             if (m != 0.f) {
+                bcol[i] = 1;
                 G.imask.push_back((int)((size_t)j * h + i));
-                imin = std::min(imin, i); imax = std::max(imax, i); jmin = std::min(jmin, j); jmax = std::max(jmax, j);
+                if (i < lo) lo = i;
+                hi = i;
             }
         }
+        if (hi >= 0) { imin = std::min(imin, lo); imax = std::max(imax, hi); jmin = std::min(jmin, j); jmax = j; }
+    }
     G.h = h; G.w = w; G.sf = sf;
     G.P = (int)G.imask.size();
     SRPS_REQUIRE(G.P > 0, SRPS_ERR_INVALID, "bind_grid: empty mask");
@@ -163,18 +182,23 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     G.plane = (size_t)G.Hs * G.Ws;
     SRPS_REQUIRE(G.plane < ((size_t)1 << 31) - 8 * (size_t)G.Hs, SRPS_ERR_UNSUPPORTED, "bind_grid: grid plane must fit int32 offsets");
     G.Hl = G.Hg / sf; G.Wl = G.Wg / sf;
-    auto M = [&](int i, int j) -> bool { return i >= 0 && i < h && j >= 0 && j < w && mask[(size_t)j * h + i] != 0.f; };
     std::vector<uint8_t> flags(G.plane, 0);
     std::vector<int> gofp(G.P);
-    for (int p = 0; p < G.P; ++p) {
-        const int lin = G.imask[p];
-        const int j = lin / h, i = lin - j * h;
-        uint8_t f = F_MASK;
-        if (M(i + 1, j)) f |= F_FY; else if (M(i - 1, j)) f |= F_BY;        // SRPS.cu:31-38
-        if (M(i, j + 1)) f |= F_FX; else if (M(i, j - 1)) f |= F_BX;        // SRPS.cu:39-46
-        const int go = (j - G.j_lo + PAD) * G.Hs + (i - G.i_lo + PAD);
-        flags[go] = f;
-        gofp[p] = go;
+    {
+        int p = 0;
+        for (int j = jmin; j <= jmax; ++j) {
+            const uint8_t* c0 = mb.data() + (size_t)(j + 1) * hb + 1;      // this column, its left and right neighbours
+            const uint8_t *cl = c0 - hb, *cr = c0 + hb;
+            const int gbase = (j - G.j_lo + PAD) * G.Hs - G.i_lo + PAD;
+            for (int i = 0; i < h; ++i) {
+                if (!c0[i]) continue;
+                uint8_t f = F_MASK;
+                if (c0[i + 1]) f |= F_FY; else if (c0[i - 1]) f |= F_BY;      // SRPS.cu:31-38
+                if (cr[i]) f |= F_FX; else if (cl[i]) f |= F_BX;              // SRPS.cu:39-46
+                flags[gbase + i] = f;
+                gofp[p++] = gbase + i;                                         // ascending linear index, like imask
+            }
+        }
     }
     // fully masked sf x sf blocks = rows of KT (D*mask == 1 exactly, SRPS.cu:110-111, 163-183)
     std::vector<int> lr_index((size_t)G.Hl * G.Wl, -1);
@@ -183,9 +207,11 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     for (int bj = 0; bj < G.Wl; ++bj)
         for (int bi = 0; bi < G.Hl; ++bi) {
             bool full = true;
-            for (int dj = 0; dj < sf && full; ++dj)
+            for (int dj = 0; dj < sf && full; ++dj) {
+                const uint8_t* bcol = mb.data() + (size_t)(G.j_lo + bj * sf + dj + 1) * hb + 1 + G.i_lo + bi * sf;      // inside the image: the box is sf-aligned
                 for (int di = 0; di < sf; ++di)
-                    if (!M(G.i_lo + bi * sf + di, G.j_lo + bj * sf + dj)) { full = false; break; }
+                    if (!bcol[di]) { full = false; break; }
+            }
             if (!full) continue;
             lr_index[(size_t)bj * G.Hl + bi] = ps++;
             G.imasks.push_back((G.j_lo / sf + bj) * hs_full + (G.i_lo / sf + bi));
@@ -416,7 +442,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "cg_resident_debug")) {
         ctx->cg_resident_debug = value;
     } else if (!strcmp(name, "light_blocks")) {
-        SRPS_REQUIRE(value >= 0 && value <= 65536, SRPS_ERR_INVALID, "light_blocks: bad value %d", value);
+        SRPS_REQUIRE(value >= 0 && value <= 2016, SRPS_ERR_INVALID, "light_blocks: 0 (automatic) .. 2016, got %d", value);
         ctx->light_blocks = value;
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "light_channel_inner")) {

@@ -58,21 +58,20 @@ void SRPS::execute() {
     bool stop_loop = false;
     int iteration = 1;
     energies.clear();
+    // The reference times every phase with a host Timer (SRPS.cu:277-295), which costs a device synchronisation per phase; here
+    // the phases record HIP events on the stream (srps_get_timings) and the host waits once per pass, for the energy.
+    srps_check(srps_set_option(ctx, "phase_timing", 1));
     do {
-        Timer timer;
-        timer.start();
-        srps_check(srps_lighting(ctx)); srps_check(srps_synchronize(ctx));                                     // SRPS.cu:281
-        timer.end();
-        printf("\n%-25s: %-6.6fs\n", "Lightning Estimation", timer.get());
-        timer.start();
-        srps_check(srps_albedo(ctx)); srps_check(srps_synchronize(ctx));                                       // SRPS.cu:287
-        timer.end();
-        printf("%-25s: %-6.6fs\n", "Albedo Estimation", timer.get());
-        timer.start();
         float error = 0.f;
+        srps_check(srps_lighting(ctx));                                                                        // SRPS.cu:281
+        srps_check(srps_albedo(ctx));                                                                          // SRPS.cu:287
         srps_check(srps_depth(ctx, &error));                                                                   // SRPS.cu:293
-        timer.end();
-        printf("%-25s: %-6.6fs\n", "Depth Estimation", timer.get());
+        float ms[SRPS_N_PHASES];
+        srps_check(srps_get_timings(ctx, ms));
+        auto sec = [&](int a, int b = -1) { return 1e-3 * ((ms[a] > 0 ? ms[a] : 0.f) + (b >= 0 && ms[b] > 0 ? ms[b] : 0.f)); };
+        printf("\n%-25s: %-6.6fs\n", "Lightning Estimation", sec(SRPS_PHASE_LIGHTING));
+        printf("%-25s: %-6.6fs\n", "Albedo Estimation", sec(SRPS_PHASE_ALBEDO_SWEEP, SRPS_PHASE_ALBEDO_SOLVE));
+        printf("%-25s: %-6.6fs\n", "Depth Estimation", sec(SRPS_PHASE_DEPTH_ASSEMBLY, SRPS_PHASE_DEPTH_SOLVE) + sec(SRPS_PHASE_ENERGY));
 
         const float rel_err = fabsf(last_error - error) / fabsf(error);                                        // SRPS.cu:298
         if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop_loop = true;       // SRPS.cu:299

@@ -1,0 +1,104 @@
+"""Strip-partitioned depth CG over several GPUs: host-side protocol (design for grids from 4096 x 4096 up, where the
+replicated CG of the image-sharded mode is what bounds the pass).
+
+The reference's CG (devicecalls.cu:229-279) on A_ = KT'KT + lambda A'A is kept step for step; what is partitioned is the
+grid: rank r owns the columns [j_r, j_{r+1}) of the bounding box, cut at multiples of sf so that no sf x sf block of KT
+(SRPS.cu:176-190) straddles two ranks.  A row of A_ at an owned pixel references, besides its own strip, only the ONE column
+to the left and the ONE to the right of it (Dx, Dx' are forward / backward differences between horizontal neighbours;
+Dy, Dy' and KT'KT stay inside a column resp. a block) -- tests/test_strip_partition.py asserts this on the assembled
+matrix.  Per CG step a rank therefore needs
+
+  * the edge columns of p from its two neighbours (2 x Hg floats each way: point-to-point, xGMI peer copies), and
+  * the two dot products of the step as all-reduces of ONE float each (p.A p, then r.r) -- or, in the one-wait form of
+    kernels_resident.hip, one all-reduce of three floats.
+
+At 4096 x 4096 on 8 ranks a strip is 4096 x 512 = 128 tiles of 256 x 64: it fits the resident kernel (one tile per CU), so
+the per-step cost becomes that kernel's ~10 us plus one small all-reduce instead of 170 us of streaming.
+
+`strip_cg` below is that protocol written against an abstract engine (the part that will drive the HIP kernels); the test
+suite runs it under gloo with an engine made from the oracle's assembled matrix and compares with the serial CG.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+CG_TOL = np.float32(1e-9)       # devicecalls.cu:230
+CG_MAX_ITER = 100               # devicecalls.cu:231 ("k <= max_iter": up to 101 steps)
+
+
+def strip_ranges(n_cols: int, sf: int, world: int) -> list[tuple[int, int]]:
+    """column ranges [begin, end) of the ranks: multiples of sf, sizes differ by at most one block column"""
+    assert n_cols % sf == 0 and world >= 1
+    blocks = n_cols // sf
+    base, rem = divmod(blocks, world)
+    out, b = [], 0
+    for r in range(world):
+        e = b + base + (1 if r < rem else 0)
+        out.append((b * sf, e * sf))
+        b = e
+    return out
+
+
+def strip_cg(engine, comm, max_iter: int = CG_MAX_ITER, tol: float = CG_TOL) -> int:
+    """The reference's recurrence (devicecalls.cu:252-275) on a strip.
+
+    engine (one per rank; all vectors live on its owned pixels):
+        residual_init()          r = b - A_ x  (x halo already exchanged by the caller of the first exchange_halo("x"))
+        edge(name) -> (left, right)   the first / last owned column of vector `name` ("x" or "p") as 1-D float32 tensors
+        set_halo(name, left, right)   the neighbours' edge columns (None at the outer strips)
+        apply() -> float         omega = A_ p on the owned pixels (uses the halo of p); returns the local p.omega
+        dot_rr() -> float        local r.r
+        update_x_r(alpha)        x += alpha p ; r -= alpha omega          (dc.cu:270-272)
+        update_p(beta, first)    p = r (first) or p = beta p + r          (dc.cu:256-264)
+    comm: exchange(left, right) -> (from_left, from_right) point-to-point with the neighbour ranks; allreduce(float) -> float
+    Returns the number of steps executed."""
+    def exchange_halo(name):
+        left, right = engine.edge(name)
+        engine.set_halo(name, *comm.exchange(left, right))
+
+    exchange_halo("x")
+    engine.residual_init()                                     # dc.cu:758
+    r1 = np.float32(comm.allreduce(engine.dot_rr()))           # dc.cu:249
+    r0 = np.float32(0)
+    k = 0                                                      # dc.cu:242
+    while r1 > np.float32(tol) * np.float32(tol) and k <= max_iter:        # dc.cu:252: tested before the increment => up to 101 steps
+        k += 1
+        if k > 1:
+            engine.update_p(np.float32(r1 / r0), False)        # dc.cu:262-264
+        else:
+            engine.update_p(np.float32(0), True)               # dc.cu:258
+        exchange_halo("p")
+        dot = np.float32(comm.allreduce(engine.apply()))       # dc.cu:267-268
+        alpha = np.float32(r1 / dot)                           # dc.cu:269
+        engine.update_x_r(alpha)
+        r0 = r1
+        r1 = np.float32(comm.allreduce(engine.dot_rr()))       # dc.cu:274
+    return k
+
+
+class TorchDistComm:
+    """comm for `strip_cg` on torch.distributed (gloo on CPU in the tests, nccl = RCCL over xGMI on GPUs)"""
+
+    def __init__(self, dist, device=None):
+        import torch
+        self.dist, self.torch, self.device = dist, torch, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def exchange(self, left, right):
+        torch, dist = self.torch, self.dist
+        from_left = torch.empty_like(left) if self.rank > 0 else None
+        from_right = torch.empty_like(right) if self.rank < self.world - 1 else None
+        ops = []
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, left, self.rank - 1), dist.P2POp(dist.irecv, from_left, self.rank - 1)]
+        if self.rank < self.world - 1:
+            ops += [dist.P2POp(dist.isend, right, self.rank + 1), dist.P2POp(dist.irecv, from_right, self.rank + 1)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return from_left, from_right
+
+    def allreduce(self, value: float) -> float:
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())

@@ -29,3 +29,21 @@ def find_main_loops(body, lo=3000, hi=8000):
         b = max(e for s, e in g if s == a)
         out.append((a, b))
     return out
+
+
+HALF = ("v_pk_", "v_bfe_", "_dpp", "f64", "v_readlane", "v_writelane", "v_readfirstlane", "v_rcp", "v_mul_lo", "v_mul_hi", "v_cvt_f64", "v_mad_u64", "v_div_")
+
+
+def issue_clocks(t):
+    """SIMD clocks one wave64 instruction occupies with two waves per SIMD (profiles/r02_valu_issue.json, measured by
+    tools/valu_issue_bench.hip): 2.3 at full rate; 4.5 for packed fp32, v_bfe, DPP, fp64, lane reads / writes -- and for any
+    instruction that reads a scalar register (v_cndmask with its mask in an SGPR pair, v_fmac with a scalar factor, ...)"""
+    import re
+    ins = t.split()[0]
+    if not ins.startswith("v_"):
+        return 0.0
+    ops = t[len(ins):]
+    src = ops.split(",", 1)[1] if "," in ops else ""
+    if any(k in t for k in HALF) or re.search(r"\bs\d+\b|\bs\[\d+:\d+\]|\bvcc\b", src):
+        return 4.5
+    return 2.3

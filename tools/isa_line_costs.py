@@ -12,23 +12,9 @@ import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from _isa_loops import find_main_loops      # noqa: E402
+from _isa_loops import find_main_loops, issue_clocks as cost      # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HALF = ("v_pk_", "v_bfe_", "_dpp", "f64", "v_readlane", "v_writelane", "v_readfirstlane", "v_rcp", "v_mul_lo", "v_mul_hi", "v_cvt_f64", "v_mad_u64", "v_div_")
-
-
-def cost(t):
-    ins = t.split()[0]
-    if not ins.startswith("v_"):
-        return 0.0
-    ops = t[len(ins):]
-    src = ops.split(",", 1)[1] if "," in ops else ""
-    if any(k in t for k in HALF) or re.search(r"\bs\d+\b|\bs\[\d+:\d+\]|\bvcc\b", src):
-        return 4.5
-    return 2.3
-
-
 def main():
     args = sys.argv[1:]
     extra = []
