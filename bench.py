@@ -106,12 +106,15 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         ach = flops / (launch_us * 1e6)                     # TFLOP/s
         isa = _profile("r02_resident_isa.json")
         issue = None
-        if isa and key in isa:
-            clk = isa[key]["valu_issue_clocks_per_wave_step"] * isa[key]["waves_per_simd"]
-            floor_us = clk / (isa[key]["GHz"] * 1e3)
-            issue = {"valu_issue_clocks_per_simd_step": clk, "issue_floor_us_per_step": floor_us,
-                     "measured_us_per_step": launch_us / 101.0, "issue_frac": floor_us / (launch_us / 101.0), "source": isa[key]["source"]}
-        out["roofline"] = {"bound": "valu", "kernel": "k_cg_resident: residual pass + the whole truncated CG (101 steps) in one persistent launch",
+        rect = bool(ctx.get_option("cg_resident_rect_active"))
+        ikey = key if rect else key + "_general_kernel"
+        if isa and ikey in isa:
+            clk = isa[ikey]["valu_issue_clocks_per_wave_step"] * isa[ikey]["waves_per_simd"]
+            floor_us = clk / (isa[ikey]["GHz"] * 1e3)
+            issue = {"valu_issue_clocks_per_simd_step": clk, "issue_floor_us_per_step": floor_us, "kernel": isa[ikey]["kernel"],
+                     "measured_us_per_step": launch_us / 101.0, "issue_frac": floor_us / (launch_us / 101.0), "source": isa[ikey]["source"]}
+        out["roofline"] = {"bound": "valu", "kernel": "k_cg_resident (" + ("mask-free body: every tile lies inside the mask" if rect else "general body") +
+                                                      "): residual pass + the whole truncated CG (101 steps) in one persistent launch",
                            "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
                            "traffic": (tj.get(key) or {}).get("resident"), "avg_launch_us": launch_us, "steps_per_launch": 101,
                            "flops_per_launch": flops, "flops_per_unknown_and_step": FLOPS_PER_UNKNOWN_STEP, "issue": issue,

@@ -84,7 +84,8 @@ int srps_synchronize(srps_ctx* ctx);
 int srps_set_option(srps_ctx* ctx, const char* name, int value);
 /* reads an option back; also "cg_resident_active" (1 when the bound grid fits one tile per CU and the depth CG
  * therefore runs as the persistent on-chip kernel), "num_cus", "persistent_fallbacks" (persistent launches that gave up a wait
- * so far), "cg_resident_rect_tiles_256" / "_512" (tiles of the bound grid that qualify for the body without structure bits) */
+ * so far), "cg_resident_rect_tiles_256" / "_512" (tiles of the bound grid that qualify for the body without structure bits),
+ * "cg_resident_rect_active" (1 when all of them do and the next depth CG therefore runs the kernel without structure bits) */
 int srps_get_option(srps_ctx* ctx, const char* name, int* value);
 
 /* ---- generic sparse operators (device pointers) -------------------------------------------*/

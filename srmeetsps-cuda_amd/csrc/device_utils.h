@@ -240,7 +240,11 @@ typedef unsigned srps_v4u __attribute__((ext_vector_type(4)));
                                  // time, and packed into 4 KB they queue on a few memory channels (16: 11.75, 64: 11.5, 256 and
                                  // 1024: 11.45 us per CG step at 2048 x 2048)
 #endif
-template <int NW = 0>      // NW: waves per block when known at compile time (the cross-wave sum is then one LDS round trip)
+// FLOAT32: the sums across the waves of a block and across the blocks in fp32 instead of fp64 -- for the depth CG, whose
+// critical path after the last block has published runs through this arithmetic (one thread's 24 dependent fp64 additions,
+// then the polling wave's fp64 DPP totals: ~0.25 us per CG step).  The per-thread and per-wave sums are fp32 either way; the
+// order is fixed, all blocks obtain the same bits.
+template <int NW = 0, bool FLOAT32 = false>      // NW: waves per block when known at compile time (the cross-wave sum is then one LDS round trip)
 __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen, unsigned long long* st = nullptr) {
     const int tid = threadIdx.x, nw = NW ? NW : (int)blockDim.x >> 6, nb = gridDim.x;
     __shared__ double sd[2][16][4];                        // per wave: three totals (+ pad)
@@ -249,7 +253,12 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
     __syncthreads();
     if (tid == 0) {
         double tot[3] = {0.0, 0.0, 0.0};
-        if (NW) {
+        if (NW && FLOAT32) {
+            float f[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < (NW ? NW : 1); ++i) { const double* d = sd[gen & 1u][i]; f[0] += (float)d[0]; f[1] += (float)d[1]; f[2] += (float)d[2]; }
+            tot[0] = f[0]; tot[1] = f[1]; tot[2] = f[2];
+        } else if (NW) {
 #pragma unroll
             for (int i = 0; i < (NW ? NW : 1); ++i) { const double* d = sd[gen & 1u][i]; tot[0] += d[0]; tot[1] += d[1]; tot[2] += d[2]; }
         } else {
@@ -264,11 +273,13 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
         if (st) st[0] = __builtin_amdgcn_s_memrealtime();
     }
 }
+template <bool FLOAT32 = false>
 __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsigned gen, double& o0, double& o1, double& o2, unsigned long long* st = nullptr) {
     const int nb = gridDim.x, tid = threadIdx.x, lane = tid & 63;
     __shared__ double res3[2][3];
     if (tid < 64) {                                        // one polling wave per block
         double acc[3] = {0.0, 0.0, 0.0};
+        float facc[3] = {0.f, 0.f, 0.f};
         const int nbr = (nb + 255) & ~255;
         const char* slot = reinterpret_cast<const char*>(ent3) + (size_t)(gen & 1u) * nbr * SRPS_G3_STRIDE;
         for (int base = 0; base < nb; base += 256) {
@@ -304,13 +315,21 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
                 }
                 __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
             }
+            if (FLOAT32) {
+                if (want0) { facc[0] += __uint_as_float(w[0].y); facc[1] += __uint_as_float(w[0].z); facc[2] += __uint_as_float(w[0].w); }
+                if (want1) { facc[0] += __uint_as_float(w[1].y); facc[1] += __uint_as_float(w[1].z); facc[2] += __uint_as_float(w[1].w); }
+                if (want2) { facc[0] += __uint_as_float(w[2].y); facc[1] += __uint_as_float(w[2].z); facc[2] += __uint_as_float(w[2].w); }
+                if (want3) { facc[0] += __uint_as_float(w[3].y); facc[1] += __uint_as_float(w[3].z); facc[2] += __uint_as_float(w[3].w); }
+            } else {
             if (want0) { acc[0] += (double)__uint_as_float(w[0].y); acc[1] += (double)__uint_as_float(w[0].z); acc[2] += (double)__uint_as_float(w[0].w); }
             if (want1) { acc[0] += (double)__uint_as_float(w[1].y); acc[1] += (double)__uint_as_float(w[1].z); acc[2] += (double)__uint_as_float(w[1].w); }
             if (want2) { acc[0] += (double)__uint_as_float(w[2].y); acc[1] += (double)__uint_as_float(w[2].z); acc[2] += (double)__uint_as_float(w[2].w); }
             if (want3) { acc[0] += (double)__uint_as_float(w[3].y); acc[1] += (double)__uint_as_float(w[3].z); acc[2] += (double)__uint_as_float(w[3].w); }
+            }
         }
         if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
-        const double t0 = wave_total(acc[0]), t1 = wave_total(acc[1]), t2 = wave_total(acc[2]);
+        const double t0 = FLOAT32 ? (double)wave_total(facc[0]) : wave_total(acc[0]), t1 = FLOAT32 ? (double)wave_total(facc[1]) : wave_total(acc[1]),
+                     t2 = FLOAT32 ? (double)wave_total(facc[2]) : wave_total(acc[2]);
         if (lane == 0) { res3[gen & 1u][0] = t0; res3[gen & 1u][1] = t1; res3[gen & 1u][2] = t2; }
     }
     __syncthreads();

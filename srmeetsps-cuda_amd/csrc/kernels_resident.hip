@@ -714,12 +714,12 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 for (int q = 0; q < RPT; ++q) rh[q] -= wr[q];
             } else {
                 ++gen;
-                grid_sum3_publish<NWV>(red, red_rw, red_ww, a.ent3, gen, SRPS_STAMP_PTR);
+                grid_sum3_publish<NWV, true>(red, red_rw, red_ww, a.ent3, gen, SRPS_STAMP_PTR);
                 request_ring();
                 SRPS_STAMP(5);
                 double pw, rw, ww;
                 if (a.debug & 1) { pw = 1e30; rw = 0.0; ww = 0.0; }
-                else grid_sum3_collect(a.ent3, gen, pw, rw, ww, SRPS_STAMP_PTR);
+                else grid_sum3_collect<true>(a.ent3, gen, pw, rw, ww, SRPS_STAMP_PTR);
                 SRPS_STAMP(6);
                 alpha = r1 / (float)pw;                    // dc.cu:269
                 asm volatile("" : "+v"(alpha));
@@ -898,6 +898,13 @@ bool resident_supported(const srps_ctx* ctx) {
     if (ctx->cg_resident_tile == 512) return resident_supported_n512(ctx);
     if (ctx->cg_resident_tile == 256) return resident_supported_n256(ctx);
     return resident_supported_n256(ctx) || resident_supported_n512(ctx);
+}
+// would the next resident launch on the bound grid be the kernel without structure bits (every tile qualifies)?
+bool resident_rect_active(const srps_ctx* ctx) {
+    if (!resident_supported(ctx) || !ctx->cg_resident_rect) return false;
+    const bool small = ctx->cg_resident_tile == 256 || (ctx->cg_resident_tile != 512 && resident_supported_n256(ctx));
+    const int shape = small ? 0 : 1;
+    return ctx->grid.n_tiles[shape] > 0 && ctx->grid.n_rect_tiles[shape] == ctx->grid.n_tiles[shape];
 }
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const bool small = ctx->cg_resident_tile == 256 || (ctx->cg_resident_tile != 512 && resident_supported_n256(ctx));

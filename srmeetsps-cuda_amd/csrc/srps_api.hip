@@ -504,6 +504,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "roctx")) *value = ctx->roctx;
     else if (!strcmp(name, "cg_one_sync")) *value = ctx->cg_one_sync;
     else if (!strcmp(name, "cg_resident_rect")) *value = ctx->cg_resident_rect;
+    else if (!strcmp(name, "cg_resident_rect_active")) *value = (ctx->grid.bound && resident_rect_active(ctx)) ? 1 : 0;
     else if (!strcmp(name, "cg_resident_rect_tiles_256")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[0] : 0;      // of the 256 x 32 tiling
     else if (!strcmp(name, "cg_resident_rect_tiles_512")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[1] : 0;      // of the 256 x 64 tiling
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;

@@ -243,6 +243,7 @@ int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_r
 int contexts_on_device(int device);      // live srps contexts of this process on that device
 int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes);
 bool resident_supported(const srps_ctx* ctx);
+bool resident_rect_active(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
 bool resident_supported_n512(const srps_ctx* ctx);       // the two tile shapes (kernels_resident.hip, kernels_resident_n256.hip)
 bool resident_supported_n256(const srps_ctx* ctx);

@@ -1,5 +1,5 @@
 // Main.cpp -- command line of the reference (Main.cpp:9-44): --dstype|-t, --dsloc|-d, --device|-g,
-// --blockx|-x, --blocky|-y, --help|-h|--usage; plus --outdir|-o and --no-output for the result dumps.
+// --blockx|-x, --blocky|-y, --help|-h|--usage; plus --outdir|-o and --no-output for the result dumps, --images, --exclusive.
 #include <cstring>
 #include <iostream>
 #include <map>
@@ -16,7 +16,8 @@ static void print_message() {
                  "\t-y, --blocky (value:4)\n\t\tblock dimension y (advisory)\n"
                  "\t-o, --outdir (value:.)\n\t\tdirectory for zs_init/z_init/s/rho/z/N .mat dumps\n"
                  "\t--no-output\n\t\tdo not write .mat dumps\n"
-                 "\t--images\n\t\twrite the reference's three views (normals initial/current, albedo) and the depth map as PNG\n";
+                 "\t--images\n\t\twrite the reference's three views (normals initial/current, albedo) and the depth map as PNG\n"
+                 "\t--exclusive\n\t\tnothing else uses the device: plain instead of cooperative launches of the persistent kernels\n";
 }
 
 int main(int argc, char* argv[]) {
@@ -32,7 +33,7 @@ int main(int argc, char* argv[]) {
         if (eq != std::string::npos) { key = a.substr(0, eq); val = a.substr(eq + 1); has_val = true; }
         auto al = alias.find(key);
         if (al != alias.end()) key = al->second;
-        if (key == "help" || key == "no-output" || key == "images") { opt[key] = "true"; continue; }
+        if (key == "help" || key == "no-output" || key == "images" || key == "exclusive") { opt[key] = "true"; continue; }
         if (!has_val && i + 1 < argc) val = argv[++i];
         if (val.size() >= 2 && val.front() == '"' && val.back() == '"') val = val.substr(1, val.size() - 2);
         opt[key] = val;
@@ -47,6 +48,7 @@ int main(int argc, char* argv[]) {
     Preferences::outDir = opt["outdir"];
     Preferences::writeOutputs = !opt.count("no-output");
     Preferences::writeImages = opt.count("images") > 0;
+    Preferences::exclusiveDevice = opt.count("exclusive") > 0;
     try {
         if (opt["dstype"] == "matlab") {                            // Main.cpp:31-36
             MatFileDataHandler dh;

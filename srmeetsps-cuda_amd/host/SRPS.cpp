@@ -16,6 +16,7 @@ void SRPS::execute() {
     const int MAX_ITERATIONS = 10;          // SRPS.cu:86
     dh->validate();
     if (!ctx) srps_check(srps_create(Preferences::deviceId, Preferences::blockX, Preferences::blockY, &ctx));   // SRPS.cu:88-98
+    srps_check(srps_set_option(ctx, "exclusive_device", Preferences::exclusiveDevice ? 1 : 0));
 
     // Depth mean, inpainting, smoothing, up-sampling (CPU) -- SRPS.cu:117-149
     std::cout << "Mean of depth values" << std::endl;

@@ -13,6 +13,7 @@ int Preferences::blockY = 4;
 int Preferences::deviceId = 0;
 bool Preferences::writeOutputs = true;
 bool Preferences::writeImages = false;
+bool Preferences::exclusiveDevice = false;
 std::string Preferences::outDir = ".";
 
 void DataHandler::freeMemory() {

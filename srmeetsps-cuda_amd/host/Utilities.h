@@ -23,6 +23,7 @@ struct Preferences {
     static int deviceId;
     static bool writeOutputs;     // new: dump s/rho/z/N .mat after every pass (SRPS.cu:330-333)
     static bool writeImages;      // new: write the three imshow views (SRPS.cu:319-327) as PNG files
+    static bool exclusiveDevice;  // new: the device is not shared (srps option "exclusive_device")
     static std::string outDir;
 
 private:
