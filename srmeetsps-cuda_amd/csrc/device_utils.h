@@ -244,9 +244,52 @@ typedef unsigned srps_v4u __attribute__((ext_vector_type(4)));
 // critical path after the last block has published runs through this arithmetic (one thread's 24 dependent fp64 additions,
 // then the polling wave's fp64 DPP totals: ~0.25 us per CG step).  The per-thread and per-wave sums are fp32 either way; the
 // order is fixed, all blocks obtain the same bits.
+// arrival counters of the barrier-free publish below (one per generation parity)
+__device__ __forceinline__ unsigned* grid_sum3_arrived() {
+    __shared__ unsigned arrived[2];
+    return arrived;
+}
+// called by every thread of a kernel that uses grid_sum3_publish<NW, true>, before its first barrier
+__device__ __forceinline__ void grid_sum3_prepare() {
+    if (threadIdx.x < 2) grid_sum3_arrived()[threadIdx.x] = 0u;
+}
 template <int NW = 0, bool FLOAT32 = false>      // NW: waves per block when known at compile time (the cross-wave sum is then one LDS round trip)
 __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen, unsigned long long* st = nullptr) {
     const int tid = threadIdx.x, nw = NW ? NW : (int)blockDim.x >> 6, nb = gridDim.x;
+    if constexpr (NW > 0 && FLOAT32) {
+        // Every wave leaves its three totals in LDS and counts itself in; the wave that arrives LAST adds the NW entries in
+        // their fixed order and publishes the granule -- the block's sums leave as soon as its slowest wave is done, without
+        // the wake-up of a summing thread behind a barrier.  (One wave's LDS accesses execute in order and the LDS is
+        // coherent within the CU; the buffers alternate with the generation, and a grid-wide collect -- with its barrier --
+        // lies between two uses of the same one.)
+        __shared__ float sf[2][NW][4];
+        unsigned* arrived = grid_sum3_arrived();            // zeroed by grid_sum3_prepare() before the kernel's first barrier
+        const float t0 = wave_total(v0), t1 = wave_total(v1), t2 = wave_total(v2);
+        if ((tid & 63) == 0) {
+            float* d = sf[gen & 1u][tid >> 6];
+            d[0] = t0; d[1] = t1; d[2] = t2;
+            // relaxed, between two compiler barriers: an acquire-release here also waits for the edge granules just stored to
+            // global memory (s_waitcnt vmcnt(0)), which is what this form is meant to avoid; the LDS itself keeps the order
+            asm volatile("" ::: "memory");
+            const unsigned before = __hip_atomic_fetch_add(&arrived[gen & 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            if (before % NW == NW - 1) {
+                float f[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NW; ++i) { const float* e = sf[gen & 1u][i]; f[0] += e[0]; f[1] += e[1]; f[2] += e[2]; }
+                const srps_v4u g = {gen, __float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2])};
+                const int nbr = (nb + 255) & ~255;
+                const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(g) : "memory");
+                if (st) st[0] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+        // The barrier stays -- without it the block's polling wave starts to poll while its other waves still compute, takes
+        // issue slots from the wave it shares a SIMD with and loads the fabric for longer (measured: +2.5 us per CG step) --
+        // but it now opens the moment the last wave has published, with no summing thread to wake up behind it.
+        __syncthreads();
+        return;
+    }
     __shared__ double sd[2][16][4];                        // per wave: three totals (+ pad)
     const double t0 = (double)wave_total(v0), t1 = (double)wave_total(v1), t2 = (double)wave_total(v2);
     if ((tid & 63) == 0) { double* d = sd[gen & 1u][tid >> 6]; d[0] = t0; d[1] = t1; d[2] = t2; }

@@ -273,6 +273,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
     // every wait below is bounded by one deadline (device_utils.h): a block that never becomes resident ends the launch
     // with an abort flag instead of hanging it; the first grid-wide sum (pass 0) doubles as the census of resident blocks
     spin_guard_init(a.spin_ticks, &a.scal->abort_flags, ABORT_DEPTH);      // here, not at the top: 44 bytes of scratch less
+    grid_sum3_prepare();
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
@@ -428,7 +429,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 x_dn = selm(m_l63, rb, x_dn);
             }
             unsigned FL = fl[c];
-            asm volatile("" : "+v"(FL));             // opaque: the 16 masks per column derived from it are not worth 16 registers
+            if (!RECT) asm volatile("" : "+v"(FL));  // opaque: the 16 masks per column derived from it are not worth 16 registers
             float send_dn = 0.f, send_up = 0.f;
             // two rows per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): rows (0,1), then rows (2,3)
 #pragma unroll
@@ -630,7 +631,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         float red = 0.f, red_rw = 0.f, red_ww = 0.f;
         unsigned flk[CPT];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) { flk[c] = fl[c]; asm volatile("" : "+v"(flk[c])); }
+        for (int c = 0; c < CPT; ++c) { flk[c] = fl[c]; if (!RECT) asm volatile("" : "+v"(flk[c])); }
 #pragma unroll
         for (int c = 0; c < CPT; ++c)
 #pragma unroll

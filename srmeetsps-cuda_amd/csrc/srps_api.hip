@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
+#include <functional>
 #include <dlfcn.h>
 #include "srps_internal.h"
 
@@ -138,7 +139,9 @@ static std::vector<uint8_t> classify_tiles(const Grid& G, const std::vector<uint
 
 // Host construction of the grid structure: what SRPS.cu:151-203 expresses as index lists and the
 // COO matrices KT, Dx, Dy becomes a bounding box, a compact->grid index map and one byte per pixel.
-static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
+// after_release (may be null) runs once the old grid has been freed and the arguments have been checked, before the host-side
+// construction: srps_setup starts its image uploads there, so that the DMA runs while the host builds the structure
+static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, const std::function<int()>* after_release = nullptr) {
     Grid& G = ctx->grid;
     grid_release(G);
     SRPS_REQUIRE(h > 0 && w > 0 && sf >= 1, SRPS_ERR_INVALID, "bind_grid: bad dimensions h=%d w=%d sf=%d", h, w, sf);
@@ -146,6 +149,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask) {
     SRPS_REQUIRE(mask != nullptr, SRPS_ERR_INVALID, "bind_grid: mask is NULL");
     const size_t hw = (size_t)h * w;
     SRPS_REQUIRE(hw < (size_t)1 << 31, SRPS_ERR_UNSUPPORTED, "bind_grid: h*w must fit int32");
+    if (after_release) SRPS_TRY((*after_release)());
     int imin = h, imax = -1, jmin = w, jmax = -1;
     G.imask.clear(); G.imasks.clear();
     G.imask.reserve(hw);
@@ -678,7 +682,34 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     auto t_all = now(), t0 = now();
     state_release(ctx);
-    SRPS_TRY(build_grid(ctx, pr->h, pr->w, pr->sf, pr->mask));
+    // The images are the one large transfer of a solve (1.0 GB at the metric's configuration, 18.7 ms at the PCIe rate), the
+    // host-side construction of the grid structure the one large piece of host work (17 ms): they overlap.  The caller's array
+    // is pinned in place (hipHostRegister: plain DMA instead of the runtime's staging), the copies of the first images -- as many
+    // as fit 2 GB of staging -- are queued before the host starts on the structure, and the gather kernels that compact them
+    // follow once the structure is on the device.
+    const int C_ = pr->n_channels, NL_ = pr->n_images;
+    const size_t per = (size_t)C_ * pr->h * pr->w;
+    struct Pin {
+        const void* p = nullptr;
+        hipStream_t st = nullptr;
+        ~Pin() { if (p) { (void)hipStreamSynchronize(st); (void)hipHostUnregister(const_cast<void*>(p)); } }      // also on the error paths: no copy in flight
+    } pin;
+    pin.st = ctx->stream;
+    int staged = 0;
+    std::function<int()> start_uploads = [&]() -> int {
+        if (!pr->I || NL_ <= 0) return SRPS_OK;
+        const size_t bytes = (size_t)NL_ * per * sizeof(float);
+        if (ctx->pin_uploads && bytes >= ((size_t)8 << 20)) {
+            if (hipHostRegister((void*)pr->I, bytes, hipHostRegisterDefault) == hipSuccess) pin.p = pr->I;
+            else (void)hipGetLastError();
+        }
+        staged = (int)std::min<size_t>((size_t)NL_, std::max<size_t>(2, ((size_t)2 << 30) / (per * sizeof(float))));
+        SRPS_TRY(ensure(ctx->ws_stage, (size_t)staged * per * sizeof(float)));
+        for (int n = 0; n < staged; ++n)
+            SRPS_HIP(hipMemcpyAsync((float*)ctx->ws_stage.p + (size_t)n * per, pr->I + (size_t)n * per, per * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        return SRPS_OK;
+    };
+    SRPS_TRY(build_grid(ctx, pr->h, pr->w, pr->sf, pr->mask, &start_uploads));
     if (tm) { fprintf(stderr, "srps_setup: grid structure (host) + workspace %.1f ms\n", ms_since(t0)); t0 = now(); }
     Grid& G = ctx->grid;
     const int P = G.P, C = pr->n_channels, NL = pr->n_images, NT = pr->n_images_total;
@@ -708,35 +739,33 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     SRPS_TRY(launch_meshgrid_compact(ctx->stream, G.d_imask, P, G.h, ctx->cx, ctx->cy, ctx->xx, ctx->yy));
     if (tm) { fprintf(stderr, "srps_setup: state allocation + initial values %.1f ms\n", ms_since(t0)); t0 = now(); }
     if (pr->I && NL > 0) {
-        // The images are the one large transfer of a solve (1.0 GB at the metric's configuration).  From pageable memory the
-        // runtime stages every copy through its own pinned chunks (about 19 GB/s measured); the caller's array is therefore
-        // pinned in place for the duration of the upload (hipHostRegister: the copies then run as plain DMA), and the per-image
-        // copies alternate between two staging buffers so that the host never waits for a gather kernel.
-        const size_t per = (size_t)C * G.h * G.w, bytes = (size_t)NL * per * sizeof(float);
-        const bool pinned = ctx->pin_uploads && bytes >= ((size_t)8 << 20) &&
-                            hipHostRegister((void*)pr->I, bytes, hipHostRegisterDefault) == hipSuccess;
-        if (!pinned) (void)hipGetLastError();
-        SRPS_TRY(ensure(ctx->ws_stage, per * sizeof(float)));
-        SRPS_TRY(ensure(ctx->ws_stage2, per * sizeof(float)));
+        const size_t hwp = (size_t)G.h * G.w;
+        for (int n = 0; n < staged; ++n)       // the copies queued before the structure was built
+            SRPS_TRY(launch_gather_image(ctx->stream, (const float*)ctx->ws_stage.p + (size_t)n * per, G.d_imask, G.P, C, hwp, ctx->I + (size_t)n * C * G.P));
+        // images beyond the staging area: two slots of it in turn, each reused once the gather that read it has run
         hipEvent_t freed[2] = {nullptr, nullptr};
         int rc = SRPS_OK;
-        for (int b = 0; b < 2 && rc == SRPS_OK; ++b)
-            if (hipEventCreateWithFlags(&freed[b], hipEventDisableTiming) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
-        for (int n = 0; n < NL && rc == SRPS_OK; ++n) {
-            const int b = n & 1;
-            float* stage = (float*)(b ? ctx->ws_stage2.p : ctx->ws_stage.p);
-            hipError_t e = (n >= 2) ? hipEventSynchronize(freed[b]) : hipSuccess;      // the gather that read this buffer two images ago
+        if (staged < NL) {
+            SRPS_HIP(hipStreamSynchronize(ctx->stream));
+            for (int b2 = 0; b2 < 2 && rc == SRPS_OK; ++b2)
+                if (hipEventCreateWithFlags(&freed[b2], hipEventDisableTiming) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
+        }
+        for (int n = staged; n < NL && rc == SRPS_OK; ++n) {
+            const int b2 = n & 1;
+            float* stage = (float*)ctx->ws_stage.p + (size_t)b2 * per;
+            hipError_t e = (n >= staged + 2) ? hipEventSynchronize(freed[b2]) : hipSuccess;
             if (e == hipSuccess) e = hipMemcpyAsync(stage, pr->I + (size_t)n * per, per * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) { rc = hip_fail(e, "image upload", __FILE__, __LINE__); break; }
-            rc = launch_gather_image(ctx->stream, stage, G.d_imask, G.P, C, (size_t)G.h * G.w, ctx->I + (size_t)n * C * G.P);
-            if (rc == SRPS_OK && hipEventRecord(freed[b], ctx->stream) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
+            rc = launch_gather_image(ctx->stream, stage, G.d_imask, G.P, C, hwp, ctx->I + (size_t)n * C * G.P);
+            if (rc == SRPS_OK && hipEventRecord(freed[b2], ctx->stream) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
         }
         (void)hipStreamSynchronize(ctx->stream);
-        for (int b = 0; b < 2; ++b) if (freed[b]) (void)hipEventDestroy(freed[b]);
-        if (tm) { fprintf(stderr, "srps_setup: %d images, %.2f GB uploaded and compacted %.1f ms (%s)\n", NL, bytes * 1e-9, ms_since(t0), pinned ? "pinned in place" : "pageable"); t0 = now(); }
-        if (pinned) (void)hipHostUnregister((void*)pr->I);
-        if (tm) { fprintf(stderr, "srps_setup: unpin %.1f ms\n", ms_since(t0)); t0 = now(); }
+        for (int b2 = 0; b2 < 2; ++b2) if (freed[b2]) (void)hipEventDestroy(freed[b2]);
+        if (tm) { fprintf(stderr, "srps_setup: %d images, %.2f GB uploaded (queued before the structure was built) and compacted: %.1f ms more (%s)\n", NL,
+                          (double)NL * per * sizeof(float) * 1e-9, ms_since(t0), pin.p ? "pinned in place" : "pageable"); t0 = now(); }
         SRPS_TRY(rc);
+        // the staging area is a set-up artefact (1 GB at the metric's size): give it back
+        if (ctx->ws_stage.bytes > ((size_t)64 << 20)) { (void)hipFree(ctx->ws_stage.p); ctx->ws_stage.p = nullptr; ctx->ws_stage.bytes = 0; }
     }
     SRPS_TRY(srps_normals(ctx));                                                            // SRPS.cu:264-270
     SRPS_HIP(hipStreamSynchronize(ctx->stream));

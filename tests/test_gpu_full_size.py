@@ -111,21 +111,22 @@ def test_metric_size_depth_phase_resident_streaming_and_oracle(pkg, oracle, cora
     assert rmse(out["resident_two_waits"]["z"], out["streaming"]["z"]) < 2e-5, report
 
 
-def test_config3_whole_pass_against_the_oracle(pkg, oracle, coracle):
-    """1024 x 1024, sf 4, 20 images (BASELINE.json configs[2]): lighting -> albedo -> depth -> normals, default options,
-    against numpy (lighting dc.cu:376-444, albedo dc.cu:395-406 + 513-548 on the diagonal system) and C (depth)"""
-    sc = pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full")
+def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True):
+    """lighting -> albedo -> depth -> normals with default options against numpy (lighting dc.cu:376-444, albedo dc.cu:395-406 +
+    513-548 on the diagonal system) and C (depth)"""
+    n_img, n_ch = sc.n_img, sc.n_ch
     ctx = pkg.Context(device_id=0)
     ctx.setup(pkg.DataHandler.from_scene(sc))
     en = pkg.alternating_loop(ctx, None, max_outer=1)
-    z = ctx.get("z"); rho = ctx.get("rho").reshape(3, -1); s = ctx.get("s").reshape(-1, 3, 4); Nrm = ctx.get("N").reshape(4, -1)
+    z = ctx.get("z"); rho = ctx.get("rho").reshape(n_ch, -1); s = ctx.get("s").reshape(-1, n_ch, 4); Nrm = ctx.get("N").reshape(4, -1)
     iters = ctx.last_cg_iterations()
-    assert ctx.get_option("cg_resident_active") == 1
+    if expect_resident:
+        assert ctx.get_option("cg_resident_active") == 1
     ctx.close()
     st, o = _oracle_start(sc, oracle, coracle)
     P = st.P
-    s_ref = np.zeros((20, 3, 4), f32); s_ref[:, :, 2] = -1
-    rho_ref = np.full((3, P), 0.5, f32)
+    s_ref = np.zeros((n_img, n_ch, 4), f32); s_ref[:, :, 2] = -1
+    rho_ref = np.full((n_ch, P), 0.5, f32)
     oracle.lighting_estimation(s_ref, rho_ref, o["N"], o["I"])
     num, den = oracle.albedo_numden(s_ref, o["N"], o["I"])
     alb_it = []
@@ -133,22 +134,34 @@ def test_config3_whole_pass_against_the_oracle(pkg, oracle, coracle):
     z_ref = o["z"].copy()
     e_ref, it_ref = coracle.depth_estimation(st, s_ref, rho_ref, o["I"], o["xx"], o["yy"], o["dz"], o["z0s"], z_ref, o["fx"], o["fy"], assembled=True)
     # normals (dc.cu:171-223) of the depth the GPU solved: N = (fx zx, fy zy, ...) / |.| multiplies depth differences by the
-    # focal length (1229 here), so they are compared on the same z rather than through the two solves
+    # focal length (1229 at 1024^2), so they are compared on the same z rather than through the two solves
     zx, zy = coracle.gradient(st, z)
     N_ref, _ = oracle.normal_init(z, zx, zy, o["xx"], o["yy"], o["fx"], o["fy"])
-    print("1024^2 pass: depth RMSE", rmse(z, z_ref), "albedo max", np.abs(rho - rho_ref).max(), "energy", en[0], e_ref, "albedo CG", iters["albedo"][:3], alb_it)
+    print(f"{sc.h}x{sc.w}, {n_img} images, one pass: depth RMSE", rmse(z, z_ref), "albedo max", np.abs(rho - rho_ref).max(), "energy", en[0], e_ref,
+          "albedo CG", iters["albedo"][:n_ch], alb_it)
     assert iters["depth"] == it_ref == 101
-    assert all(abs(a - b) <= 2 for a, b in zip(iters["albedo"][:3], alb_it))
+    assert all(abs(a - b) <= 2 for a, b in zip(iters["albedo"][:n_ch], alb_it))
     assert rmse(z, z_ref) < 1e-4
     assert np.abs(rho - rho_ref).max() < 1e-4
     assert abs(en[0] - e_ref) <= 1e-2 * abs(e_ref)            # first pass: see DESIGN.md section 6
     # lighting through the shading it predicts (the first pass's 4 x 4 systems have a flat direction)
     A = (rho_ref[:, None, :] * o["N"][None, :, :]).astype(np.float64)                 # [c][4][P]
-    for c in range(3):
+    for c in range(n_ch):
         d = (s[:, c, :] - s_ref[:, c, :]).astype(np.float64) @ A[c]
         r = s_ref[:, c, :].astype(np.float64) @ A[c]
         assert np.linalg.norm(d) / np.linalg.norm(r) < 1e-4
     assert np.abs(Nrm - N_ref).max() < 2e-5
+
+
+def test_config3_whole_pass_against_the_oracle(pkg, oracle, coracle):
+    """1024 x 1024, sf 4, 20 images (BASELINE.json configs[2]), full mask"""
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"))
+
+
+def test_three_lighting_batches_at_mid_size(pkg, oracle, coracle):
+    """45 images (the lighting sweep takes them in batches of 20: three batches, the last one partial) on a 512 x 384 ellipse,
+    sf 2: the image loops of every sweep at a size where a pixel range spans several blocks"""
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(512, 384, 2, 45, seed=1240, mask_kind="ellipse"))
 
 
 def test_largest_grid_streaming_kernels_against_the_oracle(pkg, oracle, coracle):
