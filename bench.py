@@ -127,14 +127,14 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
                                    "kernels_per_step": 2 if b["update_bytes"] > 0 else 1}
         # events around the whole 101-step loop give the time per step; an event after EVERY launch (apply_us, update_us) adds
         # ~3 us to each kernel, so it is used only to split the step between the kernels
-        share = b["apply_us"] / (b["apply_us"] + b["update_us"]) if b["update_us"] > 0 else 1.0
+        share = b["apply_us"] / (b["apply_us"] + b["update_us"]) if b["update_bytes"] > 0 else 1.0      # one launch per step: no update kernel
         apply_us = us_iter * share
         ach = b["apply_bytes"] / (1e3 * apply_us)
         out["roofline"] = {"bound": "hbm", "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial dot products, deferred x / r updates)",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": (tj.get(key) or {}).get("apply"), "avg_launch_us": apply_us,
                            "algorithmic_bytes_per_launch": b["apply_bytes"]}
-        if b["update_us"] > 0:
+        if b["update_bytes"] > 0:
             out["roofline"]["update_kernel_us"] = us_iter - apply_us
             out["roofline"]["update_kernel_GBs"] = b["update_bytes"] / (1e3 * (us_iter - apply_us))
     return out

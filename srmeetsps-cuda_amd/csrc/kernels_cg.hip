@@ -423,7 +423,7 @@ static ApplyArgs base_args(srps_ctx* ctx) {
 // Default (coop_launch = 1): the cooperative launch; option "exclusive_device" = 1 (coop_launch = 0) selects the plain launch
 // (same residency) for a device that nothing else uses.  Neither launch can see other processes, CU masks or a hardware that
 // admits one block fewer than the API reports -- which is why every wait inside the kernels is bounded (device_utils.h
-// SpinGuard): such a launch ends with an abort flag within the spin budget and the host repeats the phase with the streaming
+// SpinState): such a launch ends with an abort flag within the spin budget and the host repeats the phase with the streaming
 // kernels.  SRPS_ERR_UNSUPPORTED: does not fit, the caller streams instead.
 int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, void** args, size_t lds_bytes) {
     ctx->persistent_inflight = 1;

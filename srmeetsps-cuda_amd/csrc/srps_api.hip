@@ -280,7 +280,7 @@ static int report_fetch(srps_ctx* ctx) {
 }
 
 // After the report record has been fetched and the stream waited for: did a persistent launch give up a wait
-// (device_utils.h SpinGuard)?  Returns the ABORT_* bits, switches the kernels concerned off for this context (the phases
+// (device_utils.h SpinState)?  Returns the ABORT_* bits, switches the kernels concerned off for this context (the phases
 // fall back to the streaming kernels), clears the device flags and leaves the reason in srps_last_error().
 static int persistent_aborts(srps_ctx* ctx, int* flags_out) {
     *flags_out = 0;
@@ -379,7 +379,6 @@ int srps_destroy(srps_ctx* ctx) {
     if (ctx->ws_ssum.p) (void)hipFree(ctx->ws_ssum.p);
     if (ctx->ws_albedo.p) (void)hipFree(ctx->ws_albedo.p);
     if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
-    if (ctx->ws_stage2.p) (void)hipFree(ctx->ws_stage2.p);
     if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
     if (ctx->ev_created)
         for (int i = 0; i < SRPS_N_PHASES; ++i) { (void)hipEventDestroy(ctx->ev_begin[i]); (void)hipEventDestroy(ctx->ev_end[i]); }

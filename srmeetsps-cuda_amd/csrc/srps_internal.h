@@ -32,7 +32,7 @@ struct CgScalars {
     int iters;       // steps executed    (dc.cu:254)
     int active;      // 1 while r1 > tol^2
     float alpha;     // step length of the last update kernel; x += alpha p is applied by the NEXT operator launch
-    // status words of the persistent kernels (device_utils.h SpinGuard): a wait that outlived the spin budget
+    // status words of the persistent kernels (device_utils.h SpinState): a wait that outlived the spin budget
     int abort_flags;    // bit 0: depth CG (k_cg_resident), bit 1: albedo CG (k_dcg_persistent*); 0 = every wait completed
     int abort_arrived;  // blocks whose granule had arrived at the first wait that gave up
     int abort_gen;      // generation (wait number) of that wait: 1 = not all blocks became resident
@@ -110,7 +110,7 @@ struct srps_ctx {
     float lambda = 1.0f;             // dc.cu:644
     srps::Grid grid;
     // grow-only workspaces for the per-pixel phases
-    srps::DevBuf ws_light, ws_albedo, ws_stage, ws_stage2, ws_misc;
+    srps::DevBuf ws_light, ws_albedo, ws_stage, ws_misc;
     int pin_uploads = 1;             // srps_setup pins the caller's image array in place (hipHostRegister) while it uploads it
     float* h_pinned = nullptr;       // 256 floats of pinned host memory for scalar read-back
     // The scalars the host reads back after a pass live in ONE device record with the layout of h_pinned -- [0..3] energy terms,
@@ -146,7 +146,7 @@ struct srps_ctx {
                                      // "exclusive_device"), 2 = plain while this is the only live context of the process on its device.
                                      // Whatever the launch, every wait inside the kernels is bounded (spin_budget_ms).
     int spin_budget_ms = 200;        // a persistent launch whose waits are not all served within this time aborts (device_utils.h
-                                     // SpinGuard); the host then repeats the phase with the streaming kernels
+                                     // SpinState); the host then repeats the phase with the streaming kernels
     int persistent_fallbacks = 0;    // aborted persistent launches so far (option "persistent_fallbacks", read-only)
     int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at
     int cg_one_sync = 1;             // resident CG: r.r from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per step)

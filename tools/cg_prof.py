@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("srmeetsps-cuda_amd")
 size = sys.argv[1]; hh, ww = (int(v) for v in size.split("x")) if "x" in size else (int(size), int(size))
 sf = int(sys.argv[2]); rec = int(sys.argv[3]); strip = int(sys.argv[4])
-sc = pkg.synth.make_scene(hh, ww, sf, 2, seed=1237, mask_kind="full")
+sc = pkg.synth.make_scene(hh, ww, sf, 2, seed=int(os.environ.get("SRPS_SEED", "1237")), mask_kind="full")
 ctx = pkg.Context(device_id=0)
 ctx.set_option("tensor_recompute", rec); ctx.set_option("march_strip", strip)
 if len(sys.argv) > 6: ctx.set_option("cg_resident", int(sys.argv[6]))
