@@ -80,12 +80,16 @@ int srps_synchronize(srps_ctx* ctx);
  * "cg_fused_step" (0|1: streaming depth CG with the whole step in one launch instead of operator + update kernel),
  * "exclusive_device" (0|1: the caller states that nothing else uses the device: plain instead of cooperative launches of the
  *  persistent kernels), "spin_budget_ms" (a persistent launch whose grid-wide waits are not served within this time aborts and the
- *  phase is repeated by the streaming kernels; default 200), "phase_timing", "roctx" (see srps_get_timings) */
+ *  phase is repeated by the streaming kernels; default 200), "phase_timing", "roctx" (see srps_get_timings),
+ * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader
+ *  produces, Utilities.cpp:343 -- the context also keeps the images as bytes and the two image sweeps of a pass read those:
+ *  the same floats, the same results bit for bit, a quarter of the traffic; other images are read as floats) */
 int srps_set_option(srps_ctx* ctx, const char* name, int value);
 /* reads an option back; also "cg_resident_active" (1 when the bound grid fits one tile per CU and the depth CG
  * therefore runs as the persistent on-chip kernel), "num_cus", "persistent_fallbacks" (persistent launches that gave up a wait
  * so far), "cg_resident_rect_tiles_256" / "_512" (tiles of the bound grid that qualify for the body without structure bits),
- * "cg_resident_rect_active" (1 when all of them do and the next depth CG therefore runs the kernel without structure bits) */
+ * "cg_resident_rect_active" (1 when all of them do and the next depth CG therefore runs the kernel without structure bits),
+ * "image_store_bytes_active" (1 when the context's images are held as bytes and the sweeps read them) */
 int srps_get_option(srps_ctx* ctx, const char* name, int* value);
 
 /* ---- generic sparse operators (device pointers) -------------------------------------------*/
@@ -223,8 +227,11 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer);
  * of n floats (must equal the array length). */
 int srps_get(srps_ctx* ctx, const char* name, float* host, size_t n);
 int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n);
+/* The length (in floats) of a state array, without any side effect on what the context caches. */
+int srps_array_size(srps_ctx* ctx, const char* name, size_t* n_floats);
 /* The device array itself. The call drops the partial sums cached between phases ("fuse_energy_lighting"); a caller
- * that keeps the pointer and writes through it later must call this again (or srps_set) before the next phase. */
+ * that keeps the pointer and writes through it later must call this again (or srps_set) before the next phase.  Asking for
+ * "I" also ends the use of the 8-bit image store (option "image_store") until the images are set again. */
 int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats);
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters /*[8]*/, int* lighting_iters_max);
 

@@ -121,6 +121,7 @@ def load():
         "srps_get": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_set": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_get_device_ptr": (i, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "srps_array_size": (i, [vp, C.c_char_p, C.POINTER(C.c_size_t)]),
         "srps_last_cg_iterations": (i, [vp, ip, ip, ip]),
         "srps_bench_cg": (i, [vp, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "srps_cg_bytes": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

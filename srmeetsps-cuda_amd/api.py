@@ -267,11 +267,17 @@ class Context:
         return [buf[i] for i in range(min(n.value, 64))]
 
     def get(self, name: str) -> np.ndarray:
-        p = C.c_void_p(); n = C.c_size_t(0)
-        check(self.lib.srps_get_device_ptr(self.h, name.encode(), C.byref(p), C.byref(n)))
+        n = C.c_size_t(0)
+        check(self.lib.srps_array_size(self.h, name.encode(), C.byref(n)))
         out = np.empty(n.value, dtype=f32)
         check(self.lib.srps_get(self.h, name.encode(), _fptr(out), n.value))
         return out
+
+    def device_ptr(self, name: str) -> tuple[int, int]:
+        """(device address, length in floats) of a state array; the caller may write through it (srps.h: srps_get_device_ptr)"""
+        p = C.c_void_p(); n = C.c_size_t(0)
+        check(self.lib.srps_get_device_ptr(self.h, name.encode(), C.byref(p), C.byref(n)))
+        return int(p.value or 0), int(n.value)
 
     def set(self, name: str, value):
         a = _host(value).reshape(-1)

@@ -535,6 +535,34 @@ __device__ __forceinline__ Vec<2> ldv<2>(const float* __restrict__ p) {
     r.v[0] = t.x; r.v[1] = t.y;
     return r;
 }
+// Four image samples kept as bytes (the 8-bit image store, srps_api.hip: image_store_prepare): the float the reference's
+// loader forms from a byte is k / 255.f (Utilities.cpp:343).  The division is replaced by k R_hi + k R_lo with R_hi + R_lo =
+// 1/255 to 48 bits, the second product rounded, the sum formed by one fused multiply-add: the correctly rounded quotient for
+// each of the 256 values (tests/test_gpu_image_store.py: exact rational arithmetic on the CPU, bit comparison on the GPU).
+__device__ __forceinline__ float unit_from_byte(float k) {
+    constexpr float R_HI = 1.f / 255.f;
+    constexpr float R_LO = (float)(1.0 / 255.0 - (double)R_HI);
+    return __builtin_fmaf(k, R_HI, k * R_LO);
+}
+__device__ __forceinline__ Vec<4> ld_img8(const unsigned char* __restrict__ p) {
+    const unsigned w = *reinterpret_cast<const unsigned*>(p);
+    Vec<4> r;
+    r.v[0] = unit_from_byte((float)(w & 0xffu));            // v_cvt_f32_ubyte0 .. 3
+    r.v[1] = unit_from_byte((float)((w >> 8) & 0xffu));
+    r.v[2] = unit_from_byte((float)((w >> 16) & 0xffu));
+    r.v[3] = unit_from_byte((float)(w >> 24));
+    return r;
+}
+// the image samples of one (image, channel) row at pixel q: floats, or bytes when the context holds the 8-bit store
+template <int V, bool U8>
+__device__ __forceinline__ Vec<V> ld_img(const float* __restrict__ I, const unsigned char* __restrict__ I8, size_t row, int P, int q) {
+    if constexpr (U8) {
+        static_assert(V == 4, "the 8-bit image store is read four pixels at a time");
+        return ld_img8(I8 + row * (size_t)P + q);
+    } else {
+        return ldv<V>(I + row * (size_t)P + q);
+    }
+}
 template <int V>
 __device__ __forceinline__ void stv(float* __restrict__ p, const Vec<V>& a);
 template <>

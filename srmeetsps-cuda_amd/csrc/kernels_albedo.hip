@@ -17,9 +17,9 @@ namespace srps {
 //   q = sum_{c,i} g tau_i (I_i - rho s_i3), tau_i = (fx s_i0 - xx s_i2, fy s_i1 - yy s_i2, -s_i2)      (dc.cu:588-610)
 //     = sum_c g [ (SA - xx SB, SA' - yy SB, -SB) - rho (CA - xx CB, CA' - yy CB, -CB) ],  C. = the same sums of s_i3,
 // so that the depth assembly after the albedo step needs no second pass over I (k_depth_from_sums).
-template <int V, bool SUMS>
+template <int V, bool SUMS, bool U8 = false>
 __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__ s, const float* __restrict__ N,
-                                                       const float* __restrict__ I, int P, int n_local, int C,
+                                                       const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_local, int C,
                                                        int s_img_offset, float* __restrict__ num, float* __restrict__ den,
                                                        float fx, float fy, float* __restrict__ ssum) {
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
             const float* sv = s + ((size_t)(s_img_offset + i) * C + c) * 4;      // uniform -> scalar loads
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
             const float fs0 = fx * s0, fs1 = fy * s1;
-            const Vec<V> iv = ldv<V>(I + ((size_t)i * C + c) * P + q);
+            const Vec<V> iv = ld_img<V, U8>(I, I8, (size_t)i * C + c, P, q);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float sh = nk[0].v[e] * s0 + nk[1].v[e] * s1 + nk[2].v[e] * s2 + nk[3].v[e] * s3;
@@ -65,9 +65,11 @@ int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float
     float* num = d_numden;
     float* den = d_numden + (size_t)C * P;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_numden | (uintptr_t)d_ssum) % 16 == 0);
-#define SRPS_NUMDEN(VV, SS, NB) hipLaunchKernelGGL((k_albedo_numden<VV, SS>), dim3(NB), dim3(256), 0, ctx->stream, d_s, d_N, d_I, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum)
-    if (vec) { if (d_ssum) SRPS_NUMDEN(4, true, cdiv(P, 1024)); else SRPS_NUMDEN(4, false, cdiv(P, 1024)); }
-    else { if (d_ssum) SRPS_NUMDEN(1, true, cdiv(P, 256)); else SRPS_NUMDEN(1, false, cdiv(P, 256)); }
+    const unsigned char* d_I8 = vec ? image_store_bytes(ctx, d_I) : nullptr;      // the context's images as bytes, when they are held that way
+#define SRPS_NUMDEN(VV, SS, UU, NB) hipLaunchKernelGGL((k_albedo_numden<VV, SS, UU>), dim3(NB), dim3(256), 0, ctx->stream, d_s, d_N, d_I, d_I8, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum)
+    if (vec && d_I8) { if (d_ssum) SRPS_NUMDEN(4, true, true, cdiv(P, 1024)); else SRPS_NUMDEN(4, false, true, cdiv(P, 1024)); }
+    else if (vec) { if (d_ssum) SRPS_NUMDEN(4, true, false, cdiv(P, 1024)); else SRPS_NUMDEN(4, false, false, cdiv(P, 1024)); }
+    else { if (d_ssum) SRPS_NUMDEN(1, true, false, cdiv(P, 256)); else SRPS_NUMDEN(1, false, false, cdiv(P, 256)); }
 #undef SRPS_NUMDEN
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;

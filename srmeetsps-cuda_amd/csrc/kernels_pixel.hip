@@ -35,6 +35,35 @@ int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask,
     return SRPS_OK;
 }
 
+// The 8-bit image store.  d_out == null: only look whether every sample is k / 255.f for a byte k (bit for bit -- a negative
+// zero is not); otherwise also write the bytes.  A block that sees the flag raised stops: float-valued images cost next to nothing.
+__global__ __launch_bounds__(256) void k_pack_bytes(const float* __restrict__ I, size_t n4, unsigned char* __restrict__ out, int* __restrict__ inexact) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) {
+        if (__hip_atomic_load(inexact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        const float4 v = reinterpret_cast<const float4*>(I)[t];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        unsigned w = 0;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float k = rintf(e[i] * 255.f);
+            const unsigned kb = (k >= 0.f && k <= 255.f) ? (unsigned)k : 0u;
+            const bool ok = __float_as_uint((float)kb / 255.f) == __float_as_uint(e[i]);      // the loader's expression, from the byte
+            bad |= !ok;
+            w |= kb << (8 * i);
+        }
+        if (bad) { atomicOr(inexact, 1); return; }
+        if (out) reinterpret_cast<unsigned*>(out)[t] = w;
+    }
+}
+int launch_pack_bytes(hipStream_t st, const float* d_I, size_t n, unsigned char* d_out, int* d_inexact) {
+    const size_t n4 = n / 4;
+    const int nb = (int)std::min<size_t>((n4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_pack_bytes, dim3(std::max(nb, 1)), dim3(256), 0, st, d_I, n4, d_out, d_inexact);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
 // xx = j - cx, yy = i - cy for the masked pixels (meshgrid_create + copy_if, dc.cu:151-158, SRPS.cu:253-258)
 __global__ void k_meshgrid_compact(const int* __restrict__ imask, int P, int h, float cx, float cy,
                                    float* __restrict__ xx, float* __restrict__ yy) {

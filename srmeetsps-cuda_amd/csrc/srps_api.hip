@@ -92,6 +92,7 @@ static void grid_release(Grid& G) {
 }
 
 static void state_release(srps_ctx* c) {
+    dfree(c->I8); c->i8_state = 0;
     dfree(c->s); dfree(c->rho); dfree(c->z); dfree(c->Nrm); dfree(c->dz); dfree(c->zx); dfree(c->zy);
     dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); dfree(c->q_ex); c->q_in_exchange = false; c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
@@ -433,6 +434,10 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->cg_fused_step = value ? 1 : 0;
     } else if (!strcmp(name, "pin_uploads")) {
         ctx->pin_uploads = value ? 1 : 0;
+    } else if (!strcmp(name, "image_store")) {
+        ctx->image_store = value ? 1 : 0;
+        if (ctx->i8_state == 2 && value) ctx->i8_state = 0;      // look (again) at the next sweep
+        ctx->light_cache_valid = false;
     } else if (!strcmp(name, "phase_timing")) {
         ctx->phase_timing = value ? 1 : 0;
         ctx->ev_mask = 0;
@@ -504,6 +509,8 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_fused_step")) *value = ctx->cg_fused_step;
     else if (!strcmp(name, "phase_timing")) *value = ctx->phase_timing;
     else if (!strcmp(name, "pin_uploads")) *value = ctx->pin_uploads;
+    else if (!strcmp(name, "image_store")) *value = ctx->image_store;
+    else if (!strcmp(name, "image_store_bytes_active")) *value = (ctx->image_store && ctx->have_state && ctx->i8_state == 1) ? 1 : 0;
     else if (!strcmp(name, "roctx")) *value = ctx->roctx;
     else if (!strcmp(name, "cg_one_sync")) *value = ctx->cg_one_sync;
     else if (!strcmp(name, "cg_resident_rect")) *value = ctx->cg_resident_rect;
@@ -664,6 +671,38 @@ int srps_depth_operator_apply(srps_ctx* ctx, const float* d_x, int npix, float* 
     return grid_gather(ctx, G.d_w, d_y);
 }
 
+// ---- the 8-bit image store --------------------------------------------------------------------
+// Looks at the context's images once after they changed (one pass over them and one word read back): when every sample is a
+// byte over 255 -- the reference's image-folder input, Utilities.cpp:343 -- they are also kept as bytes, and the albedo sweep and
+// the fused energy + lighting sweep of every pass read those.  Same floats, same sums, a quarter of the bytes.
+static int image_store_prepare(srps_ctx* ctx) {
+    if (ctx->i8_state != 0) return SRPS_OK;
+    ctx->i8_state = 2;
+    const size_t n = (size_t)ctx->N_local * ctx->C * ctx->grid.P;
+    if (!ctx->image_store || n == 0 || ctx->grid.P % 4 != 0) return SRPS_OK;
+    int* flag = (int*)ctx->d_report + 200;            // a word of the report record behind everything a pass reads back
+    int inexact = 0;
+    SRPS_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    SRPS_TRY(launch_pack_bytes(ctx->stream, ctx->I, n, nullptr, flag));
+    SRPS_HIP(hipMemcpyAsync(&inexact, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    if (inexact) return SRPS_OK;
+    if (!ctx->I8) SRPS_TRY(dalloc(&ctx->I8, n));
+    SRPS_TRY(launch_pack_bytes(ctx->stream, ctx->I, n, ctx->I8, flag));
+    ctx->i8_state = 1;
+    return SRPS_OK;
+}
+extern "C++" {
+namespace srps {
+// the byte copy of d_I when d_I is the context's image array and the copy is current, else null (the caller reads the floats)
+const unsigned char* image_store_bytes(srps_ctx* ctx, const float* d_I) {
+    if (!ctx->image_store || !ctx->have_state || d_I != ctx->I) return nullptr;
+    if (ctx->i8_state == 0 && image_store_prepare(ctx) != SRPS_OK) { (void)hipGetLastError(); ctx->i8_state = 2; }
+    return ctx->i8_state == 1 ? ctx->I8 : nullptr;
+}
+}  // namespace srps
+}  // extern "C++"
+
 // ---- pipeline -------------------------------------------------------------------------------
 int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
     CTX_CHECK(ctx);
@@ -766,6 +805,9 @@ int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
         // the staging area is a set-up artefact (1 GB at the metric's size): give it back
         if (ctx->ws_stage.bytes > ((size_t)64 << 20)) { (void)hipFree(ctx->ws_stage.p); ctx->ws_stage.p = nullptr; ctx->ws_stage.bytes = 0; }
     }
+    ctx->i8_state = 0;
+    SRPS_TRY(image_store_prepare(ctx));
+    if (tm) { fprintf(stderr, "srps_setup: image store (%s) %.1f ms\n", ctx->i8_state == 1 ? "bytes" : "floats", ms_since(t0)); t0 = now(); }
     SRPS_TRY(srps_normals(ctx));                                                            // SRPS.cu:264-270
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     if (tm) fprintf(stderr, "srps_setup: total %.1f ms\n", ms_since(t_all));
@@ -777,6 +819,7 @@ int srps_upload_image(srps_ctx* ctx, int li, const float* host_image) {
     SRPS_REQUIRE(host_image && li >= 0 && li < ctx->N_local, SRPS_ERR_INVALID, "upload_image: bad arguments");
     ctx->light_cache_valid = false;
     ctx->ssum_valid = false;
+    ctx->i8_state = 0;                   // looked at again at the next sweep
     Grid& G = ctx->grid;
     const size_t hw = (size_t)G.h * G.w, n = hw * ctx->C;
     SRPS_TRY(ensure(ctx->ws_stage, n * sizeof(float)));
@@ -1009,9 +1052,16 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     ctx->light_cache_valid = false;
     ctx->ssum_valid = false;
     ctx->grad_current = false;
+    if (p == ctx->I) ctx->i8_state = 0;
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
     return SRPS_OK;
+}
+int srps_array_size(srps_ctx* ctx, const char* name, size_t* n_floats) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(name && n_floats, SRPS_ERR_INVALID, "array_size: null argument");
+    float* p;
+    return lookup(ctx, name, &p, n_floats);
 }
 int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -1019,6 +1069,10 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
     float* p; size_t len;
     SRPS_TRY(lookup(ctx, name, &p, &len));
     *d_ptr = p; *n_floats = len;
+    if (p == ctx->I && ctx->i8_state != 2) {
+        // the caller may write the images through the pointer at any later time: the byte copy cannot follow that
+        ctx->i8_state = 2;
+    }
     ctx->light_cache_valid = false;      // the caller may write through the pointer
     ctx->ssum_valid = false;
     ctx->grad_current = false;

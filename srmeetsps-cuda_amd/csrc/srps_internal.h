@@ -161,6 +161,11 @@ struct srps_ctx {
     int albedo_persistent = 1;       // albedo CG in registers (one cooperative launch) when the mask fits
     int num_cus = 256;
     bool light_cache_valid = false;
+    // The 8-bit image store: when every sample of I is k / 255.f for a byte k -- what the reference's image loader produces
+    // (Utilities.cpp:343) -- the two sweeps of a pass read the images as bytes (a quarter of the traffic) and form the same floats.
+    int image_store = 1;                  // option "image_store": 0 floats only, 1 bytes whenever the samples allow it
+    unsigned char* I8 = nullptr;          // [N_local][C][P] bytes
+    int i8_state = 0;                     // 0: not looked at since I last changed, 1: I8 holds I, 2: I is not representable
     // image sums of the depth right-hand side left by the albedo sweep of this pass (assemble_from_sums)
     int assemble_from_sums = 1;
     srps::DevBuf ws_ssum;                 // [C][3][P]
@@ -213,6 +218,8 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- kernel launchers (kernels_pixel.hip) ------------------------------------------------
 int launch_fill(hipStream_t st, float* d, size_t n, float v);
+int launch_pack_bytes(hipStream_t st, const float* d_I, size_t n, unsigned char* d_out, int* d_inexact);
+const unsigned char* image_store_bytes(srps_ctx* ctx, const float* d_I);
 int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask, int P, int C, size_t hw, float* d_out);
 int launch_meshgrid_compact(hipStream_t st, const int* d_imask, int P, int h, float cx, float cy, float* xx, float* yy);
 int launch_meshgrid_full(hipStream_t st, int w, int h, float K02, float K12, float* xx, float* yy);
