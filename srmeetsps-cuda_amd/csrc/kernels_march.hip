@@ -485,7 +485,12 @@ void march_plan(Grid& G, int tj) {
         long best = -1;
         for (int cand = 4; cand <= 128; cand += 4) {
             const long waves = (long)G.n_seg * cdiv(G.Wg, cand);
-            const long cost = ((waves + simds - 1) / simds) * (cand + 2) * 64 + cand;      // ties: narrower strips
+            long cost = ((waves + simds - 1) / simds) * (cand + 2) * 64 + cand;      // ties: narrower strips
+            // measured at 4096^2, sf 2 (same box, per CG step): 72 columns (969 waves) 161 us, 76 columns (918 waves) 152 us,
+            // 80 / 84: 181 / 176 on a slower box -- widths that are a multiple of 8 columns lose 3 - 6 % against their neighbours;
+            // 36 columns (1938 waves: two resident waves per SIMD, 38 steps each) 182 us where 76 columns took 173
+            if (cand % 8 == 0) cost += cost / 16;
+            if (waves > simds) cost += cost / 16;
             if (best < 0 || cost < best) { best = cost; tj = cand; }
         }
     }

@@ -1,0 +1,171 @@
+// stream_depth_bench.hip -- how much of the HBM rate a register-marching stream kernel at TWO waves per SIMD (the occupancy of
+// k_apply_march<., 3, 3>, 247 VGPRs) reaches as a function of how far ahead its loads run:
+//   reg1 / reg2 / reg3: loads of step c+1 / c+2 / c+3 issued into register sets before the arithmetic of step c
+//   lds2:               loads go straight to an LDS ring (global_load_lds_dwordx4, no registers while in flight), two steps
+//                       ahead, and are read back one step ahead
+// Each wave marches over columns; per step and lane: NR 16-byte reads, NW 16-byte writes (the streaming CG step: 8 and 4).
+//   hipcc -O3 --offload-arch=gfx950 tools/stream_depth_bench.hip -o tools/stream_depth_bench.bin
+//   tools/stream_depth_bench.bin [rows=4096] [cols=4096] [reps=20]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int NR = 8, NW = 4;
+struct Args {
+    const float* in[NR];
+    float* out[NW];
+    int Hs, ncol, cols_per_wave, n_items, n_seg;
+};
+struct F4 { float e[4]; };
+__device__ __forceinline__ F4 ld4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return F4{{t.x, t.y, t.z, t.w}}; }
+__device__ __forceinline__ void st4(float* p, const F4& a) { *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]); }
+
+struct Raw { F4 v[NR]; };
+__device__ __forceinline__ void consume(const Args& a, const Raw& r, size_t off, float& chk) {
+    F4 o[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[w].e[e] = fmaf(r.v[w].e[e], 0.5f, r.v[w + 4].e[e]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { st4(a.out[w] + off, o[w]); chk += o[w].e[0]; }
+}
+
+// DEPTH register sets
+template <int DEPTH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reg(Args a, float* chk_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (item >= a.n_items) return;
+    const int strip = item / a.n_seg, seg = item - strip * a.n_seg;
+    const int row = seg * 256 + lane * 4;
+    const int c0 = strip * a.cols_per_wave;
+    float chk = 0.f;
+    Raw buf[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int p = 0; p < NR; ++p) buf[d].v[p] = ld4(a.in[p] + (size_t)(c0 + d) * a.Hs + row);
+    for (int c = 0; c < a.cols_per_wave; c += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const Raw cur = buf[d];
+            const int cn = min(c + d + DEPTH, a.cols_per_wave - 1);
+#pragma unroll
+            for (int p = 0; p < NR; ++p) buf[d].v[p] = ld4(a.in[p] + (size_t)(c0 + cn) * a.Hs + row);
+            consume(a, cur, (size_t)(c0 + c + d) * a.Hs + row, chk);
+        }
+    }
+    if (chk == 1.2345f) chk_out[0] = chk;
+}
+
+// LDS ring: SLOTS steps in LDS, one more in registers
+template <int SLOTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lds(Args a, float* chk_out) {
+    extern __shared__ float4 ring[];                  // [wave][slot][plane][64 lanes]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (item >= a.n_items) return;
+    const int strip = item / a.n_seg, seg = item - strip * a.n_seg;
+    const int row = seg * 256 + lane * 4;
+    const int c0 = strip * a.cols_per_wave;
+    float chk = 0.f;
+    float4* mine = ring + (size_t)wave * SLOTS * NR * 64;
+    const unsigned lds_base = (unsigned)(uintptr_t)mine;              // byte address within LDS (wave-uniform)
+    auto issue = [&](int slot, int col) {
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const float* g = a.in[p] + (size_t)(c0 + col) * a.Hs + row;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((slot * NR + p) * 64 * 16));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
+    };
+    auto fetch = [&](Raw& r, int slot) {
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const float4 t = mine[(slot * NR + p) * 64 + lane];
+            r.v[p] = F4{{t.x, t.y, t.z, t.w}};
+        }
+    };
+    // prologue: steps 0 .. SLOTS-1 into the ring, step 0 into registers
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) issue(s, min(s, a.cols_per_wave - 1));
+    Raw cur;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SLOTS - 1) * NR) : "memory");
+    fetch(cur, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int c = 0; c < a.cols_per_wave; c += SLOTS) {
+#pragma unroll
+        for (int d = 0; d < SLOTS; ++d) {
+            // slot d held step c+d, now in registers: refill it with step c+d+SLOTS
+            issue(d, min(c + d + SLOTS, a.cols_per_wave - 1));
+            consume(a, cur, (size_t)(c0 + c + d) * a.Hs + row, chk);
+            // step c+d+1 must have landed: younger than its batch are the SLOTS-1 later batches and the stores in between
+            // (counted in issue order; the very first step has no stores before it, so the count that is always safe is used:
+            // this step's stores and the SLOTS-1 younger batches)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SLOTS - 1) * NR + NW) : "memory");
+            fetch(cur, (d + 1) % SLOTS);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    if (chk == 1.2345f) chk_out[0] = chk;
+}
+
+int main(int argc, char** argv) {
+    const int rows = argc > 1 ? atoi(argv[1]) : 4096, cols = argc > 2 ? atoi(argv[2]) : 4096, reps = argc > 3 ? atoi(argv[3]) : 20;
+    const int Hs = rows + 32;
+    const size_t pl = (size_t)Hs * (cols + 8);
+    Args a{};
+    std::vector<float*> bufs;
+    for (int p = 0; p < NR; ++p) { float* d; CHECK(hipMalloc(&d, pl * 4)); CHECK(hipMemset(d, 0, pl * 4)); a.in[p] = d; bufs.push_back(d); }
+    for (int w = 0; w < NW; ++w) { float* d; CHECK(hipMalloc(&d, pl * 4)); CHECK(hipMemset(d, 0, pl * 4)); a.out[w] = d; bufs.push_back(d); }
+    std::vector<float> h(pl);
+    for (size_t i = 0; i < pl; ++i) h[i] = (float)((i * 2654435761u >> 8) & 1023) * (1.f / 1024.f);
+    for (int p = 0; p < NR; ++p) CHECK(hipMemcpy((void*)a.in[p], h.data(), pl * 4, hipMemcpyHostToDevice));
+    float* chk; CHECK(hipMalloc(&chk, 4));
+    a.Hs = Hs; a.ncol = cols;
+    a.n_seg = rows / 256;
+    const int waves_target = 256 * 8;                      // 2 waves per SIMD on every CU: one round
+    int strips = waves_target / a.n_seg; if (strips < 1) strips = 1;
+    while (cols % strips) --strips;
+    a.cols_per_wave = cols / strips;
+    a.n_items = strips * a.n_seg;
+    const int nb = (a.n_items + 3) / 4;
+    const double bytes = (double)rows * cols * 4.0 * (NR + NW);
+    printf("rows %d cols %d: %d waves, %d columns each, %.1f MB per pass\n", rows, cols, a.n_items, a.cols_per_wave, bytes * 1e-6);
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    std::vector<float> ref(pl), got(pl);
+    auto run = [&](const char* name, auto launch, bool is_ref) {
+        for (int w = 0; w < NW; ++w) CHECK(hipMemset(a.out[w], 0, pl * 4));
+        launch(); CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(got.data(), a.out[NW - 1], pl * 4, hipMemcpyDeviceToHost));
+        if (is_ref) ref = got;
+        size_t bad = 0;
+        for (size_t i = 0; i < pl; ++i) bad += got[i] != ref[i];
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) launch();
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        printf("{\"variant\": \"%s\", \"us\": %.1f, \"GBs\": %.0f, \"frac_of_8TBs\": %.3f, \"mismatches\": %zu}\n", name, us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0, bad);
+    };
+    if (a.cols_per_wave % 6 != 0) printf("note: columns per wave %d not a multiple of 6: depth-3 variants overrun into the next strip (timing only)\n", a.cols_per_wave);
+    // 80 KB of (mostly unused) LDS per block: two blocks = 8 waves per CU = two waves per SIMD, whatever the register count
+    const int LDSB = 80 * 1024;
+    CHECK(hipFuncSetAttribute((const void*)k_reg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_reg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_reg<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    run("reg1", [&] { hipLaunchKernelGGL((k_reg<1>), dim3(nb), dim3(256), LDSB, 0, a, chk); }, true);
+    run("reg2", [&] { hipLaunchKernelGGL((k_reg<2>), dim3(nb), dim3(256), LDSB, 0, a, chk); }, false);
+    run("reg3", [&] { hipLaunchKernelGGL((k_reg<3>), dim3(nb), dim3(256), LDSB, 0, a, chk); }, false);
+    run("lds2", [&] { hipLaunchKernelGGL((k_lds<2>), dim3(nb), dim3(256), LDSB, 0, a, chk); }, false);
+    run("reg1_again", [&] { hipLaunchKernelGGL((k_reg<1>), dim3(nb), dim3(256), LDSB, 0, a, chk); }, false);
+    for (float* d : bufs) CHECK(hipFree(d));
+    return 0;
+}
