@@ -143,7 +143,9 @@ def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True):
     assert all(abs(a - b) <= 2 for a, b in zip(iters["albedo"][:n_ch], alb_it))
     assert rmse(z, z_ref) < 1e-4
     assert np.abs(rho - rho_ref).max() < 1e-4
-    assert abs(en[0] - e_ref) <= 1e-2 * abs(e_ref)            # first pass: see DESIGN.md section 6
+    # first pass.  Measured: 5e-5 at 1024 x 1024 x 20 images, 5.5e-4 at 512 x 384 x 45 images (2e-6 for the
+    # depth phase alone at 4096 x 4096)
+    assert abs(en[0] - e_ref) <= 2e-3 * abs(e_ref)
     # lighting through the shading it predicts (the first pass's 4 x 4 systems have a flat direction)
     A = (rho_ref[:, None, :] * o["N"][None, :, :]).astype(np.float64)                 # [c][4][P]
     for c in range(n_ch):
