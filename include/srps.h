@@ -209,7 +209,8 @@ int srps_normals(srps_ctx* ctx);                     /* SRPS.cu:310-315 */
  * calls the matching *_finish.  srps_exchange returns the device pointer and length of the
  * buffer the last *_partial filled. */
 int srps_lighting_local(srps_ctx* ctx);              /* s of the local images; other rows zeroed */
-int srps_albedo_partial(srps_ctx* ctx);              /* [2][C][P] num, den                        */
+int srps_albedo_partial(srps_ctx* ctx);              /* num [C][P] of the local images; den -- which does not involve the
+                                                      * images -- is formed completely on every rank and is not exchanged */
 int srps_albedo_finish(srps_ctx* ctx);
 int srps_depth_partial(srps_ctx* ctx);               /* q [3][P] (compact; one GPU: on the grid)  */
 int srps_depth_solve(srps_ctx* ctx);                 /* rhs, residual, 101 CG steps               */

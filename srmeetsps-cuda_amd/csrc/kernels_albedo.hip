@@ -17,11 +17,20 @@ namespace srps {
 //   q = sum_{c,i} g tau_i (I_i - rho s_i3), tau_i = (fx s_i0 - xx s_i2, fy s_i1 - yy s_i2, -s_i2)      (dc.cu:588-610)
 //     = sum_c g [ (SA - xx SB, SA' - yy SB, -SB) - rho (CA - xx CB, CA' - yy CB, -CB) ],  C. = the same sums of s_i3,
 // so that the depth assembly after the albedo step needs no second pass over I (k_depth_from_sums).
-template <int V, bool SUMS, bool U8 = false>
+// sh = N . s with every multiply-add spelled out: the three loops of the sweep below (and the ranks of a sharded run, which run
+// different ones of them for the same image) must produce the same bits
+__device__ __forceinline__ float shading(float n0, float n1, float n2, float n3, float s0, float s1, float s2, float s3) {
+    return __builtin_fmaf(n3, s3, __builtin_fmaf(n2, s2, __builtin_fmaf(n1, s1, n0 * s0)));
+}
+
+// SHARD (a context that holds images [s_img_offset, s_img_offset + n_local) of n_total): den = sum_i sh_i^2 does not involve the
+// images -- it is formed over ALL images here, in the single-GPU order (the same bits on every rank and as on one GPU), and only
+// num travels through the all-reduce (C P floats instead of 2 C P).
+template <int V, bool SUMS, bool U8 = false, bool SHARD = false>
 __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__ s, const float* __restrict__ N,
                                                        const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_local, int C,
                                                        int s_img_offset, float* __restrict__ num, float* __restrict__ den,
-                                                       float fx, float fy, float* __restrict__ ssum) {
+                                                       float fx, float fy, float* __restrict__ ssum, int n_total) {
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
     if (q >= P) return;
     Vec<V> nk[4];
@@ -31,6 +40,17 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
         Vec<V> nu, de, sa, sap, sb;
 #pragma unroll
         for (int e = 0; e < V; ++e) { nu.v[e] = 0.f; de.v[e] = 0.f; sa.v[e] = 0.f; sap.v[e] = 0.f; sb.v[e] = 0.f; }
+        if (SHARD) {                                                             // images before this rank's: den only
+            for (int i = 0; i < s_img_offset; ++i) {
+                const float* sv = s + ((size_t)i * C + c) * 4;
+                const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float sh = shading(nk[0].v[e], nk[1].v[e], nk[2].v[e], nk[3].v[e], s0, s1, s2, s3);
+                    de.v[e] = fmaf(sh, sh, de.v[e]);
+                }
+            }
+        }
 #pragma unroll 4
         for (int i = 0; i < n_local; ++i) {
             const float* sv = s + ((size_t)(s_img_offset + i) * C + c) * 4;      // uniform -> scalar loads
@@ -39,13 +59,24 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
             const Vec<V> iv = ld_img<V, U8>(I, I8, (size_t)i * C + c, P, q);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const float sh = nk[0].v[e] * s0 + nk[1].v[e] * s1 + nk[2].v[e] * s2 + nk[3].v[e] * s3;
+                const float sh = shading(nk[0].v[e], nk[1].v[e], nk[2].v[e], nk[3].v[e], s0, s1, s2, s3);
                 nu.v[e] = fmaf(sh, iv.v[e], nu.v[e]);
                 de.v[e] = fmaf(sh, sh, de.v[e]);
                 if (SUMS) {
                     sa.v[e] = fmaf(fs0, iv.v[e], sa.v[e]);
                     sap.v[e] = fmaf(fs1, iv.v[e], sap.v[e]);
                     sb.v[e] = fmaf(s2, iv.v[e], sb.v[e]);
+                }
+            }
+        }
+        if (SHARD) {                                                             // images after this rank's
+            for (int i = s_img_offset + n_local; i < n_total; ++i) {
+                const float* sv = s + ((size_t)i * C + c) * 4;
+                const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float sh = shading(nk[0].v[e], nk[1].v[e], nk[2].v[e], nk[3].v[e], s0, s1, s2, s3);
+                    de.v[e] = fmaf(sh, sh, de.v[e]);
                 }
             }
         }
@@ -59,17 +90,27 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
     }
 }
 
-// ssum != null: also the image sums of the depth right-hand side (fx, fy needed)
+// ssum != null: also the image sums of the depth right-hand side (fx, fy needed).  n_total > n_local: the context holds a shard
+// (see SHARD above): d_numden receives this rank's part of num and the complete den.
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
-                  int C, int s_img_offset, float* d_numden, float fx, float fy, float* d_ssum) {
+                  int C, int s_img_offset, float* d_numden, float fx, float fy, float* d_ssum, int n_total) {
     float* num = d_numden;
     float* den = d_numden + (size_t)C * P;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_numden | (uintptr_t)d_ssum) % 16 == 0);
     const unsigned char* d_I8 = vec ? image_store_bytes(ctx, d_I) : nullptr;      // the context's images as bytes, when they are held that way
-#define SRPS_NUMDEN(VV, SS, UU, NB) hipLaunchKernelGGL((k_albedo_numden<VV, SS, UU>), dim3(NB), dim3(256), 0, ctx->stream, d_s, d_N, d_I, d_I8, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum)
-    if (vec && d_I8) { if (d_ssum) SRPS_NUMDEN(4, true, true, cdiv(P, 1024)); else SRPS_NUMDEN(4, false, true, cdiv(P, 1024)); }
-    else if (vec) { if (d_ssum) SRPS_NUMDEN(4, true, false, cdiv(P, 1024)); else SRPS_NUMDEN(4, false, false, cdiv(P, 1024)); }
-    else { if (d_ssum) SRPS_NUMDEN(1, true, false, cdiv(P, 256)); else SRPS_NUMDEN(1, false, false, cdiv(P, 256)); }
+    const bool shard = n_total > n_local;
+#define SRPS_NUMDEN(VV, SS, UU, HH, NB) hipLaunchKernelGGL((k_albedo_numden<VV, SS, UU, HH>), dim3(NB), dim3(256), 0, ctx->stream, d_s, d_N, d_I, d_I8, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum, n_total)
+#define SRPS_NUMDEN_S(VV, UU, HH, NB) do { if (d_ssum) SRPS_NUMDEN(VV, true, UU, HH, NB); else SRPS_NUMDEN(VV, false, UU, HH, NB); } while (0)
+    if (shard) {
+        if (vec && d_I8) SRPS_NUMDEN_S(4, true, true, cdiv(P, 1024));
+        else if (vec) SRPS_NUMDEN_S(4, false, true, cdiv(P, 1024));
+        else SRPS_NUMDEN_S(1, false, true, cdiv(P, 256));
+    } else {
+        if (vec && d_I8) SRPS_NUMDEN_S(4, true, false, cdiv(P, 1024));
+        else if (vec) SRPS_NUMDEN_S(4, false, false, cdiv(P, 1024));
+        else SRPS_NUMDEN_S(1, false, false, cdiv(P, 256));
+    }
+#undef SRPS_NUMDEN_S
 #undef SRPS_NUMDEN
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;

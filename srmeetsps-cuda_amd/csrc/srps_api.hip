@@ -861,8 +861,9 @@ int srps_albedo_partial(srps_ctx* ctx) {
         SRPS_TRY(ensure(ctx->ws_ssum, (size_t)3 * ctx->C * ctx->grid.P * sizeof(float)));
         ssum = (float*)ctx->ws_ssum.p;
     }
+    // a shard leaves its part of num and the COMPLETE den (which does not involve the images): only num is exchanged
     SRPS_TRY(albedo_numden(ctx, ctx->s, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->albedo_ex,
-                           ctx->fx, ctx->fy, ssum));
+                           ctx->fx, ctx->fy, ssum, ctx->N_total));
     ctx->ssum_valid = ssum != nullptr;
     return SRPS_OK;
 }
@@ -976,7 +977,7 @@ int srps_exchange(srps_ctx* ctx, const char* which, void** d_ptr, size_t* n_floa
     SRPS_REQUIRE(which && d_ptr && n_floats, SRPS_ERR_INVALID, "exchange: null argument");
     Grid& G = ctx->grid;
     if (!strcmp(which, "s")) { *d_ptr = ctx->s; *n_floats = (size_t)ctx->N_total * ctx->C * 4; ctx->ssum_valid = false; }
-    else if (!strcmp(which, "albedo")) { *d_ptr = ctx->albedo_ex; *n_floats = 2 * (size_t)ctx->C * G.P; }
+    else if (!strcmp(which, "albedo")) { *d_ptr = ctx->albedo_ex; *n_floats = (size_t)ctx->C * G.P; }      // num [C][P]; den behind it is complete on every rank
     else if (!strcmp(which, "depth")) {
         if (ctx->q_ex) { *d_ptr = ctx->q_ex; *n_floats = 3 * (size_t)G.P; }       // compact: 3 P floats
         else { *d_ptr = G.d_q; *n_floats = 3 * G.plane; }                          // one GPU: nothing to exchange, the grid planes themselves

@@ -233,7 +233,7 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
                        const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
                        float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out);
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
-                  int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr);
+                  int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr, int n_total = 0);
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
 void albedo_iters_collect(srps_ctx* ctx);
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,

@@ -36,8 +36,13 @@ class OracleEngine:
     def albedo_partial(self):
         st = self.st
         num, den = self.O.albedo_numden(self.s[self.lo:self.hi], st.N, st.I)
-        self.numden = np.stack([num, den])
-        self.ex["albedo"] = torch.from_numpy(self.numden.reshape(-1))
+        if self.sharded:
+            # den = sum_i (N . s_ic)^2 does not involve the images: every rank forms it over ALL images from the all-reduced s
+            # (srps_albedo_partial does the same); only num is exchanged
+            sh = np.einsum("ick,kp->icp", self.s.astype(f32), st.N.astype(f32)).astype(f32)
+            den = (sh * sh).sum(axis=0, dtype=f32)
+        self.numden = np.ascontiguousarray(np.stack([num, den]), dtype=f32)
+        self.ex["albedo"] = torch.from_numpy(self.numden[0].reshape(-1))      # shares memory with numden[0]
 
     def albedo_finish(self):
         self.O.albedo_solve_numden(self.st.rho, self.numden[0], self.numden[1])

@@ -113,3 +113,41 @@ def test_bench_two_ranks_on_one_gpu():
     ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     np.testing.assert_allclose(two["energies"], ref["energies"], rtol=1e-4)       # same job, images sharded 3 + 3
     assert two["total_solve_outer_iterations"] == ref["total_solve_outer_iterations"]
+
+
+def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg):
+    """srps_albedo_partial on a context that holds a shard of the images: den = sum_i (N . s_i)^2 does not involve the images, so it
+    is formed over ALL images on every rank -- the same bits as on one GPU -- and only num (C P floats, not 2 C P) is exchanged;
+    the shards' num add up to the single-GPU num.  One process, three contexts."""
+    import torch
+    from importlib import import_module
+    api = import_module("srmeetsps-cuda_amd.api")
+    n_img, n_ch = 7, 3
+    full = pkg.synth.make_scene(64, 48, 2, n_img, seed=37, mask_kind="ragged")
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(full))
+    ctx.lighting()
+    s_full = ctx.get("s")
+    P = ctx.dims()["npix"]
+
+    def num_den(c):
+        c.albedo_partial()
+        ptr, n = c.exchange_ptr("albedo")
+        both = torch.as_tensor(api._DevView(ptr, 2 * n_ch * P), device="cuda:0").cpu().numpy().copy()      # den lies behind num
+        return n, both[:n_ch * P], both[n_ch * P:]
+
+    n_one, num_one, den_one = num_den(ctx)
+    assert n_one == n_ch * P
+    num_sum = np.zeros_like(num_one, dtype=np.float64)
+    for lo, hi in ((0, 3), (3, 7)):
+        sh = pkg.synth.make_scene(64, 48, 2, n_img, seed=37, mask_kind="ragged", img_begin=lo, img_end=hi)
+        c = pkg.Context(device_id=0)
+        c.setup(pkg.DataHandler.from_scene(sh))
+        c.set("s", s_full)                                            # what the all-reduce of s leaves on every rank
+        n, num, den = num_den(c)
+        assert n == n_ch * P
+        assert np.array_equal(den.view(np.uint32), den_one.view(np.uint32))
+        num_sum += num
+        c.close()
+    np.testing.assert_allclose(num_sum, num_one, rtol=2e-6, atol=1e-6)
+    ctx.close()
