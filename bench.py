@@ -230,7 +230,10 @@ def main():
         "energies": energies,
     }
     if rank == 0:
-        out.update(cg_legs(pkg, ctx, H, W, args.sf, resident_expected=True))
+        # the resident kernel runs where the grid has at most one 256 x 64 tile per CU (2048 x 2048 on 256 CUs); it must then
+        # really have run -- a persistent launch that gave up a wait would have switched the context to the streaming kernels
+        tiles = -(-dims["grid_h"] // 256) * -(-dims["grid_w"] // 64)
+        out.update(cg_legs(pkg, ctx, H, W, args.sf, resident_expected=tiles <= ctx.get_option("num_cus")))
         if not args.no_legs and world == 1:
             # the two HBM-bound legs of north_star, driver-timed with the headline: the streaming CG on the metric's grid
             # (">= 60 % of the HBM roofline on the CG SpMV + axpy loop at 2048 x 2048") and on the largest single-GPU grid
