@@ -30,7 +30,9 @@ def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
     dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(src, "bench", "**", "*kernel_stats.csv"), recursive=True)
+    # gpurun merges every call's output into the same directory: the newest file of a kind is the one of the last run
+    newest = lambda pattern: sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime, reverse=True)
+    stats = newest(os.path.join(src, "bench", "**", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{rnd}_bench_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "bench.json")):
@@ -45,7 +47,7 @@ def main():
     for cfg, (size_key, leg) in keymap.items():
         per_counter = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            files = glob.glob(os.path.join(src, f"pmc_{cfg}_{counter}", "**", "*counter_collection.csv"), recursive=True)
+            files = newest(os.path.join(src, f"pmc_{cfg}_{counter}", "**", "*counter_collection.csv"))
             if not files:
                 continue
             rows = [r for r in rows_of(files[0]) if any(k in r["Kernel_Name"] for k in CG_KERNELS)]
@@ -65,7 +67,7 @@ def main():
             d[leg + "_detail"] = {"fetch_KB": per_counter["FETCH_SIZE"][0], "write_KB": per_counter["WRITE_SIZE"][0],
                                   "median_us_under_pmc": per_counter["FETCH_SIZE"][1], "launches": per_counter["FETCH_SIZE"][2]}
     for sq in ("SQ1", "SQ2"):
-        files = glob.glob(os.path.join(src, f"pmc_resident_2048_{sq}", "**", "*counter_collection.csv"), recursive=True)
+        files = newest(os.path.join(src, f"pmc_resident_2048_{sq}", "**", "*counter_collection.csv"))
         if files:
             rows = [r for r in rows_of(files[0]) if "k_cg_resident" in r["Kernel_Name"]]
             with open(os.path.join(dst, f"{rnd}_pmc_resident_2048_{sq.lower()}.csv"), "w", newline="") as f:
