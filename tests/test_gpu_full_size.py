@@ -160,6 +160,13 @@ def test_config3_whole_pass_against_the_oracle(pkg, oracle, coracle):
     _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"))
 
 
+@pytest.mark.timeout(1200)
+def test_config4_all_images_on_one_gpu_whole_pass_against_the_oracle(pkg, oracle, coracle):
+    """2048 x 2048, sf 4, 40 images (BASELINE.json configs[3], whose 8 GPUs hold 5 images each): the same data volume as one
+    job on one GPU -- two lighting batches of 20, the resident CG at every CU, 2 GB of images"""
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 40, seed=1241, mask_kind="full"))
+
+
 def test_three_lighting_batches_at_mid_size(pkg, oracle, coracle):
     """45 images (the lighting sweep takes them in batches of 20: three batches, the last one partial) on a 512 x 384 ellipse,
     sf 2: the image loops of every sweep at a size where a pixel range spans several blocks"""
