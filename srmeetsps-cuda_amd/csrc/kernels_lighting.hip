@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void k_light_grouped(const float* __restrict__
         for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
             const int ib = b0 + grp * IBW;                 // first image of this block (may be past the end: nothing stored)
             const bool gram = (b0 == 0 && grp == 0);
+            if (ib >= n_img && !gram) continue;            // no image of this round for this group (block-uniform)
             float acc[IBW][4];
             float g[10];
 #pragma unroll
@@ -301,6 +302,9 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
     for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
         const int ib = b0 + grp * IBW;                     // first image of this block (may be past the end: nothing stored)
         const int gram_c = (b0 == 0 && grp < NCH) ? grp : -1;      // the channel whose Gram matrix this block accumulates
+        // a group none of whose images exists in this round (64 images: three of the four groups in the last round) has nothing
+        // to add; block-uniform, so the barriers below stay matched
+        if (ib >= n_img && gram_c < 0) continue;
         float acc[NCH][IBW][4];
         float g[10];
 #pragma unroll
