@@ -5,7 +5,7 @@
 //                       ahead, and are read back one step ahead
 // Each wave marches over columns; per step and lane: NR 16-byte reads, NW 16-byte writes (the streaming CG step: 8 and 4).
 //   hipcc -O3 --offload-arch=gfx950 tools/stream_depth_bench.hip -o tools/stream_depth_bench.bin
-//   tools/stream_depth_bench.bin [rows=4096] [cols=4096] [reps=20]
+//   tools/stream_depth_bench.bin [rows=4096] [cols=4096] [reps=20] [waves=2048]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
     float* chk; CHECK(hipMalloc(&chk, 4));
     a.Hs = Hs; a.ncol = cols;
     a.n_seg = rows / 256;
-    const int waves_target = 256 * 8;                      // 2 waves per SIMD on every CU: one round
+    const int waves_target = argc > 4 ? atoi(argv[4]) : 256 * 8;      // default: 2 waves per SIMD on every CU, one round
     int strips = waves_target / a.n_seg; if (strips < 1) strips = 1;
     while (cols % strips) --strips;
     a.cols_per_wave = cols / strips;
