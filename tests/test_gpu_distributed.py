@@ -115,7 +115,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert two["total_solve_outer_iterations"] == ref["total_solve_outer_iterations"]
 
 
-def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg):
+@pytest.mark.parametrize("bytes_store", [False, True])
+def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg, bytes_store):
     """srps_albedo_partial on a context that holds a shard of the images: den = sum_i (N . s_i)^2 does not involve the images, so it
     is formed over ALL images on every rank -- the same bits as on one GPU -- and only num (C P floats, not 2 C P) is exchanged;
     the shards' num add up to the single-GPU num.  One process, three contexts."""
@@ -123,9 +124,12 @@ def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg):
     from importlib import import_module
     api = import_module("srmeetsps-cuda_amd.api")
     n_img, n_ch = 7, 3
-    full = pkg.synth.make_scene(64, 48, 2, n_img, seed=37, mask_kind="ragged")
+    # bytes_store: 8-bit images (k / 255.f), which the contexts then also hold as bytes -- the sweep's byte variant on a shard
+    quant = (lambda sc: setattr(sc, "I", (np.rint(np.clip(sc.I, 0, 1) * 255).astype(np.float32) / np.float32(255))) or sc) if bytes_store else (lambda sc: sc)
+    full = quant(pkg.synth.make_scene(64, 48, 2, n_img, seed=37, mask_kind="full" if bytes_store else "ragged"))
     ctx = pkg.Context(device_id=0)
     ctx.setup(pkg.DataHandler.from_scene(full))
+    assert ctx.get_option("image_store_bytes_active") == (1 if bytes_store else 0)
     ctx.lighting()
     s_full = ctx.get("s")
     P = ctx.dims()["npix"]
@@ -140,9 +144,10 @@ def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg):
     assert n_one == n_ch * P
     num_sum = np.zeros_like(num_one, dtype=np.float64)
     for lo, hi in ((0, 3), (3, 7)):
-        sh = pkg.synth.make_scene(64, 48, 2, n_img, seed=37, mask_kind="ragged", img_begin=lo, img_end=hi)
+        sh = quant(pkg.synth.make_scene(64, 48, 2, n_img, seed=37, mask_kind="full" if bytes_store else "ragged", img_begin=lo, img_end=hi))
         c = pkg.Context(device_id=0)
         c.setup(pkg.DataHandler.from_scene(sh))
+        assert c.get_option("image_store_bytes_active") == (1 if bytes_store else 0)
         c.set("s", s_full)                                            # what the all-reduce of s leaves on every rank
         n, num, den = num_den(c)
         assert n == n_ch * P
