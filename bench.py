@@ -281,6 +281,33 @@ def main():
                                    "workload": "the headline workload with 8-bit images (k / 255.f, the reference's image-folder input): image sweeps read bytes"}
             c8.close()
             sc.I = I_keep
+            mitten = os.path.join(ROOT, "tests", "golden", "mitten_full.npz")
+            if os.path.exists(mitten):
+                # BASELINE.json config 2 at its true size: the whole frame of the reference's bundled Mitten data set (960 x 1280,
+                # sf 2, 148 600 masked pixels, the first 8 images; tests/golden/mitten_full.npz holds the masked samples), full
+                # alternating solve to the reference's stop rule -- parity against the oracle: tests/test_mitten_full.py
+                M = np.load(mitten)
+                mh, mw, msf = int(M["h"]), int(M["w"]), int(M["sf"])
+                mmask = np.unpackbits(M["mask_bits"])[: mh * mw].astype(np.float32)
+                mi = np.flatnonzero(mmask == 1)
+                mI = np.zeros((M["I_u8"].shape[0], 3, mh * mw), np.float32); mI[:, :, mi] = M["I_u8"].astype(np.float32) / np.float32(255)
+                mzs = np.zeros((mh // msf) * (mw // msf), np.float32); mzs[M["imasks"]] = M["zs_lr_masked"]
+                mzf = np.zeros(mh * mw, np.float32); mzf[mi] = M["z_full_masked"]
+                mdh = pkg.DataHandler(I=mI, mask=mmask, K=M["K"], sf=msf, z0=mzs.reshape(1, -1), I_h=mh, I_w=mw, I_c=3, I_n=mI.shape[0],
+                                      I_n_total=mI.shape[0], zs_lr=mzs, z_full=mzf)
+                cm = pkg.Context(device_id=local_rank)
+                cm.set_stream(stream.cuda_stream)
+                cm.set_option("exclusive_device", 1)
+                cm.setup(mdh); pkg.alternating_loop(cm, None)              # warm-up (first launches, allocations)
+                torch.cuda.synchronize()
+                tm0 = time.perf_counter(); cm.setup(mdh); torch.cuda.synchronize()
+                tm1 = time.perf_counter(); men = pkg.alternating_loop(cm, None); torch.cuda.synchronize()
+                tm2 = time.perf_counter()
+                legs["mitten_full_frame"] = {"total_solve_s": tm2 - tm1, "total_solve_with_setup_s": tm2 - tm0, "outer_iterations": len(men),
+                                             "final_energy": men[-1], "oracle_final_energy": float(M["energies"][-1]), "masked_pixels": int(mi.size),
+                                             "images": int(mI.shape[0]), "image_store_bytes_active": cm.get_option("image_store_bytes_active"),
+                                             "workload": "the reference's Mitten data set, whole 960x1280 frame, sf 2, 8 images: full alternating solve to its stop rule"}
+                cm.close()
             out["legs"] = legs
     if rank == 0:
         # measured device-copy ceiling: 1 GiB device-to-device copy, read + write bytes over the event time

@@ -1,0 +1,61 @@
+"""BASELINE.json config 2 at its true size ("mitten_sf2 (sf=2, ~8 images) on 1 x MI355X, full alternating solve to
+convergence"): the WHOLE frame of the reference's bundled Mitten data set (960 x 1280, 148 600 masked pixels, the first 8 images,
+real 16-bit depth, real mask), committed as tests/golden/mitten_full.npz by tests/golden/make_mitten_full.py -- masked samples
+only, the images as the bytes the PNGs hold.  Expected outputs: the oracle's faithful restatement.  Depth is in the data's
+units (~700), so the north_star tolerance applies to the RELATIVE RMSE."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+f32 = np.float32
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mitten_full.npz")
+G = np.load(PATH)
+
+
+def _inputs(oracle):
+    h, w, sf = int(G["h"]), int(G["w"]), int(G["sf"])
+    mask = np.unpackbits(G["mask_bits"])[: h * w].astype(f32)
+    geo = oracle.build_geometry(h, w, sf, mask)
+    I = np.zeros((G["I_u8"].shape[0], 3, h * w), f32)
+    I[:, :, geo.imask] = G["I_u8"].astype(f32) / f32(255)                  # what the image loader produces (Utilities.cpp:343)
+    assert np.array_equal(geo.imasks, G["imasks"])
+    zs = np.zeros((h // sf) * (w // sf), f32); zs[geo.imasks] = G["zs_lr_masked"]
+    zf = np.zeros(h * w, f32); zf[geo.imask] = G["z_full_masked"]
+    return h, w, sf, mask, G["K"], I, zs, zf, geo
+
+
+def rel_rmse(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+
+
+def test_fixture_is_self_consistent(oracle):
+    h, w, sf, mask, K, I, zs, zf, geo = _inputs(oracle)
+    assert (h, w, sf) == (960, 1280, 2)
+    assert (geo.npix, geo.npixs) == (int(G["npix"]), int(G["npixs"])) == (148600, 36915)
+    assert G["I_u8"].shape == (8, 3, geo.npix)
+    assert G["final_z"].shape == (geo.npix,) and G["final_rho"].shape == (3, geo.npix)
+    assert 400 < float(G["z_full_masked"].mean()) < 9870 and int(G["n_outer"]) == len(G["energies"]) == 4
+    assert np.all(np.diff(G["energies"]) < 0)                              # the reference's stop rule ended a converging run
+
+
+@pytest.mark.gpu
+def test_hip_full_mitten_solve_to_convergence(pkg, oracle):
+    h, w, sf, mask, K, I, zs, zf, geo = _inputs(oracle)
+    dh = pkg.DataHandler(I=I, mask=mask, K=K, sf=sf, z0=zs.reshape(1, -1), I_h=h, I_w=w, I_c=3, I_n=8, I_n_total=8, zs_lr=zs, z_full=zf)
+    ctx = pkg.Context(device_id=0)
+    srps = pkg.SRPS(dh, ctx=ctx)
+    en = srps.execute()                                                    # includes the set-up (upload of the images)
+    t0 = time.perf_counter(); en = srps.execute(); dt = time.perf_counter() - t0
+    print(f"Mitten, full frame, 8 images: {len(en)} passes, {1e3 * dt:.1f} ms with set-up; resident CG {ctx.get_option('cg_resident_active')}, "
+          f"bytes {ctx.get_option('image_store_bytes_active')}")
+    assert ctx.get_option("cg_resident_active") == 1
+    assert ctx.get_option("image_store_bytes_active") == (1 if geo.npix % 4 == 0 else 0)
+    assert len(en) == int(G["n_outer"]), (en, G["energies"])
+    np.testing.assert_allclose(en, G["energies"], rtol=1e-2)
+    assert abs(en[-1] - G["energies"][-1]) / G["energies"][-1] < 2e-3
+    assert rel_rmse(srps.z(), G["final_z"]) < 1e-4                        # relative: depth ~ 700, ulp(700) = 6e-5
+    assert np.abs(srps.rho() - G["final_rho"]).max() < 5e-3
+    ctx.close()
