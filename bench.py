@@ -67,6 +67,30 @@ def cpu_baseline(sc, pkg, budget_s=20.0):
             "sample": f"{iters} CG steps of the matrix-free 2048^2 system (numpy/scipy restatement, 1 thread)"}
 
 
+def cpu_mitten_solve():
+    """BASELINE.json config 1 ("mitten_sf2, CPU reference path on host cores"): the oracle's restatement of the whole alternating
+    optimisation (assembled depth system, the reference's order of operations) on the Mitten frame of tests/golden, timed on the
+    host.  The reference's MATLAB / .mat inputs are absent; this numpy / scipy port stands in.  Checker code, imported here only."""
+    path = os.path.join(ROOT, "tests", "golden", "mitten_full.npz")
+    if not os.path.exists(path):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import srps_oracle as O
+    M = np.load(path)
+    h, w, sf = int(M["h"]), int(M["w"]), int(M["sf"])
+    mask = np.unpackbits(M["mask_bits"])[: h * w].astype(np.float32)
+    mi = np.flatnonzero(mask == 1)
+    I = np.zeros((M["I_u8"].shape[0], 3, h * w), np.float32); I[:, :, mi] = M["I_u8"].astype(np.float32) / np.float32(255)
+    zs = np.zeros((h // sf) * (w // sf), np.float32); zs[M["imasks"]] = M["zs_lr_masked"]
+    zf = np.zeros(h * w, np.float32); zf[mi] = M["z_full_masked"]
+    t0 = time.perf_counter()
+    ref = O.execute(O.Problem(h, w, sf, mask, M["K"], I, zs, zf), depth="faithful")
+    dt = time.perf_counter() - t0
+    return {"total_solve_s": dt, "outer_iterations": ref.iterations, "final_energy": float(ref.energies[-1]), "kind": "port",
+            "implementation": "numpy / scipy restatement (oracle/srps_oracle.py, assembled depth system)",
+            "workload": "the reference's Mitten data set, whole 960x1280 frame, sf 2, 8 images: full alternating solve (compare legs.mitten_full_frame)"}
+
+
 FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X peak fp32 vector rate, /opt/skills/guides/MI355X_MICROARCH.md (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz)
 # useful flops of one CG step per unknown in the executed (tensor-recompute, one-wait) form -- DESIGN.md section 4:
 # P = sum_c g_c T_c 36, gradients 2, E'(.) 4, P(.) 15, E(.) 4, scatter 4, KT'KT + lambda 3, three dot products 6,
@@ -347,6 +371,9 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc, pkg)
+            mit = cpu_mitten_solve()
+            if mit:
+                out["cpu_baseline"]["mitten_full_frame"] = mit
         print(json.dumps(out))
     ctx.close()
     if dist:
