@@ -73,8 +73,9 @@ int srps_synchronize(srps_ctx* ctx);
  * "albedo_one_sync" (0|1: persistent albedo CG with one grid-wide wait per step),
  * "albedo_channels_together" (0|1: persistent albedo CG of 3 channels on masks up to 1 M pixels: the channels share the grid-wide waits),
  * "cg_one_sync" (0|1: resident CG with one grid-wide wait per step),
- * "cg_resident_tile" (0|256|512: tile shape of the resident CG by its threads per block; 0 = 256 x 32 tiles wherever the
- *  device has a CU for each of them, else 256 x 64),
+ * "cg_resident_tile" (0|16|256|512: tile shape of the resident CG; 0 = 256 x 16 tiles (256 threads, 4 columns per thread) while
+ *  the grid has at most 128 of them, else 256 x 32 tiles (256 threads) wherever the device has a CU for each of them, else
+ *  256 x 64 (512 threads); 16 | 256 | 512 force a shape),
  * "cg_resident_debug" (timing experiments only: wrong results),
  * "cg_resident_rect" (0|1: tiles wholly inside the mask run the resident CG's body without structure bits),
  * "cg_fused_step" (0|1: streaming depth CG with the whole step in one launch instead of operator + update kernel),
@@ -87,7 +88,7 @@ int srps_synchronize(srps_ctx* ctx);
 int srps_set_option(srps_ctx* ctx, const char* name, int value);
 /* reads an option back; also "cg_resident_active" (1 when the bound grid fits one tile per CU and the depth CG
  * therefore runs as the persistent on-chip kernel), "num_cus", "persistent_fallbacks" (persistent launches that gave up a wait
- * so far), "cg_resident_rect_tiles_256" / "_512" (tiles of the bound grid that qualify for the body without structure bits),
+ * so far), "cg_resident_rect_tiles_16" / "_256" / "_512" (tiles of the bound grid that qualify for the body without structure bits),
  * "cg_resident_rect_active" (1 when all of them do and the next depth CG therefore runs the kernel without structure bits),
  * "image_store_bytes_active" (1 when the context's images are held as bytes and the sweeps read them) */
 int srps_get_option(srps_ctx* ctx, const char* name, int* value);

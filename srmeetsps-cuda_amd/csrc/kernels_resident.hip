@@ -30,18 +30,25 @@ namespace srps {
 
 namespace {
 
-// Two tile shapes are built from this source (kernels_resident_n256.hip includes it with SRPS_RES_NT = 256): 256 x 64 with
-// 512 threads (two waves per SIMD) for grids that need up to one tile per CU at that size, and 256 x 32 with 256 threads
-// (one wave per SIMD, half the arithmetic per CU and step) for smaller grids, which would otherwise leave most CUs idle.
+// Three tile shapes are built from this source: 256 x 64 with 512 threads (two waves per SIMD, 8 columns per thread) for grids
+// that need up to one tile per CU at that size; 256 x 32 with 256 threads (kernels_resident_n256.hip: one wave per SIMD, half the
+// arithmetic per CU and step) and 256 x 16 with 256 threads and 4 columns per thread (kernels_resident_n256c4.hip: a quarter)
+// for smaller grids, which would otherwise leave most CUs idle while a few do all the arithmetic of a step.
 #ifndef SRPS_RES_NT
 #define SRPS_RES_NT 512
 #endif
+#ifndef SRPS_RES_CPT
+#define SRPS_RES_CPT 8
+#endif
+#ifndef SRPS_RES_TAG
+#define SRPS_RES_TAG SRPS_RES_NT
+#endif
 #define SRPS_RES_CAT2(a, b) a##b
 #define SRPS_RES_CAT(a, b) SRPS_RES_CAT2(a, b)
-#define SRPS_RES_NAME(base) SRPS_RES_CAT(base##_n, SRPS_RES_NT)
+#define SRPS_RES_NAME(base) SRPS_RES_CAT(base##_n, SRPS_RES_TAG)
 constexpr int NT = SRPS_RES_NT, NWV = NT / 64;  // threads, waves per block
-constexpr int CPT = 8;                         // columns per thread
-constexpr int TR = 256, TC = CPT * NWV;        // tile rows, columns (64 or 32)
+constexpr int CPT = SRPS_RES_CPT;              // columns per thread (a power of two, a multiple of sf: 8 or 4)
+constexpr int TR = 256, TC = CPT * NWV;        // tile rows, columns (64, 32 or 16)
 constexpr int RING_COL = TR + 8;               // ring column: rows -4..259 (row r at index r + 4, float4-aligned)
 constexpr int RING_ROW = TC + 8;               // ring row: columns -4..TC+3
 constexpr int RING = 2 * RING_COL + 2 * RING_ROW;
@@ -837,7 +844,7 @@ size_t resident_lds_bytes(int NC) {
 
 }  // namespace
 
-#if defined(SRPS_STAMPS) && SRPS_RES_NT == 512
+#if defined(SRPS_STAMPS) && SRPS_RES_NT == 512 && SRPS_RES_CPT == 8
 extern "C" int srps_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
@@ -878,7 +885,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     a.debug = ctx->cg_resident_debug;
     a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;      // s_memrealtime: 100 MHz
-    const int shape = NT == 512 ? 1 : 0;
+    const int shape = NT == 512 ? 1 : (CPT == 8 ? 0 : 2);
     const bool rect = ctx->cg_resident_rect && G.n_tiles[shape] == tiles && G.n_rect_tiles[shape] == tiles;      // every tile qualifies
     a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr;
     const void* fn = nullptr;
@@ -893,23 +900,34 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     return launch_persistent(ctx, fn, tiles, NT, args, lds);      // SRPS_ERR_UNSUPPORTED: the caller falls back to the streaming kernels
 }
 
-#if SRPS_RES_NT == 512
-// the smaller tile wherever it fits on the device (more CUs at work), cg_resident_tile = 256 | 512 forces one shape
-bool resident_supported(const srps_ctx* ctx) {
-    if (ctx->cg_resident_tile == 512) return resident_supported_n512(ctx);
-    if (ctx->cg_resident_tile == 256) return resident_supported_n256(ctx);
-    return resident_supported_n256(ctx) || resident_supported_n512(ctx);
+#if SRPS_RES_NT == 512 && SRPS_RES_CPT == 8
+// the smallest tile that still gives every tile a CU (more CUs at work, less arithmetic per CU and step);
+// cg_resident_tile = 16 | 256 | 512 forces the 256 x 16, 256 x 32 or 256 x 64 shape
+static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 0: 256 x 32, 1: 256 x 64, -1: none fits
+    const int want = ctx->cg_resident_tile;
+    if (want == 16) return resident_supported_n256c4(ctx) ? 2 : -1;
+    if (want == 256) return resident_supported_n256(ctx) ? 0 : -1;
+    if (want == 512) return resident_supported_n512(ctx) ? 1 : -1;
+    // 256 x 16 tiles pay while they are few (the whole Mitten frame, 69 tiles: 6.4 us per step against 7.5; 512 x 512, 64 tiles:
+    // 6.1 against 6.5): a step's cost outside the columns (ring, exchange, the grid-wide sum over more blocks) does not shrink
+    // with the tile -- at 1024 x 1024 256 of them take 7.5 us where 128 tiles of 256 x 32 take 7.0
+    if (resident_supported_n256c4(ctx) && (long)cdiv(ctx->grid.Hg, TR) * cdiv(ctx->grid.Wg, 16) <= 128) return 2;
+    if (resident_supported_n256(ctx)) return 0;
+    return resident_supported_n512(ctx) ? 1 : -1;
 }
+bool resident_supported(const srps_ctx* ctx) { return resident_shape(ctx) >= 0; }
 // would the next resident launch on the bound grid be the kernel without structure bits (every tile qualifies)?
 bool resident_rect_active(const srps_ctx* ctx) {
-    if (!resident_supported(ctx) || !ctx->cg_resident_rect) return false;
-    const bool small = ctx->cg_resident_tile == 256 || (ctx->cg_resident_tile != 512 && resident_supported_n256(ctx));
-    const int shape = small ? 0 : 1;
+    const int shape = resident_shape(ctx);
+    if (shape < 0 || !ctx->cg_resident_rect) return false;
     return ctx->grid.n_tiles[shape] > 0 && ctx->grid.n_rect_tiles[shape] == ctx->grid.n_tiles[shape];
 }
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
-    const bool small = ctx->cg_resident_tile == 256 || (ctx->cg_resident_tile != 512 && resident_supported_n256(ctx));
-    return small ? resident_cg_n256(ctx, max_steps, fixed_steps) : resident_cg_n512(ctx, max_steps, fixed_steps);
+    switch (resident_shape(ctx)) {
+        case 2: return resident_cg_n256c4(ctx, max_steps, fixed_steps);
+        case 0: return resident_cg_n256(ctx, max_steps, fixed_steps);
+        default: return resident_cg_n512(ctx, max_steps, fixed_steps);
+    }
 }
 #endif
 

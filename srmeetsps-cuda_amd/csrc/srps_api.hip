@@ -85,7 +85,7 @@ static void dfree(T*& p) {
 }
 
 static void grid_release(Grid& G) {
-    dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index); dfree(G.d_tile_cls[0]); dfree(G.d_tile_cls[1]);
+    dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index); dfree(G.d_tile_cls[0]); dfree(G.d_tile_cls[1]); dfree(G.d_tile_cls[2]);
     dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_w2); dfree(G.d_r2); dfree(G.d_part4); dfree(G.d_save);
     dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); G.d_scal = nullptr;      // d_scal lives in the context's report record
     G.bound = false;
@@ -231,8 +231,8 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     SRPS_HIP(hipMemcpy(G.d_imask, G.imask.data(), G.P * sizeof(int), hipMemcpyHostToDevice));
     SRPS_HIP(hipMemcpy(G.d_flags, flags.data(), G.plane, hipMemcpyHostToDevice));
     SRPS_HIP(hipMemcpy(G.d_lr_index, lr_index.data(), lr_index.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (int shape = 0; shape < 2; ++shape) {                    // [0] 256 x 32 tiles, [1] 256 x 64 tiles
-        const std::vector<uint8_t> cls = classify_tiles(G, flags, shape ? 64 : 32, &G.n_rect_tiles[shape]);
+    for (int shape = 0; shape < 3; ++shape) {                    // [0] 256 x 32 tiles, [1] 256 x 64 tiles, [2] 256 x 16 tiles
+        const std::vector<uint8_t> cls = classify_tiles(G, flags, shape == 0 ? 32 : shape == 1 ? 64 : 16, &G.n_rect_tiles[shape]);
         G.n_tiles[shape] = (int)cls.size();
         SRPS_TRY(dalloc(&G.d_tile_cls[shape], cls.size()));
         SRPS_HIP(hipMemcpy(G.d_tile_cls[shape], cls.data(), cls.size(), hipMemcpyHostToDevice));
@@ -463,7 +463,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->assemble_from_sums = value ? 1 : 0;
         ctx->ssum_valid = false;
     } else if (!strcmp(name, "cg_resident_tile")) {
-        SRPS_REQUIRE(value == 0 || value == 256 || value == 512, SRPS_ERR_INVALID, "cg_resident_tile: 0, 256 or 512");
+        SRPS_REQUIRE(value == 0 || value == 16 || value == 256 || value == 512, SRPS_ERR_INVALID, "cg_resident_tile: 0, 16, 256 or 512");
         ctx->cg_resident_tile = value;
     } else if (!strcmp(name, "albedo_channels_together")) {
         ctx->albedo_channels_together = value ? 1 : 0;
@@ -517,6 +517,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_resident_rect_active")) *value = (ctx->grid.bound && resident_rect_active(ctx)) ? 1 : 0;
     else if (!strcmp(name, "cg_resident_rect_tiles_256")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[0] : 0;      // of the 256 x 32 tiling
     else if (!strcmp(name, "cg_resident_rect_tiles_512")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[1] : 0;      // of the 256 x 64 tiling
+    else if (!strcmp(name, "cg_resident_rect_tiles_16")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[2] : 0;       // of the 256 x 16 tiling
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
     else if (!strcmp(name, "cg_resident_tile")) *value = ctx->cg_resident_tile;
     else if (!strcmp(name, "albedo_channels_together")) *value = ctx->albedo_channels_together;

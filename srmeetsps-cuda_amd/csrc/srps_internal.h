@@ -55,8 +55,8 @@ struct Grid {
     int* d_imask = nullptr;       // [P]   HR linear index of compact pixel p (SRPS.cu:157-162)
     uint8_t* d_flags = nullptr;   // [plane]
     int* d_lr_index = nullptr;    // [Hl*Wl] compact LR index of the block, -1 if not fully masked
-    uint8_t* d_tile_cls[2] = {nullptr, nullptr};   // TILE_* bits of the resident CG's tiles: [0] 256 x 32, [1] 256 x 64
-    int n_tiles[2] = {0, 0}, n_rect_tiles[2] = {0, 0};
+    uint8_t* d_tile_cls[3] = {nullptr, nullptr, nullptr};   // TILE_* bits of the resident CG's tiles: [0] 256 x 32, [1] 256 x 64, [2] 256 x 16
+    int n_tiles[3] = {0, 0, 0}, n_rect_tiles[3] = {0, 0, 0};
     // depth workspace (grid layout)
     float* d_M = nullptr;         // [6][plane]  photometric tensor, SoA
     float* d_q = nullptr;         // [3][plane]  (exchange buffer for the sharded depth phase)
@@ -252,10 +252,12 @@ int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, vo
 bool resident_supported(const srps_ctx* ctx);
 bool resident_rect_active(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
-bool resident_supported_n512(const srps_ctx* ctx);       // the two tile shapes (kernels_resident.hip, kernels_resident_n256.hip)
+bool resident_supported_n512(const srps_ctx* ctx);       // the three tile shapes (kernels_resident.hip, kernels_resident_n256.hip, kernels_resident_n256c4.hip)
 bool resident_supported_n256(const srps_ctx* ctx);
+bool resident_supported_n256c4(const srps_ctx* ctx);
 int resident_cg_n512(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int resident_cg_n256(srps_ctx* ctx, int max_steps, bool fixed_steps);
+int resident_cg_n256c4(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
 int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact);
 int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy, float* d_compact = nullptr);      // also gathers the plane when d_compact is given
