@@ -885,7 +885,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     a.debug = ctx->cg_resident_debug;
     a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;      // s_memrealtime: 100 MHz
-    const int shape = NT == 512 ? 1 : (CPT == 8 ? 0 : 2);
+    const int shape = TC == 64 ? 1 : (TC == 32 ? 0 : 2);      // index of the tiling in Grid::d_tile_cls
     const bool rect = ctx->cg_resident_rect && G.n_tiles[shape] == tiles && G.n_rect_tiles[shape] == tiles;      // every tile qualifies
     a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr;
     const void* fn = nullptr;
@@ -903,28 +903,34 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
 #if SRPS_RES_NT == 512 && SRPS_RES_CPT == 8
 // the smallest tile that still gives every tile a CU (more CUs at work, less arithmetic per CU and step);
 // cg_resident_tile = 16 | 256 | 512 forces the 256 x 16, 256 x 32 or 256 x 64 shape
-static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 0: 256 x 32, 1: 256 x 64, -1: none fits
+static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 3: 256 x 32 with 512 threads, 0: 256 x 32 with 256, 1: 256 x 64, -1: none fits
     const int want = ctx->cg_resident_tile;
     if (want == 16) return resident_supported_n256c4(ctx) ? 2 : -1;
+    if (want == 32) return resident_supported_n512c4(ctx) ? 3 : -1;
     if (want == 256) return resident_supported_n256(ctx) ? 0 : -1;
     if (want == 512) return resident_supported_n512(ctx) ? 1 : -1;
-    // 256 x 16 tiles pay while they are few (the whole Mitten frame, 69 tiles: 6.4 us per step against 7.5; 512 x 512, 64 tiles:
-    // 6.1 against 6.5): a step's cost outside the columns (ring, exchange, the grid-wide sum over more blocks) does not shrink
-    // with the tile -- at 1024 x 1024 256 of them take 7.5 us where 128 tiles of 256 x 32 take 7.0
-    if (resident_supported_n256c4(ctx) && (long)cdiv(ctx->grid.Hg, TR) * cdiv(ctx->grid.Wg, 16) <= 128) return 2;
+    // 256 x 16 tiles pay while they are few (the whole Mitten frame, 69 tiles: 6.4 us per step against 7.0 with 256 x 32 tiles;
+    // 640 x 480, 90 tiles: 6.5 against 7.0): a step's cost outside the columns (ring, exchange, skew of more blocks) does not
+    // shrink with the tile -- 1024 x 512: 128 of them take 6.1 us where 64 tiles of 256 x 32 take 5.9
+    if (resident_supported_n256c4(ctx) && (long)cdiv(ctx->grid.Hg, TR) * cdiv(ctx->grid.Wg, 16) <= 96) return 2;
+    // 256 x 32 tiles: eight waves of four columns each (two waves per SIMD: an instruction issues in 2.3 clocks) rather than four
+    // waves of eight columns (one wave per SIMD: 4.5)
+    if (resident_supported_n512c4(ctx)) return 3;
     if (resident_supported_n256(ctx)) return 0;
     return resident_supported_n512(ctx) ? 1 : -1;
 }
 bool resident_supported(const srps_ctx* ctx) { return resident_shape(ctx) >= 0; }
 // would the next resident launch on the bound grid be the kernel without structure bits (every tile qualifies)?
 bool resident_rect_active(const srps_ctx* ctx) {
-    const int shape = resident_shape(ctx);
+    int shape = resident_shape(ctx);
     if (shape < 0 || !ctx->cg_resident_rect) return false;
+    if (shape == 3) shape = 0;      // the same 256 x 32 tiling
     return ctx->grid.n_tiles[shape] > 0 && ctx->grid.n_rect_tiles[shape] == ctx->grid.n_tiles[shape];
 }
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     switch (resident_shape(ctx)) {
         case 2: return resident_cg_n256c4(ctx, max_steps, fixed_steps);
+        case 3: return resident_cg_n512c4(ctx, max_steps, fixed_steps);
         case 0: return resident_cg_n256(ctx, max_steps, fixed_steps);
         default: return resident_cg_n512(ctx, max_steps, fixed_steps);
     }

@@ -255,9 +255,11 @@ int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
 bool resident_supported_n512(const srps_ctx* ctx);       // the three tile shapes (kernels_resident.hip, kernels_resident_n256.hip, kernels_resident_n256c4.hip)
 bool resident_supported_n256(const srps_ctx* ctx);
 bool resident_supported_n256c4(const srps_ctx* ctx);
+bool resident_supported_n512c4(const srps_ctx* ctx);
 int resident_cg_n512(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int resident_cg_n256(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int resident_cg_n256c4(srps_ctx* ctx, int max_steps, bool fixed_steps);
+int resident_cg_n512c4(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
 int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact);
 int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy, float* d_compact = nullptr);      // also gathers the plane when d_compact is given

@@ -177,7 +177,7 @@ def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
 @pytest.mark.parametrize("h,w,sf,n_ch,kind", [(40, 32, 2, 3, "ragged"), (300, 200, 1, 3, "ragged"), (520, 136, 4, 1, "ellipse"),
                                                (257, 65, 1, 3, "full"), (1024, 640, 4, 3, "ellipse"), (768, 1280, 2, 3, "ragged"),
                                                (256, 64, 4, 3, "full"), (512, 64, 2, 3, "full"), (256, 128, 1, 1, "full"), (512, 192, 4, 3, "full")])
-@pytest.mark.parametrize("tile", [16, 256, 512])
+@pytest.mark.parametrize("tile", [16, 32, 256, 512])
 def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind, tile):
     """the depth CG as one persistent launch (state in registers + LDS, grid-wide sums and tile edges through
     generation-tagged granules) against the kernel-per-half-step form: one tile / many tiles, tiles cut by the
@@ -210,7 +210,7 @@ def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind, tile
     ctx.setup(dh)
     ctx.lighting(); ctx.albedo()
     e3 = ctx.depth()
-    n_rect = ctx.get_option(f"cg_resident_rect_tiles_{tile}")
+    n_rect = ctx.get_option(f"cg_resident_rect_tiles_{256 if tile == 32 else tile}")      # 32: the 256 x 32 tiling with 512 threads
     np.testing.assert_array_equal(ctx.get("z"), z1)
     assert e3 == e1
     ctx.close()
