@@ -81,6 +81,15 @@ def test_byte_store_is_not_used_for_other_images_and_follows_changes(pkg, oracle
     ctx.set("I", I)
     one_pass()
     assert ctx.get_option("image_store_bytes_active") == 1
+    # srps_upload_image replaces one image: the store is looked at again (a float-valued image ends it, the byte image restores it)
+    h_w = sc.h * sc.w
+    img0 = sc.I[0].reshape(3, h_w)
+    ctx.upload_image(0, (img0 * f32(0.999)).astype(f32))
+    one_pass()
+    assert ctx.get_option("image_store_bytes_active") == 0
+    ctx.upload_image(0, img0)
+    one_pass()
+    assert ctx.get_option("image_store_bytes_active") == 1
     # a device pointer to the images lets the caller write them at any time: no byte copy from then on
     ctx.device_ptr("I")
     one_pass()
