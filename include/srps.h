@@ -73,10 +73,10 @@ int srps_synchronize(srps_ctx* ctx);
  * "albedo_one_sync" (0|1: persistent albedo CG with one grid-wide wait per step),
  * "albedo_channels_together" (0|1: persistent albedo CG of 3 channels on masks up to 1 M pixels: the channels share the grid-wide waits),
  * "cg_one_sync" (0|1: resident CG with one grid-wide wait per step),
- * "cg_resident_tile" (0|16|32|256|512: tile shape of the resident CG; 0 = 256 x 16 tiles (256 threads, 4 columns per thread) while
- *  the grid has at most 96 of them, else 256 x 32 tiles (512 threads, 4 columns per thread) wherever the device has a CU for
- *  each of them, else 256 x 64 (512 threads, 8 columns per thread); 16 | 32 | 512 force one of these, 256 the 256 x 32 tiles
- *  with 256 threads and 8 columns per thread),
+ * "cg_resident_tile" (0|2|16|32|256|512: tile shape of the resident CG; 0 = 256 x 16 tiles while the grid has few of them (512
+ *  threads and 2 columns per thread for sf 1 and 2, up to 240 tiles; 256 threads and 4 columns per thread for sf 4, up to 96),
+ *  else 256 x 32 tiles (512 threads, 4 columns per thread) wherever the device has a CU for each of them, else 256 x 64 (512
+ *  threads, 8 columns per thread); 2 | 16 | 32 | 512 force one of these, 256 the 256 x 32 tiles with 256 threads),
  * "cg_resident_debug" (timing experiments only: wrong results),
  * "cg_resident_rect" (0|1: tiles wholly inside the mask run the resident CG's body without structure bits),
  * "cg_fused_step" (0|1: streaming depth CG with the whole step in one launch instead of operator + update kernel),

@@ -387,7 +387,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         for (int c = 0; c < CPT; ++c) w[c] = zero4();
         F4 u3 = zero4();                                   // forward-x u of the last column: goes to the next wave
         F4 u0 = zero4();                                   // backward-x u of the first column: goes to the previous wave
-        float ksum[CPT / 4] = {};                          // SF == 4: sums of the thread's 4 x 4 blocks
+        float ksum[CPT >= 4 ? CPT / 4 : 1] = {};           // SF == 4: sums of the thread's 4 x 4 blocks (CPT = 2 is not built for sf 4)
         F4 S[CPT];
         // the last g plane is streamed one column ahead (read-only, 2 MB per XCD: it stays in the L2)
         // the streamed plane goes through a buffer descriptor: one per-lane row offset (voffset) serves every column,
@@ -856,6 +856,7 @@ bool SRPS_RES_NAME(resident_supported)(const srps_ctx* ctx) {
     const int nc = march_recompute_channels(ctx);
     if (nc != 1 && nc != 3) return false;
     if (G.sf != 1 && G.sf != 2 && G.sf != 4) return false;
+    if (G.sf > CPT) return false;                          // a thread's columns hold whole sf x sf blocks of KT
     const long tiles = (long)cdiv(G.Hg, TR) * cdiv(G.Wg, TC);
     return tiles <= ctx->num_cus;
 }
@@ -891,8 +892,11 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const void* fn = nullptr;
 #define SRPS_RES(SFV, NCV) fn = rect ? (ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true, true> : (const void*)k_cg_resident<SFV, NCV, false, true>) \
                                     : (ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true, false> : (const void*)k_cg_resident<SFV, NCV, false, false>)
-    if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else if (G.sf == 2) SRPS_RES(2, 3); else SRPS_RES(4, 3); }
-    else { if (G.sf == 1) SRPS_RES(1, 1); else if (G.sf == 2) SRPS_RES(2, 1); else SRPS_RES(4, 1); }
+    if (G.sf == 4) {
+        if constexpr (CPT >= 4) { if (nc == 3) SRPS_RES(4, 3); else SRPS_RES(4, 1); }
+        else return SRPS_ERR_UNSUPPORTED;
+    } else if (nc == 3) { if (G.sf == 1) SRPS_RES(1, 3); else SRPS_RES(2, 3); }
+    else { if (G.sf == 1) SRPS_RES(1, 1); else SRPS_RES(2, 1); }
 #undef SRPS_RES
     const size_t lds = resident_lds_bytes(nc);
     SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -903,16 +907,21 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
 #if SRPS_RES_NT == 512 && SRPS_RES_CPT == 8
 // the smallest tile that still gives every tile a CU (more CUs at work, less arithmetic per CU and step);
 // cg_resident_tile = 16 | 256 | 512 forces the 256 x 16, 256 x 32 or 256 x 64 shape
-static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 3: 256 x 32 with 512 threads, 0: 256 x 32 with 256, 1: 256 x 64, -1: none fits
+static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 4: 256 x 16 with 512 threads, 3: 256 x 32 with 512 threads, 0: 256 x 32 with 256, 1: 256 x 64, -1: none fits
     const int want = ctx->cg_resident_tile;
+    if (want == 2) return resident_supported_n512c2(ctx) ? 4 : -1;
     if (want == 16) return resident_supported_n256c4(ctx) ? 2 : -1;
     if (want == 32) return resident_supported_n512c4(ctx) ? 3 : -1;
     if (want == 256) return resident_supported_n256(ctx) ? 0 : -1;
     if (want == 512) return resident_supported_n512(ctx) ? 1 : -1;
-    // 256 x 16 tiles pay while they are few (the whole Mitten frame, 69 tiles: 6.4 us per step against 7.0 with 256 x 32 tiles;
-    // 640 x 480, 90 tiles: 6.5 against 7.0): a step's cost outside the columns (ring, exchange, skew of more blocks) does not
-    // shrink with the tile -- 1024 x 512: 128 of them take 6.1 us where 64 tiles of 256 x 32 take 5.9
-    if (resident_supported_n256c4(ctx) && (long)cdiv(ctx->grid.Hg, TR) * cdiv(ctx->grid.Wg, 16) <= 96) return 2;
+    // 256 x 16 tiles.  With 512 threads and two columns per thread (sf 1, 2) they win up to 240 tiles (the whole Mitten frame,
+    // 69 tiles: 5.6 us per step against 7.1 with 256 x 32 tiles; 512 x 512: 4.9 / 5.8; 768 x 1280 ragged, 240 tiles: 6.5 / 7.3;
+    // 1024 x 1024 full, 256 tiles: 6.5 against 6.2 -- there the 256 x 32 tiles stay).  With 256 threads and four columns per
+    // thread (sf 4) while they are few (640 x 480, 90 tiles: 6.5 / 7.0; 1024 x 512, 128 tiles: 6.1 against 5.9): a step's cost
+    // outside the columns (ring, exchange, skew of more blocks) does not shrink with the tile.
+    const long tiles16 = (long)cdiv(ctx->grid.Hg, TR) * cdiv(ctx->grid.Wg, 16);
+    if (tiles16 <= 240 && resident_supported_n512c2(ctx)) return 4;
+    if (tiles16 <= 96 && resident_supported_n256c4(ctx)) return 2;
     // 256 x 32 tiles: eight waves of four columns each (two waves per SIMD: an instruction issues in 2.3 clocks) rather than four
     // waves of eight columns (one wave per SIMD: 4.5)
     if (resident_supported_n512c4(ctx)) return 3;
@@ -925,12 +934,14 @@ bool resident_rect_active(const srps_ctx* ctx) {
     int shape = resident_shape(ctx);
     if (shape < 0 || !ctx->cg_resident_rect) return false;
     if (shape == 3) shape = 0;      // the same 256 x 32 tiling
+    if (shape == 4) shape = 2;      // the same 256 x 16 tiling
     return ctx->grid.n_tiles[shape] > 0 && ctx->grid.n_rect_tiles[shape] == ctx->grid.n_tiles[shape];
 }
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     switch (resident_shape(ctx)) {
         case 2: return resident_cg_n256c4(ctx, max_steps, fixed_steps);
         case 3: return resident_cg_n512c4(ctx, max_steps, fixed_steps);
+        case 4: return resident_cg_n512c2(ctx, max_steps, fixed_steps);
         case 0: return resident_cg_n256(ctx, max_steps, fixed_steps);
         default: return resident_cg_n512(ctx, max_steps, fixed_steps);
     }

@@ -463,7 +463,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->assemble_from_sums = value ? 1 : 0;
         ctx->ssum_valid = false;
     } else if (!strcmp(name, "cg_resident_tile")) {
-        SRPS_REQUIRE(value == 0 || value == 16 || value == 32 || value == 256 || value == 512, SRPS_ERR_INVALID, "cg_resident_tile: 0, 16, 32, 256 or 512");
+        SRPS_REQUIRE(value == 0 || value == 2 || value == 16 || value == 32 || value == 256 || value == 512, SRPS_ERR_INVALID, "cg_resident_tile: 0, 2, 16, 32, 256 or 512");
         ctx->cg_resident_tile = value;
     } else if (!strcmp(name, "albedo_channels_together")) {
         ctx->albedo_channels_together = value ? 1 : 0;

@@ -256,10 +256,12 @@ bool resident_supported_n512(const srps_ctx* ctx);       // the three tile shape
 bool resident_supported_n256(const srps_ctx* ctx);
 bool resident_supported_n256c4(const srps_ctx* ctx);
 bool resident_supported_n512c4(const srps_ctx* ctx);
+bool resident_supported_n512c2(const srps_ctx* ctx);
 int resident_cg_n512(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int resident_cg_n256(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int resident_cg_n256c4(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int resident_cg_n512c4(srps_ctx* ctx, int max_steps, bool fixed_steps);
+int resident_cg_n512c2(srps_ctx* ctx, int max_steps, bool fixed_steps);
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane);
 int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact);
 int grid_gradient(srps_ctx* ctx, const float* d_plane, float* d_zx, float* d_zy, float* d_compact = nullptr);      // also gathers the plane when d_compact is given

@@ -177,13 +177,15 @@ def test_persistent_albedo_cg_equals_streaming_albedo_cg(pkg, h, w, sf, n_ch):
 @pytest.mark.parametrize("h,w,sf,n_ch,kind", [(40, 32, 2, 3, "ragged"), (300, 200, 1, 3, "ragged"), (520, 136, 4, 1, "ellipse"),
                                                (257, 65, 1, 3, "full"), (1024, 640, 4, 3, "ellipse"), (768, 1280, 2, 3, "ragged"),
                                                (256, 64, 4, 3, "full"), (512, 64, 2, 3, "full"), (256, 128, 1, 1, "full"), (512, 192, 4, 3, "full")])
-@pytest.mark.parametrize("tile", [16, 32, 256, 512])
+@pytest.mark.parametrize("tile", [2, 16, 32, 256, 512])
 def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind, tile):
     """the depth CG as one persistent launch (state in registers + LDS, grid-wide sums and tile edges through
     generation-tagged granules) against the kernel-per-half-step form: one tile / many tiles, tiles cut by the
-    grid border, ragged masks (backward differences, incomplete KT blocks), 1 and 3 channels, sf 1, 2, 4, the three tile
-    shapes (256 x 16 and 256 x 32 with 256 threads, 256 x 64 with 512 threads);
+    grid border, ragged masks (backward differences, incomplete KT blocks), 1 and 3 channels, sf 1, 2, 4, every tile
+    shape (256 x 16, 256 x 32 with 256 or 512 threads, 256 x 64 with 512 threads);
     101 truncated steps amplify rounding differences, hence the tolerance; two resident runs are bit-identical"""
+    if tile == 2 and sf == 4:
+        pytest.skip("two columns per thread cannot hold a 4 x 4 block of KT: that shape is built for sf 1 and 2")
     sc = pkg.synth.make_scene(h, w, sf, 3, seed=h + w, n_ch=n_ch, mask_kind=kind)
     dh = pkg.DataHandler.from_scene(sc)
     out = {}
@@ -210,7 +212,7 @@ def test_resident_cg_equals_streaming_cg(pkg, oracle, h, w, sf, n_ch, kind, tile
     ctx.setup(dh)
     ctx.lighting(); ctx.albedo()
     e3 = ctx.depth()
-    n_rect = ctx.get_option(f"cg_resident_rect_tiles_{256 if tile == 32 else tile}")      # 32: the 256 x 32 tiling with 512 threads
+    n_rect = ctx.get_option(f"cg_resident_rect_tiles_{ {32: 256, 2: 16}.get(tile, tile) }")      # 32 / 2: the 256 x 32 / 256 x 16 tiling with 512 threads
     np.testing.assert_array_equal(ctx.get("z"), z1)
     assert e3 == e1
     ctx.close()
