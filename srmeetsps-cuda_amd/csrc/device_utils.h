@@ -49,13 +49,15 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
 }
 
-// four partial-sum arrays [4][n] at once (one pair of barriers): the same pattern and the same bits per array as sum_partials
-__device__ __forceinline__ void sum_partials4(const float* __restrict__ part, int n, double (&out)[4], double (*sm_d)[4] /* [4][4] */) {
+// four partial-sum arrays [4][stride] at once (one pair of barriers), the first n entries of each -- the ones the producing
+// launch wrote: entries behind them may be left over from a launch with more blocks (another strip width) --: the same pattern
+// and the same bits per array as sum_partials
+__device__ __forceinline__ void sum_partials4(const float* __restrict__ part, int n, int stride, double (&out)[4], double (*sm_d)[4] /* [4][4] */) {
     const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = tid; i < n; i += 256) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] += (double)part[(size_t)v * n + i];
+        for (int v = 0; v < 4; ++v) acc[v] += (double)part[(size_t)v * stride + i];
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[v] = wave_sum(acc[v]);

@@ -371,12 +371,12 @@ __global__ __launch_bounds__(256) void k_cg_flush_x(float* __restrict__ x, const
 // the x update still pending after the last executed step K of the one-launch protocol: alpha_K = r_{K-1}.r_{K-1} / p_K.omega_K from
 // the sums launch K left (dc.cu:269-270)
 __global__ __launch_bounds__(256) void k_cg_flush_x2(float* __restrict__ x, const float* __restrict__ p0, const float* __restrict__ p1,
-                                                     size_t n4, const float* __restrict__ part4, int n_part, CgScalars* __restrict__ scal) {
+                                                     size_t n4, const float* __restrict__ part4, int n_part, int n_live, CgScalars* __restrict__ scal) {
     __shared__ double smd4[4][4];
     const int it = scal->iters;
     if (it < 1) return;
     double s4[4];
-    sum_partials4(part4 + (size_t)(it & 1) * 4 * n_part, n_part, s4, smd4);
+    sum_partials4(part4 + (size_t)(it & 1) * 4 * n_part, n_live, n_part, s4, smd4);
     const float alpha = (float)s4[3] / (float)s4[0];
     const float4* p4 = reinterpret_cast<const float4*>((it & 1) ? p1 : p0);
     float4* x4 = reinterpret_cast<float4*>(x);
@@ -532,7 +532,7 @@ int cg_flush_x(srps_ctx* ctx) {
     Grid& G = ctx->grid;
     if (!use_march(ctx)) return SRPS_OK;       // classic protocol: k_cg_update already moved x
     if (cg_fused_step(ctx)) {
-        hipLaunchKernelGGL(k_cg_flush_x2, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x, G.d_p, G.d_p + G.plane, G.used / 4, G.d_part4, G.n_part4, G.d_scal);
+        hipLaunchKernelGGL(k_cg_flush_x2, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x, G.d_p, G.d_p + G.plane, G.used / 4, G.d_part4, G.n_part4, march_blocks(G), G.d_scal);
         SRPS_LAUNCH_CHECK();
         return SRPS_OK;
     }

@@ -127,14 +127,21 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
     if (MODE == 3) {
         if (!a.scal->active) return;                                   // an earlier launch found r.r <= tol^2 (dc.cu:252)
         double s4[4];
-        sum_partials4(a.part4_in, a.n_part, s4, smd4);
+        sum_partials4(a.part4_in, (int)gridDim.x, a.n_part, s4, smd4);      // the previous launch had this launch's blocks
         float r1;
         const float r1_direct = (float)s4[3];                          // r_{k-2}.r_{k-2} (k == 1: of the initial residual)
         if (a.k == 1) r1 = r1_direct;
         else {
             alpha_prev3 = r1_direct / (float)s4[0];                    // dc.cu:269
-            r1 = (float)((double)r1_direct - 2.0 * (double)alpha_prev3 * s4[1] + (double)alpha_prev3 * (double)alpha_prev3 * s4[2]);
+            const double t1 = 2.0 * (double)alpha_prev3 * s4[1], t2 = (double)alpha_prev3 * (double)alpha_prev3 * s4[2];
+            r1 = (float)((double)r1_direct - t1 + t2);
             beta = r1 / r1_direct;                                     // dc.cu:262
+            // The three terms come from fp32 per-block partial sums: when they cancel to less than two digits (one step cut the
+            // residual by ~1e5: systems that converge within the 101 steps) the predicted value is noise, possibly <= 0.  Then
+            // (the resident kernel's guard, kernels_resident.hip) nothing is decided on it: the direction restarts (beta = 0, a
+            // steepest-descent step: alpha = r.r / p.omega stays exact because r is orthogonal to the previous p whatever beta
+            // was) and the stop test waits for the DIRECT sum, which the next launch holds as its r1_direct.
+            if (!((double)r1 > 1e-2 * ((double)r1_direct + fabs(t1) + t2))) { beta = 0.f; r1 = r1_direct; }
         }
         if (!(r1 > a.tol2)) {                                          // converged: dc.cu:252.  The pending x update is k_cg_flush_x2's
             if (blockIdx.x == 0 && threadIdx.x == 0) a.scal->active = 0;
@@ -474,14 +481,14 @@ bool march_supported(const srps_ctx* ctx) {
 // loaded SIMD: with W waves on 1024 SIMDs that is ceil(W/1024) rounds of tj+2 steps.  tj <= 0 picks the
 // width that minimises rounds * (tj + 2) (measured: 2048^2 -> 1152 waves at tj=16 take 42 us, 927 waves
 // at tj=20 take 32 us).
-void march_plan(Grid& G, int tj) {
+void march_plan(Grid& G, int tj, int num_cus) {
     const int nseg0 = std::max(1, cdiv(G.Hg, 248));
     int own = cdiv(G.Hg, nseg0);
     own = ((own + 3) / 4) * 4;
     G.seg_rows = own;
     G.n_seg = cdiv(G.Hg, own);
     if (tj <= 0) {
-        const int simds = 1024;                     // 256 CUs x 4 SIMDs
+        const int simds = 4 * std::max(1, num_cus);  // 256 CUs x 4 SIMDs on a whole MI355X; fewer under a CU mask or a partition
         long best = -1;
         for (int cand = 4; cand <= 128; cand += 4) {
             const long waves = (long)G.n_seg * cdiv(G.Wg, cand);

@@ -249,7 +249,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     G.nb_apply = std::max(1, std::min(nti * ntj, 1024));
     G.used = (size_t)G.Hs * (G.Wg + 2 * PAD);      // the CG vectors are zero (and stay zero) beyond the used columns
     G.nb_update = std::max(1, std::min(cdiv((long long)G.used / 4, 256 * 4), 1024));
-    march_plan(G, ctx->march_tj);
+    march_plan(G, ctx->march_tj, ctx->num_cus);
     G.n_part4 = std::max(4096, march_blocks(G) + 8);      // any strip width the options allow stays below this (see march_strip)
     SRPS_TRY(dalloc(&G.d_part4, 2 * 4 * (size_t)G.n_part4));
     SRPS_HIP(hipMemset(G.d_part4, 0, 2 * 4 * (size_t)G.n_part4 * sizeof(float)));
@@ -477,12 +477,13 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         SRPS_REQUIRE(value == 0 || (value >= 4 && value <= 512 && value % 4 == 0), SRPS_ERR_INVALID, "march_strip: 0 (automatic) or a multiple of 4 in [4, 512]");
         if (ctx->grid.bound) {
             // the partial-sum buffers were sized at bind time (build_grid): refuse a strip width whose block count exceeds them
-            srps::Grid trial = ctx->grid;
-            march_plan(trial, value);
+            srps::Grid trial;                     // only the extent enters the plan (no copy of the bound grid's index vectors)
+            trial.Hg = ctx->grid.Hg; trial.Wg = ctx->grid.Wg;
+            march_plan(trial, value, ctx->num_cus);
             SRPS_REQUIRE(march_blocks(trial) + 8 <= std::max(4096, ctx->grid.n_part4), SRPS_ERR_INVALID,
                          "march_strip: %d-column strips need %d blocks, more than the %d partial sums allocated for the bound grid (set the option before srps_bind_grid / srps_setup)",
                          value, march_blocks(trial), ctx->grid.n_part4);
-            march_plan(ctx->grid, value);
+            march_plan(ctx->grid, value, ctx->num_cus);
         }
         ctx->march_tj = value;
     } else if (!strcmp(name, "cg_max_iter")) {

@@ -277,7 +277,7 @@ int apply_blocks(const srps_ctx* ctx);      // partial sums the operator kernel 
 
 // ---- marching operator (kernels_march.hip) ------------------------------------------------
 bool march_supported(const srps_ctx* ctx);
-void march_plan(Grid& G, int strip_cols);
+void march_plan(Grid& G, int strip_cols, int num_cus);
 int march_blocks(const Grid& G);
 int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
 int march_residual(srps_ctx* ctx);

@@ -276,6 +276,39 @@ def test_one_launch_cg_step_equals_operator_plus_update(pkg, oracle, h, w, sf, n
         assert rmse(z1, ref.z) < 5e-5
 
 
+def test_strip_width_changed_on_a_bound_grid_leaves_no_stale_partial_sums(pkg):
+    """option "march_strip" on a bound grid re-plans the streaming CG: a wider strip has fewer blocks, and the partial sums the
+    narrower plan's extra blocks left behind must not enter alpha, beta or the stop test of later solves (round-2 advisor
+    finding: every launch summed the whole partial-sum array).  Narrow first, then wide, against a context that was wide from
+    the start: bit-identical."""
+    sc = pkg.synth.make_scene(512, 640, 2, 3, seed=77, mask_kind="ellipse")
+    dh = pkg.DataHandler.from_scene(sc)
+
+    def run(widths):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("cg_resident", 0)
+        ctx.setup(dh)
+        d = ctx.dims()
+        s0 = np.zeros((sc.n_img, sc.n_ch, 4), np.float32); s0[:, :, 2] = -1
+        out = None
+        for wd in widths:
+            ctx.set_option("march_strip", wd)
+            assert ctx.get_option("march_strip") == wd
+            # every solve starts from the state srps_setup leaves (SRPS.cu:209-270), WITHOUT binding the grid again
+            ctx.set("z", sc.z_init[sc.mask == 1]); ctx.set("rho", np.full(sc.n_ch * d["npix"], 0.5, np.float32)); ctx.set("s", s0)
+            ctx.normals()
+            en = pkg.alternating_loop(ctx, None, max_outer=1)
+            out = (en, ctx.get("z"), ctx.last_cg_iterations()["depth"])
+        ctx.close()
+        return out
+    # a context that only ever ran the wide plan: set the option BEFORE the first solve on the bound grid
+    e_w, z_w, it_w = run([40])
+    e_nw, z_nw, it_nw = run([8, 40])                          # 5 x the blocks first, then the wide plan on the same grid
+    assert it_w == it_nw == 101
+    assert e_w == e_nw
+    np.testing.assert_array_equal(z_w, z_nw)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json's full HR grid: properties that do not need the oracle at that size
 # ------------------------------------------------------------------------------------------------

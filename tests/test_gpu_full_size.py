@@ -39,7 +39,7 @@ def _lr_compact(sc, st, v_lr):
 def _oracle_start(sc, oracle, coracle):
     """SRPS.cu:151-270 with the C oracle's structure: compaction, initial values, first normals"""
     st = coracle.Structure(sc.h, sc.w, sc.sf, sc.mask)
-    I = np.ascontiguousarray(sc.I[:, :, st.imask])
+    I = sc.I if st.P == sc.h * sc.w else np.ascontiguousarray(sc.I[:, :, st.imask])      # full mask: no second copy (12.9 GB at 4096^2 x 64)
     z = np.ascontiguousarray(sc.z_init[st.imask])
     K = np.asarray(sc.K, f32)
     xx = ((st.imask // sc.h).astype(f32) - K[6]).astype(f32)
@@ -111,7 +111,7 @@ def test_metric_size_depth_phase_resident_streaming_and_oracle(pkg, oracle, cora
     assert rmse(out["resident_two_waits"]["z"], out["streaming"]["z"]) < 2e-5, report
 
 
-def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True):
+def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True, e_tol=2e-3, keep=None):
     """lighting -> albedo -> depth -> normals with default options against numpy (lighting dc.cu:376-444, albedo dc.cu:395-406 +
     513-548 on the diagonal system) and C (depth)"""
     n_img, n_ch = sc.n_img, sc.n_ch
@@ -120,9 +120,11 @@ def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True):
     en = pkg.alternating_loop(ctx, None, max_outer=1)
     z = ctx.get("z"); rho = ctx.get("rho").reshape(n_ch, -1); s = ctx.get("s").reshape(-1, n_ch, 4); Nrm = ctx.get("N").reshape(4, -1)
     iters = ctx.last_cg_iterations()
-    if expect_resident:
-        assert ctx.get_option("cg_resident_active") == 1
+    assert ctx.get_option("cg_resident_active") == (1 if expect_resident else 0)
+    assert ctx.get_option("persistent_fallbacks") == 0
     ctx.close()
+    if keep is not None:
+        keep.update(z=z, rho=rho, s=s, energy=en[0])
     st, o = _oracle_start(sc, oracle, coracle)
     P = st.P
     s_ref = np.zeros((n_img, n_ch, 4), f32); s_ref[:, :, 2] = -1
@@ -143,9 +145,10 @@ def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True):
     assert all(abs(a - b) <= 2 for a, b in zip(iters["albedo"][:n_ch], alb_it))
     assert rmse(z, z_ref) < 1e-4
     assert np.abs(rho - rho_ref).max() < 1e-4
-    # first pass.  Measured: 5e-5 at 1024 x 1024 x 20 images, 5.5e-4 at 512 x 384 x 45 images (2e-6 for the
-    # depth phase alone at 4096 x 4096)
-    assert abs(en[0] - e_ref) <= 2e-3 * abs(e_ref)
+    # first pass.  Measured: 5e-5 at 1024 x 1024 x 20 images, 2.4e-4 at 2048 x 2048 x 40, 5.5e-4 at
+    # 512 x 384 x 45 images (2e-6 for the depth phase alone at 4096 x 4096); the callers allow three times their measured value
+    print("first-pass energy, relative deviation", abs(en[0] - e_ref) / abs(e_ref), "allowed", e_tol)
+    assert abs(en[0] - e_ref) <= e_tol * abs(e_ref)
     # lighting through the shading it predicts (the first pass's 4 x 4 systems have a flat direction)
     A = (rho_ref[:, None, :] * o["N"][None, :, :]).astype(np.float64)                 # [c][4][P]
     for c in range(n_ch):
@@ -155,22 +158,26 @@ def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True):
     assert np.abs(Nrm - N_ref).max() < 2e-5
 
 
+# one-context results of the two large configurations, kept for the two-rank tests below (same module, same process)
+_KEEP = {"config4": {}, "config5": {}}
+
+
 def test_config3_whole_pass_against_the_oracle(pkg, oracle, coracle):
     """1024 x 1024, sf 4, 20 images (BASELINE.json configs[2]), full mask"""
-    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"))
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"), e_tol=1.5e-4)
 
 
 @pytest.mark.timeout(1200)
 def test_config4_all_images_on_one_gpu_whole_pass_against_the_oracle(pkg, oracle, coracle):
     """2048 x 2048, sf 4, 40 images (BASELINE.json configs[3], whose 8 GPUs hold 5 images each): the same data volume as one
     job on one GPU -- two lighting batches of 20, the resident CG at every CU, 2 GB of images"""
-    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 40, seed=1241, mask_kind="full"))
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 40, seed=1241, mask_kind="full"), e_tol=7.5e-4, keep=_KEEP["config4"])
 
 
 def test_three_lighting_batches_at_mid_size(pkg, oracle, coracle):
     """45 images (the lighting sweep takes them in batches of 20: three batches, the last one partial) on a 512 x 384 ellipse,
     sf 2: the image loops of every sweep at a size where a pixel range spans several blocks"""
-    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(512, 384, 2, 45, seed=1240, mask_kind="ellipse"))
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(512, 384, 2, 45, seed=1240, mask_kind="ellipse"), e_tol=1.7e-3)
 
 
 def test_largest_grid_streaming_kernels_against_the_oracle(pkg, oracle, coracle):
@@ -211,3 +218,77 @@ def test_largest_grid_streaming_kernels_against_the_oracle(pkg, oracle, coracle)
     assert it_ref == 101
     assert rmse(z, z_ref) < 1e-4
     assert abs(e - e_ref) <= 1e-3 * abs(e_ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] and configs[4] at their data volume, and sharded over two ranks at that volume
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(3000)
+def test_config5_full_volume_whole_pass_against_the_oracle(pkg, oracle, coracle):
+    """4096 x 4096, sf 2, 64 images (BASELINE.json configs[4]: 12.9 GB of images, 16.8 M unknowns) as one job on one GPU: the
+    per-image compaction of SRPS.cu:223-234 through the 2 GB staging ring of srps_setup, four lighting batches, the streaming
+    depth CG -- one whole pass against the oracle (numpy lighting + albedo, C depth step in the reference's assembled-CSR form)"""
+    sc = pkg.synth.make_scene(4096, 4096, 2, 64, seed=1242, mask_kind="full")
+    _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=False, e_tol=1e-3, keep=_KEEP["config5"])
+
+
+def _two_rank_worker(rank, world, port, H, W, sf, n_img, seed, out_dir):
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    lo, hi = pkg.shard_range(n_img, world, rank)
+    sc = pkg.synth.make_scene(H, W, sf, n_img, seed=seed, mask_kind="full", img_begin=lo, img_end=hi)
+    srps = pkg.SRPS(pkg.DataHandler.from_scene(sc), distributed=True)
+    # two processes share the device: the persistent kernels of both must be resident side by side, or give up and stream --
+    # either way the result has to agree; cooperative launches (the default) keep them from interleaving
+    en = srps.execute(max_outer=1)
+    ex = {k: srps.ctx.exchange_ptr(k)[1] for k in ("albedo", "depth", "energy", "s")}
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), energies=np.array(en), z=srps.z(), rho=srps.rho(), s=srps.s(),
+             ex_albedo=ex["albedo"], ex_depth=ex["depth"], ex_s=ex["s"], fallbacks=srps.ctx.get_option("persistent_fallbacks"),
+             iters=srps.ctx.last_cg_iterations()["depth"])
+    dist.barrier()
+    srps.ctx.close()
+    dist.destroy_process_group()
+
+
+def _two_ranks_equal_one_context(tmp_path, key, H, W, sf, n_img, seed):
+    import socket
+    import torch.multiprocessing as mp
+    one = _KEEP[key]
+    if not one:
+        pytest.skip("the one-context pass of this configuration did not run in this session")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(_two_rank_worker, args=(2, port, H, W, sf, n_img, seed, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    P = H * W
+    # what travels: num [C][P] and the compact q [3][P] (DESIGN.md section 7), s [N][C][4]
+    assert int(r0["ex_albedo"]) == 3 * P and int(r0["ex_depth"]) == 3 * P and int(r0["ex_s"]) == n_img * 3 * 4
+    assert int(r0["iters"]) == int(r1["iters"]) == 101
+    if int(r0["fallbacks"]) == int(r1["fallbacks"]):          # the replicas ran the same kernels: they stay bit-identical
+        np.testing.assert_array_equal(r0["z"], r1["z"]); np.testing.assert_array_equal(r0["rho"], r1["rho"])
+        np.testing.assert_array_equal(r0["energies"], r1["energies"])
+    d_z = rmse(r0["z"], one["z"]); d_rho = float(np.abs(r0["rho"] - one["rho"]).max()); d_e = abs(float(r0["energies"][0]) - one["energy"]) / abs(one["energy"])
+    print(f"{key}: two ranks ({n_img // 2} images each) against one context: depth RMSE {d_z:.3e}, albedo max {d_rho:.3e}, energy {d_e:.3e}, "
+          f"fallbacks {int(r0['fallbacks'])} / {int(r1['fallbacks'])}")
+    assert d_z < 2e-5 and d_rho < 1e-4 and d_e < 5e-4
+
+
+@pytest.mark.timeout(3000)
+def test_config4_volume_two_ranks_on_one_gpu_equal_one_context(tmp_path):
+    """2048 x 2048, sf 4, 40 images (configs[3]) as 2 ranks x 20 images on one GPU (gloo): shard_range, the *_partial / *_finish
+    entry points, the all-reduce of num and of the compact q at their real size (50 MB each), against the one-context pass"""
+    _two_ranks_equal_one_context(tmp_path, "config4", 2048, 2048, 4, 40, 1241)
+
+
+@pytest.mark.timeout(3000)
+def test_config5_volume_two_ranks_on_one_gpu_equal_one_context(tmp_path):
+    """4096 x 4096, sf 2, 64 images (configs[4]) as 2 ranks x 32 images on one GPU (gloo): 201 MB of num and of q per exchange"""
+    _two_ranks_equal_one_context(tmp_path, "config5", 4096, 4096, 2, 64, 1242)

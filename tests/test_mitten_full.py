@@ -54,6 +54,8 @@ def test_hip_full_mitten_solve_to_convergence(pkg, oracle):
     assert ctx.get_option("cg_resident_active") == 1
     assert ctx.get_option("image_store_bytes_active") == (1 if geo.npix % 4 == 0 else 0)
     assert len(en) == int(G["n_outer"]), (en, G["energies"])
+    print("Mitten: energies relative deviation per pass", [abs(a - b) / b for a, b in zip(en, G["energies"])], "depth rel. RMSE", rel_rmse(srps.z(), G["final_z"]),
+          "albedo max abs", float(np.abs(srps.rho() - G["final_rho"]).max()))
     np.testing.assert_allclose(en, G["energies"], rtol=1e-2)
     assert abs(en[-1] - G["energies"][-1]) / G["energies"][-1] < 2e-3
     assert rel_rmse(srps.z(), G["final_z"]) < 1e-4                        # relative: depth ~ 700, ulp(700) = 6e-5
