@@ -221,6 +221,35 @@ int srps_energy_finish(srps_ctx* ctx, float* energy);
 int srps_exchange(srps_ctx* ctx, const char* which /* "s","albedo","depth","energy" */,
                   void** d_ptr, size_t* n_floats);
 
+/* ---- multi-GPU through the boundary (new: the reference is single-GPU, its only device code is
+ * cudaSetDevice(Preferences::deviceId), SRPS.cu:88 -- the seam these calls belong to) ---------------------------------------
+ * A context that holds a shard of the images (srps_problem.n_images < n_images_total) gets an RCCL communicator; the four
+ * all-reduces of a pass (s, the albedo numerator, the compact q, the energy term) then run inside the library, as
+ * ncclAllReduce on the context's stream (xGMI between the GPUs of a node).  librccl is resolved at run time: a process that
+ * never calls these needs no RCCL.  One rank per device; one host thread per context (a thread per GPU in a one-process job).
+ *   srps_comm_unique_id + srps_comm_init_rank : one process per GPU -- rank 0 makes the id (ncclGetUniqueId), the launcher
+ *       distributes its SRPS_COMM_ID_BYTES bytes, every rank joins (ncclCommInitRank on the context's device);
+ *   srps_comm_init_all : one process, n contexts on n different devices (ncclCommInitAll); rank = index in the array;
+ *   srps_set_comm      : borrow an ncclComm_t the caller made itself (not destroyed with the context); NULL unbinds.
+ * The communicators the library creates are destroyed by srps_comm_release / srps_destroy. */
+#define SRPS_COMM_ID_BYTES 128
+int srps_comm_unique_id(void* id /* [SRPS_COMM_ID_BYTES] */);
+int srps_comm_init_rank(srps_ctx* ctx, const void* id, int rank, int world);
+int srps_comm_init_all(srps_ctx* const* ctxs, int n);
+int srps_set_comm(srps_ctx* ctx, void* rccl_comm /* ncclComm_t */, int rank, int world);
+int srps_comm_release(srps_ctx* ctx);
+int srps_comm_info(srps_ctx* ctx, int* rank, int* world /* 0: no communicator bound */);
+/* Sum of the exchange buffer `which` ("s", "albedo", "depth", "energy": see srps_exchange) over the ranks, in place, enqueued
+ * on the context's stream: what a host that drives the phases itself calls between *_partial and *_finish. */
+int srps_all_reduce(srps_ctx* ctx, const char* which);
+/* The alternating loop of SRPS.cu:272-335 on a context that holds a shard: per pass lighting_local, all-reduce s,
+ * albedo_partial, all-reduce num, albedo_finish, depth_partial, all-reduce q, depth_solve (replicated), energy_partial,
+ * all-reduce of the energy term, normals -- one host synchronisation per pass, like srps_execute.  Every rank obtains the same
+ * energies and takes the same stop decision.  Should a persistent kernel give up a wait on ANY rank, all ranks learn it
+ * through the energy all-reduce, repeat the pass's tail with the streaming kernels together and stay replicas of each other.
+ * With a one-rank communicator the results are those of srps_execute bit for bit.  Arguments as srps_execute. */
+int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_outer);
+
 /* stop rule + loop of SRPS.cu:272-335 on one GPU.  max_outer <= 0: run to the reference's stop
  * rule (at most 11 passes).  energies (may be NULL) must hold max_outer values, or 12 when
  * max_outer <= 0; *n_outer receives the number of passes executed. */

@@ -118,6 +118,14 @@ def load():
         "srps_energy_finish": (i, [vp, fp]),
         "srps_exchange": (i, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "srps_execute": (i, [vp, i, fp, ip]),
+        "srps_execute_sharded": (i, [vp, i, fp, ip]),
+        "srps_comm_unique_id": (i, [p]),
+        "srps_comm_init_rank": (i, [vp, p, i, i]),
+        "srps_comm_init_all": (i, [C.POINTER(vp), i]),
+        "srps_set_comm": (i, [vp, vp, i, i]),
+        "srps_comm_release": (i, [vp]),
+        "srps_comm_info": (i, [vp, ip, ip]),
+        "srps_all_reduce": (i, [vp, C.c_char_p]),
         "srps_get": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_set": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_get_device_ptr": (i, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),

@@ -266,6 +266,44 @@ class Context:
         check(self.lib.srps_execute(self.h, max_outer, buf, C.byref(n)))
         return [buf[i] for i in range(min(n.value, 64))]
 
+    # -- multi-GPU through the boundary: RCCL inside the library (srps.h "multi-GPU through the boundary") ----------
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId through the library: rank 0 makes it, the launcher hands its bytes to every rank"""
+        buf = C.create_string_buffer(Context.COMM_ID_BYTES)
+        check(_lib.load().srps_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rank(self, uid: bytes, rank: int, world: int):
+        assert len(uid) == self.COMM_ID_BYTES
+        check(self.lib.srps_comm_init_rank(self.h, C.c_char_p(uid), int(rank), int(world)))
+
+    @staticmethod
+    def comm_init_all(contexts):
+        """one process, one context per device: ncclCommInitAll; rank = position in `contexts`"""
+        arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+        check(_lib.load().srps_comm_init_all(arr, len(contexts)))
+
+    def comm_release(self):
+        check(self.lib.srps_comm_release(self.h))
+
+    def comm_info(self) -> tuple[int, int]:
+        r = C.c_int(0); w = C.c_int(0)
+        check(self.lib.srps_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def all_reduce(self, which: str):
+        check(self.lib.srps_all_reduce(self.h, which.encode()))
+
+    def execute_sharded(self, max_outer: int = 0):
+        """the alternating loop on a shard with the all-reduces inside the library (ncclAllReduce on the context's stream)"""
+        buf = (C.c_float * 64)()
+        n = C.c_int(0)
+        check(self.lib.srps_execute_sharded(self.h, max_outer, buf, C.byref(n)))
+        return [buf[i] for i in range(min(n.value, 64))]
+
     def get(self, name: str) -> np.ndarray:
         n = C.c_size_t(0)
         check(self.lib.srps_array_size(self.h, name.encode(), C.byref(n)))

@@ -549,6 +549,15 @@ int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
         if (rc != SRPS_ERR_UNSUPPORTED) return rc;
         ctx->cg_resident = 0;                      // the device refused the launch: stream from now on
     }
+    // A persistent kernel of this pass (the albedo CG) has not been looked at yet: should it turn out to have given up, this
+    // solve ran on an albedo that was never finished and the pass's tail is repeated -- from the iterate this solve starts
+    // from, which the streaming kernels update in place.  Keep a copy (one plane: 0.3 % of the solve's traffic); the abort
+    // check makes it the current plane again (persistent_aborts).
+    if (ctx->persistent_inflight && !ctx->x_swapped && !fixed_steps) {
+        Grid& G = ctx->grid;
+        SRPS_HIP(hipMemcpyAsync(G.d_x2, G.d_x, G.plane * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->x_swapped = true;
+    }
     SRPS_TRY(grid_residual(ctx));                  // dc.cu:758
     ctx->cg_fixed = fixed_steps;                   // bench: never stop early (tol^2 := -1)
     for (int k = 1; k <= max_steps; ++k) {

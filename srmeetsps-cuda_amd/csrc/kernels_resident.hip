@@ -118,7 +118,8 @@ struct ResidentArgs {
     const float* G;            // [NC][plane]
     const uint8_t* flags;      // [plane]
     const float* consts;       // [NC][8]: S, x*, y*, R00, R01, R11
-    float* x;                  // [plane] in/out
+    const float* x;            // [plane] the iterate the solve starts from: read, never written
+    float* x_out;              // [plane] the result (another plane: an aborted launch leaves x intact)
     const float* r;            // [plane] right-hand side b (the kernel forms the residual b - A_ x0 itself)
     unsigned long long* ent;   // [2][tiles]          reduction granules, zeroed before the launch
     unsigned long long* ent3;  // [2][256] 16-byte granules: the three-value reduction of the one-sync form
@@ -811,7 +812,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
     const bool dead = spin_block_dead();
     if (act && !dead) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) st4(a.x + (size_t)(gcol0 + c + PAD) * Hs + srow0, x[c]);
+        for (int c = 0; c < CPT; ++c) st4(a.x_out + (size_t)(gcol0 + c + PAD) * Hs + srow0, x[c]);
     }
     if (blockIdx.x == 0 && tid == 0) {
         a.scal->r0 = r0; a.scal->r1_last = r1; a.scal->iters = k; a.scal->active = (r1 > a.tol2) ? 1 : 0;
@@ -873,7 +874,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));
     ResidentArgs a;
     memset(&a, 0, sizeof(a));
-    a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.r = G.d_r;
+    a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.x_out = G.d_x2; a.r = G.d_r;
     a.ent = (unsigned long long*)ctx->ws_resident.p;
     a.ent3 = a.ent + ent_n;
     a.halo = a.ent3 + ent3_n;
@@ -901,7 +902,9 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const size_t lds = resident_lds_bytes(nc);
     SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {&a};
-    return launch_persistent(ctx, fn, tiles, NT, args, lds);      // SRPS_ERR_UNSUPPORTED: the caller falls back to the streaming kernels
+    const int rc = launch_persistent(ctx, fn, tiles, NT, args, lds);      // SRPS_ERR_UNSUPPORTED: the caller falls back to the streaming kernels
+    if (rc == SRPS_OK) { std::swap(G.d_x, G.d_x2); ctx->x_swapped = true; }      // the result is in the other plane (see persistent_aborts)
+    return rc;
 }
 
 #if SRPS_RES_NT == 512 && SRPS_RES_CPT == 8

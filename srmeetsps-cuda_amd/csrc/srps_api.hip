@@ -86,7 +86,7 @@ static void dfree(T*& p) {
 
 static void grid_release(Grid& G) {
     dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index); dfree(G.d_tile_cls[0]); dfree(G.d_tile_cls[1]); dfree(G.d_tile_cls[2]);
-    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_w2); dfree(G.d_r2); dfree(G.d_part4); dfree(G.d_save);
+    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_x2); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_w2); dfree(G.d_r2); dfree(G.d_part4); dfree(G.d_save);
     dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); G.d_scal = nullptr;      // d_scal lives in the context's report record
     G.bound = false;
 }
@@ -238,7 +238,9 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
         SRPS_HIP(hipMemcpy(G.d_tile_cls[shape], cls.data(), cls.size(), hipMemcpyHostToDevice));
     }
     SRPS_TRY(dalloc(&G.d_M, 6 * G.plane)); SRPS_TRY(dalloc(&G.d_q, 3 * G.plane));
-    SRPS_TRY(dalloc(&G.d_x, G.plane)); SRPS_TRY(dalloc(&G.d_r, G.plane)); SRPS_TRY(dalloc(&G.d_p, 2 * G.plane));
+    SRPS_TRY(dalloc(&G.d_x, G.plane)); SRPS_TRY(dalloc(&G.d_x2, G.plane)); SRPS_HIP(hipMemset(G.d_x2, 0, G.plane * sizeof(float)));
+    ctx->x_swapped = false;
+    SRPS_TRY(dalloc(&G.d_r, G.plane)); SRPS_TRY(dalloc(&G.d_p, 2 * G.plane));
     SRPS_TRY(dalloc(&G.d_w, G.plane)); SRPS_TRY(dalloc(&G.d_w2, G.plane)); SRPS_TRY(dalloc(&G.d_save, G.plane));
     SRPS_HIP(hipMemset(G.d_w2, 0, G.plane * sizeof(float)));
     SRPS_TRY(dalloc(&G.d_r2, G.plane)); SRPS_HIP(hipMemset(G.d_r2, 0, G.plane * sizeof(float)));
@@ -283,19 +285,30 @@ static int report_fetch(srps_ctx* ctx) {
 // After the report record has been fetched and the stream waited for: did a persistent launch give up a wait
 // (device_utils.h SpinState)?  Returns the ABORT_* bits, switches the kernels concerned off for this context (the phases
 // fall back to the streaming kernels), clears the device flags and leaves the reason in srps_last_error().
-static int persistent_aborts(srps_ctx* ctx, int* flags_out) {
+// `others`: ABORT_* bits that OTHER ranks of a sharded job reported (srps_execute_sharded: the ranks switch kernels together).
+static int persistent_aborts(srps_ctx* ctx, int* flags_out, int others = 0) {
     *flags_out = 0;
     const CgScalars* hs = (const CgScalars*)(ctx->h_pinned + 64);
-    const int flags = hs->abort_flags;
+    const int flags = hs->abort_flags | others;
     ctx->persistent_inflight = 0;
+    const bool swapped = ctx->x_swapped;
+    ctx->x_swapped = false;
     if (!flags) return SRPS_OK;
+    // The resident depth CG stored into the other plane: whatever it left there (nothing, the result of some blocks only when a
+    // wait gave up during the last step, or a solve on the albedo of an aborted albedo launch), the plane it started from is
+    // intact -- make it the current one again; the caller repeats the phase from it.
+    if (swapped) std::swap(ctx->grid.d_x, ctx->grid.d_x2);
     ++ctx->persistent_fallbacks;
     if (flags & ABORT_DEPTH) ctx->cg_resident = 0;
     if (flags & ABORT_ALBEDO) ctx->albedo_persistent = 0;
-    set_error("persistent %s%s%s kernel gave up a grid-wide wait after %d ms (wait %d: %d blocks had arrived) -- the device is shared or "
-              "admits fewer resident blocks than the occupancy query reports; this context now uses the streaming kernels",
-              (flags & ABORT_DEPTH) ? "depth-CG" : "", (flags & ABORT_DEPTH) && (flags & ABORT_ALBEDO) ? " and " : "",
-              (flags & ABORT_ALBEDO) ? "albedo-CG" : "", ctx->spin_budget_ms, hs->abort_gen, hs->abort_arrived);
+    if (hs->abort_flags)
+        set_error("persistent %s%s%s kernel gave up a grid-wide wait after %d ms (wait %d: %d blocks had arrived) -- the device is shared or "
+                  "admits fewer resident blocks than the occupancy query reports; this context now uses the streaming kernels",
+                  (flags & ABORT_DEPTH) ? "depth-CG" : "", (flags & ABORT_DEPTH) && (flags & ABORT_ALBEDO) ? " and " : "",
+                  (flags & ABORT_ALBEDO) ? "albedo-CG" : "", ctx->spin_budget_ms, hs->abort_gen, hs->abort_arrived);
+    else
+        set_error("a persistent %s%s%s kernel gave up a grid-wide wait on another rank of the job; all ranks now use the streaming kernels",
+                  (flags & ABORT_DEPTH) ? "depth-CG" : "", (flags & ABORT_DEPTH) && (flags & ABORT_ALBEDO) ? " and " : "", (flags & ABORT_ALBEDO) ? "albedo-CG" : "");
     SRPS_HIP(hipMemsetAsync(&((CgScalars*)(ctx->d_report + 64))->abort_flags, 0, 3 * sizeof(int), ctx->stream));
     ((CgScalars*)(ctx->h_pinned + 64))->abort_flags = 0;
     *flags_out = flags;
@@ -373,6 +386,7 @@ int srps_destroy(srps_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->device >= 0 && ctx->device < 64) g_live_contexts[ctx->device].fetch_sub(1);
+    comm_release(ctx);
     state_release(ctx);
     grid_release(ctx->grid);
     if (ctx->ws_light.p) (void)hipFree(ctx->ws_light.p);
@@ -622,7 +636,7 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
                             ctx->op_pp_set ? ctx->op_cx : NAN, ctx->op_pp_set ? ctx->op_cy : NAN));
     ctx->plane_holds_z = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy));
+        SRPS_TRY(depth_solve_impl(ctx, d_z0s, d_z, zx, zy, /*plane_current=*/attempt > 0));      // second attempt: the plane the first started from (d_z holds what the aborted launch left)
         SRPS_TRY(grid_energy_t1(ctx, d_z0s, e2));
         SRPS_TRY(energy_photometric_partial(ctx, d_s, d_rho, d_I, d_xx, d_yy, d_dz, d_z, zx, zy, K00, K11, npix, nimages, nchannels, 0, e2 + 1));
         SRPS_TRY(report_fetch(ctx));          // first: the two energy terms of this call overwrite the record's
@@ -631,7 +645,7 @@ int srps_depth_estimation(srps_ctx* ctx, const float* d_s, const float* d_rho, c
         albedo_iters_collect(ctx);
         int aborted = 0;
         SRPS_TRY(persistent_aborts(ctx, &aborted));
-        if (!(aborted & ABORT_DEPTH)) break;          // else: d_z is untouched (a dead block stores nothing), solve again by streaming
+        if (!(aborted & ABORT_DEPTH)) break;          // else: solve again, by streaming, from the iterate the aborted launch started from
     }
     *energy = ctx->h_pinned[0] + ctx->lambda * ctx->h_pinned[1];               // dc.cu:785
     ctx->last_depth_iters = ((CgScalars*)(ctx->h_pinned + 64))->iters;
@@ -874,7 +888,7 @@ int srps_albedo_finish(srps_ctx* ctx) {
     PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SOLVE);
     ctx->light_cache_valid = false;      // rho changes
     SRPS_TRY(albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C));
-    if (ctx->N_local != ctx->N_total) {  // a shard cannot repeat the pass on its own later (srps_energy_finish): look now
+    if (ctx->N_local != ctx->N_total && !ctx->defer_shard_checks) {  // a shard driven phase by phase cannot repeat the pass on its own later (srps_energy_finish): look now
         int aborted = 0;
         SRPS_TRY(persistent_sync_check(ctx, &aborted));
         if (aborted & ABORT_ALBEDO) SRPS_TRY(albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C));
@@ -906,10 +920,10 @@ int srps_depth_solve(srps_ctx* ctx) {
     ctx->grad_current = false;
     ctx->plane_holds_z = false;
     SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy, plane_current));
-    if (ctx->N_local != ctx->N_total) {  // see srps_albedo_finish
+    if (ctx->N_local != ctx->N_total && !ctx->defer_shard_checks) {  // see srps_albedo_finish
         int aborted = 0;
         SRPS_TRY(persistent_sync_check(ctx, &aborted));
-        // a dead block stores nothing: the plane still holds the iterate the launch started from
+        // the plane the launch started from is current again (persistent_aborts)
         if (aborted & ABORT_DEPTH) SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy, true));
     }
     ctx->grad_current = true;            // depth_solve_impl leaves Dx z, Dy z of the new z in zx, zy
@@ -927,6 +941,42 @@ int srps_energy_partial(srps_ctx* ctx) {
     return energy_photometric_partial(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->z, ctx->zx, ctx->zy, ctx->fx, ctx->fy,
                                       ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->energy_ex + 1);
 }
+// the abort flags of this rank's persistent kernels as two floats behind the energy terms (report record [2], [3]): they travel
+// with the energy term of a sharded pass
+__global__ void k_abort_flags_to_float(const CgScalars* __restrict__ scal, float* __restrict__ out) {
+    if (threadIdx.x == 0) { const int f = scal->abort_flags; out[0] = (f & ABORT_ALBEDO) ? 1.f : 0.f; out[1] = (f & ABORT_DEPTH) ? 1.f : 0.f; }
+}
+static int sharded_energy_exchange(srps_ctx* ctx) {
+    hipLaunchKernelGGL(k_abort_flags_to_float, dim3(1), dim3(64), 0, ctx->stream, (const CgScalars*)(ctx->d_report + 64), ctx->d_report + 2);
+    SRPS_LAUNCH_CHECK();
+    return comm_all_reduce_sum(ctx, ctx->energy_ex + 1, 3);      // t2 of the local images, albedo aborts, depth aborts
+}
+
+// A persistent kernel of this pass gave up a wait (on this rank or, in a sharded job, on any rank): the pass's tail is repeated
+// with the streaming kernels, from the state the pass had before the aborted launch.  persistent_aborts has made the depth
+// plane of the pass's start current again; the gradient, normals and dz the aborted pass took from the discarded depth are
+// formed again from it.  After an albedo abort the streaming CG starts from whatever the aborted launch left in rho (channels
+// it had finished are stored, devicecalls.cu:540 converges to the same fixed point from any start: 1e-7); in a sharded job
+// rank 0's albedo is then broadcast, so that the replicas stay bit-identical.
+static int redo_pass_tail(srps_ctx* ctx, int aborted) {
+    Grid& G = ctx->grid;
+    const bool sharded = ctx->N_local != ctx->N_total || (ctx->defer_shard_checks && comm_bound(ctx));
+    SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy, ctx->z));
+    SRPS_TRY(launch_normals(ctx->stream, ctx->z, ctx->zx, ctx->zy, ctx->xx, ctx->yy, G.P, ctx->fx, ctx->fy, ctx->Nrm, ctx->dz));
+    ctx->grad_current = true; ctx->plane_holds_z = true;
+    if (aborted & ABORT_ALBEDO) {
+        SRPS_TRY(srps_albedo_finish(ctx));
+        if (sharded && comm_bound(ctx) && ctx->comm_world > 1) SRPS_TRY(comm_broadcast(ctx, ctx->rho, (size_t)ctx->C * G.P, 0));
+        SRPS_TRY(srps_depth_partial(ctx));
+        if (sharded && ctx->q_ex) SRPS_TRY(comm_all_reduce_sum(ctx, ctx->q_ex, 3 * (size_t)G.P));
+    }
+    SRPS_TRY(srps_depth_solve(ctx));
+    SRPS_TRY(srps_energy_partial(ctx));
+    if (sharded) SRPS_TRY(sharded_energy_exchange(ctx));
+    SRPS_TRY(srps_normals(ctx));
+    return SRPS_OK;
+}
+
 int srps_energy_finish(srps_ctx* ctx, float* energy) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(energy != nullptr, SRPS_ERR_INVALID, "energy_finish: energy is NULL");
@@ -937,12 +987,12 @@ int srps_energy_finish(srps_ctx* ctx, float* energy) {
     // them), the part of the pass that followed is repeated with the streaming kernels -- on one GPU only: a shard has looked
     // already (srps_albedo_finish, srps_depth_solve), its energy term went through the all-reduce.
     int aborted = 0;
-    SRPS_TRY(persistent_aborts(ctx, &aborted));
-    if (aborted && ctx->N_local == ctx->N_total) {
-        if (aborted & ABORT_ALBEDO) { SRPS_TRY(srps_albedo_finish(ctx)); SRPS_TRY(srps_depth_partial(ctx)); }
-        SRPS_TRY(srps_depth_solve(ctx));
-        SRPS_TRY(srps_energy_partial(ctx));
-        SRPS_TRY(srps_normals(ctx));
+    // a sharded pass run by the library (srps_execute_sharded) carries every rank's abort flags in its energy all-reduce:
+    // [2] albedo, [3] depth, as counts of the ranks concerned -- the same on all ranks, which therefore decide the same
+    const int others = ctx->defer_shard_checks ? ((ctx->h_pinned[2] > 0.f ? ABORT_ALBEDO : 0) | (ctx->h_pinned[3] > 0.f ? ABORT_DEPTH : 0)) : 0;
+    SRPS_TRY(persistent_aborts(ctx, &aborted, others));
+    if (aborted && (ctx->N_local == ctx->N_total || ctx->defer_shard_checks)) {
+        SRPS_TRY(redo_pass_tail(ctx, aborted));
         SRPS_TRY(report_fetch(ctx));
         SRPS_HIP(hipStreamSynchronize(ctx->stream));
         albedo_iters_collect(ctx);
@@ -1007,6 +1057,47 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
         SRPS_TRY(srps_normals(ctx));       // SRPS.cu:310-315, enqueued before the host waits for the energy
         SRPS_TRY(srps_energy_finish(ctx, &error));
         const float rel_err = fabsf(last_error - error) / fabsf(error);          // SRPS.cu:298
+        if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop = true;   // SRPS.cu:299
+        last_error = error;
+        if (energies && done < (max_outer > 0 ? max_outer : 12)) energies[done] = error;
+        ++iteration; ++done;
+        if (max_outer > 0 && done >= max_outer) stop = true;
+    } while (!stop);
+    if (n_outer) *n_outer = done;
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    return SRPS_OK;
+}
+
+// SRPS.cu:272-335 on a context that holds a shard of the images and an RCCL communicator
+int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    SRPS_REQUIRE(comm_bound(ctx), SRPS_ERR_STATE, "execute_sharded: no communicator bound to the context (srps_comm_init_rank / srps_comm_init_all / srps_set_comm)");
+    const float TOLERANCE = 5e-3f;         // SRPS.cu:85
+    const int MAX_ITERATIONS = 10;         // SRPS.cu:86
+    float last_error = NAN;                // SRPS.cu:273
+    int iteration = 1, done = 0;
+    bool stop = false;
+    Grid& G = ctx->grid;
+    struct Defer {                         // the phases leave the abort check to the end of the pass, where the ranks decide together
+        srps_ctx* c;
+        ~Defer() { c->defer_shard_checks = false; }
+    } defer{ctx};
+    ctx->defer_shard_checks = true;
+    do {
+        float error = 0.f;
+        SRPS_TRY(srps_lighting_local(ctx));                                                     // SRPS.cu:281
+        SRPS_TRY(comm_all_reduce_sum(ctx, ctx->s, (size_t)ctx->N_total * ctx->C * 4));
+        SRPS_TRY(srps_albedo_partial(ctx));                                                     // SRPS.cu:287
+        SRPS_TRY(comm_all_reduce_sum(ctx, ctx->albedo_ex, (size_t)ctx->C * G.P));
+        SRPS_TRY(srps_albedo_finish(ctx));
+        SRPS_TRY(srps_depth_partial(ctx));                                                      // SRPS.cu:293
+        if (ctx->q_ex) SRPS_TRY(comm_all_reduce_sum(ctx, ctx->q_ex, 3 * (size_t)G.P));        // a context that holds all images has q on the grid already
+        SRPS_TRY(srps_depth_solve(ctx));
+        SRPS_TRY(srps_energy_partial(ctx));
+        SRPS_TRY(sharded_energy_exchange(ctx));
+        SRPS_TRY(srps_normals(ctx));                                                            // SRPS.cu:310-315
+        SRPS_TRY(srps_energy_finish(ctx, &error));
+        const float rel_err = fabsf(last_error - error) / fabsf(error);                         // SRPS.cu:298
         if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop = true;   // SRPS.cu:299
         last_error = error;
         if (energies && done < (max_outer > 0 ? max_outer : 12)) energies[done] = error;

@@ -1,0 +1,199 @@
+// srps_comm.hip -- RCCL behind the C ABI: communicators bound to contexts and the collectives of the
+// image-sharded pass, enqueued on the context's stream.  The reference is single-GPU (its only device code is
+// cudaSetDevice(Preferences::deviceId), SRPS.cu:88); this is the seam a multi-GPU host belongs to.
+//
+// librccl is resolved at run time (dlopen), like roctx: libsrps_hip.so loads and runs on one GPU without it, and inside a
+// Python process it binds to the copy PyTorch has already loaded (same SONAME) instead of a second one.
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>
+#include "srps_internal.h"
+
+namespace srps {
+
+namespace {
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void rccl_resolve() {
+    void* h = nullptr;
+    const char* env = getenv("SRPS_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { g_rccl.why = "librccl.so not found (set SRPS_RCCL_LIB to its path)"; return; }
+    bool all = true;
+#define SRPS_SYM(field, name)                                          \
+    do {                                                               \
+        g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);         \
+        if (!g_rccl.field) { all = false; g_rccl.why = std::string("librccl does not export ") + name; } \
+    } while (0)
+    SRPS_SYM(GetUniqueId, "ncclGetUniqueId"); SRPS_SYM(CommInitRank, "ncclCommInitRank"); SRPS_SYM(CommInitAll, "ncclCommInitAll");
+    SRPS_SYM(CommDestroy, "ncclCommDestroy"); SRPS_SYM(CommCount, "ncclCommCount"); SRPS_SYM(CommUserRank, "ncclCommUserRank");
+    SRPS_SYM(AllReduce, "ncclAllReduce"); SRPS_SYM(Broadcast, "ncclBroadcast"); SRPS_SYM(Send, "ncclSend"); SRPS_SYM(Recv, "ncclRecv");
+    SRPS_SYM(GroupStart, "ncclGroupStart"); SRPS_SYM(GroupEnd, "ncclGroupEnd"); SRPS_SYM(GetErrorString, "ncclGetErrorString");
+#undef SRPS_SYM
+    g_rccl.ok = all;
+}
+
+int rccl_need() {
+    std::call_once(g_rccl_once, rccl_resolve);
+    SRPS_REQUIRE(g_rccl.ok, SRPS_ERR_UNSUPPORTED, "RCCL is not available: %s", g_rccl.why.c_str());
+    return SRPS_OK;
+}
+
+int rccl_fail(ncclResult_t r, const char* what) {
+    set_error("RCCL error %d (%s) in %s", (int)r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", what);
+    return SRPS_ERR_HIP;
+}
+#define SRPS_RCCL(expr)                                        \
+    do {                                                       \
+        ncclResult_t r_ = (expr);                              \
+        if (r_ != ncclSuccess) return rccl_fail(r_, #expr);    \
+    } while (0)
+}  // namespace
+
+bool comm_bound(const srps_ctx* ctx) { return ctx->comm != nullptr; }
+
+int comm_all_reduce_sum(srps_ctx* ctx, float* d_buf, size_t n) {
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "all_reduce: no communicator bound to the context (srps_comm_init_rank / srps_comm_init_all / srps_set_comm)");
+    if (n == 0) return SRPS_OK;
+    SRPS_RCCL(g_rccl.AllReduce(d_buf, d_buf, n, ncclFloat32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return SRPS_OK;
+}
+int comm_broadcast(srps_ctx* ctx, float* d_buf, size_t n, int root) {
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "broadcast: no communicator bound to the context");
+    if (n == 0) return SRPS_OK;
+    SRPS_RCCL(g_rccl.Broadcast(d_buf, d_buf, n, ncclFloat32, root, (ncclComm_t)ctx->comm, ctx->stream));
+    return SRPS_OK;
+}
+// the halo exchange of the strip-partitioned CG: both directions of both neighbours as ONE group (a send and a receive that wait
+// for each other must be in flight together); a null pointer / negative peer leaves that leg out
+int comm_exchange(srps_ctx* ctx, const float* send_left, float* recv_left, int left, const float* send_right, float* recv_right, int right, size_t n) {
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "exchange: no communicator bound to the context");
+    if (n == 0 || (left < 0 && right < 0)) return SRPS_OK;
+    SRPS_RCCL(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    if (left >= 0 && r == ncclSuccess) r = g_rccl.Send(send_left, n, ncclFloat32, left, (ncclComm_t)ctx->comm, ctx->stream);
+    if (left >= 0 && r == ncclSuccess) r = g_rccl.Recv(recv_left, n, ncclFloat32, left, (ncclComm_t)ctx->comm, ctx->stream);
+    if (right >= 0 && r == ncclSuccess) r = g_rccl.Send(send_right, n, ncclFloat32, right, (ncclComm_t)ctx->comm, ctx->stream);
+    if (right >= 0 && r == ncclSuccess) r = g_rccl.Recv(recv_right, n, ncclFloat32, right, (ncclComm_t)ctx->comm, ctx->stream);
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(r, "ncclSend / ncclRecv");
+    SRPS_RCCL(e);
+    return SRPS_OK;
+}
+
+void comm_release(srps_ctx* ctx) {
+    if (ctx->comm && ctx->comm_owned && g_rccl.ok) (void)g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr; ctx->comm_owned = false; ctx->comm_rank = 0; ctx->comm_world = 1;
+}
+
+}  // namespace srps
+
+using namespace srps;
+
+extern "C" {
+
+int srps_comm_unique_id(void* id) {
+    SRPS_REQUIRE(id != nullptr, SRPS_ERR_INVALID, "comm_unique_id: id is NULL");
+    static_assert(SRPS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "srps.h: SRPS_COMM_ID_BYTES must be ncclUniqueId's size");
+    SRPS_TRY(rccl_need());
+    ncclUniqueId u;
+    SRPS_RCCL(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return SRPS_OK;
+}
+
+int srps_comm_init_rank(srps_ctx* ctx, const void* id, int rank, int world) {
+    SRPS_REQUIRE(ctx != nullptr && id != nullptr, SRPS_ERR_INVALID, "comm_init_rank: null argument");
+    SRPS_REQUIRE(world >= 1 && rank >= 0 && rank < world, SRPS_ERR_INVALID, "comm_init_rank: rank %d of %d", rank, world);
+    SRPS_TRY(rccl_need());
+    SRPS_HIP(hipSetDevice(ctx->device));
+    comm_release(ctx);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    SRPS_RCCL(g_rccl.CommInitRank(&c, world, u, rank));
+    ctx->comm = c; ctx->comm_owned = true; ctx->comm_rank = rank; ctx->comm_world = world;
+    return SRPS_OK;
+}
+
+int srps_comm_init_all(srps_ctx* const* ctxs, int n) {
+    SRPS_REQUIRE(ctxs != nullptr && n >= 1 && n <= 64, SRPS_ERR_INVALID, "comm_init_all: bad arguments");
+    std::vector<int> dev(n);
+    for (int i = 0; i < n; ++i) {
+        SRPS_REQUIRE(ctxs[i] != nullptr, SRPS_ERR_INVALID, "comm_init_all: context %d is NULL", i);
+        dev[i] = ctxs[i]->device;
+        for (int k = 0; k < i; ++k)
+            SRPS_REQUIRE(dev[k] != dev[i], SRPS_ERR_INVALID, "comm_init_all: contexts %d and %d are both on device %d (RCCL takes one rank per device)", k, i, dev[i]);
+    }
+    SRPS_TRY(rccl_need());
+    std::vector<ncclComm_t> comms(n, nullptr);
+    SRPS_RCCL(g_rccl.CommInitAll(comms.data(), n, dev.data()));
+    for (int i = 0; i < n; ++i) {
+        comm_release(ctxs[i]);
+        ctxs[i]->comm = comms[i]; ctxs[i]->comm_owned = true; ctxs[i]->comm_rank = i; ctxs[i]->comm_world = n;
+    }
+    return SRPS_OK;
+}
+
+int srps_set_comm(srps_ctx* ctx, void* rccl_comm, int rank, int world) {
+    SRPS_REQUIRE(ctx != nullptr, SRPS_ERR_INVALID, "set_comm: null context");
+    if (rccl_comm == nullptr) { comm_release(ctx); return SRPS_OK; }
+    SRPS_REQUIRE(world >= 1 && rank >= 0 && rank < world, SRPS_ERR_INVALID, "set_comm: rank %d of %d", rank, world);
+    SRPS_TRY(rccl_need());
+    // the communicator must be one of the RCCL copy this library resolved, and say the same about itself
+    int cw = 0, cr = -1;
+    SRPS_RCCL(g_rccl.CommCount((ncclComm_t)rccl_comm, &cw));
+    SRPS_RCCL(g_rccl.CommUserRank((ncclComm_t)rccl_comm, &cr));
+    SRPS_REQUIRE(cw == world && cr == rank, SRPS_ERR_INVALID, "set_comm: the communicator is rank %d of %d, the caller says %d of %d", cr, cw, rank, world);
+    comm_release(ctx);
+    ctx->comm = rccl_comm; ctx->comm_owned = false; ctx->comm_rank = rank; ctx->comm_world = world;
+    return SRPS_OK;
+}
+
+int srps_comm_release(srps_ctx* ctx) {
+    SRPS_REQUIRE(ctx != nullptr, SRPS_ERR_INVALID, "comm_release: null context");
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
+    return SRPS_OK;
+}
+
+int srps_comm_info(srps_ctx* ctx, int* rank, int* world) {
+    SRPS_REQUIRE(ctx != nullptr, SRPS_ERR_INVALID, "comm_info: null context");
+    if (rank) *rank = ctx->comm ? ctx->comm_rank : 0;
+    if (world) *world = ctx->comm ? ctx->comm_world : 0;      // 0: no communicator bound
+    return SRPS_OK;
+}
+
+int srps_all_reduce(srps_ctx* ctx, const char* which) {
+    SRPS_REQUIRE(ctx != nullptr && which != nullptr, SRPS_ERR_INVALID, "all_reduce: null argument");
+    SRPS_HIP(hipSetDevice(ctx->device));
+    void* p = nullptr; size_t n = 0;
+    SRPS_TRY(srps_exchange(ctx, which, &p, &n));
+    return comm_all_reduce_sum(ctx, (float*)p, n);
+}
+
+}  // extern "C"

@@ -67,6 +67,8 @@ struct Grid {
     bool M_valid = false;         // d_M holds the tensor of the last assembly
     float cx = 0.f, cy = 0.f;     // principal point used by the last assembly (xx = j - cx, yy = i - cy)
     float* d_x = nullptr;         // [plane] z on the grid
+    float* d_x2 = nullptr;        // [plane] the resident CG stores its result here and the two planes swap roles: the iterate a persistent
+                                  // launch started from survives it (an aborted launch is repeated by the streaming kernels from exactly that iterate)
     float* d_r = nullptr;         // [plane] rhs, then residual
     float* d_r2 = nullptr;        // [plane] second residual plane of the one-launch CG step
     float* d_p = nullptr;         // [2][plane] search direction, double-buffered by step parity
@@ -148,6 +150,12 @@ struct srps_ctx {
     int spin_budget_ms = 200;        // a persistent launch whose waits are not all served within this time aborts (device_utils.h
                                      // SpinState); the host then repeats the phase with the streaming kernels
     int persistent_fallbacks = 0;    // aborted persistent launches so far (option "persistent_fallbacks", read-only)
+    // multi-GPU (srps_comm.hip): the RCCL communicator of the image-sharded pass
+    void* comm = nullptr;            // ncclComm_t
+    bool comm_owned = false;         // created by srps_comm_init_rank / srps_comm_init_all (destroyed with the context), not borrowed (srps_set_comm)
+    int comm_rank = 0, comm_world = 1;
+    bool defer_shard_checks = false; // srps_execute_sharded: a shard's phases do not look at the abort flags themselves; the ranks decide together at the end of the pass
+    bool x_swapped = false;          // the resident CG launched since the abort flags were last looked at swapped grid.d_x and grid.d_x2
     int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at
     int cg_one_sync = 1;             // resident CG: r.r from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per step)
     int cg_fused_step = 1;           // streaming depth CG: the whole step in one launch (kernels_march.hip MODE 3) instead of operator + update
@@ -286,6 +294,13 @@ int march_cg_step(srps_ctx* ctx, int k);
 bool cg_fused_step(const srps_ctx* ctx);      // the streaming CG runs one launch per step
 int cg_flush_x(srps_ctx* ctx);
 int march_recompute_channels(const srps_ctx* ctx);
+
+// ---- RCCL (srps_comm.hip) -------------------------------------------------------------------
+bool comm_bound(const srps_ctx* ctx);
+int comm_all_reduce_sum(srps_ctx* ctx, float* d_buf, size_t n);      // in place, on the context's stream
+int comm_broadcast(srps_ctx* ctx, float* d_buf, size_t n, int root);
+int comm_exchange(srps_ctx* ctx, const float* send_left, float* recv_left, int left, const float* send_right, float* recv_right, int right, size_t n);
+void comm_release(srps_ctx* ctx);
 
 // ---- generic CSR (kernels_csr.hip) --------------------------------------------------------
 int csr_spmv(srps_ctx* ctx, const int* rp, const int* ci, const float* v, int n_rows, int n_cols, int nnz,

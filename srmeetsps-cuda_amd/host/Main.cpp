@@ -1,5 +1,7 @@
 // Main.cpp -- command line of the reference (Main.cpp:9-44): --dstype|-t, --dsloc|-d, --device|-g,
-// --blockx|-x, --blocky|-y, --help|-h|--usage; plus --outdir|-o and --no-output for the result dumps, --images, --exclusive.
+// --blockx|-x, --blocky|-y, --help|-h|--usage; plus --outdir|-o and --no-output for the result dumps, --images, --exclusive,
+// --gpus|-n N (images sharded over N devices of this node, RCCL inside the library) and --sharded.
+#include <algorithm>
 #include <cstring>
 #include <iostream>
 #include <map>
@@ -17,13 +19,15 @@ static void print_message() {
                  "\t-o, --outdir (value:.)\n\t\tdirectory for zs_init/z_init/s/rho/z/N .mat dumps\n"
                  "\t--no-output\n\t\tdo not write .mat dumps\n"
                  "\t--images\n\t\twrite the reference's three views (normals initial/current, albedo) and the depth map as PNG\n"
-                 "\t--exclusive\n\t\tnothing else uses the device: plain instead of cooperative launches of the persistent kernels\n";
+                 "\t--exclusive\n\t\tnothing else uses the device: plain instead of cooperative launches of the persistent kernels\n"
+                 "\t-n, --gpus (value:1)\n\t\tshard the images over this many devices of the node, starting at --device (RCCL all-reduce of the partial sums)\n"
+                 "\t--sharded\n\t\ttake the communicator path even with one GPU (diagnostic)\n";
 }
 
 int main(int argc, char* argv[]) {
     static const std::map<std::string, std::string> alias = {{"h", "help"}, {"usage", "help"}, {"t", "dstype"}, {"d", "dsloc"}, {"g", "device"},
-                                                            {"x", "blockx"}, {"y", "blocky"}, {"o", "outdir"}};
-    std::map<std::string, std::string> opt = {{"dstype", "matlab"}, {"device", "0"}, {"blockx", "256"}, {"blocky", "4"}, {"outdir", "."}};   // Main.cpp:11-16
+                                                            {"x", "blockx"}, {"y", "blocky"}, {"o", "outdir"}, {"n", "gpus"}};
+    std::map<std::string, std::string> opt = {{"dstype", "matlab"}, {"device", "0"}, {"blockx", "256"}, {"blocky", "4"}, {"outdir", "."}, {"gpus", "1"}};   // Main.cpp:11-16
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a.rfind("--", 0) == 0) a = a.substr(2); else if (a.rfind("-", 0) == 0) a = a.substr(1); else continue;
@@ -33,7 +37,7 @@ int main(int argc, char* argv[]) {
         if (eq != std::string::npos) { key = a.substr(0, eq); val = a.substr(eq + 1); has_val = true; }
         auto al = alias.find(key);
         if (al != alias.end()) key = al->second;
-        if (key == "help" || key == "no-output" || key == "images" || key == "exclusive") { opt[key] = "true"; continue; }
+        if (key == "help" || key == "no-output" || key == "images" || key == "exclusive" || key == "sharded") { opt[key] = "true"; continue; }
         if (!has_val && i + 1 < argc) val = argv[++i];
         if (val.size() >= 2 && val.front() == '"' && val.back() == '"') val = val.substr(1, val.size() - 2);
         opt[key] = val;
@@ -49,6 +53,8 @@ int main(int argc, char* argv[]) {
     Preferences::writeOutputs = !opt.count("no-output");
     Preferences::writeImages = opt.count("images") > 0;
     Preferences::exclusiveDevice = opt.count("exclusive") > 0;
+    Preferences::numGpus = std::max(1, std::stoi(opt["gpus"]));
+    Preferences::forceSharded = opt.count("sharded") > 0;
     try {
         if (opt["dstype"] == "matlab") {                            // Main.cpp:31-36
             MatFileDataHandler dh;

@@ -7,6 +7,8 @@ class SRPS {
 private:
     DataHandler* dh;
     srps_ctx* ctx = nullptr;
+    std::vector<srps_ctx*> shard_ctx;     // --gpus N: one context per device (shard_ctx[0] == ctx)
+    void execute_sharded(const std::vector<float>& zs, const std::vector<float>& z_full, int n_gpus);
 
 public:
     SRPS(DataHandler& dh);

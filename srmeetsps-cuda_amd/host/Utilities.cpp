@@ -14,6 +14,8 @@ int Preferences::deviceId = 0;
 bool Preferences::writeOutputs = true;
 bool Preferences::writeImages = false;
 bool Preferences::exclusiveDevice = false;
+int Preferences::numGpus = 1;
+bool Preferences::forceSharded = false;
 std::string Preferences::outDir = ".";
 
 void DataHandler::freeMemory() {

@@ -24,6 +24,10 @@ struct Preferences {
     static bool writeOutputs;     // new: dump s/rho/z/N .mat after every pass (SRPS.cu:330-333)
     static bool writeImages;      // new: write the three imshow views (SRPS.cu:319-327) as PNG files
     static bool exclusiveDevice;  // new: the device is not shared (srps option "exclusive_device")
+    static int numGpus;           // new: --gpus N: the images are sharded over devices deviceId .. deviceId + N - 1 of this node (one
+                                  // thread and one context per device, RCCL all-reduces inside the library); the seam is the reference's
+                                  // cudaSetDevice(Preferences::deviceId), SRPS.cu:88
+    static bool forceSharded;     // new: --sharded: take the communicator path even on one GPU (a one-rank communicator; diagnostic)
     static std::string outDir;
 
 private:

@@ -1,0 +1,140 @@
+"""RCCL behind the C ABI (include/srps.h "multi-GPU through the boundary"): communicators bound to contexts, the all-reduces of
+the image-sharded pass inside the library, the C++ host's --gpus / --sharded path.  A one-GPU box can only form one-rank
+communicators (RCCL takes one rank per device): they run the real ncclAllReduce calls on the real buffers and streams, and
+the results must be those of srps_execute bit for bit.  The N > 1 arithmetic of the same phases is covered by the gloo tests
+(tests/test_distributed_gloo.py, tests/test_gpu_distributed.py) and at volume by tests/test_gpu_full_size.py."""
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(pkg, seed=51):
+    return pkg.synth.make_scene(96, 80, 2, 5, seed=seed, mask_kind="ragged")
+
+
+def _run(pkg, dh, how):
+    ctx = pkg.Context(device_id=0)
+    if how == "init_all":
+        pkg.Context.comm_init_all([ctx])
+    elif how == "init_rank":
+        ctx.comm_init_rank(pkg.Context.comm_unique_id(), 0, 1)
+    ctx.setup(dh)
+    en = ctx.execute(0) if how == "plain" else ctx.execute_sharded(0)
+    out = dict(en=en, z=ctx.get("z"), rho=ctx.get("rho"), s=ctx.get("s"), N=ctx.get("N"), it=ctx.last_cg_iterations(), comm=ctx.comm_info())
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("how", ["init_all", "init_rank"])
+def test_sharded_loop_on_a_one_rank_communicator_equals_execute(pkg, how):
+    dh = pkg.DataHandler.from_scene(_scene(pkg))
+    a = _run(pkg, dh, "plain")
+    b = _run(pkg, dh, how)
+    assert a["comm"] == (0, 0) and b["comm"] == (0, 1)
+    assert a["en"] == b["en"] and len(a["en"]) >= 2
+    for k in ("z", "rho", "s", "N"):
+        np.testing.assert_array_equal(a[k], b[k])
+    assert a["it"] == b["it"]
+
+
+def test_all_reduce_entry_point_and_errors(pkg):
+    import torch
+    from importlib import import_module
+    api = import_module("srmeetsps-cuda_amd.api")
+    dh = pkg.DataHandler.from_scene(_scene(pkg, 52))
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(dh)
+    with pytest.raises(pkg.SRPSError) as ei:
+        ctx.all_reduce("albedo")                         # no communicator bound
+    assert ei.value.code == 3
+    with pytest.raises(pkg.SRPSError) as ei:
+        ctx.execute_sharded(1)
+    assert ei.value.code == 3
+    pkg.Context.comm_init_all([ctx])
+    ctx.lighting_local(); ctx.all_reduce("s")
+    ctx.albedo_partial()
+    ptr, n = ctx.exchange_ptr("albedo")
+    before = torch.as_tensor(api._DevView(ptr, n), device="cuda:0").clone()
+    ctx.all_reduce("albedo"); ctx.synchronize()
+    after = torch.as_tensor(api._DevView(ptr, n), device="cuda:0")
+    assert torch.equal(before, after)                    # the sum over one rank
+    with pytest.raises(pkg.SRPSError):
+        ctx.all_reduce("nonsense")
+    # two contexts on one device cannot form a communicator: refused by the library, not by a hang inside RCCL
+    c2 = pkg.Context(device_id=0)
+    with pytest.raises(pkg.SRPSError) as ei:
+        pkg.Context.comm_init_all([ctx, c2])
+    assert ei.value.code == 1 and "one rank per device" in str(ei.value)
+    c2.close()
+    ctx.comm_release()
+    assert ctx.comm_info() == (0, 0)
+    ctx.close()
+
+
+def test_a_persistent_abort_in_the_sharded_loop_repeats_the_pass_and_matches_streaming(pkg):
+    """the sharded loop defers the look at the abort flags to the end of the pass (they travel with the energy term): a depth
+    CG whose waits cannot be served (a 1 ms budget against a co-tenant holding CUs) gives up, the pass's tail is repeated by
+    the streaming kernels from the iterate the launch started from -- the result is that of a context that streamed from the
+    start, bit for bit"""
+    import ctypes
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tools", "libcu_holder.so")
+    if not os.path.exists(so):
+        pytest.skip("tools/libcu_holder.so is not built")
+    import time
+    holder = ctypes.CDLL(so)
+    sc = pkg.synth.make_scene(1024, 1024, 4, 3, seed=53, mask_kind="full")      # 256 tiles of 256 x 32: every CU
+    dh = pkg.DataHandler.from_scene(sc)
+
+    def run(resident, with_holder):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("cg_resident", resident); ctx.set_option("albedo_persistent", 0)
+        ctx.set_option("spin_budget_ms", 40)
+        pkg.Context.comm_init_all([ctx])
+        ctx.setup(dh)
+        if with_holder:
+            assert holder.cu_holder_launch(64, 1500, 16) == 0   # 64 blocks that pin LDS on a CU each for 1.5 s, on another stream
+            time.sleep(0.2)
+        en = ctx.execute_sharded(1)
+        if with_holder:
+            assert holder.cu_holder_wait() == 0
+        out = dict(en=en, z=ctx.get("z"), rho=ctx.get("rho"), fb=ctx.get_option("persistent_fallbacks"), it=ctx.last_cg_iterations()["depth"])
+        ctx.close()
+        torch.cuda.synchronize()
+        return out
+    ref = run(0, False)
+    got = run(1, True)
+    assert got["fb"] == 1 and ref["fb"] == 0
+    assert got["it"] == ref["it"] == 101
+    assert got["en"] == ref["en"]
+    np.testing.assert_array_equal(got["z"], ref["z"]); np.testing.assert_array_equal(got["rho"], ref["rho"])
+
+
+def test_command_line_program_sharded_path_equals_one_gpu_path(pkg, tmp_path):
+    """`srps --sharded` (C++ host: one context per device on its own thread, ncclCommInitAll, srps_execute_sharded) writes the
+    same s / rho / z / N as `srps` on the same file; --gpus beyond the devices of the box is an error message, not a crash"""
+    import scipy.io
+    pkg.host.load()
+    sc = pkg.synth.make_scene(40, 48, 2, 4, seed=41, mask_kind="ragged")
+    h, w = sc.h, sc.w
+    I4 = np.transpose(sc.I.reshape(sc.n_img, sc.n_ch, w, h), (3, 2, 1, 0)).astype(np.float64)
+    path = str(tmp_path / "scene.mat")
+    scipy.io.savemat(path, {"I": I4, "K": sc.K.reshape(3, 3).T.astype(np.float64), "mask": sc.mask.reshape(w, h).T.astype(np.uint8),
+                            "sf": float(sc.sf), "z0": sc.z0.reshape(w // sc.sf, h // sc.sf).T.astype(np.float64)}, do_compression=True)
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    one = subprocess.run([pkg.host.CLI, f"--dsloc={path}", "-o", str(tmp_path / "a")], capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr
+    sh = subprocess.run([pkg.host.CLI, f"--dsloc={path}", "-o", str(tmp_path / "b"), "--sharded", "--gpus", "1"], capture_output=True, text=True)
+    assert sh.returncode == 0, sh.stderr
+    assert "Images sharded over 1 GPU" in sh.stdout and sh.stdout.count("Iteration") == one.stdout.count("Iteration") and "Done!" in sh.stdout
+    for name in ("s.mat", "rho.mat", "z.mat", "N.mat", "z_init.mat", "zs_init.mat"):
+        np.testing.assert_array_equal(scipy.io.loadmat(str(tmp_path / "a" / name))["x"], scipy.io.loadmat(str(tmp_path / "b" / name))["x"])
+    import torch
+    n_dev = torch.cuda.device_count()
+    bad = subprocess.run([pkg.host.CLI, f"--dsloc={path}", "--no-output", "--gpus", str(n_dev + 1)], capture_output=True, text=True)
+    assert bad.returncode == 1 and "out of range" in bad.stderr
