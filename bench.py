@@ -135,7 +135,8 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         if isa and ikey in isa:
             clk = isa[ikey]["valu_issue_clocks_per_wave_step"] * isa[ikey]["waves_per_simd"]
             floor_us = clk / (isa[ikey]["GHz"] * 1e3)
-            issue = {"valu_issue_clocks_per_simd_step": clk, "issue_floor_us_per_step": floor_us, "kernel": isa[ikey]["kernel"],
+            issue = {"kind": "static_estimate: the emitted instruction stream priced with measured issue costs per class, both branches of the direct-sum path counted; not a counter",
+                     "valu_issue_clocks_per_simd_step": clk, "issue_floor_us_per_step": floor_us, "kernel": isa[ikey]["kernel"],
                      "measured_us_per_step": launch_us / 101.0, "issue_frac": floor_us / (launch_us / 101.0), "source": isa[ikey]["source"]}
         out["roofline"] = {"bound": "valu", "kernel": "k_cg_resident (" + ("mask-free body: every tile lies inside the mask" if rect else "general body") +
                                                       "): residual pass + the whole truncated CG (101 steps) in one persistent launch",
@@ -177,6 +178,9 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the streaming-CG legs (2048^2 streaming, 4096^2 sf 2)")
     ap.add_argument("--apply-mode", type=int, default=0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="srps_set_option before setup (A/B runs)")
+    ap.add_argument("--comm", choices=["library", "torch"], default="library",
+                    help="N > 1: the all-reduces of a pass as ncclAllReduce inside libsrps_hip.so (srps_execute_sharded; default) or as "
+                         "torch.distributed.all_reduce on views of the library's exchange buffers")
     args = ap.parse_args()
 
     import torch
@@ -218,15 +222,41 @@ def main():
     for kv in args.option:
         name, val = kv.split("=")
         ctx.set_option(name, int(val))
+    # N > 1: RCCL behind the C ABI -- rank 0 makes the communicator id (ncclGetUniqueId through the library), torch.distributed only
+    # carries its 128 bytes to the other ranks (and the timing barrier); every rank joins with its context.  Should that fail on
+    # any rank (no librccl), all ranks fall back to torch.distributed's collectives together.
+    comm_kind = "none"
+    if world > 1:
+        comm_kind = "torch"
+        if args.comm == "library" and not shared_gpu:
+            ok = 1
+            try:
+                uid = [pkg.Context.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init_rank(uid[0], rank, world)
+            except Exception as exc:
+                print(f"bench.py rank {rank}: library communicator failed ({exc}); torch.distributed collectives instead", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm_kind = "library"
+            elif ok:
+                ctx.comm_release()
     ctx.setup(dh)
     dims = ctx.dims()
 
     def all_reduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    ar = all_reduce if world > 1 else None
+    ar = all_reduce if (world > 1 and comm_kind == "torch") else None
+
+    def solve(max_outer=None):
+        if comm_kind == "library":
+            return ctx.execute_sharded(max_outer or 0)
+        return pkg.alternating_loop(ctx, ar, max_outer=max_outer)
 
     def step():
-        return pkg.alternating_loop(ctx, ar, max_outer=1)[0]
+        return solve(1)[0]
 
     for _ in range(args.warmup):
         step()
@@ -241,14 +271,22 @@ def main():
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    cg_iters = 101 * args.steps
+    # the rate is that of the steps the device executed: a CG that stopped early or a pass that fell back to the streaming kernels
+    # would not be the workload named below
+    depth_steps = ctx.last_cg_iterations()["depth"]
+    fallbacks = ctx.get_option("persistent_fallbacks")
+    assert depth_steps == 101, f"the depth CG ran {depth_steps} steps, not the 101 of devicecalls.cu:252"
+    cg_iters = depth_steps * args.steps
     out = {
         "metric": "cg_iterations_per_sec", "value": cg_iters / dt, "unit": "cg_iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic full-mask HR grid {H}x{W}, sf {args.sf}, {args.images} images/GPU x {world} GPU, 3 channels",
                    "hr_grid": [H, W], "sf": args.sf, "images_per_gpu": args.images, "images_total": n_total,
-                   "unknowns": dims["npix"], "cg_steps_per_solve": 101,
+                   "unknowns": dims["npix"], "cg_steps_per_solve": depth_steps, "persistent_fallbacks": fallbacks,
+                   "exclusive_device": ctx.get_option("exclusive_device"),       # 1: plain launches of the persistent kernels (the library's default is the cooperative launch: ~26 us per pass more)
+                   "comm": {"none": "none (1 GPU)", "library": "ncclAllReduce inside libsrps_hip.so (srps_execute_sharded), communicator from srps_comm_init_rank",
+                            "torch": "torch.distributed.all_reduce on views of the library's exchange buffers"}[comm_kind],
                    "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, replicated CG"
                                    + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},
         "energies": energies,
@@ -282,6 +320,21 @@ def main():
                                                  workload="depth CG on a synthetic full-mask 4096x4096 HR grid, sf 2 (16.8 M unknowns; 2 images: the CG does not depend on their number)")
             c4.close()
             del sc4
+            # the headline's mask is the best case of the resident kernel (every tile inside the mask: the body without structure
+            # bits); any other mask -- the reference's own data -- takes the general body.  An ellipse in the same frame:
+            scg = pkg.synth.make_scene(H, W, args.sf, 2, seed=1234 + 6, mask_kind="ellipse")
+            cg_ = pkg.Context(device_id=local_rank)
+            cg_.set_stream(stream.cuda_stream)
+            cg_.set_option("exclusive_device", 1)
+            cg_.setup(pkg.DataHandler.from_scene(scg))
+            pkg.alternating_loop(cg_, None, max_outer=1)
+            gd = cg_.dims()
+            legs["general_mask_2048"] = dict(cg_legs(pkg, cg_, H, W, args.sf, resident_expected=False, solves=5),
+                                             resident=cg_.get_option("cg_resident_active"), rect_body=cg_.get_option("cg_resident_rect_active"),
+                                             unknowns=gd["npix"], grid=[gd["grid_h"], gd["grid_w"]], persistent_fallbacks=cg_.get_option("persistent_fallbacks"),
+                                             workload=f"depth CG on an elliptical mask (semi-axes 0.45 h x 0.45 w) in the {H}x{W} frame, sf {args.sf}: the resident kernel's general body")
+            cg_.close()
+            del scg
             # The headline workload with its images rounded to 8 bits, i.e. as the reference's image-folder loader delivers them
             # (k / 255.f, Utilities.cpp:343): the library then also keeps them as bytes and the two image sweeps of a pass read a
             # quarter of the bytes (option "image_store"; results identical bit for bit to the float store on the same input).
@@ -300,7 +353,9 @@ def main():
                 pkg.alternating_loop(c8, None, max_outer=1)
             torch.cuda.synchronize()
             d8 = time.perf_counter() - t8
-            legs["images_8bit"] = {"cg_iterations_per_sec": 101 * args.steps / d8, "ms_per_step": 1e3 * d8 / args.steps,
+            it8 = c8.last_cg_iterations()["depth"]
+            assert it8 == 101 and c8.get_option("persistent_fallbacks") == 0, (it8, c8.get_option("persistent_fallbacks"))
+            legs["images_8bit"] = {"cg_iterations_per_sec": it8 * args.steps / d8, "ms_per_step": 1e3 * d8 / args.steps,
                                    "image_store_bytes_active": c8.get_option("image_store_bytes_active"),
                                    "workload": "the headline workload with 8-bit images (k / 255.f, the reference's image-folder input): image sweeps read bytes"}
             c8.close()
@@ -359,7 +414,7 @@ def main():
         torch.cuda.synchronize()
         if dist: dist.barrier()
         t0 = time.perf_counter()
-        en = pkg.alternating_loop(ctx, ar)
+        en = solve()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if rank == 0:

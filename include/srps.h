@@ -192,12 +192,17 @@ typedef struct srps_problem {
     const float* I;         /* [n_images][n_channels][h*w] or NULL (then srps_upload_image) */
     const float* zs_lr;     /* [(h/sf)*(w/sf)] */
     const float* z_full;    /* [h*w] */
+    const unsigned char* I_u8;  /* [n_images][n_channels][h*w] or NULL: the images as the BYTES the image-folder loader read
+                             * (Utilities.cpp:343 forms I = byte / 255.f from them); then I must be NULL.  A quarter of the bytes cross
+                             * PCIe, the floats are formed on the device with the loader's expression (same bits), and the bytes
+                             * are what the context's 8-bit image store keeps (option "image_store"). */
 } srps_problem;
 
 /* replaces: SRPS.cu:100-270 (mask indices, KT/Dx/Dy structure, compaction, s/rho init,
  * meshgrid, first normals). */
 int srps_setup(srps_ctx* ctx, const srps_problem* prob);
 int srps_upload_image(srps_ctx* ctx, int local_index, const float* host_image /* [c][h*w] */);
+int srps_upload_image_u8(srps_ctx* ctx, int local_index, const unsigned char* host_image /* [c][h*w] bytes; I = byte / 255.f */);
 int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, int* n_images, int* n_channels);
 
 /* one-GPU phases on the context's own state; each replaces the call at the cited line */

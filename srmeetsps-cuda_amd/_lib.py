@@ -35,7 +35,7 @@ class Problem(C.Structure):
         ("h", C.c_int), ("w", C.c_int), ("n_channels", C.c_int), ("n_images", C.c_int),
         ("n_images_total", C.c_int), ("image_offset", C.c_int), ("sf", C.c_int),
         ("mask", C.POINTER(C.c_float)), ("K", C.POINTER(C.c_float)), ("I", C.POINTER(C.c_float)),
-        ("zs_lr", C.POINTER(C.c_float)), ("z_full", C.POINTER(C.c_float)),
+        ("zs_lr", C.POINTER(C.c_float)), ("z_full", C.POINTER(C.c_float)), ("I_u8", C.POINTER(C.c_ubyte)),
     ]
 
 
@@ -104,6 +104,7 @@ def load():
         "srps_depth_operator_apply": (i, [vp, p, i, p]),
         "srps_setup": (i, [vp, C.POINTER(Problem)]),
         "srps_upload_image": (i, [vp, i, fp]),
+        "srps_upload_image_u8": (i, [vp, i, C.POINTER(C.c_ubyte)]),
         "srps_dims": (i, [vp, ip, ip, ip, ip, ip, ip]),
         "srps_lighting": (i, [vp]),
         "srps_albedo": (i, [vp]),

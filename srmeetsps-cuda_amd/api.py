@@ -51,6 +51,8 @@ class DataHandler:
     z0_n: int = 1
     zs_lr: np.ndarray | None = None
     z_full: np.ndarray | None = None
+    I_u8: np.ndarray | None = None   # [I_n][I_c][I_h*I_w] uint8: the images as the bytes the image-folder loader read (I = byte / 255.f,
+                                     # Utilities.cpp:343); when set, the bytes are what crosses PCIe and I may be None
 
     @property
     def z0_h(self):
@@ -211,16 +213,23 @@ class Context:
     def setup(self, dh: DataHandler):
         assert dh.zs_lr is not None and dh.z_full is not None, "run the depth pre-processing first"
         mask = _host(dh.mask); K = _host(dh.K); zs = _host(dh.zs_lr); zf = _host(dh.z_full)
-        I = _host(dh.I) if dh.I is not None else None
-        n_loc = dh.I_n if dh.I_n else (I.shape[0] if I is not None else 0)
+        I8 = np.ascontiguousarray(dh.I_u8, dtype=np.uint8) if getattr(dh, "I_u8", None) is not None else None
+        I = _host(dh.I) if (dh.I is not None and I8 is None) else None
+        n_loc = dh.I_n if dh.I_n else (I.shape[0] if I is not None else (I8.shape[0] if I8 is not None else 0))
         n_tot = dh.I_n_total if dh.I_n_total else n_loc
         pr = Problem(dh.I_h, dh.I_w, dh.I_c, n_loc, n_tot, dh.image_offset, int(dh.sf),
-                     _fptr(mask), _fptr(K), _fptr(I) if I is not None else None, _fptr(zs), _fptr(zf))
-        self._keep = [mask, K, zs, zf, I]
+                     _fptr(mask), _fptr(K), _fptr(I) if I is not None else None, _fptr(zs), _fptr(zf),
+                     I8.ctypes.data_as(C.POINTER(C.c_ubyte)) if I8 is not None else None)
+        self._keep = [mask, K, zs, zf, I, I8]
         check(self.lib.srps_setup(self.h, C.byref(pr)))
         self._keep = []
 
     def upload_image(self, local_index: int, image_host):
+        a = np.asarray(image_host)
+        if a.dtype == np.uint8:                      # the bytes of the image loader: I = byte / 255.f is formed on the device
+            a = np.ascontiguousarray(a)
+            check(self.lib.srps_upload_image_u8(self.h, local_index, a.ctypes.data_as(C.POINTER(C.c_ubyte))))
+            return
         a = _host(image_host)
         check(self.lib.srps_upload_image(self.h, local_index, _fptr(a)))
 

@@ -35,6 +35,66 @@ int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask,
     return SRPS_OK;
 }
 
+// the same for a batch of images (blockIdx.z), four pixels per thread when the rows of the output are 16-byte aligned
+template <int V>
+__global__ __launch_bounds__(256) void k_gather_images(const float* __restrict__ full, const int* __restrict__ imask, int P, size_t hw, int C, float* __restrict__ out) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float* src = full + ((size_t)n * C + c) * hw;
+    float* dst = out + ((size_t)n * C + c) * P;
+    if (V == 4) {
+        const int P4 = P >> 2;
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < P4; t += gridDim.x * blockDim.x) {
+            const int4 ix = reinterpret_cast<const int4*>(imask)[t];
+            reinterpret_cast<float4*>(dst)[t] = make_float4(src[ix.x], src[ix.y], src[ix.z], src[ix.w]);
+        }
+    } else {
+        for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) dst[p] = src[imask[p]];
+    }
+}
+int launch_gather_images(hipStream_t st, const float* d_full, const int* d_imask, int P, int C, size_t hw, int n_img, float* d_out) {
+    if (n_img <= 0) return SRPS_OK;
+    const bool vec = (P % 4 == 0) && ((uintptr_t)d_out % 16 == 0) && ((uintptr_t)d_imask % 16 == 0);
+    const int nb = std::max(1, std::min(cdiv(vec ? P / 4 : P, 256), 2048));
+    if (vec) hipLaunchKernelGGL((k_gather_images<4>), dim3(nb, C, n_img), dim3(256), 0, st, d_full, d_imask, P, hw, C, d_out);
+    else hipLaunchKernelGGL((k_gather_images<1>), dim3(nb, C, n_img), dim3(256), 0, st, d_full, d_imask, P, hw, C, d_out);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+// images handed over as the bytes the image-folder loader read: the float is the loader's own expression byte / 255.f
+// (Utilities.cpp:343), formed here; the bytes themselves go to the 8-bit image store (d_out8, may be null)
+template <int V>
+__global__ __launch_bounds__(256) void k_gather_images_u8(const unsigned char* __restrict__ full, const int* __restrict__ imask, int P, size_t hw, int C,
+                                                          float* __restrict__ out, unsigned char* __restrict__ out8) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const unsigned char* src = full + ((size_t)n * C + c) * hw;
+    float* dst = out + ((size_t)n * C + c) * P;
+    unsigned char* dst8 = out8 ? out8 + ((size_t)n * C + c) * P : nullptr;
+    if (V == 4) {
+        const int P4 = P >> 2;
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < P4; t += gridDim.x * blockDim.x) {
+            const int4 ix = reinterpret_cast<const int4*>(imask)[t];
+            const unsigned b0 = src[ix.x], b1 = src[ix.y], b2 = src[ix.z], b3 = src[ix.w];
+            reinterpret_cast<float4*>(dst)[t] = make_float4((float)b0 / 255.f, (float)b1 / 255.f, (float)b2 / 255.f, (float)b3 / 255.f);
+            if (dst8) reinterpret_cast<unsigned*>(dst8)[t] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+    } else {
+        for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+            const unsigned b = src[imask[p]];
+            dst[p] = (float)b / 255.f;
+            if (dst8) dst8[p] = (unsigned char)b;
+        }
+    }
+}
+int launch_gather_images_u8(hipStream_t st, const unsigned char* d_full, const int* d_imask, int P, int C, size_t hw, int n_img, float* d_out, unsigned char* d_out8) {
+    if (n_img <= 0) return SRPS_OK;
+    const bool vec = (P % 4 == 0) && ((uintptr_t)d_out % 16 == 0) && ((uintptr_t)d_imask % 16 == 0) && ((uintptr_t)d_out8 % 4 == 0);
+    const int nb = std::max(1, std::min(cdiv(vec ? P / 4 : P, 256), 2048));
+    if (vec) hipLaunchKernelGGL((k_gather_images_u8<4>), dim3(nb, C, n_img), dim3(256), 0, st, d_full, d_imask, P, hw, C, d_out, d_out8);
+    else hipLaunchKernelGGL((k_gather_images_u8<1>), dim3(nb, C, n_img), dim3(256), 0, st, d_full, d_imask, P, hw, C, d_out, d_out8);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
+}
+
 // The 8-bit image store.  d_out == null: only look whether every sample is k / 255.f for a byte k (bit for bit -- a negative
 // zero is not); otherwise also write the bytes.  A block that sees the flag raised stops: float-valued images cost next to nothing.
 __global__ __launch_bounds__(256) void k_pack_bytes(const float* __restrict__ I, size_t n4, unsigned char* __restrict__ out, int* __restrict__ inexact) {
@@ -371,14 +431,8 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
     const bool rec = ctx->tensor_recompute && (C == 1 || C == 3) && cx == cx && cy == cy;
     float* Gp = nullptr;
     if (rec) {
-        if (G.G_planes < (size_t)C) {
-            if (G.d_G) SRPS_HIP(hipFree(G.d_G));
-            G.d_G = nullptr; G.G_planes = 0;
-            SRPS_HIP(hipMalloc((void**)&G.d_G, (size_t)C * G.plane * sizeof(float)));
-            SRPS_HIP(hipMemsetAsync(G.d_G, 0, (size_t)C * G.plane * sizeof(float), ctx->stream));     // zero outside the mask
-            G.G_planes = C;
-        }
-        Gp = G.d_G;
+        SRPS_REQUIRE(G.G_planes >= (size_t)C, SRPS_ERR_STATE, "depth assembly: the grid holds %zu g planes, %d channels need %d", G.G_planes, C, C);
+        Gp = G.d_G;                                        // [3][plane] of the grid's arena, zero outside the mask since the bind
         hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset,
                            d_ssum ? G.d_tconsts + 64 : (float*)nullptr);
         G.tensor_channels = C; G.cx = cx; G.cy = cy;
@@ -386,7 +440,9 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
         G.tensor_channels = 0;
     }
     // the stored tensor is only needed by the simple operator kernel and by the stored-tensor marching form
-    float* Mp = (rec && use_march(ctx) && !ctx->keep_stored_tensor) ? nullptr : G.d_M;
+    const bool want_M = !(rec && use_march(ctx) && !ctx->keep_stored_tensor);
+    if (want_M) SRPS_TRY(grid_need_M(ctx));           // allocated (and zeroed) when the first assembly asks for it
+    float* Mp = want_M ? G.d_M : nullptr;
     G.M_valid = Mp != nullptr;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy | (uintptr_t)d_dz) % 16 == 0);
     if (d_ssum) {

@@ -2,6 +2,7 @@
 // SRPS::execute, SRPS.cu:100-270), the phase operators and the alternating loop (SRPS.cu:272-335).
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -84,64 +85,48 @@ static void dfree(T*& p) {
     p = nullptr;
 }
 
+// The grid's arrays are carved out of one arena (Grid::arena), which outlives a release: a later bind that needs no more than it
+// holds allocates nothing.  grid_free gives the arena back (srps_destroy).
 static void grid_release(Grid& G) {
-    dfree(G.d_gofp); dfree(G.d_imask); dfree(G.d_flags); dfree(G.d_lr_index); dfree(G.d_tile_cls[0]); dfree(G.d_tile_cls[1]); dfree(G.d_tile_cls[2]);
-    dfree(G.d_M); dfree(G.d_q); dfree(G.d_G); dfree(G.d_tconsts); G.G_planes = 0; G.tensor_channels = 0; dfree(G.d_x); dfree(G.d_x2); dfree(G.d_r); dfree(G.d_p); dfree(G.d_w); dfree(G.d_w2); dfree(G.d_r2); dfree(G.d_part4); dfree(G.d_save);
-    dfree(G.d_pw_part); dfree(G.d_rr_part); dfree(G.d_misc_part); G.d_scal = nullptr;      // d_scal lives in the context's report record
+    G.d_gofp = nullptr; G.d_imask = nullptr; G.d_imasks = nullptr; G.d_flags = nullptr; G.d_lr_index = nullptr;
+    G.d_tile_cls[0] = G.d_tile_cls[1] = G.d_tile_cls[2] = nullptr;
+    dfree(G.d_M);                                         // the stored tensor is allocated on demand (grid_need_M), outside the arena
+    G.d_q = nullptr; G.d_G = nullptr; G.d_tconsts = nullptr; G.G_planes = 0; G.tensor_channels = 0;
+    G.d_x = G.d_x2 = G.d_r = G.d_r2 = G.d_p = G.d_w = G.d_w2 = G.d_save = nullptr; G.d_part4 = nullptr;
+    G.d_pw_part = G.d_rr_part = G.d_misc_part = nullptr; G.d_scal = nullptr;      // d_scal lives in the context's report record
+    G.arena_used = 0;
+    G.M_valid = false;
     G.bound = false;
+}
+static void grid_free(Grid& G) {
+    grid_release(G);
+    if (G.arena) (void)hipFree(G.arena);
+    G.arena = nullptr; G.arena_bytes = 0;
 }
 
 static void state_release(srps_ctx* c) {
-    dfree(c->I8); c->i8_state = 0;
-    dfree(c->s); dfree(c->rho); dfree(c->z); dfree(c->Nrm); dfree(c->dz); dfree(c->zx); dfree(c->zy);
-    dfree(c->xx); dfree(c->yy); dfree(c->z0s); dfree(c->I); dfree(c->albedo_ex); dfree(c->q_ex); c->q_in_exchange = false; c->energy_ex = nullptr;      // energy_ex lives in the report record
+    c->i8_state = 0;                       // I8 (its own allocation, made when the images turn out to be bytes) is kept for the next set-up
+    c->s = c->rho = c->z = c->Nrm = c->dz = c->zx = c->zy = c->xx = c->yy = c->z0s = c->I = c->albedo_ex = c->q_ex = nullptr;      // carved out of state_arena
+    c->q_in_exchange = false; c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
 }
 
-// Classes of the resident CG's tiles (kernels_resident.hip, tile = 256 rows x tc columns, tile index = column of tiles *
-// tiles per column + row of tiles): TILE_RECT when every pixel of the tile is masked and inside a complete KT block and the
-// ring row below / ring column to the right is either wholly masked (with no backward difference pointing into the tile) or
-// wholly empty -- then the only backward differences of the tile are those of its last row / last column, which the RECT
-// body handles without structure bits.
-static std::vector<uint8_t> classify_tiles(const Grid& G, const std::vector<uint8_t>& flags, int tc, int* n_rect) {
-    const int TRr = 256, nbr = cdiv(G.Hg, TRr), nbc = cdiv(G.Wg, tc);
-    auto F = [&](int r, int c) -> uint8_t {
-        const int sr = r + PAD, sc = c + PAD;
-        if (sr < 0 || sr >= G.Hs || sc < 0 || sc >= G.Ws) return 0;
-        return flags[(size_t)sc * G.Hs + sr];
-    };
-    std::vector<uint8_t> cls((size_t)nbr * nbc, 0);
-    *n_rect = 0;
-    const uint64_t need = 0x0101010101010101ull * (F_MASK | F_KB);
-    for (int bc = 0; bc < nbc; ++bc)
-        for (int br = 0; br < nbr; ++br) {
-            const int r0 = br * TRr, c0 = bc * tc;
-            bool rect = r0 + TRr <= G.Hg && c0 + tc <= G.Wg;
-            // the tile's 256 rows of a column are contiguous bytes (PAD + r0 is a multiple of 4): eight pixels per test
-            for (int c = c0; c < c0 + tc && rect; ++c) {
-                const uint8_t* col = flags.data() + (size_t)(c + PAD) * G.Hs + r0 + PAD;
-                for (int r = 0; r < TRr; r += 8) {
-                    uint64_t w8;
-                    memcpy(&w8, col + r, 8);
-                    if ((w8 & need) != need) { rect = false; break; }
-                }
-            }
-            if (!rect) continue;
-            int nb = 0, nr = 0;
-            bool bad = false;
-            for (int c = c0; c < c0 + tc; ++c) { const uint8_t f = F(r0 + TRr, c); nb += (f & F_MASK) ? 1 : 0; bad |= (f & F_BY) != 0; }
-            for (int r = r0; r < r0 + TRr; ++r) { const uint8_t f = F(r, c0 + tc); nr += (f & F_MASK) ? 1 : 0; bad |= (f & F_BX) != 0; }
-            if (bad || (nb != 0 && nb != tc) || (nr != 0 && nr != TRr)) continue;
-            cls[(size_t)bc * nbr + br] = (uint8_t)(TILE_RECT | (nb == 0 ? TILE_BOTTOM_EMPTY : 0) | (nr == 0 ? TILE_RIGHT_EMPTY : 0));
-            ++*n_rect;
-        }
-    return cls;
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// The stored 6-plane tensor: only the operator kernels that stream it need it (the simple kernel, the marching kernel without
+// tensor recompute, channel counts other than 1 and 3) -- allocated and zeroed when the first such assembly asks for it.
+int grid_need_M(srps_ctx* ctx) {
+    Grid& G = ctx->grid;
+    if (G.d_M) return SRPS_OK;
+    SRPS_TRY(dalloc(&G.d_M, 6 * G.plane));
+    SRPS_HIP(hipMemsetAsync(G.d_M, 0, 6 * G.plane * sizeof(float), ctx->stream));      // zero outside the mask
+    return SRPS_OK;
 }
 
-// Host construction of the grid structure: what SRPS.cu:151-203 expresses as index lists and the
-// COO matrices KT, Dx, Dy becomes a bounding box, a compact->grid index map and one byte per pixel.
-// after_release (may be null) runs once the old grid has been freed and the arguments have been checked, before the host-side
-// construction: srps_setup starts its image uploads there, so that the DMA runs while the host builds the structure
+// Construction of the grid structure: what SRPS.cu:151-203 expresses as index lists and the COO matrices KT, Dx, Dy becomes a
+// bounding box, a compact->grid index map and one byte per pixel -- built on the device (kernels_structure.hip) on the context's
+// auxiliary stream.  after_release (may be null) runs first, once the old grid has been released and the arguments have been
+// checked: srps_setup starts its image uploads there, so that the DMA runs while the structure is built.
 static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, const std::function<int()>* after_release = nullptr) {
     Grid& G = ctx->grid;
     grid_release(G);
@@ -150,34 +135,27 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     SRPS_REQUIRE(mask != nullptr, SRPS_ERR_INVALID, "bind_grid: mask is NULL");
     const size_t hw = (size_t)h * w;
     SRPS_REQUIRE(hw < (size_t)1 << 31, SRPS_ERR_UNSUPPORTED, "bind_grid: h*w must fit int32");
+    hipStream_t ax = ctx->aux_stream;
+    // scratch first (growing it frees the old one, and hipFree waits for the device: not while the images are in flight)
+    const size_t mask_bytes = al256(hw * sizeof(float));
+    SRPS_TRY(ensure(ctx->ws_struct, mask_bytes + struct_scratch_bytes(h, w, sf) + 256));
     if (after_release) SRPS_TRY((*after_release)());
-    int imin = h, imax = -1, jmin = w, jmax = -1;
-    G.imask.clear(); G.imasks.clear();
-    G.imask.reserve(hw);
-    // the mask as bytes with a one-pixel empty border: the neighbour tests below need no bounds checks (this set-up is host
-    // time inside every solve: 4 M pixels at the metric's size)
-    const size_t hb = (size_t)h + 2;
-    std::vector<uint8_t> mb(hb * ((size_t)w + 2), 0);
-    for (int j = 0; j < w; ++j) {
-        const float* mc = mask + (size_t)j * h;
-        uint8_t* bcol = mb.data() + (size_t)(j + 1) * hb + 1;
-        int lo = h, hi = -1;
-        for (int i = 0; i < h; ++i) {
-            const float m = mc[i];
-            // the reference indexes with mask != 0 (SRPS.cu:158) but compacts with mask == 1
-            // (devicecalls.cuh:19-24): anything but {0,1} silently corrupts it; we refuse.
-            SRPS_REQUIRE(m == 0.f || m == 1.f, SRPS_ERR_INVALID, "bind_grid: mask must be {0,1}, found %g at (%d,%d)", (double)m, i, j);
-            if (m != 0.f) {
-                bcol[i] = 1;
-                G.imask.push_back((int)((size_t)j * h + i));
-                if (i < lo) lo = i;
-                hi = i;
-            }
-        }
-        if (hi >= 0) { imin = std::min(imin, lo); imax = std::max(imax, hi); jmin = std::min(jmin, j); jmax = j; }
+    float* d_mask = (float*)ctx->ws_struct.p;
+    const StructScratch sc = struct_scratch((char*)ctx->ws_struct.p + mask_bytes, h, w, sf);
+    SRPS_HIP(hipMemcpyAsync(d_mask, mask, hw * sizeof(float), hipMemcpyHostToDevice, ax));
+    SRPS_TRY(struct_phase1(ax, d_mask, h, w, sf, sc));
+    int* hdr = (int*)(ctx->h_pinned + 128);                // behind everything a pass reads back
+    SRPS_HIP(hipMemcpyAsync(hdr, sc.header, 8 * sizeof(int), hipMemcpyDeviceToHost, ax));
+    SRPS_HIP(hipStreamSynchronize(ax));
+    const int P = hdr[0], Ps = hdr[1], imin = hdr[2], imax = hdr[3], jmin = hdr[4], jmax = hdr[5], bad = hdr[6];
+    if (bad != INT_MAX) {
+        // the reference indexes with mask != 0 (SRPS.cu:158) but compacts with mask == 1
+        // (devicecalls.cuh:19-24): anything but {0,1} silently corrupts it; we refuse.
+        const int bi = bad % h, bj = bad / h;
+        SRPS_REQUIRE(false, SRPS_ERR_INVALID, "bind_grid: mask must be {0,1}, found %g at (%d,%d)", (double)mask[bad], bi, bj);
     }
     G.h = h; G.w = w; G.sf = sf;
-    G.P = (int)G.imask.size();
+    G.P = P;
     SRPS_REQUIRE(G.P > 0, SRPS_ERR_INVALID, "bind_grid: empty mask");
     G.i_lo = (imin / sf) * sf; G.j_lo = (jmin / sf) * sf;
     const int i_hi = ((imax + sf) / sf) * sf, j_hi = ((jmax + sf) / sf) * sf;
@@ -187,79 +165,58 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     G.plane = (size_t)G.Hs * G.Ws;
     SRPS_REQUIRE(G.plane < ((size_t)1 << 31) - 8 * (size_t)G.Hs, SRPS_ERR_UNSUPPORTED, "bind_grid: grid plane must fit int32 offsets");
     G.Hl = G.Hg / sf; G.Wl = G.Wg / sf;
-    std::vector<uint8_t> flags(G.plane, 0);
-    std::vector<int> gofp(G.P);
-    {
-        int p = 0;
-        for (int j = jmin; j <= jmax; ++j) {
-            const uint8_t* c0 = mb.data() + (size_t)(j + 1) * hb + 1;      // this column, its left and right neighbours
-            const uint8_t *cl = c0 - hb, *cr = c0 + hb;
-            const int gbase = (j - G.j_lo + PAD) * G.Hs - G.i_lo + PAD;
-            for (int i = 0; i < h; ++i) {
-                if (!c0[i]) continue;
-                uint8_t f = F_MASK;
-                if (c0[i + 1]) f |= F_FY; else if (c0[i - 1]) f |= F_BY;      // SRPS.cu:31-38
-                if (cr[i]) f |= F_FX; else if (cl[i]) f |= F_BX;              // SRPS.cu:39-46
-                flags[gbase + i] = f;
-                gofp[p++] = gbase + i;                                         // ascending linear index, like imask
-            }
-        }
-    }
-    // fully masked sf x sf blocks = rows of KT (D*mask == 1 exactly, SRPS.cu:110-111, 163-183)
-    std::vector<int> lr_index((size_t)G.Hl * G.Wl, -1);
-    int ps = 0;
-    const int hs_full = h / sf;
-    for (int bj = 0; bj < G.Wl; ++bj)
-        for (int bi = 0; bi < G.Hl; ++bi) {
-            bool full = true;
-            for (int dj = 0; dj < sf && full; ++dj) {
-                const uint8_t* bcol = mb.data() + (size_t)(G.j_lo + bj * sf + dj + 1) * hb + 1 + G.i_lo + bi * sf;      // inside the image: the box is sf-aligned
-                for (int di = 0; di < sf; ++di)
-                    if (!bcol[di]) { full = false; break; }
-            }
-            if (!full) continue;
-            lr_index[(size_t)bj * G.Hl + bi] = ps++;
-            G.imasks.push_back((G.j_lo / sf + bj) * hs_full + (G.i_lo / sf + bi));
-            for (int dj = 0; dj < sf; ++dj)
-                for (int di = 0; di < sf; ++di) flags[(size_t)(bj * sf + dj + PAD) * G.Hs + bi * sf + di + PAD] |= F_KB;
-        }
-    G.Ps = ps;
-    // device copies + workspace
-    SRPS_TRY(dalloc(&G.d_gofp, G.P)); SRPS_TRY(dalloc(&G.d_imask, G.P)); SRPS_TRY(dalloc(&G.d_flags, G.plane));
-    SRPS_TRY(dalloc(&G.d_lr_index, lr_index.size()));
-    SRPS_HIP(hipMemcpy(G.d_gofp, gofp.data(), G.P * sizeof(int), hipMemcpyHostToDevice));
-    SRPS_HIP(hipMemcpy(G.d_imask, G.imask.data(), G.P * sizeof(int), hipMemcpyHostToDevice));
-    SRPS_HIP(hipMemcpy(G.d_flags, flags.data(), G.plane, hipMemcpyHostToDevice));
-    SRPS_HIP(hipMemcpy(G.d_lr_index, lr_index.data(), lr_index.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (int shape = 0; shape < 3; ++shape) {                    // [0] 256 x 32 tiles, [1] 256 x 64 tiles, [2] 256 x 16 tiles
-        const std::vector<uint8_t> cls = classify_tiles(G, flags, shape == 0 ? 32 : shape == 1 ? 64 : 16, &G.n_rect_tiles[shape]);
-        G.n_tiles[shape] = (int)cls.size();
-        SRPS_TRY(dalloc(&G.d_tile_cls[shape], cls.size()));
-        SRPS_HIP(hipMemcpy(G.d_tile_cls[shape], cls.data(), cls.size(), hipMemcpyHostToDevice));
-    }
-    SRPS_TRY(dalloc(&G.d_M, 6 * G.plane)); SRPS_TRY(dalloc(&G.d_q, 3 * G.plane));
-    SRPS_TRY(dalloc(&G.d_x, G.plane)); SRPS_TRY(dalloc(&G.d_x2, G.plane)); SRPS_HIP(hipMemset(G.d_x2, 0, G.plane * sizeof(float)));
-    ctx->x_swapped = false;
-    SRPS_TRY(dalloc(&G.d_r, G.plane)); SRPS_TRY(dalloc(&G.d_p, 2 * G.plane));
-    SRPS_TRY(dalloc(&G.d_w, G.plane)); SRPS_TRY(dalloc(&G.d_w2, G.plane)); SRPS_TRY(dalloc(&G.d_save, G.plane));
-    SRPS_HIP(hipMemset(G.d_w2, 0, G.plane * sizeof(float)));
-    SRPS_TRY(dalloc(&G.d_r2, G.plane)); SRPS_HIP(hipMemset(G.d_r2, 0, G.plane * sizeof(float)));
-    SRPS_HIP(hipMemset(G.d_M, 0, 6 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_q, 0, 3 * G.plane * sizeof(float)));
-    SRPS_HIP(hipMemset(G.d_x, 0, G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_r, 0, G.plane * sizeof(float)));
-    SRPS_HIP(hipMemset(G.d_p, 0, 2 * G.plane * sizeof(float))); SRPS_HIP(hipMemset(G.d_w, 0, G.plane * sizeof(float)));
+    G.Ps = Ps;
     const int nti = cdiv(G.Hg, 64), ntj = cdiv(G.Wg, 4);
     G.nb_apply = std::max(1, std::min(nti * ntj, 1024));
     G.used = (size_t)G.Hs * (G.Wg + 2 * PAD);      // the CG vectors are zero (and stay zero) beyond the used columns
     G.nb_update = std::max(1, std::min(cdiv((long long)G.used / 4, 256 * 4), 1024));
     march_plan(G, ctx->march_tj, ctx->num_cus);
     G.n_part4 = std::max(4096, march_blocks(G) + 8);      // any strip width the options allow stays below this (see march_strip)
-    SRPS_TRY(dalloc(&G.d_part4, 2 * 4 * (size_t)G.n_part4));
-    SRPS_HIP(hipMemset(G.d_part4, 0, 2 * 4 * (size_t)G.n_part4 * sizeof(float)));
     const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
-    SRPS_TRY(dalloc(&G.d_pw_part, n_pw)); SRPS_TRY(dalloc(&G.d_rr_part, 2 * (size_t)G.nb_update)); SRPS_TRY(dalloc(&G.d_misc_part, 4096));
-    G.d_scal = (CgScalars*)(ctx->d_report + 64); SRPS_TRY(dalloc(&G.d_tconsts, 128));      // [8][8] tensor constants + [8][4] right-hand-side constants
-    SRPS_HIP(hipMemset(G.d_pw_part, 0, n_pw * sizeof(float))); SRPS_HIP(hipMemset(G.d_rr_part, 0, 2 * (size_t)G.nb_update * sizeof(float)));
-    SRPS_HIP(hipMemset(G.d_scal, 0, sizeof(CgScalars)));
+    for (int shape = 0; shape < 3; ++shape) G.n_tiles[shape] = cdiv(G.Hg, 256) * cdiv(G.Wg, shape == 0 ? 32 : shape == 1 ? 64 : 16);
+    // ---- one arena for every array of the grid ----
+    const size_t pl = al256(G.plane * sizeof(float));
+    size_t need = 2 * al256((size_t)G.P * sizeof(int)) + al256((size_t)std::max(G.Ps, 1) * sizeof(int)) + al256(G.plane) + al256((size_t)G.Hl * G.Wl * sizeof(int) + 4);
+    for (int shape = 0; shape < 3; ++shape) need += al256((size_t)G.n_tiles[shape]);
+    need += (3 + 3 + 9) * pl + 256;                       // q [3], g [3], x, x2, r, r2, p [2], w, w2, save
+    need += al256(128 * sizeof(float)) + al256(2 * 4 * (size_t)G.n_part4 * sizeof(float)) + al256(n_pw * sizeof(float)) +
+            al256(2 * (size_t)G.nb_update * sizeof(float)) + al256(4096 * sizeof(float));
+    if (G.arena_bytes < need) {
+        if (G.arena) SRPS_HIP(hipFree(G.arena));
+        G.arena = nullptr; G.arena_bytes = 0;
+        SRPS_HIP(hipMalloc(&G.arena, need));
+        G.arena_bytes = need;
+    }
+    G.arena_used = 0;
+    auto carve = [&](size_t bytes) -> void* { void* p = (char*)G.arena + G.arena_used; G.arena_used += al256(bytes); return p; };
+    G.d_gofp = (int*)carve((size_t)G.P * sizeof(int)); G.d_imask = (int*)carve((size_t)G.P * sizeof(int));
+    G.d_imasks = (int*)carve((size_t)std::max(G.Ps, 1) * sizeof(int));
+    G.d_flags = (uint8_t*)carve(G.plane);
+    G.d_lr_index = (int*)carve((size_t)G.Hl * G.Wl * sizeof(int) + 4);
+    for (int shape = 0; shape < 3; ++shape) G.d_tile_cls[shape] = (uint8_t*)carve((size_t)G.n_tiles[shape]);
+    const size_t pb = G.plane * sizeof(float);             // multi-plane arrays are [k][plane], contiguous
+    G.d_q = (float*)carve(3 * pb);
+    G.d_G = (float*)carve(3 * pb); G.G_planes = 3;
+    G.d_x = (float*)carve(pb); G.d_x2 = (float*)carve(pb); G.d_r = (float*)carve(pb); G.d_r2 = (float*)carve(pb);
+    G.d_p = (float*)carve(2 * pb); G.d_w = (float*)carve(pb); G.d_w2 = (float*)carve(pb); G.d_save = (float*)carve(pb);
+    G.d_tconsts = (float*)carve(128 * sizeof(float));      // [8][8] tensor constants + [8][4] right-hand-side constants
+    G.d_part4 = (float*)carve(2 * 4 * (size_t)G.n_part4 * sizeof(float));
+    G.d_pw_part = (float*)carve(n_pw * sizeof(float)); G.d_rr_part = (float*)carve(2 * (size_t)G.nb_update * sizeof(float));
+    G.d_misc_part = (float*)carve(4096 * sizeof(float));
+    SRPS_REQUIRE(G.arena_used <= G.arena_bytes, SRPS_ERR_NOMEM, "bind_grid: arena accounting");
+    G.d_scal = (CgScalars*)(ctx->d_report + 64);
+    // every plane is zero outside the mask (and the vectors start at zero): one memset for the lot
+    SRPS_HIP(hipMemsetAsync(G.arena, 0, G.arena_used, ax));
+    SRPS_HIP(hipMemsetAsync(G.d_scal, 0, sizeof(CgScalars), ax));
+    SRPS_TRY(struct_phase2(ax, G, sc, G.d_imasks));
+    int* hrect = hdr + 8;
+    SRPS_HIP(hipMemcpyAsync(hrect, sc.n_rect, 3 * sizeof(int), hipMemcpyDeviceToHost, ax));
+    // whatever the caller enqueues next on the context's stream sees the finished structure; the tile counts are read by the host
+    SRPS_HIP(hipEventRecord(ctx->aux_event, ax));
+    SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
+    SRPS_HIP(hipStreamSynchronize(ax));
+    for (int shape = 0; shape < 3; ++shape) G.n_rect_tiles[shape] = hrect[shape];
+    ctx->x_swapped = false;
     G.bound = true;
     ctx->tensor_valid = false;
     return SRPS_OK;
@@ -369,6 +326,10 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
     c->stream = c->own_stream;
+    e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->gather_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux_event, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__); }
     e = hipHostMalloc((void**)&c->h_pinned, 256 * sizeof(float));
     if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
     memset(c->h_pinned, 0, 256 * sizeof(float));
@@ -388,7 +349,15 @@ int srps_destroy(srps_ctx* ctx) {
     if (ctx->device >= 0 && ctx->device < 64) g_live_contexts[ctx->device].fetch_sub(1);
     comm_release(ctx);
     state_release(ctx);
-    grid_release(ctx->grid);
+    grid_free(ctx->grid);
+    dfree(ctx->I8);
+    if (ctx->state_arena.p) (void)hipFree(ctx->state_arena.p);
+    if (ctx->ws_struct.p) (void)hipFree(ctx->ws_struct.p);
+    for (hipEvent_t e : ctx->ev_copied) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_gathered) (void)hipEventDestroy(e);
+    if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->gather_stream) (void)hipStreamDestroy(ctx->gather_stream);
     if (ctx->ws_light.p) (void)hipFree(ctx->ws_light.p);
     if (ctx->ws_resident.p) (void)hipFree(ctx->ws_resident.p);
     if (ctx->ws_ssum.p) (void)hipFree(ctx->ws_ssum.p);
@@ -703,7 +672,11 @@ static int image_store_prepare(srps_ctx* ctx) {
     SRPS_HIP(hipMemcpyAsync(&inexact, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     if (inexact) return SRPS_OK;
-    if (!ctx->I8) SRPS_TRY(dalloc(&ctx->I8, n));
+    if (!ctx->I8_cap_ok(n)) {
+        if (ctx->I8) { SRPS_HIP(hipFree(ctx->I8)); ctx->I8 = nullptr; }
+        SRPS_TRY(dalloc(&ctx->I8, n));
+        ctx->I8_cap = n;
+    }
     SRPS_TRY(launch_pack_bytes(ctx->stream, ctx->I, n, ctx->I8, flag));
     ctx->i8_state = 1;
     return SRPS_OK;
@@ -720,128 +693,197 @@ const unsigned char* image_store_bytes(srps_ctx* ctx, const float* d_I) {
 }  // extern "C++"
 
 // ---- pipeline -------------------------------------------------------------------------------
-int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
-    CTX_CHECK(ctx);
-    SRPS_REQUIRE(pr != nullptr, SRPS_ERR_INVALID, "setup: problem is NULL");
+// s = (0, 0, -1, 0) for every image and channel (SRPS.cu:209-217)
+__global__ void k_init_s(float* __restrict__ s, int n) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) s[t] = ((t & 3) == 2) ? -1.f : 0.f;
+}
+
+// events of the upload pipeline, made once per context
+static int setup_events(srps_ctx* ctx, int slots) {
+    while ((int)ctx->ev_copied.size() < slots) {
+        hipEvent_t a = nullptr, b = nullptr;
+        SRPS_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        ctx->ev_copied.push_back(a);
+        SRPS_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        ctx->ev_gathered.push_back(b);
+    }
+    return SRPS_OK;
+}
+
+// SRPS.cu:100-270.  Where the time of a set-up goes, and what overlaps with what:
+//   * the images are the one large transfer (1.0 GB of floats at the metric's configuration = 18.7 ms at the PCIe rate; 0.25 GB
+//     when the caller hands over the bytes its image loader read, srps_problem.I_u8).  The caller's array is pinned in place
+//     (hipHostRegister: plain DMA instead of the runtime's staging) and the copies are queued on the context's stream FIRST;
+//   * the grid structure is built on the device, on the auxiliary stream, from the mask (kernels_structure.hip: 16.8 MB up,
+//     a few kernels, 32 bytes back) while the images are in flight -- round 2's host loop over h*w took as long as the DMA;
+//   * every image is compacted (copy_if with the mask, SRPS.cu:223-234) on a third stream as soon as its copy has landed, so the
+//     compaction overlaps with the next copies and only the last image's gather is left when the DMA ends;
+//   * the arrays come out of two arenas that survive a re-setup of the same size: no hipMalloc / hipFree per solve.
+static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     ctx->light_cache_valid = false;
     ctx->ssum_valid = false;
     ctx->grad_current = false;
     SRPS_REQUIRE(pr->mask && pr->K && pr->zs_lr && pr->z_full, SRPS_ERR_INVALID, "setup: mask, K, zs_lr and z_full are required");
     SRPS_REQUIRE(pr->n_channels > 0 && pr->n_channels <= 8 && pr->n_images >= 0 && pr->n_images_total > 0, SRPS_ERR_INVALID, "setup: bad image counts");
     SRPS_REQUIRE(pr->image_offset >= 0 && pr->image_offset + pr->n_images <= pr->n_images_total, SRPS_ERR_INVALID, "setup: shard [%d,%d) outside [0,%d)", pr->image_offset, pr->image_offset + pr->n_images, pr->n_images_total);
+    SRPS_REQUIRE(!(pr->I && pr->I_u8), SRPS_ERR_INVALID, "setup: give the images as floats (I) or as bytes (I_u8), not both");
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    // SRPS_SETUP_TIMING=1: where the set-up time goes (stderr), for the set-up inclusive solve time of bench.py
+    // SRPS_SETUP_TIMING=1: where the host's set-up time goes (stderr)
     const bool tm = getenv("SRPS_SETUP_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     auto t_all = now(), t0 = now();
     state_release(ctx);
-    // The images are the one large transfer of a solve (1.0 GB at the metric's configuration, 18.7 ms at the PCIe rate), the
-    // host-side construction of the grid structure the one large piece of host work (17 ms): they overlap.  The caller's array
-    // is pinned in place (hipHostRegister: plain DMA instead of the runtime's staging), the copies of the first images -- as many
-    // as fit 2 GB of staging -- are queued before the host starts on the structure, and the gather kernels that compact them
-    // follow once the structure is on the device.
     const int C_ = pr->n_channels, NL_ = pr->n_images;
-    const size_t per = (size_t)C_ * pr->h * pr->w;
+    const bool bytes_in = pr->I_u8 != nullptr;
+    const size_t esz = bytes_in ? 1 : sizeof(float);
+    const size_t per = (size_t)C_ * pr->h * pr->w;                   // samples of one image
+    const char* host_I = bytes_in ? (const char*)pr->I_u8 : (const char*)pr->I;
     struct Pin {
         const void* p = nullptr;
-        hipStream_t st = nullptr;
-        ~Pin() { if (p) { (void)hipStreamSynchronize(st); (void)hipHostUnregister(const_cast<void*>(p)); } }      // also on the error paths: no copy in flight
+        srps_ctx* c = nullptr;
+        ~Pin() {      // also on the error paths: no copy in flight when the caller's array is unpinned
+            if (p) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->gather_stream); (void)hipHostUnregister(const_cast<void*>(p)); }
+        }
     } pin;
-    pin.st = ctx->stream;
-    int staged = 0;
+    pin.c = ctx;
+    int slots = 0, queued = 0;
     std::function<int()> start_uploads = [&]() -> int {
-        if (!pr->I || NL_ <= 0) return SRPS_OK;
-        const size_t bytes = (size_t)NL_ * per * sizeof(float);
+        if (!host_I || NL_ <= 0) return SRPS_OK;
+        const size_t bytes = (size_t)NL_ * per * esz;
+        slots = (int)std::min<size_t>((size_t)NL_, std::max<size_t>(2, ((size_t)2 << 30) / (per * esz)));
+        SRPS_TRY(ensure(ctx->ws_stage, (size_t)slots * per * esz));      // kept across set-ups (grow-only)
+        SRPS_TRY(setup_events(ctx, slots));
         if (ctx->pin_uploads && bytes >= ((size_t)8 << 20)) {
-            if (hipHostRegister((void*)pr->I, bytes, hipHostRegisterDefault) == hipSuccess) pin.p = pr->I;
+            if (hipHostRegister((void*)host_I, bytes, hipHostRegisterDefault) == hipSuccess) pin.p = host_I;
             else (void)hipGetLastError();
         }
-        staged = (int)std::min<size_t>((size_t)NL_, std::max<size_t>(2, ((size_t)2 << 30) / (per * sizeof(float))));
-        SRPS_TRY(ensure(ctx->ws_stage, (size_t)staged * per * sizeof(float)));
-        for (int n = 0; n < staged; ++n)
-            SRPS_HIP(hipMemcpyAsync((float*)ctx->ws_stage.p + (size_t)n * per, pr->I + (size_t)n * per, per * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        // the copies that need no slot to come free are queued now, before the structure is built
+        for (int n = 0; n < slots; ++n) {
+            SRPS_HIP(hipMemcpyAsync((char*)ctx->ws_stage.p + (size_t)n * per * esz, host_I + (size_t)n * per * esz, per * esz, hipMemcpyHostToDevice, ctx->stream));
+            SRPS_HIP(hipEventRecord(ctx->ev_copied[n], ctx->stream));
+        }
+        queued = slots;
         return SRPS_OK;
     };
     SRPS_TRY(build_grid(ctx, pr->h, pr->w, pr->sf, pr->mask, &start_uploads));
-    if (tm) { fprintf(stderr, "srps_setup: grid structure (host) + workspace %.1f ms\n", ms_since(t0)); t0 = now(); }
+    if (tm) { fprintf(stderr, "srps_setup: uploads queued (%s), grid structure on the device, grid arena: %.2f ms\n", pin.p ? "pinned in place" : "pageable", ms_since(t0)); t0 = now(); }
     Grid& G = ctx->grid;
+    hipStream_t ax = ctx->aux_stream;
     const int P = G.P, C = pr->n_channels, NL = pr->n_images, NT = pr->n_images_total;
     ctx->C = C; ctx->N_local = NL; ctx->N_total = NT; ctx->img_offset = pr->image_offset;
     ctx->fx = pr->K[0]; ctx->fy = pr->K[4]; ctx->cx = pr->K[6]; ctx->cy = pr->K[7];       // SRPS.cu:256, 269
-    SRPS_TRY(dalloc(&ctx->s, (size_t)NT * C * 4)); SRPS_TRY(dalloc(&ctx->rho, (size_t)C * P)); SRPS_TRY(dalloc(&ctx->z, P));
-    SRPS_TRY(dalloc(&ctx->Nrm, 4 * (size_t)P)); SRPS_TRY(dalloc(&ctx->dz, P)); SRPS_TRY(dalloc(&ctx->zx, P)); SRPS_TRY(dalloc(&ctx->zy, P));
-    SRPS_TRY(dalloc(&ctx->xx, P)); SRPS_TRY(dalloc(&ctx->yy, P)); SRPS_TRY(dalloc(&ctx->z0s, std::max(G.Ps, 1)));
-    SRPS_TRY(dalloc(&ctx->I, (size_t)std::max(NL, 1) * C * P));
-    SRPS_TRY(dalloc(&ctx->albedo_ex, 2 * (size_t)C * P)); ctx->energy_ex = ctx->d_report;
-    if (NL != NT) SRPS_TRY(dalloc(&ctx->q_ex, 3 * (size_t)P));      // a shard exchanges q compactly (3 P floats, not 3 padded planes)
-    ctx->have_state = true;
-    // lighting init s = (0,0,-1,0)  SRPS.cu:209-217
-    std::vector<float> s0((size_t)NT * C * 4, 0.f);
-    for (size_t t = 0; t < (size_t)NT * C; ++t) s0[t * 4 + 2] = -1.f;
-    SRPS_HIP(hipMemcpy(ctx->s, s0.data(), s0.size() * sizeof(float), hipMemcpyHostToDevice));
-    SRPS_TRY(launch_fill(ctx->stream, ctx->rho, (size_t)C * P, 0.5f));                      // SRPS.cu:220
-    // masked LR depth and initial HR depth (copy_if SRPS.cu:237-246), gathered on the host: O(P)
+    // ---- state arena ----
     {
-        std::vector<float> tmp(std::max(G.Ps, 1));
-        for (int t = 0; t < G.Ps; ++t) tmp[t] = pr->zs_lr[G.imasks[t]];
-        SRPS_HIP(hipMemcpy(ctx->z0s, tmp.data(), std::max(G.Ps, 1) * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<float> zt(P);
-        for (int p = 0; p < P; ++p) zt[p] = pr->z_full[G.imask[p]];
-        SRPS_HIP(hipMemcpy(ctx->z, zt.data(), (size_t)P * sizeof(float), hipMemcpyHostToDevice));
+        const size_t fP = al256((size_t)P * sizeof(float));
+        size_t need = al256((size_t)NT * C * 4 * sizeof(float)) + al256((size_t)C * P * sizeof(float)) + al256(4 * (size_t)P * sizeof(float)) + 7 * fP +
+                      al256((size_t)std::max(G.Ps, 1) * sizeof(float)) + al256((size_t)std::max(NL, 1) * C * P * sizeof(float)) + al256(2 * (size_t)C * P * sizeof(float)) +
+                      (NL != NT ? al256(3 * (size_t)P * sizeof(float)) : 0) + 256;
+        SRPS_TRY(ensure(ctx->state_arena, need));                    // grows only when this problem is larger than every earlier one
+        size_t used = 0;
+        auto carve = [&](size_t bytes) -> float* { float* p = (float*)((char*)ctx->state_arena.p + used); used += al256(bytes); return p; };
+        ctx->s = carve((size_t)NT * C * 4 * sizeof(float)); ctx->rho = carve((size_t)C * P * sizeof(float)); ctx->z = carve((size_t)P * sizeof(float));
+        ctx->Nrm = carve(4 * (size_t)P * sizeof(float)); ctx->dz = carve((size_t)P * sizeof(float)); ctx->zx = carve((size_t)P * sizeof(float));
+        ctx->zy = carve((size_t)P * sizeof(float)); ctx->xx = carve((size_t)P * sizeof(float)); ctx->yy = carve((size_t)P * sizeof(float));
+        ctx->z0s = carve((size_t)std::max(G.Ps, 1) * sizeof(float));
+        ctx->I = carve((size_t)std::max(NL, 1) * C * P * sizeof(float));
+        ctx->albedo_ex = carve(2 * (size_t)C * P * sizeof(float)); ctx->energy_ex = ctx->d_report;
+        if (NL != NT) ctx->q_ex = carve(3 * (size_t)P * sizeof(float));      // a shard exchanges q compactly (3 P floats, not 3 padded planes)
     }
-    SRPS_TRY(launch_meshgrid_compact(ctx->stream, G.d_imask, P, G.h, ctx->cx, ctx->cy, ctx->xx, ctx->yy));
-    if (tm) { fprintf(stderr, "srps_setup: state allocation + initial values %.1f ms\n", ms_since(t0)); t0 = now(); }
-    if (pr->I && NL > 0) {
+    ctx->have_state = true;
+    // initial values on the auxiliary stream (the context's stream is busy with the images)
+    hipLaunchKernelGGL(k_init_s, dim3(std::max(1, std::min(cdiv((long long)NT * C * 4, 256), 1024))), dim3(256), 0, ax, ctx->s, NT * C * 4);      // SRPS.cu:209-217
+    SRPS_LAUNCH_CHECK();
+    SRPS_TRY(launch_fill(ax, ctx->rho, (size_t)C * P, 0.5f));                               // SRPS.cu:220
+    // masked LR depth and initial HR depth (copy_if SRPS.cu:237-246): uploaded whole into the scratch the mask came through,
+    // compacted with the index lists
+    {
+        float* d_tmp = (float*)ctx->ws_struct.p;
+        const size_t hw = (size_t)G.h * G.w, hws = hw / ((size_t)G.sf * G.sf);
+        SRPS_HIP(hipMemcpyAsync(d_tmp, pr->z_full, hw * sizeof(float), hipMemcpyHostToDevice, ax));
+        SRPS_TRY(launch_gather_index(ax, d_tmp, G.d_imask, P, ctx->z));
+        // (stream order: the second copy into the scratch follows the gather that read the first)
+        SRPS_HIP(hipMemcpyAsync(d_tmp, pr->zs_lr, hws * sizeof(float), hipMemcpyHostToDevice, ax));
+        SRPS_TRY(launch_gather_index(ax, d_tmp, G.d_imasks, G.Ps, ctx->z0s));
+    }
+    SRPS_TRY(launch_meshgrid_compact(ax, G.d_imask, P, G.h, ctx->cx, ctx->cy, ctx->xx, ctx->yy));
+    SRPS_HIP(hipEventRecord(ctx->aux_event, ax));
+    if (tm) { fprintf(stderr, "srps_setup: state arena + initial values queued: %.2f ms\n", ms_since(t0)); t0 = now(); }
+    // ---- compaction of the images, pipelined with their copies ----
+    const bool want_bytes = bytes_in && ctx->image_store && P % 4 == 0;
+    if (want_bytes && !ctx->I8_cap_ok((size_t)NL * C * P)) {
+        if (ctx->I8) { (void)hipFree(ctx->I8); ctx->I8 = nullptr; }
+        SRPS_TRY(dalloc(&ctx->I8, (size_t)NL * C * P));
+        ctx->I8_cap = (size_t)NL * C * P;
+    }
+    if (host_I && NL > 0) {
         const size_t hwp = (size_t)G.h * G.w;
-        for (int n = 0; n < staged; ++n)       // the copies queued before the structure was built
-            SRPS_TRY(launch_gather_image(ctx->stream, (const float*)ctx->ws_stage.p + (size_t)n * per, G.d_imask, G.P, C, hwp, ctx->I + (size_t)n * C * G.P));
-        // images beyond the staging area: two slots of it in turn, each reused once the gather that read it has run
-        hipEvent_t freed[2] = {nullptr, nullptr};
-        int rc = SRPS_OK;
-        if (staged < NL) {
-            SRPS_HIP(hipStreamSynchronize(ctx->stream));
-            for (int b2 = 0; b2 < 2 && rc == SRPS_OK; ++b2)
-                if (hipEventCreateWithFlags(&freed[b2], hipEventDisableTiming) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
+        hipStream_t gs = ctx->gather_stream;
+        SRPS_HIP(hipStreamWaitEvent(gs, ctx->aux_event, 0));      // the index lists
+        for (int n = 0; n < NL; ++n) {
+            const int sl = n % slots;
+            char* stage = (char*)ctx->ws_stage.p + (size_t)sl * per * esz;
+            if (n >= queued) {                                     // a slot in its second use: the copy waits, on the device, for the gather that read it
+                SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[sl], 0));
+                SRPS_HIP(hipMemcpyAsync(stage, host_I + (size_t)n * per * esz, per * esz, hipMemcpyHostToDevice, ctx->stream));
+                SRPS_HIP(hipEventRecord(ctx->ev_copied[sl], ctx->stream));
+            }
+            SRPS_HIP(hipStreamWaitEvent(gs, ctx->ev_copied[sl], 0));
+            if (bytes_in)
+                SRPS_TRY(launch_gather_images_u8(gs, (const unsigned char*)stage, G.d_imask, P, C, hwp, 1, ctx->I + (size_t)n * C * P,
+                                                 want_bytes ? ctx->I8 + (size_t)n * C * P : nullptr));
+            else
+                SRPS_TRY(launch_gather_images(gs, (const float*)stage, G.d_imask, P, C, hwp, 1, ctx->I + (size_t)n * C * P));
+            SRPS_HIP(hipEventRecord(ctx->ev_gathered[sl], gs));
         }
-        for (int n = staged; n < NL && rc == SRPS_OK; ++n) {
-            const int b2 = n & 1;
-            float* stage = (float*)ctx->ws_stage.p + (size_t)b2 * per;
-            hipError_t e = (n >= staged + 2) ? hipEventSynchronize(freed[b2]) : hipSuccess;
-            if (e == hipSuccess) e = hipMemcpyAsync(stage, pr->I + (size_t)n * per, per * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) { rc = hip_fail(e, "image upload", __FILE__, __LINE__); break; }
-            rc = launch_gather_image(ctx->stream, stage, G.d_imask, G.P, C, hwp, ctx->I + (size_t)n * C * G.P);
-            if (rc == SRPS_OK && hipEventRecord(freed[b2], ctx->stream) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
-        }
-        (void)hipStreamSynchronize(ctx->stream);
-        for (int b2 = 0; b2 < 2; ++b2) if (freed[b2]) (void)hipEventDestroy(freed[b2]);
-        if (tm) { fprintf(stderr, "srps_setup: %d images, %.2f GB uploaded (queued before the structure was built) and compacted: %.1f ms more (%s)\n", NL,
-                          (double)NL * per * sizeof(float) * 1e-9, ms_since(t0), pin.p ? "pinned in place" : "pageable"); t0 = now(); }
-        SRPS_TRY(rc);
-        // the staging area is a set-up artefact (1 GB at the metric's size): give it back
-        if (ctx->ws_stage.bytes > ((size_t)64 << 20)) { (void)hipFree(ctx->ws_stage.p); ctx->ws_stage.p = nullptr; ctx->ws_stage.bytes = 0; }
+        SRPS_HIP(hipEventRecord(ctx->ev_gathered[0], gs));        // everything compacted
+        SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[0], 0));
     }
-    ctx->i8_state = 0;
-    SRPS_TRY(image_store_prepare(ctx));
-    if (tm) { fprintf(stderr, "srps_setup: image store (%s) %.1f ms\n", ctx->i8_state == 1 ? "bytes" : "floats", ms_since(t0)); t0 = now(); }
+    SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
+    if (tm) { fprintf(stderr, "srps_setup: %d image copies + compactions queued: %.2f ms\n", NL, ms_since(t0)); t0 = now(); }
+    if (want_bytes) ctx->i8_state = 1;                     // the bytes ARE the images: nothing to look at
+    else { ctx->i8_state = 0; SRPS_TRY(image_store_prepare(ctx)); }
+    if (tm) { fprintf(stderr, "srps_setup: %.2f GB of images on the device and compacted, image store (%s): %.2f ms (the host waited here)\n",
+                      (double)NL * per * esz * 1e-9, ctx->i8_state == 1 ? "bytes" : "floats", ms_since(t0)); t0 = now(); }
     SRPS_TRY(srps_normals(ctx));                                                            // SRPS.cu:264-270
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    if (tm) fprintf(stderr, "srps_setup: total %.1f ms\n", ms_since(t_all));
+    SRPS_HIP(hipStreamSynchronize(ctx->gather_stream));
+    if (tm) fprintf(stderr, "srps_setup: total %.2f ms\n", ms_since(t_all));
     return SRPS_OK;
 }
 
-int srps_upload_image(srps_ctx* ctx, int li, const float* host_image) {
-    CTX_CHECK(ctx); STATE_CHECK(ctx);
+int srps_setup(srps_ctx* ctx, const srps_problem* pr) {
+    CTX_CHECK(ctx);
+    SRPS_REQUIRE(pr != nullptr, SRPS_ERR_INVALID, "setup: problem is NULL");
+    return setup_impl(ctx, pr);
+}
+
+static int upload_image_impl(srps_ctx* ctx, int li, const void* host_image, bool bytes_in) {
     SRPS_REQUIRE(host_image && li >= 0 && li < ctx->N_local, SRPS_ERR_INVALID, "upload_image: bad arguments");
     ctx->light_cache_valid = false;
     ctx->ssum_valid = false;
-    ctx->i8_state = 0;                   // looked at again at the next sweep
     Grid& G = ctx->grid;
-    const size_t hw = (size_t)G.h * G.w, n = hw * ctx->C;
-    SRPS_TRY(ensure(ctx->ws_stage, n * sizeof(float)));
+    const size_t hw = (size_t)G.h * G.w, n = hw * ctx->C, esz = bytes_in ? 1 : sizeof(float);
     SRPS_HIP(hipStreamSynchronize(ctx->stream));     // staging buffer reuse
-    SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, host_image, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    return launch_gather_image(ctx->stream, (const float*)ctx->ws_stage.p, G.d_imask, G.P, ctx->C, hw, ctx->I + (size_t)li * ctx->C * G.P);
+    SRPS_TRY(ensure(ctx->ws_stage, n * esz));
+    SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, host_image, n * esz, hipMemcpyHostToDevice, ctx->stream));
+    float* out = ctx->I + (size_t)li * ctx->C * G.P;
+    if (!bytes_in) {
+        ctx->i8_state = 0;                   // looked at again at the next sweep
+        return launch_gather_images(ctx->stream, (const float*)ctx->ws_stage.p, G.d_imask, G.P, ctx->C, hw, 1, out);
+    }
+    // bytes: the byte store stays current when it is in use (every other image is a byte image already)
+    unsigned char* out8 = (ctx->i8_state == 1 && ctx->I8) ? ctx->I8 + (size_t)li * ctx->C * G.P : nullptr;
+    if (!out8) ctx->i8_state = 0;
+    return launch_gather_images_u8(ctx->stream, (const unsigned char*)ctx->ws_stage.p, G.d_imask, G.P, ctx->C, hw, 1, out, out8);
+}
+int srps_upload_image(srps_ctx* ctx, int li, const float* host_image) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    return upload_image_impl(ctx, li, host_image, false);
+}
+int srps_upload_image_u8(srps_ctx* ctx, int li, const unsigned char* host_image) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    return upload_image_impl(ctx, li, host_image, true);
 }
 
 int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, int* n_images, int* n_channels) {

@@ -53,6 +53,7 @@ struct Grid {
     // device
     int* d_gofp = nullptr;        // [P]   grid offset of compact pixel p
     int* d_imask = nullptr;       // [P]   HR linear index of compact pixel p (SRPS.cu:157-162)
+    int* d_imasks = nullptr;      // [Ps]  LR linear index of complete block t (SRPS.cu:163-168)
     uint8_t* d_flags = nullptr;   // [plane]
     int* d_lr_index = nullptr;    // [Hl*Wl] compact LR index of the block, -1 if not fully masked
     uint8_t* d_tile_cls[3] = {nullptr, nullptr, nullptr};   // TILE_* bits of the resident CG's tiles: [0] 256 x 32, [1] 256 x 64, [2] 256 x 16
@@ -85,7 +86,18 @@ struct Grid {
     int nb_apply = 0, nb_update = 0;
     // marching-kernel decomposition
     int seg_rows = 0, n_seg = 0, strip_cols = 0, n_strip = 0;
-    std::vector<int> imask, imasks;
+    // Everything above is carved out of ONE device allocation, kept while a later bind asks for no more than it holds (a re-setup
+    // on the same frame size allocates nothing): hipMalloc / hipFree of ~25 arrays cost milliseconds per solve
+    void* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+};
+
+// scratch of the device-side structure build (kernels_structure.hip)
+struct StructScratch {
+    uint8_t* mb = nullptr;        // [w][h] the mask as bytes
+    uint8_t* lr_full = nullptr;   // [w/sf][h/sf] complete sf x sf blocks of the image's LR grid
+    int *col_count = nullptr, *col_lo = nullptr, *col_hi = nullptr, *col_start = nullptr, *lr_count = nullptr, *lr_start = nullptr;
+    int *bad = nullptr, *header = nullptr, *n_rect = nullptr;
 };
 
 struct DevBuf {
@@ -112,7 +124,11 @@ struct srps_ctx {
     float lambda = 1.0f;             // dc.cu:644
     srps::Grid grid;
     // grow-only workspaces for the per-pixel phases
-    srps::DevBuf ws_light, ws_albedo, ws_stage, ws_misc;
+    srps::DevBuf ws_light, ws_albedo, ws_stage, ws_misc, ws_struct;
+    hipStream_t aux_stream = nullptr;   // non-blocking: the structure build of srps_setup / srps_bind_grid runs here while the images cross PCIe on `stream`
+    hipStream_t gather_stream = nullptr;   // non-blocking: the compaction of image n runs here while image n + 1 is copied
+    hipEvent_t aux_event = nullptr;
+    srps::DevBuf state_arena;        // the context's state arrays (srps_setup), kept across set-ups like the grid's arena
     int pin_uploads = 1;             // srps_setup pins the caller's image array in place (hipHostRegister) while it uploads it
     float* h_pinned = nullptr;       // 256 floats of pinned host memory for scalar read-back
     // The scalars the host reads back after a pass live in ONE device record with the layout of h_pinned -- [0..3] energy terms,
@@ -173,6 +189,9 @@ struct srps_ctx {
     // (Utilities.cpp:343) -- the two sweeps of a pass read the images as bytes (a quarter of the traffic) and form the same floats.
     int image_store = 1;                  // option "image_store": 0 floats only, 1 bytes whenever the samples allow it
     unsigned char* I8 = nullptr;          // [N_local][C][P] bytes
+    size_t I8_cap = 0;                    // bytes allocated behind I8 (kept across set-ups)
+    bool I8_cap_ok(size_t n) const { return I8 != nullptr && I8_cap >= n; }
+    std::vector<hipEvent_t> ev_copied, ev_gathered;      // upload pipeline of srps_setup: per staging slot
     int i8_state = 0;                     // 0: not looked at since I last changed, 1: I8 holds I, 2: I is not representable
     // image sums of the depth right-hand side left by the albedo sweep of this pass (assemble_from_sums)
     int assemble_from_sums = 1;
@@ -294,6 +313,16 @@ int march_cg_step(srps_ctx* ctx, int k);
 bool cg_fused_step(const srps_ctx* ctx);      // the streaming CG runs one launch per step
 int cg_flush_x(srps_ctx* ctx);
 int march_recompute_channels(const srps_ctx* ctx);
+
+int grid_need_M(srps_ctx* ctx);            // srps_api.hip: the stored 6-plane tensor, allocated on demand
+// ---- structure build on the device (kernels_structure.hip) ----------------------------------
+size_t struct_scratch_bytes(int h, int w, int sf);
+StructScratch struct_scratch(void* base, int h, int w, int sf);
+int struct_phase1(hipStream_t st, const float* d_mask, int h, int w, int sf, const StructScratch& s);
+int struct_phase2(hipStream_t st, Grid& G, const StructScratch& s, int* d_imasks);
+int launch_gather_index(hipStream_t st, const float* d_full, const int* d_index, int n, float* d_out);
+int launch_gather_images(hipStream_t st, const float* d_full, const int* d_imask, int P, int C, size_t hw, int n_img, float* d_out);
+int launch_gather_images_u8(hipStream_t st, const unsigned char* d_full, const int* d_imask, int P, int C, size_t hw, int n_img, float* d_out, unsigned char* d_out8);
 
 // ---- RCCL (srps_comm.hip) -------------------------------------------------------------------
 bool comm_bound(const srps_ctx* ctx);

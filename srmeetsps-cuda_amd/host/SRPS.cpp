@@ -43,7 +43,7 @@ void SRPS::execute() {
     std::cout << "Masked resample matrix" << std::endl;
     std::cout << "Masked gradient matrix" << std::endl;
     std::cout << "Initialization" << std::endl;
-    srps_problem pr;
+    srps_problem pr{};
     pr.h = dh->I_h; pr.w = dh->I_w; pr.n_channels = dh->I_c; pr.n_images = dh->I_n; pr.n_images_total = dh->I_n;
     pr.image_offset = 0; pr.sf = (int)dh->sf;
     pr.mask = dh->mask.data(); pr.K = dh->K.data(); pr.I = dh->I.data(); pr.zs_lr = zs.data(); pr.z_full = z_full.data();
@@ -149,7 +149,7 @@ void SRPS::execute_sharded(const std::vector<float>& zs, const std::vector<float
         // contiguous shards whose sizes differ by at most one (api.py shard_range)
         const int base = dh->I_n / n_gpus, rem = dh->I_n % n_gpus;
         const int lo = r * base + std::min(r, rem), cnt = base + (r < rem ? 1 : 0);
-        srps_problem pr;
+        srps_problem pr{};
         pr.h = dh->I_h; pr.w = dh->I_w; pr.n_channels = dh->I_c; pr.n_images = cnt; pr.n_images_total = dh->I_n;
         pr.image_offset = lo; pr.sf = (int)dh->sf;
         pr.mask = dh->mask.data(); pr.K = dh->K.data(); pr.I = dh->I.data() + (size_t)lo * per_image; pr.zs_lr = zs.data(); pr.z_full = z_full.data();

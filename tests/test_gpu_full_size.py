@@ -145,8 +145,8 @@ def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True, e_tol=2e
     assert all(abs(a - b) <= 2 for a, b in zip(iters["albedo"][:n_ch], alb_it))
     assert rmse(z, z_ref) < 1e-4
     assert np.abs(rho - rho_ref).max() < 1e-4
-    # first pass.  Measured: 5e-5 at 1024 x 1024 x 20 images, 2.4e-4 at 2048 x 2048 x 40, 5.5e-4 at
-    # 512 x 384 x 45 images (2e-6 for the depth phase alone at 4096 x 4096); the callers allow three times their measured value
+    # first pass.  Measured (round 3): 4.3e-6 at 1024 x 1024 x 20 images, 2.1e-4 at 2048 x 2048 x 40, 3.1e-4 at
+    # 512 x 384 x 45 images, 2.4e-6 at 4096 x 4096 x 64; the callers allow about three times their measured value
     print("first-pass energy, relative deviation", abs(en[0] - e_ref) / abs(e_ref), "allowed", e_tol)
     assert abs(en[0] - e_ref) <= e_tol * abs(e_ref)
     # lighting through the shading it predicts (the first pass's 4 x 4 systems have a flat direction)
@@ -164,20 +164,20 @@ _KEEP = {"config4": {}, "config5": {}}
 
 def test_config3_whole_pass_against_the_oracle(pkg, oracle, coracle):
     """1024 x 1024, sf 4, 20 images (BASELINE.json configs[2]), full mask"""
-    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"), e_tol=1.5e-4)
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"), e_tol=2e-5)
 
 
 @pytest.mark.timeout(1200)
 def test_config4_all_images_on_one_gpu_whole_pass_against_the_oracle(pkg, oracle, coracle):
     """2048 x 2048, sf 4, 40 images (BASELINE.json configs[3], whose 8 GPUs hold 5 images each): the same data volume as one
     job on one GPU -- two lighting batches of 20, the resident CG at every CU, 2 GB of images"""
-    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 40, seed=1241, mask_kind="full"), e_tol=7.5e-4, keep=_KEEP["config4"])
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 40, seed=1241, mask_kind="full"), e_tol=6.5e-4, keep=_KEEP["config4"])
 
 
 def test_three_lighting_batches_at_mid_size(pkg, oracle, coracle):
     """45 images (the lighting sweep takes them in batches of 20: three batches, the last one partial) on a 512 x 384 ellipse,
     sf 2: the image loops of every sweep at a size where a pixel range spans several blocks"""
-    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(512, 384, 2, 45, seed=1240, mask_kind="ellipse"), e_tol=1.7e-3)
+    _one_pass_vs_oracle(pkg, oracle, coracle, pkg.synth.make_scene(512, 384, 2, 45, seed=1240, mask_kind="ellipse"), e_tol=1e-3)
 
 
 def test_largest_grid_streaming_kernels_against_the_oracle(pkg, oracle, coracle):
@@ -229,7 +229,7 @@ def test_config5_full_volume_whole_pass_against_the_oracle(pkg, oracle, coracle)
     per-image compaction of SRPS.cu:223-234 through the 2 GB staging ring of srps_setup, four lighting batches, the streaming
     depth CG -- one whole pass against the oracle (numpy lighting + albedo, C depth step in the reference's assembled-CSR form)"""
     sc = pkg.synth.make_scene(4096, 4096, 2, 64, seed=1242, mask_kind="full")
-    _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=False, e_tol=1e-3, keep=_KEEP["config5"])
+    _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=False, e_tol=2e-5, keep=_KEEP["config5"])
 
 
 def _two_rank_worker(rank, world, port, H, W, sf, n_img, seed, out_dir):
@@ -278,7 +278,8 @@ def _two_ranks_equal_one_context(tmp_path, key, H, W, sf, n_img, seed):
     d_z = rmse(r0["z"], one["z"]); d_rho = float(np.abs(r0["rho"] - one["rho"]).max()); d_e = abs(float(r0["energies"][0]) - one["energy"]) / abs(one["energy"])
     print(f"{key}: two ranks ({n_img // 2} images each) against one context: depth RMSE {d_z:.3e}, albedo max {d_rho:.3e}, energy {d_e:.3e}, "
           f"fallbacks {int(r0['fallbacks'])} / {int(r1['fallbacks'])}")
-    assert d_z < 2e-5 and d_rho < 1e-4 and d_e < 5e-4
+    # measured: 2048 x 2048 x 40: 1.8e-6 / 3.6e-7 / 9.2e-5; 4096 x 4096 x 64: 2.1e-7 / 4.8e-7 / 2.5e-6 (another summation order of the images)
+    assert d_z < 6e-6 and d_rho < 2e-6 and d_e < 3e-4
 
 
 @pytest.mark.timeout(3000)

@@ -111,3 +111,55 @@ def test_byte_store_is_not_used_for_other_images_and_follows_changes(pkg, oracle
     assert float(np.sqrt(np.mean((srps.z() - ref.z) ** 2))) < 1e-4
     np.testing.assert_allclose(en, ref.energies, rtol=2e-2)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,sf,n_img,kind", [(96, 64, 2, 7, "ragged"), (256, 128, 4, 20, "full"), (60, 44, 1, 3, "ellipse")])
+def test_images_handed_over_as_bytes_equal_their_floats(pkg, h, w, sf, n_img, kind):
+    """srps_problem.I_u8 (the bytes the reference's image-folder loader read, Utilities.cpp:343) against the same images handed
+    over as the floats byte / 255.f: the floats formed on the device, the byte store, and every result of a solve are the same
+    bits; a quarter of the bytes crossed PCIe.  Also srps_upload_image_u8 for one image at a time."""
+    sc = _quantised_scene(pkg, h, w, sf, n_img, seed=431 + n_img, mask_kind=kind)
+    k = np.rint(sc.I * f32(255)).astype(np.uint8)
+    assert np.array_equal(k.astype(f32) / f32(255), sc.I)
+    out = []
+    for how in ("floats", "bytes", "bytes_one_by_one"):
+        ctx = pkg.Context(device_id=0)
+        dh = pkg.DataHandler.from_scene(sc)
+        if how == "bytes":
+            dh.I_u8 = k; dh.I = None
+        elif how == "bytes_one_by_one":
+            dh.I = None                                    # set-up without images, then srps_upload_image_u8 per image
+        ctx.setup(dh)
+        if how == "bytes_one_by_one":
+            for i in range(n_img):
+                ctx.upload_image(i, k[i])
+        P = ctx.dims()["npix"]
+        I_dev = ctx.get("I")
+        np.testing.assert_array_equal(I_dev.view(np.uint32), np.ascontiguousarray(sc.I[:, :, sc.mask == 1]).reshape(-1).view(np.uint32))
+        en = pkg.alternating_loop(ctx, None, max_outer=3)
+        if how == "bytes":
+            assert ctx.get_option("image_store_bytes_active") == (1 if P % 4 == 0 else 0)
+        out.append((np.array(en, f32), ctx.get("z"), ctx.get("rho"), ctx.get("s")))
+        ctx.close()
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_setup_refuses_floats_and_bytes_together(pkg):
+    sc = _quantised_scene(pkg, 40, 32, 2, 2, seed=440)
+    dh = pkg.DataHandler.from_scene(sc)
+    import ctypes as C
+    from importlib import import_module
+    lib = pkg.load()
+    api = import_module("srmeetsps-cuda_amd.api")
+    k = np.rint(sc.I * f32(255)).astype(np.uint8)
+    mask = np.ascontiguousarray(dh.mask, f32); K = np.ascontiguousarray(dh.K, f32); zs = np.ascontiguousarray(dh.zs_lr, f32); zf = np.ascontiguousarray(dh.z_full, f32)
+    I = np.ascontiguousarray(dh.I, f32)
+    pr = api.Problem(dh.I_h, dh.I_w, dh.I_c, 2, 2, 0, 2, api._fptr(mask), api._fptr(K), api._fptr(I), api._fptr(zs), api._fptr(zf),
+                     k.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    ctx = pkg.Context(device_id=0)
+    assert lib.srps_setup(ctx.h, C.byref(pr)) == 1 and b"not both" in lib.srps_last_error()
+    ctx.close()

@@ -56,8 +56,9 @@ def test_hip_full_mitten_solve_to_convergence(pkg, oracle):
     assert len(en) == int(G["n_outer"]), (en, G["energies"])
     print("Mitten: energies relative deviation per pass", [abs(a - b) / b for a, b in zip(en, G["energies"])], "depth rel. RMSE", rel_rmse(srps.z(), G["final_z"]),
           "albedo max abs", float(np.abs(srps.rho() - G["final_rho"]).max()))
-    np.testing.assert_allclose(en, G["energies"], rtol=1e-2)
-    assert abs(en[-1] - G["energies"][-1]) / G["energies"][-1] < 2e-3
-    assert rel_rmse(srps.z(), G["final_z"]) < 1e-4                        # relative: depth ~ 700, ulp(700) = 6e-5
-    assert np.abs(srps.rho() - G["final_rho"]).max() < 5e-3
+    # measured (round 3): every pass's energy within 2.4e-5, depth 1.8e-6 relative, albedo 1.0e-3 -- the asserts allow three times that
+    np.testing.assert_allclose(en, G["energies"], rtol=8e-5)
+    assert rel_rmse(srps.z(), G["final_z"]) < 1e-4                        # north_star's bar; relative: depth ~ 700, ulp(700) = 6e-5
+    assert rel_rmse(srps.z(), G["final_z"]) < 6e-6                        # ... and what a regression would have to stay under
+    assert np.abs(srps.rho() - G["final_rho"]).max() < 3e-3
     ctx.close()
