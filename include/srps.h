@@ -83,6 +83,7 @@ int srps_synchronize(srps_ctx* ctx);
  * "exclusive_device" (0|1: the caller states that nothing else uses the device: plain instead of cooperative launches of the
  *  persistent kernels), "spin_budget_ms" (a persistent launch whose grid-wide waits are not served within this time aborts and the
  *  phase is repeated by the streaming kernels; default 200), "phase_timing", "roctx" (see srps_get_timings),
+ * "cg_partition" (0|1: the depth CG as column strips over the ranks of the context's communicator, see srps_strip_group_solve),
  * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader
  *  produces, Utilities.cpp:343 -- the context also keeps the images as bytes and the two image sweeps of a pass read those:
  *  the same floats, the same results bit for bit, a quarter of the traffic; other images are read as floats) */
@@ -254,6 +255,17 @@ int srps_all_reduce(srps_ctx* ctx, const char* which);
  * through the energy all-reduce, repeat the pass's tail with the streaming kernels together and stay replicas of each other.
  * With a one-rank communicator the results are those of srps_execute bit for bit.  Arguments as srps_execute. */
 int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_outer);
+
+/* The depth CG partitioned into column strips over the communicator's ranks (option "cg_partition" = 1; srps_strips.hip): rank r
+ * owns the bounding-box columns [c_r, c_{r+1}) (cut at multiples of sf), runs the one-launch CG step on them, and between two
+ * steps the ranks all-reduce the step's four sums (32 bytes) and exchange their edge columns of p, r and omega with their
+ * neighbours (ncclSend / ncclRecv); after the last step the strips of the depth are gathered on every rank.  The recurrence is
+ * devicecalls.cu:252-275 unchanged.  With it srps_depth_solve / srps_execute_sharded scale the CG itself with the GPUs; without
+ * it (default) every rank runs the whole CG (replicas).
+ * srps_strip_group_solve: the same solve on n contexts of ONE process that share a device and a stream (srps_set_stream), as a
+ * stand-in for n ranks -- the collectives are device copies, the arithmetic is the multi-GPU path's.  Every context must have
+ * gone through srps_depth_partial on the same problem; afterwards each holds the new depth as after srps_depth_solve. */
+int srps_strip_group_solve(srps_ctx* const* ctxs, int n);
 
 /* stop rule + loop of SRPS.cu:272-335 on one GPU.  max_outer <= 0: run to the reference's stop
  * rule (at most 11 passes).  energies (may be NULL) must hold max_outer values, or 12 when

@@ -127,6 +127,7 @@ def load():
         "srps_comm_release": (i, [vp]),
         "srps_comm_info": (i, [vp, ip, ip]),
         "srps_all_reduce": (i, [vp, C.c_char_p]),
+        "srps_strip_group_solve": (i, [C.POINTER(vp), i]),
         "srps_get": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_set": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_get_device_ptr": (i, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),

@@ -295,6 +295,12 @@ class Context:
         arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
         check(_lib.load().srps_comm_init_all(arr, len(contexts)))
 
+    @staticmethod
+    def strip_group_solve(contexts):
+        """the depth solve of `contexts` (one process, one device, one stream) as the ranks of the strip-partitioned CG"""
+        arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+        check(_lib.load().srps_strip_group_solve(arr, len(contexts)))
+
     def comm_release(self):
         check(self.lib.srps_comm_release(self.h))
 

@@ -371,12 +371,13 @@ __global__ __launch_bounds__(256) void k_cg_flush_x(float* __restrict__ x, const
 // the x update still pending after the last executed step K of the one-launch protocol: alpha_K = r_{K-1}.r_{K-1} / p_K.omega_K from
 // the sums launch K left (dc.cu:269-270)
 __global__ __launch_bounds__(256) void k_cg_flush_x2(float* __restrict__ x, const float* __restrict__ p0, const float* __restrict__ p1,
-                                                     size_t n4, const float* __restrict__ part4, int n_part, int n_live, CgScalars* __restrict__ scal) {
+                                                     size_t n4, const float* __restrict__ part4, int n_part, int n_live, CgScalars* __restrict__ scal, const double* __restrict__ totals4) {
     __shared__ double smd4[4][4];
     const int it = scal->iters;
     if (it < 1) return;
     double s4[4];
-    sum_partials4(part4 + (size_t)(it & 1) * 4 * n_part, n_live, n_part, s4, smd4);
+    if (totals4) { s4[0] = totals4[4 * (it & 1)]; s4[3] = totals4[4 * (it & 1) + 3]; }      // strip-partitioned CG: the sums of launch `it` over all ranks
+    else sum_partials4(part4 + (size_t)(it & 1) * 4 * n_part, n_live, n_part, s4, smd4);
     const float alpha = (float)s4[3] / (float)s4[0];
     const float4* p4 = reinterpret_cast<const float4*>((it & 1) ? p1 : p0);
     float4* x4 = reinterpret_cast<float4*>(x);
@@ -532,7 +533,10 @@ int cg_flush_x(srps_ctx* ctx) {
     Grid& G = ctx->grid;
     if (!use_march(ctx)) return SRPS_OK;       // classic protocol: k_cg_update already moved x
     if (cg_fused_step(ctx)) {
-        hipLaunchKernelGGL(k_cg_flush_x2, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x, G.d_p, G.d_p + G.plane, G.used / 4, G.d_part4, G.n_part4, march_blocks(G), G.d_scal);
+        // a rank of the strip-partitioned CG moves its own columns only (the others arrive with the all-gather of x)
+        const size_t off = G.view_w > 0 ? (size_t)(G.view_c0 + PAD) * G.Hs : 0, n4 = G.view_w > 0 ? (size_t)G.view_w * G.Hs / 4 : G.used / 4;
+        hipLaunchKernelGGL(k_cg_flush_x2, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x + off, G.d_p + off, G.d_p + G.plane + off, n4, G.d_part4, G.n_part4,
+                           march_blocks(G), G.d_scal, (const double*)G.d_totals4);
         SRPS_LAUNCH_CHECK();
         return SRPS_OK;
     }
@@ -544,6 +548,7 @@ int cg_flush_x(srps_ctx* ctx) {
 // the residual of devicecalls.cu:758 (G.d_r: b -> b - A_ x) and the loop of devicecalls.cu:252-275: "while (r1 > tol^2 && k <= max_iter)" => up to max_iter+1 steps.
 // Convergence is tested on the device by every kernel; the host just enqueues the steps.
 int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
+    if (strips_active(ctx)) return strips_cg(ctx, max_steps, fixed_steps);      // this rank's columns only, RCCL between the steps
     if (resident_supported(ctx)) {                 // residual and CG in one persistent launch
         const int rc = resident_cg(ctx, max_steps, fixed_steps);
         if (rc != SRPS_ERR_UNSUPPORTED) return rc;

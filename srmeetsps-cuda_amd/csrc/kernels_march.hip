@@ -54,6 +54,9 @@ struct MarchArgs {
     const float* part4_in;
     float* part4_out;
     int n_part;
+    // strip-partitioned CG (several ranks, each a range of columns): the four sums of the previous step over ALL ranks, all-reduced
+    // between the launches (double, the same bits on every rank); null: one rank, the sums are this grid's block partials
+    const double* totals4;
 };
 
 __device__ __forceinline__ float dpp_from_prev_lane(float v) {      // lane i <- lane i-1 ; lane 0 <- 0
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
     if (MODE == 3) {
         if (!a.scal->active) return;                                   // an earlier launch found r.r <= tol^2 (dc.cu:252)
         double s4[4];
-        sum_partials4(a.part4_in, (int)gridDim.x, a.n_part, s4, smd4);      // the previous launch had this launch's blocks
+        if (a.totals4) { s4[0] = a.totals4[0]; s4[1] = a.totals4[1]; s4[2] = a.totals4[2]; s4[3] = a.totals4[3]; }
+        else sum_partials4(a.part4_in, (int)gridDim.x, a.n_part, s4, smd4);      // the previous launch had this launch's blocks
         float r1;
         const float r1_direct = (float)s4[3];                          // r_{k-2}.r_{k-2} (k == 1: of the initial residual)
         if (a.k == 1) r1 = r1_direct;
@@ -402,7 +406,9 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
                     SRPS_ROW(3, FL0, 16, fl_dn, 0, V0.e[2], v_dn)
 #undef SRPS_ROW
                 }
-                if (owned) {
+                // a strip wider than what is left of the (view of the) grid computes columns beyond it: zeros on a whole grid, a
+                // neighbouring rank's columns on a strip view -- neither stored nor summed
+                if (owned && (unsigned)(c - PAD) < (unsigned)a.Wg) {
                     const size_t off = (size_t)c * Hs + row0;
                     if (MODE == 0) {
                         st4(a.out + off, acc);
@@ -487,11 +493,12 @@ void march_plan(Grid& G, int tj, int num_cus) {
     own = ((own + 3) / 4) * 4;
     G.seg_rows = own;
     G.n_seg = cdiv(G.Hg, own);
+    const int Wv = G.view_w > 0 ? G.view_w : G.Wg;      // a rank of the strip-partitioned CG plans its own columns only
     if (tj <= 0) {
         const int simds = 4 * std::max(1, num_cus);  // 256 CUs x 4 SIMDs on a whole MI355X; fewer under a CU mask or a partition
         long best = -1;
         for (int cand = 4; cand <= 128; cand += 4) {
-            const long waves = (long)G.n_seg * cdiv(G.Wg, cand);
+            const long waves = (long)G.n_seg * cdiv(Wv, cand);
             long cost = ((waves + simds - 1) / simds) * (cand + 2) * 64 + cand;      // ties: narrower strips
             // measured at 4096^2, sf 2 (same box, per CG step): 72 columns (969 waves) 161 us, 76 columns (918 waves) 152 us,
             // 80 / 84: 181 / 176 on a slower box -- widths that are a multiple of 8 columns lose 3 - 6 % against their neighbours;
@@ -502,13 +509,21 @@ void march_plan(Grid& G, int tj, int num_cus) {
         }
     }
     G.strip_cols = tj;
-    G.n_strip = cdiv(G.Wg, tj);
+    G.n_strip = cdiv(Wv, tj);
 }
 
 template <int MODE>
 static int launch_march(srps_ctx* ctx, MarchArgs& a) {
     Grid& G = ctx->grid;
     a.own = G.seg_rows; a.n_seg = G.n_seg; a.n_strip = G.n_strip; a.n_items = G.n_seg * G.n_strip;
+    if (G.view_w > 0) {
+        // this rank's columns [view_c0, view_c0 + view_w) of the grid as a grid of their own: every plane has the column stride
+        // Hs, so the view is a pointer offset; the columns left and right of it are the halo the neighbours keep current
+        const size_t off = (size_t)G.view_c0 * G.Hs;
+        auto sh = [&](auto*& ptr) { if (ptr) ptr += off; };
+        sh(a.M); sh(a.flags); sh(a.xin); sh(a.p_in); sh(a.p_out); sh(a.r); sh(a.r_out); sh(a.out); sh(a.x); sh(a.G); sh(a.w_prev);
+        a.Wg = G.view_w; a.j_lo += G.view_c0;
+    }
     const int nb = cdiv(a.n_items, 4);
 #define SRPS_MARCH_TJ(SF)                                                                                     \
     switch (nc) {                                                                                             \
@@ -578,7 +593,23 @@ int march_cg_step(srps_ctx* ctx, int k) {
     a.part4_out = G.d_part4 + (size_t)(k & 1) * 4 * G.n_part4;
     a.k = k;
     a.tol2 = ctx->cg_fixed ? -1.f : ctx->cg_tol * ctx->cg_tol;
+    a.totals4 = G.d_totals4 ? G.d_totals4 + 4 * ((k + 1) & 1) : nullptr;      // the previous launch's sums over all ranks; null unless the strip-partitioned CG is driving (srps_strips.hip)
     return launch_march<3>(ctx, a);
+}
+
+// the block partials a launch of this grid left (p.omega, r.omega, omega.omega, r.r; `which` = the launch's parity, 0 for the
+// residual launch) summed in the fixed order into four doubles: what a rank contributes to the all-reduce between two steps
+__global__ __launch_bounds__(256) void k_part4_totals(const float* __restrict__ part4, int n_live, int n_part, double* __restrict__ out) {
+    __shared__ double smd4[4][4];
+    double s4[4];
+    sum_partials4(part4, n_live, n_part, s4, smd4);
+    if (threadIdx.x < 4) out[threadIdx.x] = s4[threadIdx.x];
+}
+int march_part4_totals(srps_ctx* ctx, int which, double* d_out) {
+    Grid& G = ctx->grid;
+    hipLaunchKernelGGL(k_part4_totals, dim3(1), dim3(256), 0, ctx->stream, (const float*)(G.d_part4 + (size_t)(which & 1) * 4 * G.n_part4), march_blocks(G), G.n_part4, d_out);
+    SRPS_LAUNCH_CHECK();
+    return SRPS_OK;
 }
 
 int march_cg_apply(srps_ctx* ctx, int k) {

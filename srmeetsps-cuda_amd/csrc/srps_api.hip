@@ -351,6 +351,7 @@ int srps_destroy(srps_ctx* ctx) {
     state_release(ctx);
     grid_free(ctx->grid);
     dfree(ctx->I8);
+    dfree(ctx->d_strip_tot);
     if (ctx->state_arena.p) (void)hipFree(ctx->state_arena.p);
     if (ctx->ws_struct.p) (void)hipFree(ctx->ws_struct.p);
     for (hipEvent_t e : ctx->ev_copied) (void)hipEventDestroy(e);
@@ -469,6 +470,9 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
             march_plan(ctx->grid, value, ctx->num_cus);
         }
         ctx->march_tj = value;
+    } else if (!strcmp(name, "cg_partition")) {
+        SRPS_REQUIRE(value == 0 || value == 1, SRPS_ERR_INVALID, "cg_partition: 0 (every rank runs the whole depth CG) or 1 (column strips over the communicator's ranks)");
+        ctx->cg_strips = value;
     } else if (!strcmp(name, "cg_max_iter")) {
         SRPS_REQUIRE(value >= 0, SRPS_ERR_INVALID, "cg_max_iter: bad value %d", value);
         ctx->cg_max_iter = value;
@@ -503,6 +507,8 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_resident_rect_tiles_512")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[1] : 0;      // of the 256 x 64 tiling
     else if (!strcmp(name, "cg_resident_rect_tiles_16")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[2] : 0;       // of the 256 x 16 tiling
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
+    else if (!strcmp(name, "cg_partition")) *value = ctx->cg_strips;
+    else if (!strcmp(name, "cg_partition_active")) *value = strips_active(ctx) ? 1 : 0;
     else if (!strcmp(name, "cg_resident_tile")) *value = ctx->cg_resident_tile;
     else if (!strcmp(name, "albedo_channels_together")) *value = ctx->albedo_channels_together;
     else if (!strcmp(name, "albedo_one_sync")) *value = ctx->albedo_one_sync;
@@ -952,25 +958,41 @@ int srps_depth_partial(srps_ctx* ctx) {
     return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
                           ctx->N_total, ctx->img_offset, ctx->cx, ctx->cy, ssum, ctx->q_ex);
 }
-int srps_depth_solve(srps_ctx* ctx) {
-    CTX_CHECK(ctx); STATE_CHECK(ctx);
-    PhaseSpan span(ctx, SRPS_PHASE_DEPTH_SOLVE);
-    SRPS_REQUIRE(ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
+extern "C++" {
+namespace srps {
+// the two halves of srps_depth_solve around the CG (the strip-partitioned group solve runs the CG of several contexts in lockstep)
+int depth_solve_prepare(srps_ctx* ctx) {
+    SRPS_REQUIRE(ctx->have_state && ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
     if (ctx->q_in_exchange) { SRPS_TRY(depth_q_scatter(ctx, ctx->q_ex)); ctx->q_in_exchange = false; }      // the all-reduced q of a shard
     ctx->light_cache_valid = false;      // z changes
     const bool plane_current = ctx->grad_current && ctx->plane_holds_z;      // nothing wrote z or the plane since the last solve
     ctx->grad_current = false;
     ctx->plane_holds_z = false;
-    SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy, plane_current));
+    if (!plane_current) SRPS_TRY(grid_scatter(ctx, ctx->z, ctx->grid.d_x));      // else the last solve left z on the grid plane
+    return grid_rhs(ctx, ctx->z0s);                                                // dc.cu:743-745
+}
+int depth_solve_finish(srps_ctx* ctx) {
+    SRPS_TRY(grid_gradient(ctx, ctx->grid.d_x, ctx->zx, ctx->zy, ctx->z));         // the new z in the compact layout, and Dx z, Dy z (energy + normals)
+    ctx->report_pending = true;          // the CG scalars are fetched with the rest of the report record
+    ctx->grad_current = true;
+    ctx->plane_holds_z = true;
+    return SRPS_OK;
+}
+}  // namespace srps
+}  // extern "C++"
+
+int srps_depth_solve(srps_ctx* ctx) {
+    CTX_CHECK(ctx); STATE_CHECK(ctx);
+    PhaseSpan span(ctx, SRPS_PHASE_DEPTH_SOLVE);
+    SRPS_TRY(depth_solve_prepare(ctx));
+    SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false));          // dc.cu:758-759 (residual; k <= max_iter => 101 steps)
     if (ctx->N_local != ctx->N_total && !ctx->defer_shard_checks) {  // see srps_albedo_finish
         int aborted = 0;
         SRPS_TRY(persistent_sync_check(ctx, &aborted));
         // the plane the launch started from is current again (persistent_aborts)
-        if (aborted & ABORT_DEPTH) SRPS_TRY(depth_solve_impl(ctx, ctx->z0s, ctx->z, ctx->zx, ctx->zy, true));
+        if (aborted & ABORT_DEPTH) { SRPS_TRY(grid_rhs(ctx, ctx->z0s)); SRPS_TRY(grid_cg(ctx, ctx->cg_max_iter + 1, false)); }
     }
-    ctx->grad_current = true;            // depth_solve_impl leaves Dx z, Dy z of the new z in zx, zy
-    ctx->plane_holds_z = true;           // ... and z itself on the grid plane
-    return SRPS_OK;
+    return depth_solve_finish(ctx);
 }
 int srps_energy_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);

@@ -87,19 +87,42 @@ int comm_broadcast(srps_ctx* ctx, float* d_buf, size_t n, int root) {
     SRPS_RCCL(g_rccl.Broadcast(d_buf, d_buf, n, ncclFloat32, root, (ncclComm_t)ctx->comm, ctx->stream));
     return SRPS_OK;
 }
-// the halo exchange of the strip-partitioned CG: both directions of both neighbours as ONE group (a send and a receive that wait
-// for each other must be in flight together); a null pointer / negative peer leaves that leg out
-int comm_exchange(srps_ctx* ctx, const float* send_left, float* recv_left, int left, const float* send_right, float* recv_right, int right, size_t n) {
+int comm_all_reduce_sum_f64(srps_ctx* ctx, const double* d_in, double* d_out, size_t n) {
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "all_reduce: no communicator bound to the context");
+    if (n == 0) return SRPS_OK;
+    SRPS_RCCL(g_rccl.AllReduce(d_in, d_out, n, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return SRPS_OK;
+}
+// The halo exchange of the strip-partitioned CG: for each of `nbuf` buffers, n floats to and from the left neighbour (rank
+// `left`, < 0: none) and the right neighbour, all as ONE group (sends and receives that wait for each other must be in flight
+// together).
+int comm_exchange(srps_ctx* ctx, int nbuf, const float* const* send_left, float* const* recv_left, int left,
+                  const float* const* send_right, float* const* recv_right, int right, size_t n) {
     SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "exchange: no communicator bound to the context");
-    if (n == 0 || (left < 0 && right < 0)) return SRPS_OK;
+    if (n == 0 || nbuf == 0 || (left < 0 && right < 0)) return SRPS_OK;
     SRPS_RCCL(g_rccl.GroupStart());
     ncclResult_t r = ncclSuccess;
-    if (left >= 0 && r == ncclSuccess) r = g_rccl.Send(send_left, n, ncclFloat32, left, (ncclComm_t)ctx->comm, ctx->stream);
-    if (left >= 0 && r == ncclSuccess) r = g_rccl.Recv(recv_left, n, ncclFloat32, left, (ncclComm_t)ctx->comm, ctx->stream);
-    if (right >= 0 && r == ncclSuccess) r = g_rccl.Send(send_right, n, ncclFloat32, right, (ncclComm_t)ctx->comm, ctx->stream);
-    if (right >= 0 && r == ncclSuccess) r = g_rccl.Recv(recv_right, n, ncclFloat32, right, (ncclComm_t)ctx->comm, ctx->stream);
+    for (int b = 0; b < nbuf; ++b) {
+        if (left >= 0 && r == ncclSuccess) r = g_rccl.Send(send_left[b], n, ncclFloat32, left, (ncclComm_t)ctx->comm, ctx->stream);
+        if (left >= 0 && r == ncclSuccess) r = g_rccl.Recv(recv_left[b], n, ncclFloat32, left, (ncclComm_t)ctx->comm, ctx->stream);
+        if (right >= 0 && r == ncclSuccess) r = g_rccl.Send(send_right[b], n, ncclFloat32, right, (ncclComm_t)ctx->comm, ctx->stream);
+        if (right >= 0 && r == ncclSuccess) r = g_rccl.Recv(recv_right[b], n, ncclFloat32, right, (ncclComm_t)ctx->comm, ctx->stream);
+    }
     const ncclResult_t e = g_rccl.GroupEnd();
     if (r != ncclSuccess) return rccl_fail(r, "ncclSend / ncclRecv");
+    SRPS_RCCL(e);
+    return SRPS_OK;
+}
+// every rank's piece of a buffer to every rank: piece q = [offset[q], offset[q] + count[q]) floats of d_buf, broadcast from rank q
+// (the pieces differ in size by up to one block column, which ncclAllGather does not take)
+int comm_all_gather_pieces(srps_ctx* ctx, float* d_buf, const size_t* offset, const size_t* count) {
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "all_gather: no communicator bound to the context");
+    SRPS_RCCL(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int q = 0; q < ctx->comm_world && r == ncclSuccess; ++q)
+        if (count[q]) r = g_rccl.Broadcast(d_buf + offset[q], d_buf + offset[q], count[q], ncclFloat32, q, (ncclComm_t)ctx->comm, ctx->stream);
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(r, "ncclBroadcast");
     SRPS_RCCL(e);
     return SRPS_OK;
 }

@@ -86,6 +86,10 @@ struct Grid {
     int nb_apply = 0, nb_update = 0;
     // marching-kernel decomposition
     int seg_rows = 0, n_seg = 0, strip_cols = 0, n_strip = 0;
+    // strip-partitioned CG (srps_strips.hip): this rank's columns [view_c0, view_c0 + view_w) of the grid (view_w == 0: the whole grid)
+    int view_c0 = 0, view_w = 0;
+    double* d_totals4 = nullptr;  // [2][4] the sums over all ranks of the launches of even / odd parity (null: the block partials of this grid are
+                                  // summed by the next launch itself)
     // Everything above is carved out of ONE device allocation, kept while a later bind asks for no more than it holds (a re-setup
     // on the same frame size allocates nothing): hipMalloc / hipFree of ~25 arrays cost milliseconds per solve
     void* arena = nullptr;
@@ -170,6 +174,9 @@ struct srps_ctx {
     void* comm = nullptr;            // ncclComm_t
     bool comm_owned = false;         // created by srps_comm_init_rank / srps_comm_init_all (destroyed with the context), not borrowed (srps_set_comm)
     int comm_rank = 0, comm_world = 1;
+    int cg_strips = 0;               // option "cg_partition": 1 = the depth CG partitioned into column strips over the communicator's ranks
+    double* d_strip_tot = nullptr;   // [12]: [0..3] this rank's sums of a launch, [4..7] / [8..11] the sums over all ranks of the launches of even / odd
+                                     // parity (Grid::d_totals4 points at [4])
     bool defer_shard_checks = false; // srps_execute_sharded: a shard's phases do not look at the abort flags themselves; the ranks decide together at the end of the pass
     bool x_swapped = false;          // the resident CG launched since the abort flags were last looked at swapped grid.d_x and grid.d_x2
     int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at
@@ -313,6 +320,7 @@ int march_cg_step(srps_ctx* ctx, int k);
 bool cg_fused_step(const srps_ctx* ctx);      // the streaming CG runs one launch per step
 int cg_flush_x(srps_ctx* ctx);
 int march_recompute_channels(const srps_ctx* ctx);
+int march_part4_totals(srps_ctx* ctx, int which, double* d_out);
 
 int grid_need_M(srps_ctx* ctx);            // srps_api.hip: the stored 6-plane tensor, allocated on demand
 // ---- structure build on the device (kernels_structure.hip) ----------------------------------
@@ -328,7 +336,18 @@ int launch_gather_images_u8(hipStream_t st, const unsigned char* d_full, const i
 bool comm_bound(const srps_ctx* ctx);
 int comm_all_reduce_sum(srps_ctx* ctx, float* d_buf, size_t n);      // in place, on the context's stream
 int comm_broadcast(srps_ctx* ctx, float* d_buf, size_t n, int root);
-int comm_exchange(srps_ctx* ctx, const float* send_left, float* recv_left, int left, const float* send_right, float* recv_right, int right, size_t n);
+int comm_all_reduce_sum_f64(srps_ctx* ctx, const double* d_in, double* d_out, size_t n);
+int comm_exchange(srps_ctx* ctx, int nbuf, const float* const* send_left, float* const* recv_left, int left,
+                  const float* const* send_right, float* const* recv_right, int right, size_t n);
+int comm_all_gather_pieces(srps_ctx* ctx, float* d_buf, const size_t* offset, const size_t* count);
+
+// ---- strip-partitioned depth CG (srps_strips.hip) --------------------------------------------
+bool strips_active(const srps_ctx* ctx);                       // option "cg_partition" = 1, a communicator of more than one rank, a grid the streaming step handles
+int strips_bind_view(srps_ctx* ctx, int rank, int world);      // this rank's columns of the bound grid
+void strips_clear_view(srps_ctx* ctx);
+int strips_cg(srps_ctx* ctx, int max_steps, bool fixed_steps); // the CG of devicecalls.cu:252-275 on this rank's strip (RCCL between the steps)
+int depth_solve_prepare(srps_ctx* ctx);                        // srps_api.hip: the two halves of srps_depth_solve around the CG
+int depth_solve_finish(srps_ctx* ctx);
 void comm_release(srps_ctx* ctx);
 
 // ---- generic CSR (kernels_csr.hip) --------------------------------------------------------

@@ -76,7 +76,7 @@ def test_all_reduce_entry_point_and_errors(pkg):
 
 def test_a_persistent_abort_in_the_sharded_loop_repeats_the_pass_and_matches_streaming(pkg):
     """the sharded loop defers the look at the abort flags to the end of the pass (they travel with the energy term): a depth
-    CG whose waits cannot be served (a 1 ms budget against a co-tenant holding CUs) gives up, the pass's tail is repeated by
+    CG whose waits cannot be served (a 40 ms budget against a co-tenant holding CUs for 1.5 s) gives up, the pass's tail is repeated by
     the streaming kernels from the iterate the launch started from -- the result is that of a context that streamed from the
     start, bit for bit"""
     import ctypes
@@ -88,7 +88,7 @@ def test_a_persistent_abort_in_the_sharded_loop_repeats_the_pass_and_matches_str
         pytest.skip("tools/libcu_holder.so is not built")
     import time
     holder = ctypes.CDLL(so)
-    sc = pkg.synth.make_scene(1024, 1024, 4, 3, seed=53, mask_kind="full")      # 256 tiles of 256 x 32: every CU
+    sc = pkg.synth.make_scene(2048, 2048, 4, 2, seed=53, mask_kind="full")      # 256 tiles of 256 x 64, 157 KiB of LDS each: every CU, and none that a co-tenant holds
     dh = pkg.DataHandler.from_scene(sc)
 
     def run(resident, with_holder):

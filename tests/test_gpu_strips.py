@@ -1,0 +1,114 @@
+"""The strip-partitioned depth CG on the GPU (srps_strips.hip): 2, 3 and 4 ranks as contexts of ONE process on one device and one
+stream (srps_strip_group_solve: the collectives are device copies and a summing kernel; views, halo columns, totals and kernels
+are those of the multi-GPU path) against the single-grid CG of the same library, and against the oracle.  The recurrence is
+devicecalls.cu:252-275; what changes with the partition is only the grouping of the four dot-product sums (per rank, then over
+ranks), so the results agree to rounding, not to the bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+def _pass_with_group(pkg, dh, world, stream):
+    ctxs = []
+    for r in range(world):
+        c = pkg.Context(device_id=0)
+        c.set_stream(stream)
+        c.set_option("cg_resident", 0)
+        c.setup(dh)
+        ctxs.append(c)
+    for c in ctxs:
+        c.lighting(); c.albedo(); c.depth_partial()
+    pkg.Context.strip_group_solve(ctxs)
+    out = []
+    for c in ctxs:
+        c.energy_partial(); c.normals()
+        e = c.energy_finish()
+        out.append((e, c.get("z"), c.last_cg_iterations()["depth"]))
+        c.close()
+    return out
+
+
+def _pass_single(pkg, dh, stream, fused=1):
+    c = pkg.Context(device_id=0)
+    c.set_stream(stream)
+    c.set_option("cg_resident", 0); c.set_option("cg_fused_step", fused)
+    c.setup(dh)
+    c.lighting(); c.albedo()
+    e = c.depth()
+    out = (e, c.get("z"), c.last_cg_iterations()["depth"])
+    c.close()
+    return out
+
+
+@pytest.mark.parametrize("h,w,sf,kind,world", [(96, 80, 2, "ragged", 2), (96, 80, 2, "ragged", 3), (300, 200, 1, "ragged", 4), (512, 384, 4, "ellipse", 2),
+                                               (512, 384, 4, "ellipse", 4), (256, 640, 2, "full", 3)])
+def test_strip_ranks_in_one_process_equal_the_single_grid_cg(pkg, oracle, h, w, sf, kind, world):
+    import torch
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=h + 7 * w + world, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        e1, z1, it1 = _pass_single(pkg, dh, stream.cuda_stream)
+        group = _pass_with_group(pkg, dh, world, stream.cuda_stream)
+    for e, z, it in group[1:]:                                  # every rank ends with the same depth, bit for bit
+        assert e == group[0][0] and it == group[0][2]
+        np.testing.assert_array_equal(z, group[0][1])
+    e, z, it = group[0]
+    print(f"{h}x{w} sf {sf} {kind}, {world} strips: depth RMSE vs single grid {rmse(z, z1):.3e}, energy {e} vs {e1}, steps {it} / {it1}")
+    assert abs(it - it1) <= 1 and it >= 10
+    assert rmse(z, z1) < 2e-5
+    assert abs(e - e1) <= 1e-3 * abs(e1)
+    if h * w <= 96 * 80:
+        ref = oracle.execute(oracle.Problem(sc.h, sc.w, sc.sf, sc.mask, sc.K, sc.I, sc.zs_lr, sc.z_init), depth="faithful", max_outer=1)
+        assert rmse(z, ref.z) < 5e-5
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("world", [2, 4])
+def test_strips_at_the_largest_grid(pkg, world):
+    """4096 x 4096, sf 2 (BASELINE.json configs[4]'s grid): 2 and 4 strips of 2048 / 1024 columns against the single grid,
+    all 101 steps"""
+    import torch
+    sc = pkg.synth.make_scene(4096, 4096, 2, 2, seed=1238, mask_kind="full")
+    dh = pkg.DataHandler.from_scene(sc)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        e1, z1, it1 = _pass_single(pkg, dh, stream.cuda_stream)
+        group = _pass_with_group(pkg, dh, world, stream.cuda_stream)
+    e, z, it = group[0]
+    print(f"4096^2, {world} strips: depth RMSE vs single grid {rmse(z, z1):.3e}, energy {e} vs {e1}")
+    assert it == it1 == 101
+    for e_r, z_r, it_r in group[1:]:
+        np.testing.assert_array_equal(z_r, z)
+    assert rmse(z, z1) < 2e-5
+    assert abs(e - e1) <= 1e-4 * abs(e1)
+
+
+def test_group_solve_refuses_contexts_that_do_not_belong_together(pkg):
+    import torch
+    sc = pkg.synth.make_scene(40, 32, 2, 2, seed=5, mask_kind="full")
+    dh = pkg.DataHandler.from_scene(sc)
+    a = pkg.Context(device_id=0); b = pkg.Context(device_id=0)
+    a.setup(dh); b.setup(dh)
+    for c in (a, b):
+        c.lighting(); c.albedo(); c.depth_partial()
+    with pytest.raises(pkg.SRPSError) as ei:
+        pkg.Context.strip_group_solve([a, b])                   # two streams
+    assert ei.value.code == 1 and "one stream" in str(ei.value)
+    s = torch.cuda.Stream()
+    a.set_stream(s.cuda_stream); b.set_stream(s.cuda_stream)
+    c = pkg.Context(device_id=0); c.set_stream(s.cuda_stream)
+    with pytest.raises(pkg.SRPSError) as ei:
+        pkg.Context.strip_group_solve([a, c])                   # c has no system
+    assert ei.value.code == 3
+    with torch.cuda.stream(s):
+        pkg.Context.strip_group_solve([a, b])                   # and this works
+    np.testing.assert_array_equal(a.get("z"), b.get("z"))
+    for x in (a, b, c):
+        x.close()
