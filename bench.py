@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the streaming-CG legs (2048^2 streaming, 4096^2 sf 2)")
     ap.add_argument("--apply-mode", type=int, default=0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="srps_set_option before setup (A/B runs)")
+    ap.add_argument("--partition", choices=["images", "strips"], default="images",
+                    help="N > 1: 'images' shards the images and replicates the depth CG (default); 'strips' also partitions the depth CG into "
+                         "column strips over the ranks (option cg_partition; needs --comm library) -- meant for --size 4096 --sf 2")
     ap.add_argument("--comm", choices=["library", "torch"], default="library",
                     help="N > 1: the all-reduces of a pass as ncclAllReduce inside libsrps_hip.so (srps_execute_sharded; default) or as "
                          "torch.distributed.all_reduce on views of the library's exchange buffers")
@@ -243,6 +246,8 @@ def main():
                 comm_kind = "library"
             elif ok:
                 ctx.comm_release()
+    if args.partition == "strips" and comm_kind == "library":
+        ctx.set_option("cg_partition", 1)
     ctx.setup(dh)
     dims = ctx.dims()
 
@@ -287,7 +292,8 @@ def main():
                    "exclusive_device": ctx.get_option("exclusive_device"),       # 1: plain launches of the persistent kernels (the library's default is the cooperative launch: ~26 us per pass more)
                    "comm": {"none": "none (1 GPU)", "library": "ncclAllReduce inside libsrps_hip.so (srps_execute_sharded), communicator from srps_comm_init_rank",
                             "torch": "torch.distributed.all_reduce on views of the library's exchange buffers"}[comm_kind],
-                   "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, replicated CG"
+                   "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, "
+                                   + ("depth CG partitioned into column strips (4-double all-reduce + edge-column exchange per step)" if ctx.get_option("cg_partition_active") else "replicated CG")
                                    + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},
         "energies": energies,
     }
@@ -319,6 +325,35 @@ def main():
             legs["largest_grid_4096_sf2"] = dict(cg_legs(pkg, c4, 4096, 4096, 2, resident_expected=False, solves=3),
                                                  workload="depth CG on a synthetic full-mask 4096x4096 HR grid, sf 2 (16.8 M unknowns; 2 images: the CG does not depend on their number)")
             c4.close()
+            # The strip-partitioned CG (srps_strips.hip) with its ranks as 8 contexts on this one device (device copies instead of
+            # RCCL): the group's time / 8 is what ONE rank computes per step on its eighth of the columns -- the compute side of the
+            # per-step budget of an 8-GPU run; its communication side (a 32-byte all-reduce and a 48 KB neighbour exchange per step)
+            # cannot be measured here.
+            try:
+                group = []
+                for _ in range(8):
+                    cs = pkg.Context(device_id=local_rank)
+                    cs.set_stream(stream.cuda_stream)
+                    cs.set_option("exclusive_device", 1)
+                    cs.setup(pkg.DataHandler.from_scene(sc4))
+                    cs.lighting(); cs.albedo(); cs.depth_partial()
+                    group.append(cs)
+                pkg.Context.strip_group_solve(group)
+                for cs in group:
+                    cs.depth_partial()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                pkg.Context.strip_group_solve(group)
+                torch.cuda.synchronize()
+                dg = time.perf_counter() - tg
+                legs["strip_cg_4096_sf2_8_ranks_on_one_device"] = {
+                    "group_solve_s": dg, "us_per_step_and_rank": 1e6 * dg / (101 * 8), "ranks": 8, "columns_per_rank": 512,
+                    "depth_steps": group[0].last_cg_iterations()["depth"],
+                    "workload": "101 CG steps of the 4096x4096, sf 2 system as 8 column strips, all 8 ranks on this one device in lockstep (device copies for the collectives): time / 8 = one rank's compute per step"}
+                for cs in group:
+                    cs.close()
+            except Exception as exc:                      # a side measurement: never fail the bench line because of it
+                legs["strip_cg_4096_sf2_8_ranks_on_one_device"] = {"error": str(exc)}
             del sc4
             # the headline's mask is the best case of the resident kernel (every tile inside the mask: the body without structure
             # bits); any other mask -- the reference's own data -- takes the general body.  An ellipse in the same frame:

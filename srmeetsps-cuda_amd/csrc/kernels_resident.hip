@@ -134,7 +134,9 @@ struct ResidentArgs {
     int i_lo, j_lo;
     int debug;                 // timing experiments only: 1 = no grid-wide sums, no ring polls (wrong results)
     unsigned long long spin_ticks;   // budget of the whole launch in s_memrealtime ticks (10 ns): waits give up after it
-    const uint8_t* tile_cls;   // [tiles] TILE_* bits per tile (host: classify_tiles), nullptr: every tile takes the general body
+    const uint8_t* tile_cls;   // [tiles] TILE_* bits per tile (kernels_structure.hip), nullptr: every tile takes the general body
+    const uint8_t* tile_occ;   // [tiles] the same array, always: TILE_OCCUPIED says whether a neighbouring tile has a block at all
+    const int* tile_list;      // [blocks] the occupied tiles, ascending: block b works on tile tile_list[b]
 };
 
 // per-channel constants of the tensor-recompute form (uniform)
@@ -299,7 +301,8 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         const int dbr = pr < 0 ? -1 : (pr >= TR ? 1 : 0), dbc = pc < 0 ? -1 : (pc >= TC ? 1 : 0);
         const int nbr_ = br + dbr, nbc_ = bc + dbc;
         const int lr = pr - TR * dbr, lc = pc - TC * dbc;      // coordinates inside the owning tile
-        if (nbr_ >= 0 && nbr_ < a.nbr && nbc_ >= 0 && nbc_ < a.nbc) {
+        // a neighbouring tile without a masked pixel has no block: nothing is published for it, its side of the ring is empty
+        if (nbr_ >= 0 && nbr_ < a.nbr && nbc_ >= 0 && nbc_ < a.nbc && (a.tile_occ[nbc_ * a.nbr + nbr_] & TILE_OCCUPIED)) {
             const int nt = nbc_ * a.nbr + nbr_;
             int gi;
             if (lc == 0) gi = lr;                               // its first column
@@ -834,6 +837,7 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
         const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = tile & 7, kk = tile >> 3;
         tile = xcd * q + min(xcd, rem) + kk;
     }
+    tile = a.tile_list[tile];                              // one block per occupied tile
     const unsigned cls = RECT ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.tile_cls[tile]) : 0u;
     resident_body<SF, NC, ONE_SYNC, RECT>(a, tile, cls);
 }
@@ -858,8 +862,8 @@ bool SRPS_RES_NAME(resident_supported)(const srps_ctx* ctx) {
     if (nc != 1 && nc != 3) return false;
     if (G.sf != 1 && G.sf != 2 && G.sf != 4) return false;
     if (G.sf > CPT) return false;                          // a thread's columns hold whole sf x sf blocks of KT
-    const long tiles = (long)cdiv(G.Hg, TR) * cdiv(G.Wg, TC);
-    return tiles <= ctx->num_cus;
+    const int shape = TC == 64 ? 1 : (TC == 32 ? 0 : 2);      // index of the tiling in Grid::d_tile_cls
+    return G.n_occ[shape] > 0 && G.n_occ[shape] <= ctx->num_cus;      // a CU for every tile that holds unknowns; empty tiles of the bounding box take none
 }
 
 // the residual b - A_ x0 (devicecalls.cu:758) and the whole CG of devicecalls.cu:252-275: G.d_r holds b, G.d_x holds x0
@@ -888,8 +892,11 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.debug = ctx->cg_resident_debug;
     a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;      // s_memrealtime: 100 MHz
     const int shape = TC == 64 ? 1 : (TC == 32 ? 0 : 2);      // index of the tiling in Grid::d_tile_cls
-    const bool rect = ctx->cg_resident_rect && G.n_tiles[shape] == tiles && G.n_rect_tiles[shape] == tiles;      // every tile qualifies
+    const int blocks = G.n_occ[shape];
+    const bool rect = ctx->cg_resident_rect && G.n_tiles[shape] == tiles && G.n_rect_tiles[shape] == blocks;      // every occupied tile qualifies
     a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr;
+    a.tile_occ = G.d_tile_cls[shape];
+    a.tile_list = G.d_tile_list[shape];
     const void* fn = nullptr;
 #define SRPS_RES(SFV, NCV) fn = rect ? (ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true, true> : (const void*)k_cg_resident<SFV, NCV, false, true>) \
                                     : (ctx->cg_one_sync ? (const void*)k_cg_resident<SFV, NCV, true, false> : (const void*)k_cg_resident<SFV, NCV, false, false>)
@@ -902,7 +909,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const size_t lds = resident_lds_bytes(nc);
     SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {&a};
-    const int rc = launch_persistent(ctx, fn, tiles, NT, args, lds);      // SRPS_ERR_UNSUPPORTED: the caller falls back to the streaming kernels
+    const int rc = launch_persistent(ctx, fn, blocks, NT, args, lds);      // SRPS_ERR_UNSUPPORTED: the caller falls back to the streaming kernels
     if (rc == SRPS_OK) { std::swap(G.d_x, G.d_x2); ctx->x_swapped = true; }      // the result is in the other plane (see persistent_aborts)
     return rc;
 }
@@ -922,7 +929,7 @@ static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 4: 256 x 1
     // 1024 x 1024 full, 256 tiles: 6.5 against 6.2 -- there the 256 x 32 tiles stay).  With 256 threads and four columns per
     // thread (sf 4) while they are few (640 x 480, 90 tiles: 6.5 / 7.0; 1024 x 512, 128 tiles: 6.1 against 5.9): a step's cost
     // outside the columns (ring, exchange, skew of more blocks) does not shrink with the tile.
-    const long tiles16 = (long)cdiv(ctx->grid.Hg, TR) * cdiv(ctx->grid.Wg, 16);
+    const long tiles16 = ctx->grid.n_occ[2];               // occupied 256 x 16 tiles
     if (tiles16 <= 240 && resident_supported_n512c2(ctx)) return 4;
     if (tiles16 <= 96 && resident_supported_n256c4(ctx)) return 2;
     // 256 x 32 tiles: eight waves of four columns each (two waves per SIMD: an instruction issues in 2.3 clocks) rather than four
@@ -938,7 +945,7 @@ bool resident_rect_active(const srps_ctx* ctx) {
     if (shape < 0 || !ctx->cg_resident_rect) return false;
     if (shape == 3) shape = 0;      // the same 256 x 32 tiling
     if (shape == 4) shape = 2;      // the same 256 x 16 tiling
-    return ctx->grid.n_tiles[shape] > 0 && ctx->grid.n_rect_tiles[shape] == ctx->grid.n_tiles[shape];
+    return ctx->grid.n_occ[shape] > 0 && ctx->grid.n_rect_tiles[shape] == ctx->grid.n_occ[shape];
 }
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     switch (resident_shape(ctx)) {

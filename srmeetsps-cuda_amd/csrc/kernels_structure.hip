@@ -212,21 +212,24 @@ __global__ __launch_bounds__(256) void k_struct_tiles(const uint8_t* __restrict_
         return (sr < 0 || sr >= Hs || sc < 0 || sc >= Ws) ? 0u : (unsigned)flags[(size_t)sc * Hs + sr];
     };
     const bool inside = r0 + 256 <= Hg && c0 + tc <= Wg;
-    int ok = 1;
-    if (inside) {
-        for (int c = 0; c < tc; ++c) ok &= (F(r0 + r, c0 + c) & (F_MASK | F_KB)) == (F_MASK | F_KB);
+    int ok = 1, occ = 0;
+    for (int c = 0; c < tc; ++c) {
+        const unsigned f = F(r0 + r, c0 + c);
+        ok &= (f & (F_MASK | F_KB)) == (F_MASK | F_KB);
+        occ |= (f & F_MASK) ? 1 : 0;
     }
     const unsigned fr = F(r0 + r, c0 + tc);                              // ring column to the right: one pixel per thread
     const unsigned fb = (r < tc) ? F(r0 + 256, c0 + r) : 0u;             // ring row below: the first tc threads
     int bad = ((fr & F_BX) != 0) | ((r < tc) && (fb & F_BY) != 0);
     const int all_ok = block_reduce_min(ok, sm);
+    const int any_occ = block_reduce_max(occ, sm);
     const int any_bad = block_reduce_max(bad, sm);
     const int nr = block_reduce_sum((fr & F_MASK) ? 1 : 0, sm);
     const int nb = block_reduce_sum((r < tc && (fb & F_MASK)) ? 1 : 0, sm);
     if (threadIdx.x == 0) {
-        uint8_t v = 0;
+        uint8_t v = any_occ ? TILE_OCCUPIED : 0;
         if (inside && all_ok && !any_bad && (nb == 0 || nb == tc) && (nr == 0 || nr == 256)) {
-            v = (uint8_t)(TILE_RECT | (nb == 0 ? TILE_BOTTOM_EMPTY : 0) | (nr == 0 ? TILE_RIGHT_EMPTY : 0));
+            v |= (uint8_t)(TILE_RECT | (nb == 0 ? TILE_BOTTOM_EMPTY : 0) | (nr == 0 ? TILE_RIGHT_EMPTY : 0));
             atomicAdd(n_rect, 1);
         }
         cls[tile] = v;

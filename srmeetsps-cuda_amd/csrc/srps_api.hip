@@ -90,6 +90,7 @@ static void dfree(T*& p) {
 static void grid_release(Grid& G) {
     G.d_gofp = nullptr; G.d_imask = nullptr; G.d_imasks = nullptr; G.d_flags = nullptr; G.d_lr_index = nullptr;
     G.d_tile_cls[0] = G.d_tile_cls[1] = G.d_tile_cls[2] = nullptr;
+    G.d_tile_list[0] = G.d_tile_list[1] = G.d_tile_list[2] = nullptr;
     dfree(G.d_M);                                         // the stored tensor is allocated on demand (grid_need_M), outside the arena
     G.d_q = nullptr; G.d_G = nullptr; G.d_tconsts = nullptr; G.G_planes = 0; G.tensor_channels = 0;
     G.d_x = G.d_x2 = G.d_r = G.d_r2 = G.d_p = G.d_w = G.d_w2 = G.d_save = nullptr; G.d_part4 = nullptr;
@@ -177,7 +178,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     // ---- one arena for every array of the grid ----
     const size_t pl = al256(G.plane * sizeof(float));
     size_t need = 2 * al256((size_t)G.P * sizeof(int)) + al256((size_t)std::max(G.Ps, 1) * sizeof(int)) + al256(G.plane) + al256((size_t)G.Hl * G.Wl * sizeof(int) + 4);
-    for (int shape = 0; shape < 3; ++shape) need += al256((size_t)G.n_tiles[shape]);
+    for (int shape = 0; shape < 3; ++shape) need += al256((size_t)G.n_tiles[shape]) + al256((size_t)G.n_tiles[shape] * sizeof(int));
     need += (3 + 3 + 9) * pl + 256;                       // q [3], g [3], x, x2, r, r2, p [2], w, w2, save
     need += al256(128 * sizeof(float)) + al256(2 * 4 * (size_t)G.n_part4 * sizeof(float)) + al256(n_pw * sizeof(float)) +
             al256(2 * (size_t)G.nb_update * sizeof(float)) + al256(4096 * sizeof(float));
@@ -194,6 +195,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     G.d_flags = (uint8_t*)carve(G.plane);
     G.d_lr_index = (int*)carve((size_t)G.Hl * G.Wl * sizeof(int) + 4);
     for (int shape = 0; shape < 3; ++shape) G.d_tile_cls[shape] = (uint8_t*)carve((size_t)G.n_tiles[shape]);
+    for (int shape = 0; shape < 3; ++shape) G.d_tile_list[shape] = (int*)carve((size_t)G.n_tiles[shape] * sizeof(int));
     const size_t pb = G.plane * sizeof(float);             // multi-plane arrays are [k][plane], contiguous
     G.d_q = (float*)carve(3 * pb);
     G.d_G = (float*)carve(3 * pb); G.G_planes = 3;
@@ -214,8 +216,25 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     // whatever the caller enqueues next on the context's stream sees the finished structure; the tile counts are read by the host
     SRPS_HIP(hipEventRecord(ctx->aux_event, ax));
     SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
+    // the occupied tiles of each tiling, in ascending order: what the resident CG launches its blocks for (a few hundred bytes
+    // back, the lists up)
+    std::vector<uint8_t> h_cls[3];
+    std::vector<int> h_list[3];
+    for (int shape = 0; shape < 3; ++shape) {
+        h_cls[shape].resize((size_t)G.n_tiles[shape]);
+        SRPS_HIP(hipMemcpyAsync(h_cls[shape].data(), G.d_tile_cls[shape], (size_t)G.n_tiles[shape], hipMemcpyDeviceToHost, ax));
+    }
     SRPS_HIP(hipStreamSynchronize(ax));
-    for (int shape = 0; shape < 3; ++shape) G.n_rect_tiles[shape] = hrect[shape];
+    for (int shape = 0; shape < 3; ++shape) {
+        G.n_rect_tiles[shape] = hrect[shape];
+        for (int t = 0; t < G.n_tiles[shape]; ++t)
+            if (h_cls[shape][t] & TILE_OCCUPIED) h_list[shape].push_back(t);
+        G.n_occ[shape] = (int)h_list[shape].size();
+        if (G.n_occ[shape]) SRPS_HIP(hipMemcpyAsync(G.d_tile_list[shape], h_list[shape].data(), (size_t)G.n_occ[shape] * sizeof(int), hipMemcpyHostToDevice, ax));
+    }
+    SRPS_HIP(hipEventRecord(ctx->aux_event, ax));
+    SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
+    SRPS_HIP(hipStreamSynchronize(ax));                    // the host vectors go out of scope
     ctx->x_swapped = false;
     G.bound = true;
     ctx->tensor_valid = false;
@@ -505,6 +524,12 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_resident_rect_active")) *value = (ctx->grid.bound && resident_rect_active(ctx)) ? 1 : 0;
     else if (!strcmp(name, "cg_resident_rect_tiles_256")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[0] : 0;      // of the 256 x 32 tiling
     else if (!strcmp(name, "cg_resident_rect_tiles_512")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[1] : 0;      // of the 256 x 64 tiling
+    else if (!strcmp(name, "cg_resident_tiles_occupied_256")) *value = ctx->grid.bound ? ctx->grid.n_occ[0] : 0;         // of the 256 x 32 tiling: the blocks it would launch
+    else if (!strcmp(name, "cg_resident_tiles_occupied_512")) *value = ctx->grid.bound ? ctx->grid.n_occ[1] : 0;
+    else if (!strcmp(name, "cg_resident_tiles_occupied_16")) *value = ctx->grid.bound ? ctx->grid.n_occ[2] : 0;
+    else if (!strcmp(name, "cg_resident_tiles_256")) *value = ctx->grid.bound ? ctx->grid.n_tiles[0] : 0;               // all tiles of the bounding box
+    else if (!strcmp(name, "cg_resident_tiles_512")) *value = ctx->grid.bound ? ctx->grid.n_tiles[1] : 0;
+    else if (!strcmp(name, "cg_resident_tiles_16")) *value = ctx->grid.bound ? ctx->grid.n_tiles[2] : 0;
     else if (!strcmp(name, "cg_resident_rect_tiles_16")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[2] : 0;       // of the 256 x 16 tiling
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
     else if (!strcmp(name, "cg_partition")) *value = ctx->cg_strips;

@@ -39,7 +39,7 @@ struct CgScalars {
 };
 enum { ABORT_DEPTH = 1, ABORT_ALBEDO = 2 };
 // class of a tile of the resident CG (kernels_resident.hip: resident_body<.., RECT>), per tile shape, set by build_grid
-enum : uint8_t { TILE_RECT = 1, TILE_BOTTOM_EMPTY = 2, TILE_RIGHT_EMPTY = 4 };
+enum : uint8_t { TILE_RECT = 1, TILE_BOTTOM_EMPTY = 2, TILE_RIGHT_EMPTY = 4, TILE_OCCUPIED = 8 /* the tile holds at least one masked pixel */ };
 
 struct Grid {
     bool bound = false;
@@ -58,6 +58,10 @@ struct Grid {
     int* d_lr_index = nullptr;    // [Hl*Wl] compact LR index of the block, -1 if not fully masked
     uint8_t* d_tile_cls[3] = {nullptr, nullptr, nullptr};   // TILE_* bits of the resident CG's tiles: [0] 256 x 32, [1] 256 x 64, [2] 256 x 16
     int n_tiles[3] = {0, 0, 0}, n_rect_tiles[3] = {0, 0, 0};
+    // The resident CG launches one block per OCCUPIED tile (a sparse mask in a large frame -- an ellipse, the reference's Mitten --
+    // leaves bounding-box tiles empty: they hold no unknowns, need no CU, and their neighbours see an empty ring side)
+    int* d_tile_list[3] = {nullptr, nullptr, nullptr};      // [n_occ] tile index (column of tiles * tiles per column + row of tiles), ascending
+    int n_occ[3] = {0, 0, 0};
     // depth workspace (grid layout)
     float* d_M = nullptr;         // [6][plane]  photometric tensor, SoA
     float* d_q = nullptr;         // [3][plane]  (exchange buffer for the sharded depth phase)

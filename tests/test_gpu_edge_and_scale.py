@@ -375,3 +375,63 @@ def test_tile_shape_option_rejects_other_values(pkg):
     ctx.set_option("cg_resident_tile", 256); assert ctx.get_option("cg_resident_tile") == 256
     ctx.set_option("cg_resident_tile", 0)
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# one block per OCCUPIED tile: sparse masks in large frames run the resident CG
+# ------------------------------------------------------------------------------------------------
+def test_resident_cg_launches_blocks_for_occupied_tiles_only(pkg):
+    """an ellipse in a 2304 x 2304 frame, sf 4: its bounding box is 9 x 33 = 297 tiles of 256 x 64 -- more than the chip has CUs,
+    which used to send the solve to the streaming kernels -- but fewer than 256 of them hold a masked pixel.  The resident CG
+    now runs on those (empty neighbours = the empty ring side a mask's border always had); against the streaming kernels < 2e-5."""
+    sc = pkg.synth.make_scene(2304, 2304, 4, 2, seed=91, mask_kind="ellipse")
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for resident in (1, 0):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("cg_resident", resident)
+        ctx.setup(dh)
+        ctx.lighting(); ctx.albedo()
+        e = ctx.depth()
+        info = {k: ctx.get_option(k) for k in ("cg_resident_active", "cg_resident_tiles_512", "cg_resident_tiles_occupied_512", "cg_resident_tiles_occupied_256",
+                                               "persistent_fallbacks", "num_cus")}
+        out[resident] = (e, ctx.get("z"), ctx.last_cg_iterations()["depth"], info)
+        ctx.close()
+    (e1, z1, it1, i1), (e0, z0, it0, i0) = out[1], out[0]
+    print("2304^2 ellipse:", i1)
+    assert i1["cg_resident_tiles_512"] > i1["num_cus"] >= i1["cg_resident_tiles_occupied_512"] > 0
+    assert i1["cg_resident_active"] == 1 and i1["persistent_fallbacks"] == 0 and i0["cg_resident_active"] == 0
+    assert it1 == it0 == 101
+    assert rmse(z1, z0) < 2e-5
+    assert abs(e1 - e0) <= 1e-4 * abs(e0)
+
+
+@pytest.mark.parametrize("tile", [2, 16, 32, 512])
+def test_sparse_mask_with_empty_tiles_inside_its_bounding_box(pkg, oracle, tile):
+    """two separate blobs in opposite corners of a frame (plus a one-pixel bridge row): most tiles of the bounding box are empty,
+    some occupied tiles have empty neighbours on every side -- every tile shape against the streaming kernels"""
+    h, w, sf = 768, 640, 2
+    m = np.zeros((h, w), bool)
+    ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    m |= (ii - 120) ** 2 + (jj - 100) ** 2 < 90 ** 2
+    m |= ((ii - 640) / 100.0) ** 2 + ((jj - 520) / 90.0) ** 2 < 1.0
+    m[300, 90:540] = True
+    sc = _scene_with_mask(pkg, m, sf, 3, 3, seed=92)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for resident in (1, 0):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("cg_resident", resident)
+        if resident:
+            ctx.set_option("cg_resident_tile", tile)
+        srps = pkg.SRPS(dh, ctx=ctx)
+        en = srps.execute(max_outer=2)
+        key = {2: "16", 16: "16", 32: "256", 512: "512"}[tile]
+        out[resident] = (en, srps.z(), ctx.get_option("cg_resident_active"), ctx.get_option("cg_resident_tiles_occupied_" + key), ctx.get_option("cg_resident_tiles_" + key),
+                         ctx.get_option("persistent_fallbacks"))
+        ctx.close()
+    (en1, z1, act1, occ, tot, fb), (en0, z0, act0, _, _, _) = out[1], out[0]
+    print(f"tile option {tile}: {occ} of {tot} tiles occupied")
+    assert act1 == 1 and act0 == 0 and fb == 0 and 0 < occ < tot
+    assert rmse(z1, z0) < 2e-5
+    np.testing.assert_allclose(en1, en0, rtol=1e-3)

@@ -52,6 +52,9 @@ def test_hip_full_mitten_solve_to_convergence(pkg, oracle):
     print(f"Mitten, full frame, 8 images: {len(en)} passes, {1e3 * dt:.1f} ms with set-up; resident CG {ctx.get_option('cg_resident_active')}, "
           f"bytes {ctx.get_option('image_store_bytes_active')}")
     assert ctx.get_option("cg_resident_active") == 1
+    occ, tot = ctx.get_option("cg_resident_tiles_occupied_16"), ctx.get_option("cg_resident_tiles_16")
+    print(f"Mitten: {occ} of the bounding box's {tot} tiles of 256 x 16 hold a masked pixel: that many blocks")
+    assert 0 < occ < tot
     assert ctx.get_option("image_store_bytes_active") == (1 if geo.npix % 4 == 0 else 0)
     assert len(en) == int(G["n_outer"]), (en, G["energies"])
     print("Mitten: energies relative deviation per pass", [abs(a - b) / b for a, b in zip(en, G["energies"])], "depth rel. RMSE", rel_rmse(srps.z(), G["final_z"]),

@@ -1,0 +1,166 @@
+// hbm_ceiling_bench.hip -- what an HBM-bound kernel can reach on THIS box, and whether the number of concurrent plane streams of
+// the streaming depth-CG step (8 planes read + 4 written, one 1-KiB wave access per plane and column) is what holds it at
+// 0.53 - 0.62 of the 8 TB/s peak (round-2 review, weak #5):
+//   linear_read / linear_copy / linear_rw21   grid-stride float4 streams over ~800 MB: read only, 1:1 copy, 2 reads : 1 write
+//   march_planar                              the CG step's shape: a wave marches over columns, 8 planes read, 4 written per column
+//   march_paired                              same bytes, (p, r) and (x, omega) stored as interleaved pairs: 5 read + 2 write streams
+//   march_records                             same bytes, ONE 32-byte read record and ONE 16-byte write record per pixel: 1 + 1 streams
+// All at two waves per SIMD (the occupancy of k_apply_march<., 3, 3>), loads of column c+1 and c+2 in flight.
+//   hipcc -O3 --offload-arch=gfx950 tools/hbm_ceiling_bench.hip -o tools/hbm_ceiling_bench.bin ; tools/hbm_ceiling_bench.bin [rows=4096] [cols=4096] [reps=20]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void k_linear_read(const float4* __restrict__ a, size_t n4, float* __restrict__ out) {
+    float s = 0.f;
+    size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * 256;
+    for (; i + 3 * st < n4; i += 4 * st) {
+        const float4 v0 = a[i], v1 = a[i + st], v2 = a[i + 2 * st], v3 = a[i + 3 * st];
+        s += (v0.x + v1.y) + (v2.z + v3.w);
+    }
+    for (; i < n4; i += st) s += a[i].x;
+    if (s == 1.2345f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_linear_copy(const float4* __restrict__ a, float4* __restrict__ b, size_t n4) {
+    size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * 256;
+    for (; i + 3 * st < n4; i += 4 * st) {
+        const float4 v0 = a[i], v1 = a[i + st], v2 = a[i + 2 * st], v3 = a[i + 3 * st];
+        b[i] = v0; b[i + st] = v1; b[i + 2 * st] = v2; b[i + 3 * st] = v3;
+    }
+    for (; i < n4; i += st) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_linear_rw21(const float4* __restrict__ a, const float4* __restrict__ c, float4* __restrict__ b, size_t n4) {
+    size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * 256;
+    for (; i + st < n4; i += 2 * st) {
+        const float4 v0 = a[i], v1 = a[i + st], w0 = c[i], w1 = c[i + st];
+        b[i] = make_float4(v0.x + w0.x, v0.y + w0.y, v0.z + w0.z, v0.w + w0.w);
+        b[i + st] = make_float4(v1.x + w1.x, v1.y + w1.y, v1.z + w1.z, v1.w + w1.w);
+    }
+    for (; i < n4; i += st) b[i] = a[i];
+}
+
+struct F4 { float e[4]; };
+__device__ __forceinline__ F4 ld4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return F4{{t.x, t.y, t.z, t.w}}; }
+__device__ __forceinline__ void st4(float* p, const F4& a) { *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]); }
+
+// LAYOUT 0: 8 read planes, 4 write planes (element = float).  1: reads g0, g1, g2 (3 planes) + [p r] + [x w] (2 planes of pairs),
+// writes [p r] + [x w].  2: reads one plane of 8-float records, writes one plane of 4-float records.
+struct MArgs {
+    const float* in[8];
+    float* out[4];
+    int Hs, cols_per_wave, n_items, n_seg;
+};
+template <int LAYOUT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_march(MArgs a, float* chk_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (item >= a.n_items) return;
+    const int strip = item / a.n_seg, seg = item - strip * a.n_seg;
+    const int row = seg * 256 + lane * 4;
+    const int c0 = strip * a.cols_per_wave;
+    float chk = 0.f;
+    struct Raw { F4 v[8]; };
+    auto issue = [&](Raw& r, int col) {
+        const size_t e = (size_t)(c0 + col) * a.Hs + row;      // element index of the lane's first row
+        if (LAYOUT == 0) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) r.v[p] = ld4(a.in[p] + e);
+        } else if (LAYOUT == 1) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) r.v[p] = ld4(a.in[p] + e);
+            r.v[3] = ld4(a.in[3] + 2 * e); r.v[4] = ld4(a.in[3] + 2 * e + 4);
+            r.v[5] = ld4(a.in[4] + 2 * e); r.v[6] = ld4(a.in[4] + 2 * e + 4);
+            r.v[7] = r.v[0];                                    // (the structure bytes: a quarter plane, left out)
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) r.v[p] = ld4(a.in[0] + 8 * e + 4 * p);
+        }
+    };
+    auto consume = [&](const Raw& r, int col) {
+        const size_t e = (size_t)(c0 + col) * a.Hs + row;
+        F4 o[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[w].e[q] = fmaf(r.v[w].e[q], 0.5f, r.v[w + 4].e[q]);
+        if (LAYOUT == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) st4(a.out[w] + e, o[w]);
+        } else if (LAYOUT == 1) {
+            st4(a.out[0] + 2 * e, o[0]); st4(a.out[0] + 2 * e + 4, o[1]);
+            st4(a.out[1] + 2 * e, o[2]); st4(a.out[1] + 2 * e + 4, o[3]);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) st4(a.out[0] + 4 * e + 4 * w, o[w]);
+        }
+        chk += o[0].e[0];
+    };
+    Raw b0, b1;
+    issue(b0, 0); issue(b1, min(1, a.cols_per_wave - 1));
+    for (int c = 0; c < a.cols_per_wave; c += 2) {
+        { const Raw cur = b0; issue(b0, min(c + 2, a.cols_per_wave - 1)); consume(cur, c); }
+        { const Raw cur = b1; issue(b1, min(c + 3, a.cols_per_wave - 1)); consume(cur, c + 1); }
+    }
+    if (chk == 1.2345f) chk_out[0] = chk;
+}
+
+int main(int argc, char** argv) {
+    const int rows = argc > 1 ? atoi(argv[1]) : 4096, cols = argc > 2 ? atoi(argv[2]) : 4096, reps = argc > 3 ? atoi(argv[3]) : 20;
+    const int Hs = rows + 32;
+    const size_t pl = (size_t)Hs * (cols + 8);                 // elements of one plane
+    // one arena of 12 planes, carved differently per layout
+    float* arena; CHECK(hipMalloc(&arena, 12 * pl * sizeof(float)));
+    CHECK(hipMemset(arena, 0, 12 * pl * sizeof(float)));
+    float* chk; CHECK(hipMalloc(&chk, 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, double bytes, auto launch) {
+        launch(); CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) launch();
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        printf("{\"variant\": \"%s\", \"MB\": %.1f, \"us\": %.1f, \"GBs\": %.0f, \"frac_of_8TBs\": %.3f}\n", name, bytes * 1e-6, us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0);
+    };
+    const size_t n4 = 12 * pl / 4;                              // float4 elements of the arena (~806 MB at 4096^2)
+    for (int nb : {2048, 4096, 8192}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "linear_read_%dblk", nb);
+        timeit(nm, 16.0 * n4, [&] { hipLaunchKernelGGL(k_linear_read, dim3(nb), dim3(256), 0, 0, (const float4*)arena, n4, chk); });
+        snprintf(nm, sizeof nm, "linear_copy_%dblk", nb);
+        timeit(nm, 16.0 * n4, [&] { hipLaunchKernelGGL(k_linear_copy, dim3(nb), dim3(256), 0, 0, (const float4*)arena, (float4*)arena + n4 / 2, n4 / 2); });
+        snprintf(nm, sizeof nm, "linear_rw21_%dblk", nb);
+        timeit(nm, 16.0 * n4, [&] { hipLaunchKernelGGL(k_linear_rw21, dim3(nb), dim3(256), 0, 0, (const float4*)arena, (const float4*)arena + n4 / 3, (float4*)arena + 2 * (n4 / 3), n4 / 3); });
+    }
+    MArgs a{};
+    a.Hs = Hs; a.n_seg = rows / 256;
+    const double bytes = (double)rows * cols * 4.0 * 12;
+    const int LDSB = 80 * 1024;                                  // two blocks per CU = two waves per SIMD whatever the register count
+    CHECK(hipFuncSetAttribute((const void*)k_march<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_march<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_march<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    for (int waves_target : {2048, 1024}) {
+        int strips = waves_target / a.n_seg; if (strips < 1) strips = 1;
+        while (cols % strips) --strips;
+        a.cols_per_wave = cols / strips; a.n_items = strips * a.n_seg;
+        const int nb = (a.n_items + 3) / 4;
+        printf("march: rows %d cols %d: %d waves, %d columns each, %.1f MB per pass\n", rows, cols, a.n_items, a.cols_per_wave, bytes * 1e-6);
+        for (int p = 0; p < 8; ++p) a.in[p] = arena + (size_t)p * pl;
+        for (int w = 0; w < 4; ++w) a.out[w] = arena + (size_t)(8 + w) * pl;
+        timeit("march_planar_8r_4w", bytes, [&] { hipLaunchKernelGGL((k_march<0>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
+        // pairs: g0 g1 g2 | [p r] (2 planes) | [x w] (2 planes) read; [p r] | [x w] written
+        a.in[0] = arena; a.in[1] = arena + pl; a.in[2] = arena + 2 * pl; a.in[3] = arena + 3 * pl; a.in[4] = arena + 5 * pl;
+        a.out[0] = arena + 7 * pl; a.out[1] = arena + 9 * pl;
+        timeit("march_paired_5r_2w", bytes * 11.0 / 12.0, [&] { hipLaunchKernelGGL((k_march<1>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
+        a.in[0] = arena; a.out[0] = arena + 8 * pl;
+        timeit("march_records_1r_1w", bytes, [&] { hipLaunchKernelGGL((k_march<2>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
+    }
+    CHECK(hipFree(arena));
+    return 0;
+}
