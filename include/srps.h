@@ -266,6 +266,21 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
  * stand-in for n ranks -- the collectives are device copies, the arithmetic is the multi-GPU path's.  Every context must have
  * gone through srps_depth_partial on the same problem; afterwards each holds the new depth as after srps_depth_solve. */
 int srps_strip_group_solve(srps_ctx* const* ctxs, int n);
+/* The strips over a transport of the caller's instead of RCCL (MPI, gloo, shared memory ...): three host functions that work on
+ * DEVICE pointers.  srps_depth_solve calls them between the launches with the context's stream drained; each returns 0 after
+ * its reads and writes are complete.
+ *   allreduce(user, d_in, d_out)        : d_out[0..3] = sum over the ranks of d_in[0..3] (doubles; the same bits on every rank)
+ *   exchange(user, nbuf, send_left, recv_left, send_right, recv_right, n) : for b < nbuf send n floats from send_left[b] to the left
+ *                                          neighbour and receive n into recv_left[b], likewise to the right; a NULL array: no
+ *                                          neighbour on that side
+ *   allgather(user, d_x, offset, count) : piece q = d_x[offset[q] .. + count[q]) is rank q's; every rank ends with all pieces
+ * All three NULL removes the transport. */
+typedef int (*srps_strip_allreduce_fn)(void* user, const double* d_in, double* d_out);
+typedef int (*srps_strip_exchange_fn)(void* user, int nbuf, const float* const* d_send_left, float* const* d_recv_left,
+                                      const float* const* d_send_right, float* const* d_recv_right, size_t n);
+typedef int (*srps_strip_allgather_fn)(void* user, float* d_x, const size_t* offset, const size_t* count);
+int srps_set_strip_transport(srps_ctx* ctx, int rank, int world, srps_strip_allreduce_fn allreduce, srps_strip_exchange_fn exchange,
+                             srps_strip_allgather_fn allgather, void* user);
 
 /* stop rule + loop of SRPS.cu:272-335 on one GPU.  max_outer <= 0: run to the reference's stop
  * rule (at most 11 passes).  energies (may be NULL) must hold max_outer values, or 12 when

@@ -39,6 +39,12 @@ class Problem(C.Structure):
     ]
 
 
+# callbacks of srps_set_strip_transport (include/srps.h): host functions on device pointers
+STRIP_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+STRIP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t)
+STRIP_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
+
+
 def build(force: bool = False) -> str:
     """Compile libsrps_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if force or not os.path.exists(LIB_PATH) or _stale():
@@ -128,6 +134,7 @@ def load():
         "srps_comm_info": (i, [vp, ip, ip]),
         "srps_all_reduce": (i, [vp, C.c_char_p]),
         "srps_strip_group_solve": (i, [C.POINTER(vp), i]),
+        "srps_set_strip_transport": (i, [vp, i, i, STRIP_ALLREDUCE_FN, STRIP_EXCHANGE_FN, STRIP_ALLGATHER_FN, vp]),
         "srps_get": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_set": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_get_device_ptr": (i, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),

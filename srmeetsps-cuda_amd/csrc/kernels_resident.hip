@@ -82,6 +82,12 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {      // lane i <-
 // bit BIT of the structure word as an all-ones / all-zeros mask. Written in assembly: the compiler turns the
 // portable forms into and + compare + select (three instructions and a scalar register pair per use).
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// lane l of `old` replaced by the (wave-uniform) value s: v_writelane_b32 -- no lane mask, no select
+template <int L>
+__device__ __forceinline__ float writelane_c(float old, float s) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(s), "n"(L));      // the lane is an inline constant (one scalar operand per instruction)
+    return old;
+}
 template <int BIT>
 __device__ __forceinline__ int msk(unsigned flword) {
     int m;
@@ -565,11 +571,16 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             const int j = lane & (CPT - 1);
             const bool bot = (lane & CPT) != 0;
             float pown = 0.f;                                  // p of the own pixel next to the ring pixel
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-                const float t0 = readlane_f(p[c].e[0], 0), t3 = readlane_f(p[c].e[3], 63);
-                pown = (j == c) ? (bot ? t3 : t0) : pown;
-            }
+            // lane c takes row 0 of column c (from lane 0), lane CPT + c row 255 (from lane 63): written straight into the lanes
+            // (as selects, the eight lane masks (j == c) lived in scalar register pairs that were spilled and reloaded every step)
+#define SRPS_ROWPICK(C)                                                                                        \
+    if (C < CPT) {                                                                                             \
+        const float t0 = readlane_f(p[C < CPT ? C : 0].e[0], 0), t3 = readlane_f(p[C < CPT ? C : 0].e[3], 63); \
+        pown = writelane_c<C>(pown, t0);                                                                       \
+        pown = writelane_c<(C < CPT ? C + CPT : C)>(pown, t3);                                                 \
+    }
+            SRPS_ROWPICK(0) SRPS_ROWPICK(1) SRPS_ROWPICK(2) SRPS_ROWPICK(3) SRPS_ROWPICK(4) SRPS_ROWPICK(5) SRPS_ROWPICK(6) SRPS_ROWPICK(7)
+#undef SRPS_ROWPICK
             const int cc = CPT * wave + j;
             const int ir = bot ? ring_rowB(cc) : ring_rowT(cc);
             const unsigned f = hfl[ir];

@@ -181,6 +181,12 @@ struct srps_ctx {
     int cg_strips = 0;               // option "cg_partition": 1 = the depth CG partitioned into column strips over the communicator's ranks
     double* d_strip_tot = nullptr;   // [12]: [0..3] this rank's sums of a launch, [4..7] / [8..11] the sums over all ranks of the launches of even / odd
                                      // parity (Grid::d_totals4 points at [4])
+    // the caller's transport for the strips (srps_set_strip_transport) instead of the communicator
+    srps_strip_allreduce_fn strip_allreduce = nullptr;
+    srps_strip_exchange_fn strip_exchange = nullptr;
+    srps_strip_allgather_fn strip_allgather = nullptr;
+    void* strip_user = nullptr;
+    int strip_rank = 0, strip_world = 1;
     bool defer_shard_checks = false; // srps_execute_sharded: a shard's phases do not look at the abort flags themselves; the ranks decide together at the end of the pass
     bool x_swapped = false;          // the resident CG launched since the abort flags were last looked at swapped grid.d_x and grid.d_x2
     int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at

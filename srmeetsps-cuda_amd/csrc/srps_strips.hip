@@ -46,9 +46,13 @@ __global__ void k_sum_totals_tab(int n, PtrTable t) {
 
 // the collectives of a group of ranks, two ways
 struct Collectives {
-    std::vector<srps_ctx*> L;          // the ranks this caller drives (loopback: all of them; RCCL: its own)
+    std::vector<srps_ctx*> L;          // the ranks this caller drives (loopback: all of them; RCCL / caller's transport: its own)
     bool loopback = false;
     int world = 1;
+    // the caller's own transport (srps_set_strip_transport): host functions on device pointers, called with the stream drained
+    bool hosted() const { return !loopback && L[0]->strip_allreduce != nullptr; }
+    int rank_of(size_t li) const { return loopback ? (int)li : (hosted() ? L[0]->strip_rank : L[li]->comm_rank); }
+    static int drained(srps_ctx* c) { SRPS_HIP(hipStreamSynchronize(c->stream)); return SRPS_OK; }
 
     // the sums a launch of parity `par` left on every rank ([0..3] of d_strip_tot) -> their total over the ranks, slot `par`
     // ([4 + 4 par ..]): launch k + 1 reads slot k & 1, and so does the final x update when step k was the last one executed
@@ -60,6 +64,12 @@ struct Collectives {
             SRPS_LAUNCH_CHECK();
             return SRPS_OK;
         }
+        if (hosted()) {
+            SRPS_TRY(drained(L[0]));
+            const int rc = L[0]->strip_allreduce(L[0]->strip_user, L[0]->d_strip_tot, L[0]->d_strip_tot + 4 + 4 * (par & 1));
+            SRPS_REQUIRE(rc == 0, SRPS_ERR_HIP, "strip transport: the caller's all-reduce returned %d", rc);
+            return SRPS_OK;
+        }
         return comm_all_reduce_sum_f64(L[0], L[0]->d_strip_tot, L[0]->d_strip_tot + 4 + 4 * (par & 1), 4);
     }
     // the edge columns of the planes planes[.][b] (b < nbuf), both directions
@@ -67,7 +77,7 @@ struct Collectives {
         for (size_t li = 0; li < L.size(); ++li) {
             srps_ctx* c = L[li];
             const Grid& G = c->grid;
-            const int rank = loopback ? (int)li : c->comm_rank;
+            const int rank = rank_of(li);
             const size_t first = (size_t)(G.view_c0 + PAD) * G.Hs, last = (size_t)(G.view_c0 + G.view_w - 1 + PAD) * G.Hs, n = (size_t)G.Hs;
             if (loopback) {
                 // my last column -> the right neighbour's plane (its left halo), its first column -> my right halo
@@ -85,6 +95,13 @@ struct Collectives {
             for (int b = 0; b < nbuf; ++b) {
                 sl[b] = planes[li][b] + first; rl[b] = planes[li][b] + first - G.Hs;      // my first column out, the column left of it in
                 sr[b] = planes[li][b] + last; rr[b] = planes[li][b] + last + G.Hs;
+            }
+            if (hosted()) {
+                SRPS_TRY(drained(c));
+                const int rc = c->strip_exchange(c->strip_user, nbuf, rank > 0 ? sl : nullptr, rank > 0 ? rl : nullptr, rank + 1 < world ? sr : nullptr,
+                                                 rank + 1 < world ? rr : nullptr, n);
+                SRPS_REQUIRE(rc == 0, SRPS_ERR_HIP, "strip transport: the caller's exchange returned %d", rc);
+                continue;
             }
             SRPS_TRY(comm_exchange(c, nbuf, sl, rl, rank > 0 ? rank - 1 : -1, sr, rr, rank + 1 < world ? rank + 1 : -1, n));
         }
@@ -106,6 +123,12 @@ struct Collectives {
         for (int q = 0; q < world; ++q) {
             const Range rg = strip_range(G.Wg, G.sf, world, q);
             off[q] = (size_t)(rg.c0 + PAD) * G.Hs; cnt[q] = (size_t)rg.w * G.Hs;
+        }
+        if (hosted()) {
+            SRPS_TRY(drained(c));
+            const int rc = c->strip_allgather(c->strip_user, G.d_x, off.data(), cnt.data());
+            SRPS_REQUIRE(rc == 0, SRPS_ERR_HIP, "strip transport: the caller's all-gather returned %d", rc);
+            return SRPS_OK;
         }
         return comm_all_gather_pieces(c, G.d_x, off.data(), cnt.data());
     }
@@ -162,7 +185,8 @@ int ensure_strip_buffers(srps_ctx* ctx) {
 }  // namespace
 
 bool strips_active(const srps_ctx* ctx) {
-    return ctx->cg_strips && ctx->comm != nullptr && ctx->comm_world > 1 && ctx->grid.bound && cg_fused_step(ctx);
+    const bool transport = (ctx->comm != nullptr && ctx->comm_world > 1) || (ctx->strip_allreduce != nullptr && ctx->strip_world > 1);
+    return ctx->cg_strips && transport && ctx->grid.bound && cg_fused_step(ctx);
 }
 
 void strips_clear_view(srps_ctx* ctx) {
@@ -189,9 +213,10 @@ int strips_bind_view(srps_ctx* ctx, int rank, int world) {
 
 int strips_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     Collectives co;
-    co.L = {ctx}; co.loopback = false; co.world = ctx->comm_world;
+    const bool hosted = ctx->strip_allreduce != nullptr;
+    co.L = {ctx}; co.loopback = false; co.world = hosted ? ctx->strip_world : ctx->comm_world;
     // the view lasts for the solve only: every other user of the marching kernels (srps_depth_operator_apply, ...) sees the whole grid
-    SRPS_TRY(strips_bind_view(ctx, ctx->comm_rank, ctx->comm_world));
+    SRPS_TRY(strips_bind_view(ctx, hosted ? ctx->strip_rank : ctx->comm_rank, co.world));
     const int rc = strips_run(co, max_steps, fixed_steps);
     strips_clear_view(ctx);
     return rc;
@@ -228,6 +253,20 @@ int srps_strip_group_solve(srps_ctx* const* ctxs, int n) {
     for (int i = 0; i < n && rc == SRPS_OK; ++i) rc = depth_solve_finish(ctxs[i]);
     for (int i = 0; i < n; ++i) strips_clear_view(ctxs[i]);
     return rc;
+}
+
+
+// The caller's own transport for the strip-partitioned CG (instead of RCCL): three host functions on DEVICE pointers, called
+// from srps_depth_solve with the context's stream drained; each must have completed its reads and writes when it returns.
+int srps_set_strip_transport(srps_ctx* ctx, int rank, int world, srps_strip_allreduce_fn allreduce, srps_strip_exchange_fn exchange,
+                             srps_strip_allgather_fn allgather, void* user) {
+    SRPS_REQUIRE(ctx != nullptr, SRPS_ERR_INVALID, "set_strip_transport: null context");
+    if (!allreduce && !exchange && !allgather) { ctx->strip_allreduce = nullptr; ctx->strip_exchange = nullptr; ctx->strip_allgather = nullptr; ctx->strip_world = 1; ctx->strip_rank = 0; return SRPS_OK; }
+    SRPS_REQUIRE(allreduce && exchange && allgather, SRPS_ERR_INVALID, "set_strip_transport: all three functions, or none");
+    SRPS_REQUIRE(world >= 1 && world <= 16 && rank >= 0 && rank < world, SRPS_ERR_INVALID, "set_strip_transport: rank %d of %d", rank, world);
+    ctx->strip_allreduce = allreduce; ctx->strip_exchange = exchange; ctx->strip_allgather = allgather; ctx->strip_user = user;
+    ctx->strip_rank = rank; ctx->strip_world = world;
+    return SRPS_OK;
 }
 
 }  // extern "C"

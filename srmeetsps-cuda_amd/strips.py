@@ -17,6 +17,10 @@ the per-step cost becomes that kernel's ~10 us plus one small all-reduce instead
 
 `strip_cg` below is that protocol written against an abstract engine (the part that will drive the HIP kernels); the test
 suite runs it under gloo with an engine made from the oracle's assembled matrix and compares with the serial CG.
+
+The GPU engine exists since round 3 (csrc/srps_strips.hip, option "cg_partition"): RCCL between the launches on several GPUs,
+device copies between several contexts of one process (srps_strip_group_solve), or -- `HostedTransport` below -- any transport
+the caller brings (srps_set_strip_transport): here torch.distributed, which lets two PROCESSES on one GPU run the strips over gloo.
 """
 from __future__ import annotations
 
@@ -102,3 +106,81 @@ class TorchDistComm:
         t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+
+
+class HostedTransport:
+    """The three host functions of srps_set_strip_transport on torch.distributed (gloo in the tests: two processes that share one
+    GPU cannot form an RCCL communicator).  Device memory is reached through zero-copy torch views of the pointers the library
+    hands over; the collectives run on CPU copies."""
+
+    def __init__(self, ctx, dist, device: str = "cuda:0"):
+        import ctypes as C
+        import torch
+        from . import _lib
+        self.ctx, self.dist, self.torch, self.device = ctx, dist, torch, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.errors = []
+
+        def view(ptr, n, typestr="<f4"):
+            class V:
+                pass
+            v = V()
+            v.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(v, device=device)
+
+        def guarded(fn):
+            def wrapper(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as exc:          # an exception must not cross the C boundary
+                    self.errors.append(repr(exc))
+                    return 1
+            return wrapper
+
+        @guarded
+        def allreduce(user, d_in, d_out):
+            t = view(d_in, 4, "<f8").cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            view(d_out, 4, "<f8").copy_(t)
+            torch.cuda.synchronize()
+
+        @guarded
+        def exchange(user, nbuf, sl, rl, sr, rr, n):
+            ops, landing = [], []
+            for b in range(nbuf):
+                if sl:
+                    out = view(sl[b], n).cpu(); inn = torch.empty(n, dtype=torch.float32)
+                    ops += [dist.P2POp(dist.isend, out, self.rank - 1), dist.P2POp(dist.irecv, inn, self.rank - 1)]
+                    landing.append((rl[b], inn))
+                if sr:
+                    out = view(sr[b], n).cpu(); inn = torch.empty(n, dtype=torch.float32)
+                    ops += [dist.P2POp(dist.isend, out, self.rank + 1), dist.P2POp(dist.irecv, inn, self.rank + 1)]
+                    landing.append((rr[b], inn))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for ptr, t in landing:
+                view(ptr, n).copy_(t)
+            torch.cuda.synchronize()
+
+        @guarded
+        def allgather(user, d_x, offset, count):
+            for q in range(self.world):
+                if count[q] == 0:
+                    continue
+                piece = view(d_x + 4 * offset[q], count[q])
+                t = piece.cpu() if q == self.rank else torch.empty(count[q], dtype=torch.float32)
+                dist.broadcast(t, src=q)
+                if q != self.rank:
+                    piece.copy_(t)
+            torch.cuda.synchronize()
+
+        # the ctypes objects must outlive the registration
+        self._fns = (_lib.STRIP_ALLREDUCE_FN(allreduce), _lib.STRIP_EXCHANGE_FN(exchange), _lib.STRIP_ALLGATHER_FN(allgather))
+        _lib.check(ctx.lib.srps_set_strip_transport(ctx.h, self.rank, self.world, *self._fns, None))
+
+    def remove(self):
+        from . import _lib
+        _lib.check(self.ctx.lib.srps_set_strip_transport(self.ctx.h, 0, 1, _lib.STRIP_ALLREDUCE_FN(), _lib.STRIP_EXCHANGE_FN(), _lib.STRIP_ALLGATHER_FN(), None))

@@ -112,3 +112,59 @@ def test_group_solve_refuses_contexts_that_do_not_belong_together(pkg):
     np.testing.assert_array_equal(a.get("z"), b.get("z"))
     for x in (a, b, c):
         x.close()
+
+
+def _hosted_worker(rank, world, port, h, w, sf, kind, seed, out_dir):
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
+    ctx = pkg.Context(device_id=0)
+    ctx.set_option("cg_resident", 0)
+    ctx.set_option("cg_partition", 1)
+    tr = strips.HostedTransport(ctx, dist)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    ctx.lighting(); ctx.albedo()
+    assert ctx.get_option("cg_partition_active") == 1
+    e = ctx.depth()
+    assert not tr.errors, tr.errors
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), e=e, z=ctx.get("z"), it=ctx.last_cg_iterations()["depth"])
+    dist.barrier()
+    tr.remove()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("h,w,sf,kind,world", [(96, 80, 2, "ragged", 2), (512, 384, 4, "ellipse", 3)])
+def test_strips_over_two_processes_and_the_callers_transport(pkg, tmp_path, h, w, sf, kind, world):
+    """the strips through srps_depth (option cg_partition) with the collectives supplied by the caller (srps_set_strip_transport):
+    here torch.distributed over gloo between PROCESSES that share the GPU -- the multi-process protocol (views, halo columns,
+    totals, final gather) with the real kernels, which RCCL cannot run on a one-GPU box"""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    seed = h + 3 * w
+    mp.spawn(_hosted_worker, args=(world, port, h, w, sf, kind, seed, str(tmp_path)), nprocs=world, join=True)
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        e1, z1, it1 = _pass_single(pkg, pkg.DataHandler.from_scene(sc), stream.cuda_stream)
+    r = [np.load(tmp_path / f"rank{q}.npz") for q in range(world)]
+    for q in range(1, world):
+        np.testing.assert_array_equal(r[q]["z"], r[0]["z"])
+        assert float(r[q]["e"]) == float(r[0]["e"])
+    print(f"{world} processes, gloo transport: depth RMSE vs single grid {rmse(r[0]['z'], z1):.3e}")
+    assert int(r[0]["it"]) == it1
+    assert rmse(r[0]["z"], z1) < 2e-5
+    assert abs(float(r[0]["e"]) - e1) <= 1e-3 * abs(e1)
