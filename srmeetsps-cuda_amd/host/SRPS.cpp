@@ -46,7 +46,9 @@ void SRPS::execute() {
     srps_problem pr{};
     pr.h = dh->I_h; pr.w = dh->I_w; pr.n_channels = dh->I_c; pr.n_images = dh->I_n; pr.n_images_total = dh->I_n;
     pr.image_offset = 0; pr.sf = (int)dh->sf;
-    pr.mask = dh->mask.data(); pr.K = dh->K.data(); pr.I = dh->I.data(); pr.zs_lr = zs.data(); pr.z_full = z_full.data();
+    pr.mask = dh->mask.data(); pr.K = dh->K.data(); pr.zs_lr = zs.data(); pr.z_full = z_full.data();
+    if (dh->I_u8.size() == dh->I.size() && !dh->I_u8.empty()) pr.I_u8 = dh->I_u8.data();      // 8-bit image files: the bytes cross PCIe (I = byte / 255.f is formed on the device)
+    else pr.I = dh->I.data();
     srps_check(srps_setup(ctx, &pr));
     int nimg = 0, nch = 0, gh = 0, gw = 0;
     srps_check(srps_dims(ctx, &npix, &npixs, &gh, &gw, &nimg, &nch));
@@ -152,7 +154,9 @@ void SRPS::execute_sharded(const std::vector<float>& zs, const std::vector<float
         srps_problem pr{};
         pr.h = dh->I_h; pr.w = dh->I_w; pr.n_channels = dh->I_c; pr.n_images = cnt; pr.n_images_total = dh->I_n;
         pr.image_offset = lo; pr.sf = (int)dh->sf;
-        pr.mask = dh->mask.data(); pr.K = dh->K.data(); pr.I = dh->I.data() + (size_t)lo * per_image; pr.zs_lr = zs.data(); pr.z_full = z_full.data();
+        pr.mask = dh->mask.data(); pr.K = dh->K.data(); pr.zs_lr = zs.data(); pr.z_full = z_full.data();
+        if (dh->I_u8.size() == dh->I.size() && !dh->I_u8.empty()) pr.I_u8 = dh->I_u8.data() + (size_t)lo * per_image;
+        else pr.I = dh->I.data() + (size_t)lo * per_image;
         srps_check(srps_setup(c, &pr));
         std::vector<float> N_init;
         if (r == 0) {

@@ -19,7 +19,7 @@ bool Preferences::forceSharded = false;
 std::string Preferences::outDir = ".";
 
 void DataHandler::freeMemory() {
-    I.clear(); K.clear(); mask.clear(); z0.clear(); D.freeMemory();
+    I.clear(); I_u8.clear(); K.clear(); mask.clear(); z0.clear(); D.freeMemory();
 }
 
 void DataHandler::validate() const {
@@ -95,14 +95,20 @@ void ImageDataHandler::loadDataFromImages(const char* dataFolder) {
     PngImage first = png_read(files[0]);
     I_n = (int)files.size(); I_w = first.width; I_h = first.height; I_c = 3;        // imread default: 3 channels
     I.resize((size_t)I_h * I_w * I_c * I_n);
+    I_u8.resize(I.size());
     for (int n = 0; n < I_n; ++n) {
         PngImage im = n == 0 ? first : png_read(files[n]);
         if (im.width != I_w || im.height != I_h) throw std::runtime_error(files[n] + ": image size differs");
         std::vector<uint8_t> rgb = png_as_rgb8(im);
         float* dst = I.data() + (size_t)n * I_w * I_h * I_c;
+        unsigned char* dst8 = I_u8.data() + (size_t)n * I_w * I_h * I_c;
         for (int c = 0; c < 3; ++c)                                                   // plane 0 = R, 1 = G, 2 = B (Utilities.cpp:343)
             for (int i = 0; i < I_h; ++i)
-                for (int j = 0; j < I_w; ++j) dst[i + (size_t)j * I_h + (size_t)c * I_h * I_w] = rgb[((size_t)i * I_w + j) * 3 + c] / 255.f;
+                for (int j = 0; j < I_w; ++j) {
+                    const uint8_t b = rgb[((size_t)i * I_w + j) * 3 + c];
+                    dst8[i + (size_t)j * I_h + (size_t)c * I_h * I_w] = b;            // what the device gets
+                    dst[i + (size_t)j * I_h + (size_t)c * I_h * I_w] = b / 255.f;     // the DataHandler's float view of it
+                }
     }
     std::ifstream fk(root + "/K.txt");
     if (!fk) throw std::runtime_error("cannot open " + root + "/K.txt");

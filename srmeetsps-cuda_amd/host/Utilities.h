@@ -56,6 +56,9 @@ struct SparseCOO {
 // Utilities.h:166-181. Column-major everywhere: I is h x w x c x n, mask h x w, K 3x3, z0 (h/sf) x (w/sf) x n.
 struct DataHandler {
     std::vector<float> I;
+    std::vector<unsigned char> I_u8;   // new: the same images as the bytes the image files hold (ImageDataHandler: I = byte / 255.f, Utilities.cpp:343),
+                                       // same layout as I; empty when the data set did not come from 8-bit images.  SRPS::execute hands these to the
+                                       // device instead of the floats (srps_problem.I_u8): a quarter of the bytes cross PCIe, the same floats are formed there
     int I_w = 0, I_h = 0, I_c = 0, I_n = 0;
     int z0_w = 0, z0_h = 0;
     std::vector<float> K;        // 9

@@ -138,3 +138,39 @@ def test_command_line_program_sharded_path_equals_one_gpu_path(pkg, tmp_path):
     n_dev = torch.cuda.device_count()
     bad = subprocess.run([pkg.host.CLI, f"--dsloc={path}", "--no-output", "--gpus", str(n_dev + 1)], capture_output=True, text=True)
     assert bad.returncode == 1 and "out of range" in bad.stderr
+
+
+def test_command_line_program_on_an_image_folder_hands_the_bytes_to_the_device(pkg, tmp_path):
+    """`srps --dstype images` (reference: ImageDataHandler, Utilities.cpp:349-395): the C++ host keeps the bytes of the 8-bit PNGs
+    and passes them as srps_problem.I_u8; the Python host on the same folder passes the floats byte / 255.f.  Same results, bit
+    for bit, and the same again through --sharded."""
+    import scipy.io
+    from PIL import Image
+    pkg.host.load()
+    sc = pkg.synth.make_scene(48, 64, 2, 5, seed=61, mask_kind="ellipse")
+    h, w = sc.h, sc.w
+    root = tmp_path / "ds"; (root / "RGB").mkdir(parents=True); (root / "Depth").mkdir()
+    I8 = np.rint(np.clip(sc.I, 0, 1) * 255).astype(np.uint8).reshape(sc.n_img, 3, w, h)            # [n][c][j][i]
+    for n in range(sc.n_img):
+        Image.fromarray(np.ascontiguousarray(np.transpose(I8[n], (2, 1, 0))), "RGB").save(root / "RGB" / f"I_{n + 1}.png")
+    Image.fromarray((sc.mask.reshape(w, h).T * 255).astype(np.uint8), "L").save(root / "mask.png")
+    z0 = sc.z0.reshape(w // sc.sf, h // sc.sf).T
+    lo, hi = 0.5, 1.5
+    Image.fromarray(np.rint((z0 - lo) / (hi - lo) * 65535).astype(np.uint16)).save(root / "Depth" / "D_0.png")
+    K = sc.K.reshape(3, 3).T
+    (root / "K.txt").write_text("\n".join(",".join(repr(float(v)) for v in K[r]) for r in range(3)) + f"\n{sc.sf},{lo},{hi}")
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    one = subprocess.run([pkg.host.CLI, "--dstype=images", f"--dsloc={root}", "-o", str(tmp_path / "a")], capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr
+    sh = subprocess.run([pkg.host.CLI, "-t", "images", "-d", str(root), "-o", str(tmp_path / "b"), "--sharded"], capture_output=True, text=True)
+    assert sh.returncode == 0, sh.stderr
+    dh = pkg.host.load_dataset("images", str(root))
+    ctx = pkg.Context(device_id=0)
+    srps = pkg.SRPS(dh, ctx=ctx)
+    en = srps.execute()
+    assert one.stdout.count("Iteration") == len(en)
+    for d in ("a", "b"):
+        np.testing.assert_array_equal(scipy.io.loadmat(str(tmp_path / d / "z.mat"))["x"][:, 0], srps.z())
+        np.testing.assert_array_equal(scipy.io.loadmat(str(tmp_path / d / "rho.mat"))["x"][:, 0], srps.rho().reshape(-1))
+        np.testing.assert_array_equal(scipy.io.loadmat(str(tmp_path / d / "s.mat"))["x"][:, 0], srps.s().reshape(-1))
+    ctx.close()
