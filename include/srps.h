@@ -83,6 +83,9 @@ int srps_synchronize(srps_ctx* ctx);
  * "exclusive_device" (0|1: the caller states that nothing else uses the device: plain instead of cooperative launches of the
  *  persistent kernels), "spin_budget_ms" (a persistent launch whose grid-wide waits are not served within this time aborts and the
  *  phase is repeated by the streaming kernels; default 200), "phase_timing", "roctx" (see srps_get_timings),
+ * "overlap_exchange" (0|1, default 0: srps_execute_sharded cuts the albedo sweep and the depth assembly into four pixel ranges and
+ *  all-reduces a range on a second stream while the next is computed -- same bits, the bytes travel under the sweeps; off until a
+ *  multi-GPU run has timed it),
  * "cg_partition" (0|1: the depth CG as column strips over the ranks of the context's communicator, see srps_strip_group_solve),
  * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader
  *  produces, Utilities.cpp:343 -- the context also keeps the images as bytes and the two image sweeps of a pass read those:

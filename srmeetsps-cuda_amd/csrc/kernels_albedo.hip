@@ -30,8 +30,8 @@ template <int V, bool SUMS, bool U8 = false, bool SHARD = false>
 __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__ s, const float* __restrict__ N,
                                                        const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_local, int C,
                                                        int s_img_offset, float* __restrict__ num, float* __restrict__ den,
-                                                       float fx, float fy, float* __restrict__ ssum, int n_total) {
-    const int q = (blockIdx.x * 256 + threadIdx.x) * V;
+                                                       float fx, float fy, float* __restrict__ ssum, int n_total, int blk0) {
+    const int q = ((blockIdx.x + blk0) * 256 + threadIdx.x) * V;      // blk0: a launch that covers a range of the pixels only (overlapped exchange)
     if (q >= P) return;
     Vec<V> nk[4];
 #pragma unroll
@@ -93,13 +93,17 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
 // ssum != null: also the image sums of the depth right-hand side (fx, fy needed).  n_total > n_local: the context holds a shard
 // (see SHARD above): d_numden receives this rank's part of num and the complete den.
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
-                  int C, int s_img_offset, float* d_numden, float fx, float fy, float* d_ssum, int n_total) {
+                  int C, int s_img_offset, float* d_numden, float fx, float fy, float* d_ssum, int n_total, int q0, int q1) {
     float* num = d_numden;
     float* den = d_numden + (size_t)C * P;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_numden | (uintptr_t)d_ssum) % 16 == 0);
     const unsigned char* d_I8 = vec ? image_store_bytes(ctx, d_I) : nullptr;      // the context's images as bytes, when they are held that way
     const bool shard = n_total > n_local;
-#define SRPS_NUMDEN(VV, SS, UU, HH, NB) hipLaunchKernelGGL((k_albedo_numden<VV, SS, UU, HH>), dim3(NB), dim3(256), 0, ctx->stream, d_s, d_N, d_I, d_I8, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum, n_total)
+    // [q0, q1): the pixels of this launch (q1 <= 0: all; q0 a multiple of 1024 -- whole blocks of either vector width)
+    const bool part = q1 > 0;
+    auto blocks = [&](int per) { return part ? cdiv(std::min(q1, P) - q0, per) : cdiv(P, per); };
+    auto first = [&](int per) { return part ? q0 / per : 0; };
+#define SRPS_NUMDEN(VV, SS, UU, HH, NB) hipLaunchKernelGGL((k_albedo_numden<VV, SS, UU, HH>), dim3(blocks(256 * VV)), dim3(256), 0, ctx->stream, d_s, d_N, d_I, d_I8, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum, n_total, first(256 * VV))
 #define SRPS_NUMDEN_S(VV, UU, HH, NB) do { if (d_ssum) SRPS_NUMDEN(VV, true, UU, HH, NB); else SRPS_NUMDEN(VV, false, UU, HH, NB); } while (0)
     if (shard) {
         if (vec && d_I8) SRPS_NUMDEN_S(4, true, true, cdiv(P, 1024));

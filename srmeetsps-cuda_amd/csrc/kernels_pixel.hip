@@ -311,8 +311,9 @@ __global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict
                                                          const float* __restrict__ xx, const float* __restrict__ yy,
                                                          const float* __restrict__ dz, float fx, float fy, int P, int C, int n_total,
                                                          const int* __restrict__ gofp, size_t plane,
-                                                         float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp, float* __restrict__ Qc /* compact [3][P] or null */) {
-    const int q = (blockIdx.x * 256 + threadIdx.x) * V;
+                                                         float* __restrict__ M, float* __restrict__ Q, float* __restrict__ Gp, float* __restrict__ Qc /* compact [3][P] or null */,
+                                                         int blk0) {
+    const int q = ((blockIdx.x + blk0) * 256 + threadIdx.x) * V;
     if (q >= P) return;
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
     float m[6][V], qq[3][V];
@@ -425,16 +426,18 @@ int depth_q_scatter(srps_ctx* ctx, const float* d_q_compact) {
 
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset, float cx, float cy, const float* d_ssum, float* d_q_compact) {
+                   int n_total, int img_offset, float cx, float cy, const float* d_ssum, float* d_q_compact, int q0, int q1) {
     Grid& G = ctx->grid;
+    const bool part = q1 > 0 && d_ssum != nullptr, later = part && q0 > 0;      // a later range of a chunked assembly: the constants exist already
     // tensor-recompute form needs the principal point (xx = j - cx, yy = i - cy are rebuilt in the kernel)
     const bool rec = ctx->tensor_recompute && (C == 1 || C == 3) && cx == cx && cy == cy;
     float* Gp = nullptr;
     if (rec) {
         SRPS_REQUIRE(G.G_planes >= (size_t)C, SRPS_ERR_STATE, "depth assembly: the grid holds %zu g planes, %d channels need %d", G.G_planes, C, C);
         Gp = G.d_G;                                        // [3][plane] of the grid's arena, zero outside the mask since the bind
-        hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset,
-                           d_ssum ? G.d_tconsts + 64 : (float*)nullptr);
+        if (!later)
+            hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset,
+                               d_ssum ? G.d_tconsts + 64 : (float*)nullptr);
         G.tensor_channels = C; G.cx = cx; G.cy = cy;
     } else {
         G.tensor_channels = 0;
@@ -448,13 +451,14 @@ int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const fl
     if (d_ssum) {
         // the albedo sweep of this pass left the image sums: no second pass over I
         float* qc = G.d_tconsts + 64;                      // [8][4] behind the 8 x 8 tensor constants
-        if (!rec) hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset, qc);
+        if (!rec && !later) hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset, qc);
+        const int n_px = part ? std::min(q1, P) - q0 : P;
         if (vec && ((uintptr_t)d_ssum % 16 == 0))
-            hipLaunchKernelGGL((k_depth_from_sums<4>), dim3(cdiv(P, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
-                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact);
+            hipLaunchKernelGGL((k_depth_from_sums<4>), dim3(cdiv(n_px, 1024)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
+                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact, part ? q0 / 1024 : 0);
         else
-            hipLaunchKernelGGL((k_depth_from_sums<1>), dim3(cdiv(P, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
-                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact);
+            hipLaunchKernelGGL((k_depth_from_sums<1>), dim3(cdiv(n_px, 256)), dim3(256), 0, ctx->stream, d_s, d_rho, d_ssum, qc, d_xx, d_yy, d_dz,
+                               fx, fy, P, C, n_total, G.d_gofp, G.plane, Mp, G.d_q, Gp, d_q_compact, part ? q0 / 256 : 0);
         SRPS_LAUNCH_CHECK();
         ctx->tensor_valid = true;
         return SRPS_OK;

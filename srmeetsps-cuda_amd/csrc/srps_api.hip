@@ -489,6 +489,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
             march_plan(ctx->grid, value, ctx->num_cus);
         }
         ctx->march_tj = value;
+    } else if (!strcmp(name, "overlap_exchange")) {
+        ctx->overlap_exchange = value ? 1 : 0;
     } else if (!strcmp(name, "cg_partition")) {
         SRPS_REQUIRE(value == 0 || value == 1, SRPS_ERR_INVALID, "cg_partition: 0 (every rank runs the whole depth CG) or 1 (column strips over the communicator's ranks)");
         ctx->cg_strips = value;
@@ -533,6 +535,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_resident_rect_tiles_16")) *value = ctx->grid.bound ? ctx->grid.n_rect_tiles[2] : 0;       // of the 256 x 16 tiling
     else if (!strcmp(name, "cg_max_iter")) *value = ctx->cg_max_iter;
     else if (!strcmp(name, "cg_partition")) *value = ctx->cg_strips;
+    else if (!strcmp(name, "overlap_exchange")) *value = ctx->overlap_exchange;
     else if (!strcmp(name, "cg_partition_active")) *value = strips_active(ctx) ? 1 : 0;
     else if (!strcmp(name, "cg_resident_tile")) *value = ctx->cg_resident_tile;
     else if (!strcmp(name, "albedo_channels_together")) *value = ctx->albedo_channels_together;
@@ -1157,6 +1160,65 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
     return SRPS_OK;
 }
 
+// Option "overlap_exchange": the sweep that feeds an all-reduce (the albedo sweep over the images -> num; the depth assembly from
+// the image sums -> q) is cut into pixel ranges, and the all-reduce of a range runs on a second stream while the next range is
+// computed.  Same kernels, same sums, same bits; what changes is when the bytes travel.
+static int sharded_albedo_partial_overlapped(srps_ctx* ctx) {
+    PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SWEEP);
+    Grid& G = ctx->grid;
+    const int P = G.P, C = ctx->C, K = 4;
+    float* ssum = nullptr;
+    ctx->ssum_valid = false;
+    if (ctx->assemble_from_sums && ctx->N_local > 0) {
+        SRPS_TRY(ensure(ctx->ws_ssum, (size_t)3 * C * P * sizeof(float)));
+        ssum = (float*)ctx->ws_ssum.p;
+    }
+    SRPS_TRY(setup_events(ctx, K + 1));
+    hipStream_t cs = ctx->gather_stream;
+    const int step = std::max(1024, cdiv(cdiv(P, K), 1024) * 1024);
+    for (int q0 = 0, k = 0; q0 < P; q0 += step, ++k) {
+        const int q1 = std::min(P, q0 + step);
+        SRPS_TRY(albedo_numden(ctx, ctx->s, ctx->Nrm, ctx->I, P, ctx->N_local, C, ctx->img_offset, ctx->albedo_ex, ctx->fx, ctx->fy, ssum, ctx->N_total, q0, q1));
+        SRPS_HIP(hipEventRecord(ctx->ev_copied[k], ctx->stream));
+        SRPS_HIP(hipStreamWaitEvent(cs, ctx->ev_copied[k], 0));
+        float* piece[8]; size_t n[8];
+        for (int c = 0; c < C; ++c) { piece[c] = ctx->albedo_ex + (size_t)c * P + q0; n[c] = (size_t)(q1 - q0); }
+        SRPS_TRY(comm_all_reduce_pieces_on(ctx, cs, piece, n, C));
+    }
+    SRPS_HIP(hipEventRecord(ctx->ev_gathered[0], cs));
+    SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[0], 0));
+    ctx->ssum_valid = ssum != nullptr;
+    return SRPS_OK;
+}
+static int sharded_depth_partial_overlapped(srps_ctx* ctx) {
+    PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
+    Grid& G = ctx->grid;
+    const int P = G.P, K = 4;
+    const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
+    if (!ssum || !ctx->q_ex) {                             // nothing to cut into ranges (the assembly streams the images, or q stays on the grid)
+        SRPS_TRY(srps_depth_partial(ctx));
+        if (ctx->q_ex) SRPS_TRY(comm_all_reduce_sum(ctx, ctx->q_ex, 3 * (size_t)P));
+        return SRPS_OK;
+    }
+    ctx->q_in_exchange = true;
+    SRPS_TRY(setup_events(ctx, K + 1));
+    hipStream_t cs = ctx->gather_stream;
+    const int step = std::max(1024, cdiv(cdiv(P, K), 1024) * 1024);
+    for (int q0 = 0, k = 0; q0 < P; q0 += step, ++k) {
+        const int q1 = std::min(P, q0 + step);
+        SRPS_TRY(depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
+                                ctx->cx, ctx->cy, ssum, ctx->q_ex, q0, q1));
+        SRPS_HIP(hipEventRecord(ctx->ev_copied[k], ctx->stream));
+        SRPS_HIP(hipStreamWaitEvent(cs, ctx->ev_copied[k], 0));
+        float* piece[3]; size_t n[3];
+        for (int t = 0; t < 3; ++t) { piece[t] = ctx->q_ex + (size_t)t * P + q0; n[t] = (size_t)(q1 - q0); }
+        SRPS_TRY(comm_all_reduce_pieces_on(ctx, cs, piece, n, 3));
+    }
+    SRPS_HIP(hipEventRecord(ctx->ev_gathered[0], cs));
+    SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[0], 0));
+    return SRPS_OK;
+}
+
 // SRPS.cu:272-335 on a context that holds a shard of the images and an RCCL communicator
 int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
@@ -1176,11 +1238,17 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
         float error = 0.f;
         SRPS_TRY(srps_lighting_local(ctx));                                                     // SRPS.cu:281
         SRPS_TRY(comm_all_reduce_sum(ctx, ctx->s, (size_t)ctx->N_total * ctx->C * 4));
-        SRPS_TRY(srps_albedo_partial(ctx));                                                     // SRPS.cu:287
-        SRPS_TRY(comm_all_reduce_sum(ctx, ctx->albedo_ex, (size_t)ctx->C * G.P));
-        SRPS_TRY(srps_albedo_finish(ctx));
-        SRPS_TRY(srps_depth_partial(ctx));                                                      // SRPS.cu:293
-        if (ctx->q_ex) SRPS_TRY(comm_all_reduce_sum(ctx, ctx->q_ex, 3 * (size_t)G.P));        // a context that holds all images has q on the grid already
+        if (ctx->overlap_exchange) {
+            SRPS_TRY(sharded_albedo_partial_overlapped(ctx));                                   // SRPS.cu:287, the all-reduce of num under the sweep
+            SRPS_TRY(srps_albedo_finish(ctx));
+            SRPS_TRY(sharded_depth_partial_overlapped(ctx));                                    // SRPS.cu:293, the all-reduce of q under the assembly
+        } else {
+            SRPS_TRY(srps_albedo_partial(ctx));                                                 // SRPS.cu:287
+            SRPS_TRY(comm_all_reduce_sum(ctx, ctx->albedo_ex, (size_t)ctx->C * G.P));
+            SRPS_TRY(srps_albedo_finish(ctx));
+            SRPS_TRY(srps_depth_partial(ctx));                                                  // SRPS.cu:293
+            if (ctx->q_ex) SRPS_TRY(comm_all_reduce_sum(ctx, ctx->q_ex, 3 * (size_t)G.P));    // a context that holds all images has q on the grid already
+        }
         SRPS_TRY(srps_depth_solve(ctx));
         SRPS_TRY(srps_energy_partial(ctx));
         SRPS_TRY(sharded_energy_exchange(ctx));

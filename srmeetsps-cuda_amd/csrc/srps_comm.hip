@@ -81,6 +81,18 @@ int comm_all_reduce_sum(srps_ctx* ctx, float* d_buf, size_t n) {
     SRPS_RCCL(g_rccl.AllReduce(d_buf, d_buf, n, ncclFloat32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     return SRPS_OK;
 }
+// several pieces of one buffer, as one group, on a stream of the caller's choice (the overlapped exchange of srps_execute_sharded)
+int comm_all_reduce_pieces_on(srps_ctx* ctx, hipStream_t st, float* const* d_piece, const size_t* n, int pieces) {
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "all_reduce: no communicator bound to the context");
+    SRPS_RCCL(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int k = 0; k < pieces && r == ncclSuccess; ++k)
+        if (n[k]) r = g_rccl.AllReduce(d_piece[k], d_piece[k], n[k], ncclFloat32, ncclSum, (ncclComm_t)ctx->comm, st);
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce");
+    SRPS_RCCL(e);
+    return SRPS_OK;
+}
 int comm_broadcast(srps_ctx* ctx, float* d_buf, size_t n, int root) {
     SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "broadcast: no communicator bound to the context");
     if (n == 0) return SRPS_OK;

@@ -187,6 +187,8 @@ struct srps_ctx {
     srps_strip_allgather_fn strip_allgather = nullptr;
     void* strip_user = nullptr;
     int strip_rank = 0, strip_world = 1;
+    int overlap_exchange = 0;        // option: srps_execute_sharded cuts the two sweeps that feed an all-reduce into pixel ranges and reduces a range
+                                     // (on a second stream) while the next one is computed
     bool defer_shard_checks = false; // srps_execute_sharded: a shard's phases do not look at the abort flags themselves; the ranks decide together at the end of the pass
     bool x_swapped = false;          // the resident CG launched since the abort flags were last looked at swapped grid.d_x and grid.d_x2
     int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at
@@ -277,12 +279,14 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
                        const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
                        float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out);
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
-                  int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr, int n_total = 0);
+                  int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr, int n_total = 0,
+                  int q0 = 0, int q1 = 0 /* > 0: the pixels [q0, q1) only, q0 a multiple of 1024 */);
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
 void albedo_iters_collect(srps_ctx* ctx);
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
-                   int n_total, int img_offset, float cx, float cy, const float* d_ssum = nullptr, float* d_q_compact = nullptr);
+                   int n_total, int img_offset, float cx, float cy, const float* d_ssum = nullptr, float* d_q_compact = nullptr,
+                   int q0 = 0, int q1 = 0 /* > 0 (from sums only): the pixels [q0, q1); the constants are formed by the launch with q0 == 0 */);
 int depth_q_scatter(srps_ctx* ctx, const float* d_q_compact);
 int energy_photometric_partial(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I,
                                const float* d_xx, const float* d_yy, const float* d_dz, const float* d_z,
@@ -345,6 +349,7 @@ int launch_gather_images_u8(hipStream_t st, const unsigned char* d_full, const i
 // ---- RCCL (srps_comm.hip) -------------------------------------------------------------------
 bool comm_bound(const srps_ctx* ctx);
 int comm_all_reduce_sum(srps_ctx* ctx, float* d_buf, size_t n);      // in place, on the context's stream
+int comm_all_reduce_pieces_on(srps_ctx* ctx, hipStream_t st, float* const* d_piece, const size_t* n, int pieces);
 int comm_broadcast(srps_ctx* ctx, float* d_buf, size_t n, int root);
 int comm_all_reduce_sum_f64(srps_ctx* ctx, const double* d_in, double* d_out, size_t n);
 int comm_exchange(srps_ctx* ctx, int nbuf, const float* const* send_left, float* const* recv_left, int left,
