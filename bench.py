@@ -117,7 +117,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
     P = ctx.dims()["npix"]
     resident = bool(ctx.get_option("cg_resident_active"))
     assert resident == resident_expected or not resident_expected, "the resident CG kernel was expected to run"
-    tj = _profile("r02_traffic.json") or _profile("r01_traffic.json") or {}
+    tj = _profile("r03_traffic.json") or _profile("r02_traffic.json") or {}
     key = f"{H}x{W}_sf{sf}"
     if resident:
         # ONE launch runs the residual pass and all 101 steps with the CG state in registers + LDS (kernels_resident.hip).
@@ -128,7 +128,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         launch_us = 1e6 * b["seconds"] / (b["iterations"] / 101)
         flops = float(P) * (101 * FLOPS_PER_UNKNOWN_STEP + FLOPS_PER_UNKNOWN_RESIDUAL_PASS)
         ach = flops / (launch_us * 1e6)                     # TFLOP/s
-        isa = _profile("r02_resident_isa.json")
+        isa = _profile("r03_resident_isa.json") or _profile("r02_resident_isa.json")
         issue = None
         rect = bool(ctx.get_option("cg_resident_rect_active"))
         ikey = key if rect else key + "_general_kernel"
