@@ -395,6 +395,27 @@ def main():
                                    "workload": "the headline workload with 8-bit images (k / 255.f, the reference's image-folder input): image sweeps read bytes"}
             c8.close()
             sc.I = I_keep
+            # The headline workload with albedo_mode = SRPS_ALBEDO_FUSED (not the default: the reference runs its CG on the diagonal
+            # albedo system; this is that CG's fixed point, formed together with the depth system inside the albedo sweep -- no
+            # num / den / image-sum planes, no albedo solve, no assembly kernel).  Reported next to the headline, never as it.
+            cf = pkg.Context(device_id=local_rank)
+            cf.set_stream(stream.cuda_stream)
+            cf.set_option("exclusive_device", 1)
+            cf.set_option("albedo_mode", 2)
+            cf.setup(dh)
+            for _ in range(max(args.warmup, 1)):
+                pkg.alternating_loop(cf, None, max_outer=1)
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for _ in range(args.steps):
+                pkg.alternating_loop(cf, None, max_outer=1)
+            torch.cuda.synchronize()
+            df = time.perf_counter() - tf
+            itf = cf.last_cg_iterations()["depth"]
+            assert itf == 101 and cf.get_option("persistent_fallbacks") == 0
+            legs["albedo_fused_closed_form"] = {"cg_iterations_per_sec": itf * args.steps / df, "ms_per_step": 1e3 * df / args.steps,
+                                                "workload": "the headline workload with albedo_mode = SRPS_ALBEDO_FUSED (the albedo CG's fixed point and the depth system formed inside the albedo sweep; not the default)"}
+            cf.close()
             mitten = os.path.join(ROOT, "tests", "golden", "mitten_full.npz")
             if os.path.exists(mitten):
                 # BASELINE.json config 2 at its true size: the whole frame of the reference's bundled Mitten data set (960 x 1280,

@@ -47,7 +47,12 @@ enum {
 
 /* albedo solver: the reference solves the per-pixel diagonal system with its global CG
  * (devicecalls.cu:513-548); CLOSED_FORM is the fixed point of that CG (num/den per pixel). */
-enum { SRPS_ALBEDO_CG = 0, SRPS_ALBEDO_CLOSED_FORM = 1 };
+enum { SRPS_ALBEDO_CG = 0, SRPS_ALBEDO_CLOSED_FORM = 1,
+       /* the fixed point AND the depth system (g, q) formed inside the one albedo sweep over the images: no num / den / image-sum
+        * planes, no albedo solve, no depth assembly kernel.  The same bits as CLOSED_FORM; pipeline phases on one GPU (elsewhere it
+        * behaves as CLOSED_FORM).  Not the default: the reference runs its CG on the diagonal system (devicecalls.cu:513-548),
+        * which stops within 1e-6 of this fixed point. */
+       SRPS_ALBEDO_FUSED = 2 };
 /* operator used by the depth CG: AUTO picks the register-marching kernel when sf is 1, 2 or 4 */
 enum { SRPS_APPLY_AUTO = 0, SRPS_APPLY_SIMPLE = 1, SRPS_APPLY_MARCH = 2 };
 

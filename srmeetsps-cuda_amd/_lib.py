@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsrps_hip.so")
 HEADER = os.path.join(ROOT, "include", "srps.h")
 
 SRPS_OK = 0
-ALBEDO_CG, ALBEDO_CLOSED_FORM = 0, 1
+ALBEDO_CG, ALBEDO_CLOSED_FORM, ALBEDO_FUSED = 0, 1, 2
 APPLY_AUTO, APPLY_SIMPLE, APPLY_MARCH = 0, 1, 2
 
 

@@ -424,6 +424,21 @@ int depth_q_scatter(srps_ctx* ctx, const float* d_q_compact) {
     return SRPS_OK;
 }
 
+// SRPS_ALBEDO_FUSED: what depth_assemble does besides its sweep -- the per-channel constants (tensor recompute form and the
+// right-hand side's) and the grid's bookkeeping -- for an albedo sweep that writes g and q itself.  *ok = false: the fused sweep
+// does not apply (no tensor-recompute operator: other channel counts, stored tensor wanted), the caller takes the unfused route.
+int depth_fused_prepare(srps_ctx* ctx, const float* d_s, float fx, float fy, int C, int n_total, int n_local, int img_offset, float cx, float cy, bool* ok) {
+    Grid& G = ctx->grid;
+    const bool rec = ctx->tensor_recompute && (C == 1 || C == 3) && cx == cx && cy == cy;
+    *ok = rec && march_supported(ctx) && ctx->apply_mode != SRPS_APPLY_SIMPLE && !ctx->keep_stored_tensor && G.G_planes >= (size_t)C;
+    if (!*ok) return SRPS_OK;
+    hipLaunchKernelGGL(k_tensor_consts, dim3(1), dim3(64), 0, ctx->stream, d_s, n_total, C, fx, fy, G.d_tconsts, n_local, img_offset, G.d_tconsts + 64);
+    SRPS_LAUNCH_CHECK();
+    G.tensor_channels = C; G.cx = cx; G.cy = cy;
+    G.M_valid = false;
+    return SRPS_OK;
+}
+
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,
                    int n_total, int img_offset, float cx, float cy, const float* d_ssum, float* d_q_compact, int q0, int q1) {

@@ -410,7 +410,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     CTX_CHECK(ctx);
     SRPS_REQUIRE(name != nullptr, SRPS_ERR_INVALID, "set_option: name is NULL");
     if (!strcmp(name, "albedo_mode")) {
-        SRPS_REQUIRE(value == SRPS_ALBEDO_CG || value == SRPS_ALBEDO_CLOSED_FORM, SRPS_ERR_INVALID, "albedo_mode: bad value %d", value);
+        SRPS_REQUIRE(value == SRPS_ALBEDO_CG || value == SRPS_ALBEDO_CLOSED_FORM || value == SRPS_ALBEDO_FUSED, SRPS_ERR_INVALID, "albedo_mode: bad value %d", value);
         ctx->albedo_mode = value;
     } else if (!strcmp(name, "apply_mode")) {
         SRPS_REQUIRE(value >= SRPS_APPLY_AUTO && value <= SRPS_APPLY_MARCH, SRPS_ERR_INVALID, "apply_mode: bad value %d", value);
@@ -757,6 +757,7 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     ctx->light_cache_valid = false;
     ctx->ssum_valid = false;
     ctx->grad_current = false;
+    ctx->depth_assembled = false;
     SRPS_REQUIRE(pr->mask && pr->K && pr->zs_lr && pr->z_full, SRPS_ERR_INVALID, "setup: mask, K, zs_lr and z_full are required");
     SRPS_REQUIRE(pr->n_channels > 0 && pr->n_channels <= 8 && pr->n_images >= 0 && pr->n_images_total > 0, SRPS_ERR_INVALID, "setup: bad image counts");
     SRPS_REQUIRE(pr->image_offset >= 0 && pr->image_offset + pr->n_images <= pr->n_images_total, SRPS_ERR_INVALID, "setup: shard [%d,%d) outside [0,%d)", pr->image_offset, pr->image_offset + pr->n_images, pr->n_images_total);
@@ -935,6 +936,7 @@ int srps_lighting_local(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_LIGHTING);
     ctx->ssum_valid = false;             // s changes
+    ctx->depth_assembled = false;
     return lighting(ctx, ctx->s, ctx->rho, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
                     ctx->N_local != ctx->N_total, /*use_cache=*/true);
 }
@@ -949,6 +951,20 @@ int srps_albedo_partial(srps_ctx* ctx) {
     PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SWEEP);
     float* ssum = nullptr;
     ctx->ssum_valid = false;
+    ctx->depth_assembled = false;
+    if (ctx->albedo_mode == SRPS_ALBEDO_FUSED && ctx->N_local == ctx->N_total && ctx->N_local > 0) {
+        // one sweep over the images: the albedo's fixed point, g = (rho / dz)^2 and q straight onto the grid
+        bool ok = false;
+        SRPS_TRY(depth_fused_prepare(ctx, ctx->s, ctx->fx, ctx->fy, ctx->C, ctx->N_total, ctx->N_local, ctx->img_offset, ctx->cx, ctx->cy, &ok));
+        if (ok) {
+            ctx->light_cache_valid = false;      // rho changes
+            SRPS_TRY(albedo_fused(ctx, ctx->s, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->rho, ctx->grid.d_tconsts + 64, ctx->xx, ctx->yy, ctx->dz,
+                                  ctx->fx, ctx->fy));
+            ctx->tensor_valid = true;
+            ctx->depth_assembled = true;
+            return SRPS_OK;
+        }
+    }
     if (ctx->assemble_from_sums && ctx->N_local > 0) {      // this sweep over I also leaves the image sums of the depth right-hand side
         SRPS_TRY(ensure(ctx->ws_ssum, (size_t)3 * ctx->C * ctx->grid.P * sizeof(float)));
         ssum = (float*)ctx->ws_ssum.p;
@@ -961,6 +977,7 @@ int srps_albedo_partial(srps_ctx* ctx) {
 }
 int srps_albedo_finish(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    if (ctx->depth_assembled) return SRPS_OK;      // SRPS_ALBEDO_FUSED: the sweep formed the albedo itself
     PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SOLVE);
     ctx->light_cache_valid = false;      // rho changes
     SRPS_TRY(albedo_finish(ctx, ctx->rho, ctx->albedo_ex, ctx->grid.P, ctx->C));
@@ -980,6 +997,7 @@ int srps_albedo(srps_ctx* ctx) {
 
 int srps_depth_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
+    if (ctx->depth_assembled) { ctx->depth_assembled = false; ctx->q_in_exchange = false; return SRPS_OK; }      // SRPS_ALBEDO_FUSED: g and q are on the grid
     PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
     const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
     ctx->q_in_exchange = ctx->q_ex != nullptr;
@@ -1303,6 +1321,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     ctx->light_cache_valid = false;
     ctx->ssum_valid = false;
     ctx->grad_current = false;
+    ctx->depth_assembled = false;
     if (p == ctx->I) ctx->i8_state = 0;
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
@@ -1325,6 +1344,7 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
         ctx->i8_state = 2;
     }
     ctx->light_cache_valid = false;      // the caller may write through the pointer
+    ctx->depth_assembled = false;
     ctx->ssum_valid = false;
     ctx->grad_current = false;
     return SRPS_OK;

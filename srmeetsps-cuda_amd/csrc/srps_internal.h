@@ -160,6 +160,7 @@ struct srps_ctx {
     int albedo_iters_pending = 0;    // channels whose counts still sit in the pinned buffer (persistent albedo CG)
     // what the last depth assembly was built from (srps_depth_operator_apply)
     bool tensor_valid = false;
+    bool depth_assembled = false;    // SRPS_ALBEDO_FUSED: this pass's albedo sweep has left g and q on the grid (srps_depth_partial has nothing to do)
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
     int fuse_energy_lighting = 1;
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
@@ -282,6 +283,9 @@ int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float
                   int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr, int n_total = 0,
                   int q0 = 0, int q1 = 0 /* > 0: the pixels [q0, q1) only, q0 a multiple of 1024 */);
 int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
+int albedo_fused(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_img, int C, float* d_rho, const float* d_qc,
+                 const float* d_xx, const float* d_yy, const float* d_dz, float fx, float fy);
+int depth_fused_prepare(srps_ctx* ctx, const float* d_s, float fx, float fy, int C, int n_total, int n_local, int img_offset, float cx, float cy, bool* ok);
 void albedo_iters_collect(srps_ctx* ctx);
 int depth_assemble(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                    const float* d_yy, const float* d_dz, float fx, float fy, int P, int n_local, int C,

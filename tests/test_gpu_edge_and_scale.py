@@ -435,3 +435,31 @@ def test_sparse_mask_with_empty_tiles_inside_its_bounding_box(pkg, oracle, tile)
     assert act1 == 1 and act0 == 0 and fb == 0 and 0 < occ < tot
     assert rmse(z1, z0) < 2e-5
     np.testing.assert_allclose(en1, en0, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# albedo_mode = SRPS_ALBEDO_FUSED: the albedo's fixed point and the depth system inside the albedo sweep
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w,sf,n_img,n_ch,kind,bytes_in", [(96, 80, 2, 5, 3, "ragged", False), (512, 384, 4, 7, 3, "ellipse", False), (300, 200, 1, 3, 1, "ragged", False),
+                                                             (256, 128, 4, 20, 3, "full", True), (64, 48, 2, 4, 2, "full", False), (1024, 1024, 4, 6, 3, "full", False)])
+def test_fused_albedo_sweep_equals_the_closed_form_bit_for_bit(pkg, h, w, sf, n_img, n_ch, kind, bytes_in):
+    """SRPS_ALBEDO_FUSED forms rho = num / den, g = (rho / dz)^2 and q inside the albedo sweep with the expressions of the unfused
+    route (k_albedo_numden + k_albedo_closed + k_depth_from_sums): whole solves agree bit for bit with SRPS_ALBEDO_CLOSED_FORM --
+    also with 8-bit images (the byte store), one channel, and two channels (where the fused sweep does not apply and the mode
+    falls back to the closed form); and within 1e-5 of the default, the reference's CG on the diagonal system"""
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img, n_ch=n_ch, mask_kind=kind)
+    if bytes_in:
+        sc.I = (np.rint(np.clip(sc.I, 0, 1) * 255).astype(f32) / f32(255)).astype(f32)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for mode in (2, 1, 0):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("albedo_mode", mode)
+        srps = pkg.SRPS(dh, ctx=ctx)
+        en = srps.execute(max_outer=3)
+        out[mode] = (np.array(en, f32), srps.z(), srps.rho(), ctx.get("s"), ctx.last_cg_iterations())
+        ctx.close()
+    for a, b in zip(out[2][:4], out[1][:4]):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    assert out[2][4]["depth"] == out[1][4]["depth"] == out[0][4]["depth"]
+    assert rmse(out[2][1], out[0][1]) < 1e-5 and np.abs(out[2][2] - out[0][2]).max() < 2e-5
