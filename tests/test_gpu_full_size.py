@@ -295,3 +295,19 @@ def test_config4_volume_two_ranks_on_one_gpu_equal_one_context(tmp_path):
 def test_config5_volume_two_ranks_on_one_gpu_equal_one_context(tmp_path):
     """4096 x 4096, sf 2, 64 images (configs[4]) as 2 ranks x 32 images on one GPU (gloo): 201 MB of num and of q per exchange"""
     _two_ranks_equal_one_context(tmp_path, "config5", 4096, 4096, 2, 64, 1242)
+
+
+@pytest.mark.parametrize("kind,n_img,seed", [("ellipse", 20, 4321), ("full", 40, 977)])
+def test_one_wait_against_two_waits_and_streaming_on_further_scenes(pkg, kind, n_img, seed):
+    """the drift bound of the one-wait form (r.r predicted from three products, anchored on direct sums) at the metric's size on
+    scenes other than the four-image one above: an elliptical mask (the general body, 232 blocks) with 20 images and the full
+    frame with 40 -- one wait, two waits and the streaming kernels among each other, all 101 steps"""
+    sc = pkg.synth.make_scene(2048, 2048, 4, n_img, seed=seed, mask_kind=kind)
+    variants = {"one": dict(cg_resident=1, cg_one_sync=1), "two": dict(cg_resident=1, cg_one_sync=0), "streaming": dict(cg_resident=0)}
+    _, out = _depth_three_ways(pkg, sc, variants)
+    assert out["one"]["resident"] == 1 and out["two"]["resident"] == 1 and out["streaming"]["resident"] == 0
+    assert all(o["it"] == 101 for o in out.values())
+    d = {f"{a}-{b}": rmse(out[a]["z"], out[b]["z"]) for a, b in (("one", "two"), ("one", "streaming"), ("two", "streaming"))}
+    print(f"2048^2 {kind}, {n_img} images: depth RMSE between the paths", d, "energies", {k: o["e"] for k, o in out.items()})
+    assert max(d.values()) < 2e-5
+    assert abs(out["one"]["e"] - out["streaming"]["e"]) <= 1e-4 * abs(out["streaming"]["e"])
