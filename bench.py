@@ -443,6 +443,28 @@ def main():
                                              "images": int(mI.shape[0]), "image_store_bytes_active": cm.get_option("image_store_bytes_active"),
                                              "workload": "the reference's Mitten data set, whole 960x1280 frame, sf 2, 8 images: full alternating solve to its stop rule"}
                 cm.close()
+            # what a bare stream of the CG step's shape reaches on THIS box (tools/hbm_ceiling_bench.hip, a child process; the pool's
+            # boxes differ by 15 %): the streaming legs' fraction of that, next to their fraction of the 8 TB/s peak
+            ceil_bin = os.path.join(ROOT, "tools", "hbm_ceiling_bench.bin")
+            if os.path.exists(ceil_bin):
+                try:
+                    import subprocess
+                    torch.cuda.synchronize()
+                    res = subprocess.run([ceil_bin, "4096", "4096", "10"], capture_output=True, text=True, timeout=120)
+                    rows = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+                    best = {}
+                    for r in rows:
+                        name = r["variant"].split("_blk")[0].rstrip("0123456789").rstrip("_") if r["variant"].startswith("linear") else r["variant"]
+                        best[name] = max(best.get(name, 0.0), r["GBs"])
+                    legs["hbm_ceiling_this_box"] = {"GBs": best, "workload": "tools/hbm_ceiling_bench.bin 4096 4096 10: pure float4 streams over 813 MB and the CG step's access shape (8 planes read, 4 written, marching), best of the block / wave counts tried"}
+                    march = best.get("march_planar_8r_4w")
+                    if march:
+                        for key in ("largest_grid_4096_sf2",):
+                            if key in legs and "roofline" in legs[key]:
+                                legs[key]["roofline"]["frac_of_measured_ceiling"] = legs[key]["roofline"]["achieved"] / march
+                                legs[key]["roofline"]["measured_ceiling_GBs"] = march
+                except Exception as exc:
+                    legs["hbm_ceiling_this_box"] = {"error": str(exc)}
             out["legs"] = legs
     if rank == 0:
         # measured device-copy ceiling: 1 GiB device-to-device copy, read + write bytes over the event time
