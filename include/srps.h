@@ -70,6 +70,8 @@ int srps_synchronize(srps_ctx* ctx);
 /* options: "albedo_mode" (SRPS_ALBEDO_*), "apply_mode" (SRPS_APPLY_*), "cg_max_iter", "march_strip" (0 = automatic,
  * or a multiple of 4 in [4,512]), "march_snake" (0|1), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1),
  * "fuse_energy_lighting" (0|1: the energy sweep over I also leaves the lighting sums of the next pass),
+ * "fuse_normals" (0|1, default 1: that sweep also stores the normals and dz of the depth just solved, which it forms in registers anyway --
+ *  srps_normals then launches nothing; same bits as the normals kernel),
  * "albedo_persistent" (0|1: albedo CG in registers, one cooperative launch, when the mask fits),
  * "cg_resident" (0|1: depth CG as one persistent launch with its state in registers and LDS, when the grid fits one
  * 256 x 64 tile per CU; otherwise, and with 0, one operator + one update kernel per step), "light_grouped" (0|1), "light_channel_inner" (0|1),

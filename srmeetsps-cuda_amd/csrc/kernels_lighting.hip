@@ -22,6 +22,11 @@ struct EnergyArgs {
     float fx, fy;
     int img_offset;
     float* part_e;
+    // the fused energy + lighting sweep forms the normals of the depth just solved in registers anyway: with these set it also
+    // stores them (N0, N1, N2; N3 == 1 stays from the set-up) and the new dz -- into a SECOND dz array, the sweep's other blocks
+    // still read the dz the system was built from -- and srps_normals has no kernel to launch (null: nothing is stored)
+    float* N_out;
+    float* dz_out;
 };
 
 template <int V, int IB, bool ENERGY>
@@ -321,13 +326,19 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
             {
                 const Vec<V> vxx = ldv<V>(ea.xx + q), vyy = ldv<V>(ea.yy + q);
                 const Vec<V> vz = ldv<V>(ea.z + q), vzx = ldv<V>(ea.zx + q), vzy = ldv<V>(ea.zy + q);
+                Vec<V> vnrm;
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     float nrm;
                     perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
+                    vnrm.v[e] = nrm;
                     T[0].v[e] = ea.fx * vzx.v[e];
                     T[1].v[e] = ea.fy * vzy.v[e];
                     T[2].v[e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                }
+                if (ea.N_out && grp == 0 && b0 == 0) {                       // block-uniform: one of the four image groups, its first round
+                    stv<V>(ea.N_out + q, nk[0]); stv<V>(ea.N_out + (size_t)P + q, nk[1]); stv<V>(ea.N_out + 2 * (size_t)P + q, nk[2]);
+                    stv<V>(ea.dz_out + q, vnrm);
                 }
             }
 #pragma unroll
@@ -595,9 +606,14 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
                                        (uintptr_t)d_dz | (uintptr_t)d_z | (uintptr_t)d_zx | (uintptr_t)d_zy) % 16 == 0);
     LightPlan L;
     SRPS_TRY(light_plan(ctx, vec, P, n_local, C, L, /*fused=*/true));
-    EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part};
+    EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part, nullptr, nullptr};
+    // the channel-inner sweep (the one the pipeline runs for 1 and 3 channels) can leave the normals and dz of the new depth
+    const bool ci = ctx->light_grouped && L.V == 4 && ctx->light_channel_inner && (C == 1 || C == 3);
+    const bool write_normals = ci && ctx->fuse_normals && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && n_local > 0;
+    if (write_normals) { ea.N_out = ctx->Nrm; ea.dz_out = ctx->dz2; }
     SRPS_TRY(light_partial_launch<true>(ctx, L, d_rho, nullptr, d_I, P, n_local, C, ea));
     SRPS_TRY(launch_final_sum(ctx->stream, G.d_misc_part, L.n_epart, d_out));
+    ctx->normals_pending = write_normals;      // srps_normals only has to make dz2 the current dz
     ctx->light_cache_valid = true;
     ctx->light_cache_normals = false;
     ctx->light_cache_V = L.V;

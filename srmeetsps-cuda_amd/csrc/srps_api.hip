@@ -107,7 +107,8 @@ static void grid_free(Grid& G) {
 
 static void state_release(srps_ctx* c) {
     c->i8_state = 0;                       // I8 (its own allocation, made when the images turn out to be bytes) is kept for the next set-up
-    c->s = c->rho = c->z = c->Nrm = c->dz = c->zx = c->zy = c->xx = c->yy = c->z0s = c->I = c->albedo_ex = c->q_ex = nullptr;      // carved out of state_arena
+    c->s = c->rho = c->z = c->Nrm = c->dz = c->dz2 = c->zx = c->zy = c->xx = c->yy = c->z0s = c->I = c->albedo_ex = c->q_ex = nullptr;      // carved out of state_arena
+    c->normals_pending = false;
     c->q_in_exchange = false; c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
 }
@@ -300,6 +301,16 @@ static int persistent_sync_check(srps_ctx* ctx, int* flags_out) {
     return persistent_aborts(ctx, flags_out);
 }
 
+// Option "fuse_normals": the energy + lighting sweep has already stored the normals of the new depth (Nrm) and its dz (dz2).  Whoever
+// reads Nrm or dz next -- a phase, a getter -- must see the pair of ONE depth: completing the update (what srps_normals does) is a
+// pointer swap.
+static inline void normals_flush(srps_ctx* ctx) {
+    if (!ctx->normals_pending) return;
+    std::swap(ctx->dz, ctx->dz2);
+    ctx->normals_pending = false;
+    ctx->light_cache_normals = true;
+}
+
 }  // namespace srps
 
 using namespace srps;
@@ -462,6 +473,9 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "light_grouped")) {
         ctx->light_grouped = value ? 1 : 0;
         ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "fuse_normals")) {
+        ctx->fuse_normals = value ? 1 : 0;
+        ctx->normals_pending = false;
     } else if (!strcmp(name, "assemble_from_sums")) {
         ctx->assemble_from_sums = value ? 1 : 0;
         ctx->ssum_valid = false;
@@ -513,6 +527,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "march_strip")) *value = ctx->grid.bound ? ctx->grid.strip_cols : ctx->march_tj;
     else if (!strcmp(name, "keep_stored_tensor")) *value = ctx->keep_stored_tensor;
     else if (!strcmp(name, "fuse_energy_lighting")) *value = ctx->fuse_energy_lighting;
+    else if (!strcmp(name, "fuse_normals")) *value = ctx->fuse_normals;
     else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
     else if (!strcmp(name, "cg_fused_step")) *value = ctx->cg_fused_step;
@@ -811,14 +826,15 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     // ---- state arena ----
     {
         const size_t fP = al256((size_t)P * sizeof(float));
-        size_t need = al256((size_t)NT * C * 4 * sizeof(float)) + al256((size_t)C * P * sizeof(float)) + al256(4 * (size_t)P * sizeof(float)) + 7 * fP +
+        size_t need = al256((size_t)NT * C * 4 * sizeof(float)) + al256((size_t)C * P * sizeof(float)) + al256(4 * (size_t)P * sizeof(float)) + 8 * fP +
                       al256((size_t)std::max(G.Ps, 1) * sizeof(float)) + al256((size_t)std::max(NL, 1) * C * P * sizeof(float)) + al256(2 * (size_t)C * P * sizeof(float)) +
                       (NL != NT ? al256(3 * (size_t)P * sizeof(float)) : 0) + 256;
         SRPS_TRY(ensure(ctx->state_arena, need));                    // grows only when this problem is larger than every earlier one
         size_t used = 0;
         auto carve = [&](size_t bytes) -> float* { float* p = (float*)((char*)ctx->state_arena.p + used); used += al256(bytes); return p; };
         ctx->s = carve((size_t)NT * C * 4 * sizeof(float)); ctx->rho = carve((size_t)C * P * sizeof(float)); ctx->z = carve((size_t)P * sizeof(float));
-        ctx->Nrm = carve(4 * (size_t)P * sizeof(float)); ctx->dz = carve((size_t)P * sizeof(float)); ctx->zx = carve((size_t)P * sizeof(float));
+        ctx->Nrm = carve(4 * (size_t)P * sizeof(float)); ctx->dz = carve((size_t)P * sizeof(float)); ctx->dz2 = carve((size_t)P * sizeof(float));
+        ctx->zx = carve((size_t)P * sizeof(float));
         ctx->zy = carve((size_t)P * sizeof(float)); ctx->xx = carve((size_t)P * sizeof(float)); ctx->yy = carve((size_t)P * sizeof(float));
         ctx->z0s = carve((size_t)std::max(G.Ps, 1) * sizeof(float));
         ctx->I = carve((size_t)std::max(NL, 1) * C * P * sizeof(float));
@@ -935,6 +951,7 @@ int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, in
 int srps_lighting_local(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_LIGHTING);
+    normals_flush(ctx);
     ctx->ssum_valid = false;             // s changes
     ctx->depth_assembled = false;
     return lighting(ctx, ctx->s, ctx->rho, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
@@ -949,6 +966,7 @@ int srps_lighting(srps_ctx* ctx) {
 int srps_albedo_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SWEEP);
+    normals_flush(ctx);
     float* ssum = nullptr;
     ctx->ssum_valid = false;
     ctx->depth_assembled = false;
@@ -999,6 +1017,7 @@ int srps_depth_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     if (ctx->depth_assembled) { ctx->depth_assembled = false; ctx->q_in_exchange = false; return SRPS_OK; }      // SRPS_ALBEDO_FUSED: g and q are on the grid
     PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
+    normals_flush(ctx);
     const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
     ctx->q_in_exchange = ctx->q_ex != nullptr;
     return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
@@ -1011,6 +1030,7 @@ int depth_solve_prepare(srps_ctx* ctx) {
     SRPS_REQUIRE(ctx->have_state && ctx->tensor_valid, SRPS_ERR_STATE, "depth_solve: call srps_depth_partial first");
     if (ctx->q_in_exchange) { SRPS_TRY(depth_q_scatter(ctx, ctx->q_ex)); ctx->q_in_exchange = false; }      // the all-reduced q of a shard
     ctx->light_cache_valid = false;      // z changes
+    ctx->normals_pending = false;
     const bool plane_current = ctx->grad_current && ctx->plane_holds_z;      // nothing wrote z or the plane since the last solve
     ctx->grad_current = false;
     ctx->plane_holds_z = false;
@@ -1071,6 +1091,7 @@ static int sharded_energy_exchange(srps_ctx* ctx) {
 static int redo_pass_tail(srps_ctx* ctx, int aborted) {
     Grid& G = ctx->grid;
     const bool sharded = ctx->N_local != ctx->N_total || (ctx->defer_shard_checks && comm_bound(ctx));
+    ctx->normals_pending = false;
     SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy, ctx->z));
     SRPS_TRY(launch_normals(ctx->stream, ctx->z, ctx->zx, ctx->zy, ctx->xx, ctx->yy, G.P, ctx->fx, ctx->fy, ctx->Nrm, ctx->dz));
     ctx->grad_current = true; ctx->plane_holds_z = true;
@@ -1125,6 +1146,15 @@ int srps_normals(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_NORMALS);
     Grid& G = ctx->grid;
+    if (ctx->normals_pending && ctx->grad_current) {
+        // the fused energy + lighting sweep of this pass has stored the normals of the new depth and its dz (option
+        // "fuse_normals"): the second dz array becomes the current one, nothing is launched
+        std::swap(ctx->dz, ctx->dz2);
+        ctx->normals_pending = false;
+        ctx->light_cache_normals = true;
+        return SRPS_OK;
+    }
+    ctx->normals_pending = false;
     if (!ctx->grad_current) {
         SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));
         SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy));                           // SRPS.cu:310-311
@@ -1183,6 +1213,7 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
 // computed.  Same kernels, same sums, same bits; what changes is when the bytes travel.
 static int sharded_albedo_partial_overlapped(srps_ctx* ctx) {
     PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SWEEP);
+    normals_flush(ctx);
     Grid& G = ctx->grid;
     const int P = G.P, C = ctx->C, K = 4;
     float* ssum = nullptr;
@@ -1210,6 +1241,7 @@ static int sharded_albedo_partial_overlapped(srps_ctx* ctx) {
 }
 static int sharded_depth_partial_overlapped(srps_ctx* ctx) {
     PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
+    normals_flush(ctx);
     Grid& G = ctx->grid;
     const int P = G.P, K = 4;
     const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
@@ -1286,6 +1318,7 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
 
 static int lookup(srps_ctx* ctx, const char* name, float** p, size_t* n) {
     Grid& G = ctx->grid;
+    normals_flush(ctx);                  // "N" and "dz" of one depth
     const size_t P = G.P;
     if (!strcmp(name, "z")) { *p = ctx->z; *n = P; }
     else if (!strcmp(name, "rho")) { *p = ctx->rho; *n = P * ctx->C; }
@@ -1322,6 +1355,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     ctx->ssum_valid = false;
     ctx->grad_current = false;
     ctx->depth_assembled = false;
+    ctx->normals_pending = false;
     if (p == ctx->I) ctx->i8_state = 0;
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
@@ -1345,6 +1379,7 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
     }
     ctx->light_cache_valid = false;      // the caller may write through the pointer
     ctx->depth_assembled = false;
+    ctx->normals_pending = false;
     ctx->ssum_valid = false;
     ctx->grad_current = false;
     return SRPS_OK;

@@ -464,3 +464,33 @@ def test_fused_albedo_sweep_equals_the_closed_form_bit_for_bit(pkg, h, w, sf, n_
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
     assert out[2][4]["depth"] == out[1][4]["depth"] == out[0][4]["depth"]
     assert rmse(out[2][1], out[0][1]) < 1e-5 and np.abs(out[2][2] - out[0][2]).max() < 5e-4
+
+
+@pytest.mark.parametrize("h,w,sf,n_img,n_ch,kind", [(96, 80, 2, 5, 3, "ragged"), (512, 384, 4, 21, 3, "ellipse"), (300, 200, 1, 3, 1, "ragged"), (1024, 1024, 4, 6, 3, "full")])
+def test_normals_stored_by_the_energy_sweep_equal_the_normals_kernel(pkg, h, w, sf, n_img, n_ch, kind):
+    """option fuse_normals: the fused energy + lighting sweep stores the normals and dz of the depth just solved (it forms them in
+    registers anyway) and srps_normals only swaps the two dz arrays -- every result of a solve, N and dz included, bit for bit as
+    with the normals kernel; also when a caller reads the state between the sweep and srps_normals"""
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img + 5, n_ch=n_ch, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = []
+    for fuse in (1, 0):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("fuse_normals", fuse)
+        ctx.setup(dh)
+        en = pkg.alternating_loop(ctx, None, max_outer=3)
+        state = [ctx.get(k) for k in ("z", "rho", "s", "N", "dz", "zx", "zy")]
+        # one more pass by hand, looking at N and dz BEFORE srps_normals
+        ctx.lighting(); ctx.albedo(); ctx.depth_partial(); ctx.depth_solve(); ctx.energy_partial()
+        mid = [ctx.get("N"), ctx.get("dz")]
+        ctx.normals()
+        e = ctx.energy_finish()
+        state += [ctx.get("N"), ctx.get("dz"), np.array([e], f32)]
+        out.append((np.array(en, f32), state, mid))
+        ctx.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # read between the sweep and srps_normals: with the option the pair is already that of the new depth (N and dz of ONE depth
+    # either way); after srps_normals both agree (asserted above)
+    np.testing.assert_array_equal(out[0][2][0], out[0][1][-3]); np.testing.assert_array_equal(out[0][2][1], out[0][1][-2])
