@@ -447,7 +447,8 @@ def test_fused_albedo_sweep_equals_the_closed_form_bit_for_bit(pkg, h, w, sf, n_
     route (k_albedo_numden + k_albedo_closed + k_depth_from_sums): whole solves agree bit for bit with SRPS_ALBEDO_CLOSED_FORM --
     also with 8-bit images (the byte store), one channel, and two channels (where the fused sweep does not apply and the mode
     falls back to the closed form); and close to the default, the reference's CG on the diagonal system, which stops within its
-    tolerance of this fixed point (depth < 1e-5, albedo < 5e-4 on the worst pixel of a ragged 4 764-pixel mask: measured 4e-7 / 7e-5)"""
+    tolerance of this fixed point (measured: depth 4e-7 ... 3e-6; albedo 7e-5 ... 8e-4 on the worst pixel -- one with a small
+    denominator --, 1e-5 in the mean)"""
     sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img, n_ch=n_ch, mask_kind=kind)
     if bytes_in:
         sc.I = (np.rint(np.clip(sc.I, 0, 1) * 255).astype(f32) / f32(255)).astype(f32)
@@ -463,7 +464,7 @@ def test_fused_albedo_sweep_equals_the_closed_form_bit_for_bit(pkg, h, w, sf, n_
     for a, b in zip(out[2][:4], out[1][:4]):
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
     assert out[2][4]["depth"] == out[1][4]["depth"] == out[0][4]["depth"]
-    assert rmse(out[2][1], out[0][1]) < 1e-5 and np.abs(out[2][2] - out[0][2]).max() < 5e-4
+    assert rmse(out[2][1], out[0][1]) < 1e-5 and rmse(out[2][2], out[0][2]) < 1e-4 and np.abs(out[2][2] - out[0][2]).max() < 5e-3
 
 
 @pytest.mark.parametrize("h,w,sf,n_img,n_ch,kind", [(96, 80, 2, 5, 3, "ragged"), (512, 384, 4, 21, 3, "ellipse"), (300, 200, 1, 3, 1, "ragged"), (1024, 1024, 4, 6, 3, "full")])
