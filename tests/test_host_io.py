@@ -215,3 +215,8 @@ def test_cli_help_and_errors(host, pkg):
     assert out.returncode == 0 and "Usage" in out.stdout
     out = subprocess.run([cli, "-d", "/nonexistent.mat"], capture_output=True, text=True)
     assert out.returncode == 1 and "Failed opening MAT file" in out.stderr
+    # round 3: the multi-GPU switches are part of the command line; a bad data set fails before any device is touched
+    out = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert "--gpus" in out.stdout and "--sharded" in out.stdout
+    out = subprocess.run([cli, "--gpus", "4", "-d", "/nonexistent.mat"], capture_output=True, text=True)
+    assert out.returncode == 1 and "Failed opening MAT file" in out.stderr
