@@ -255,6 +255,14 @@ int srps_comm_init_all(srps_ctx* const* ctxs, int n);
 int srps_set_comm(srps_ctx* ctx, void* rccl_comm /* ncclComm_t */, int rank, int world);
 int srps_comm_release(srps_ctx* ctx);
 int srps_comm_info(srps_ctx* ctx, int* rank, int* world /* 0: no communicator bound */);
+/* The image-sharded pass over collectives of the caller's instead of RCCL (MPI, gloo, ...): two host functions on DEVICE pointers;
+ * the library calls them with the stream drained, each returns 0 once its reads and writes are complete.
+ *   allreduce(user, d_buf, n, f64): in-place sum over the ranks of n floats (f64 == 0) or doubles (f64 != 0)
+ *   broadcast(user, d_buf, n, root): n floats from rank `root` to every rank
+ * srps_execute_sharded and srps_all_reduce then use them; both NULL removes them.  (tests: two processes on one GPU over gloo) */
+typedef int (*srps_host_allreduce_fn)(void* user, void* d_buf, size_t n, int f64);
+typedef int (*srps_host_broadcast_fn)(void* user, float* d_buf, size_t n, int root);
+int srps_set_host_collectives(srps_ctx* ctx, int rank, int world, srps_host_allreduce_fn allreduce, srps_host_broadcast_fn broadcast, void* user);
 /* Sum of the exchange buffer `which` ("s", "albedo", "depth", "energy": see srps_exchange) over the ranks, in place, enqueued
  * on the context's stream: what a host that drives the phases itself calls between *_partial and *_finish. */
 int srps_all_reduce(srps_ctx* ctx, const char* which);

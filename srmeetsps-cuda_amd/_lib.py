@@ -43,6 +43,9 @@ class Problem(C.Structure):
 STRIP_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 STRIP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t)
 STRIP_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
+# callbacks of srps_set_host_collectives
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+HOST_BROADCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 
 def build(force: bool = False) -> str:
@@ -133,6 +136,7 @@ def load():
         "srps_comm_release": (i, [vp]),
         "srps_comm_info": (i, [vp, ip, ip]),
         "srps_all_reduce": (i, [vp, C.c_char_p]),
+        "srps_set_host_collectives": (i, [vp, i, i, HOST_ALLREDUCE_FN, HOST_BROADCAST_FN, vp]),
         "srps_strip_group_solve": (i, [C.POINTER(vp), i]),
         "srps_set_strip_transport": (i, [vp, i, i, STRIP_ALLREDUCE_FN, STRIP_EXCHANGE_FN, STRIP_ALLGATHER_FN, vp]),
         "srps_get": (i, [vp, C.c_char_p, fp, C.c_size_t]),

@@ -73,16 +73,31 @@ int rccl_fail(ncclResult_t r, const char* what) {
     } while (0)
 }  // namespace
 
-bool comm_bound(const srps_ctx* ctx) { return ctx->comm != nullptr; }
+bool comm_bound(const srps_ctx* ctx) { return ctx->comm != nullptr || ctx->host_allreduce != nullptr; }
+
+// the caller's collectives (srps_set_host_collectives) instead of RCCL: host functions on device pointers, called with the
+// stream(s) that produced the data drained
+static int hosted_all_reduce(srps_ctx* ctx, hipStream_t st, void* d_buf, size_t n, int f64) {
+    SRPS_HIP(hipStreamSynchronize(st));
+    const int rc = ctx->host_allreduce(ctx->host_user, d_buf, n, f64);
+    SRPS_REQUIRE(rc == 0, SRPS_ERR_HIP, "host collectives: the caller's all-reduce returned %d", rc);
+    return SRPS_OK;
+}
 
 int comm_all_reduce_sum(srps_ctx* ctx, float* d_buf, size_t n) {
-    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "all_reduce: no communicator bound to the context (srps_comm_init_rank / srps_comm_init_all / srps_set_comm)");
     if (n == 0) return SRPS_OK;
+    if (ctx->host_allreduce) return hosted_all_reduce(ctx, ctx->stream, d_buf, n, 0);
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "all_reduce: no communicator bound to the context (srps_comm_init_rank / srps_comm_init_all / srps_set_comm)");
     SRPS_RCCL(g_rccl.AllReduce(d_buf, d_buf, n, ncclFloat32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     return SRPS_OK;
 }
 // several pieces of one buffer, as one group, on a stream of the caller's choice (the overlapped exchange of srps_execute_sharded)
 int comm_all_reduce_pieces_on(srps_ctx* ctx, hipStream_t st, float* const* d_piece, const size_t* n, int pieces) {
+    if (ctx->host_allreduce) {
+        for (int k = 0; k < pieces; ++k)
+            if (n[k]) SRPS_TRY(hosted_all_reduce(ctx, st, d_piece[k], n[k], 0));
+        return SRPS_OK;
+    }
     SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "all_reduce: no communicator bound to the context");
     SRPS_RCCL(g_rccl.GroupStart());
     ncclResult_t r = ncclSuccess;
@@ -94,8 +109,14 @@ int comm_all_reduce_pieces_on(srps_ctx* ctx, hipStream_t st, float* const* d_pie
     return SRPS_OK;
 }
 int comm_broadcast(srps_ctx* ctx, float* d_buf, size_t n, int root) {
-    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "broadcast: no communicator bound to the context");
     if (n == 0) return SRPS_OK;
+    if (ctx->host_broadcast) {
+        SRPS_HIP(hipStreamSynchronize(ctx->stream));
+        const int rc = ctx->host_broadcast(ctx->host_user, d_buf, n, root);
+        SRPS_REQUIRE(rc == 0, SRPS_ERR_HIP, "host collectives: the caller's broadcast returned %d", rc);
+        return SRPS_OK;
+    }
+    SRPS_REQUIRE(ctx->comm != nullptr, SRPS_ERR_STATE, "broadcast: no communicator bound to the context");
     SRPS_RCCL(g_rccl.Broadcast(d_buf, d_buf, n, ncclFloat32, root, (ncclComm_t)ctx->comm, ctx->stream));
     return SRPS_OK;
 }
@@ -142,6 +163,7 @@ int comm_all_gather_pieces(srps_ctx* ctx, float* d_buf, const size_t* offset, co
 void comm_release(srps_ctx* ctx) {
     if (ctx->comm && ctx->comm_owned && g_rccl.ok) (void)g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr; ctx->comm_owned = false; ctx->comm_rank = 0; ctx->comm_world = 1;
+    ctx->host_allreduce = nullptr; ctx->host_broadcast = nullptr; ctx->host_user = nullptr;      // one way of reaching the other ranks at a time
 }
 
 }  // namespace srps
@@ -218,8 +240,27 @@ int srps_comm_release(srps_ctx* ctx) {
 
 int srps_comm_info(srps_ctx* ctx, int* rank, int* world) {
     SRPS_REQUIRE(ctx != nullptr, SRPS_ERR_INVALID, "comm_info: null context");
-    if (rank) *rank = ctx->comm ? ctx->comm_rank : 0;
-    if (world) *world = ctx->comm ? ctx->comm_world : 0;      // 0: no communicator bound
+    const bool any = ctx->comm != nullptr || ctx->host_allreduce != nullptr;
+    if (rank) *rank = any ? ctx->comm_rank : 0;
+    if (world) *world = any ? ctx->comm_world : 0;      // 0: no communicator bound
+    return SRPS_OK;
+}
+
+// Collectives of the caller's instead of RCCL for the image-sharded pass (MPI, gloo, ...): host functions on DEVICE pointers,
+// called with the stream drained; each returns 0 once its reads and writes are complete.
+int srps_set_host_collectives(srps_ctx* ctx, int rank, int world, srps_host_allreduce_fn allreduce, srps_host_broadcast_fn broadcast, void* user) {
+    SRPS_REQUIRE(ctx != nullptr, SRPS_ERR_INVALID, "set_host_collectives: null context");
+    if (!allreduce && !broadcast) {
+        ctx->host_allreduce = nullptr; ctx->host_broadcast = nullptr; ctx->host_user = nullptr;
+        if (!ctx->comm) { ctx->comm_rank = 0; ctx->comm_world = 1; }
+        return SRPS_OK;
+    }
+    SRPS_REQUIRE(allreduce && broadcast, SRPS_ERR_INVALID, "set_host_collectives: both functions, or none");
+    SRPS_REQUIRE(world >= 1 && rank >= 0 && rank < world, SRPS_ERR_INVALID, "set_host_collectives: rank %d of %d", rank, world);
+    SRPS_REQUIRE(ctx->comm == nullptr, SRPS_ERR_STATE, "set_host_collectives: the context has an RCCL communicator (srps_comm_release first)");
+    (void)hipSetDevice(ctx->device);
+    ctx->host_allreduce = allreduce; ctx->host_broadcast = broadcast; ctx->host_user = user;
+    ctx->comm_rank = rank; ctx->comm_world = world;
     return SRPS_OK;
 }
 

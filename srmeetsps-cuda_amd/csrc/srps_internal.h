@@ -185,6 +185,10 @@ struct srps_ctx {
     int cg_strips = 0;               // option "cg_partition": 1 = the depth CG partitioned into column strips over the communicator's ranks
     double* d_strip_tot = nullptr;   // [12]: [0..3] this rank's sums of a launch, [4..7] / [8..11] the sums over all ranks of the launches of even / odd
                                      // parity (Grid::d_totals4 points at [4])
+    // the caller's collectives for the image-sharded pass (srps_set_host_collectives) instead of an RCCL communicator
+    srps_host_allreduce_fn host_allreduce = nullptr;
+    srps_host_broadcast_fn host_broadcast = nullptr;
+    void* host_user = nullptr;
     // the caller's transport for the strips (srps_set_strip_transport) instead of the communicator
     srps_strip_allreduce_fn strip_allreduce = nullptr;
     srps_strip_exchange_fn strip_exchange = nullptr;

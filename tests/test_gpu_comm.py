@@ -195,3 +195,60 @@ def test_overlapped_exchange_gives_the_same_bits(pkg, h, w, sf, kind):
     assert out[0][0] == out[1][0] and len(out[0][0]) == 2
     for a, b in zip(out[0][1:], out[1][1:]):
         np.testing.assert_array_equal(a, b)
+
+
+def _hosted_sharded_worker(rank, world, port, h, w, sf, n_img, kind, seed, overlap, out_dir):
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    lo, hi = pkg.shard_range(n_img, world, rank)
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=seed, mask_kind=kind, img_begin=lo, img_end=hi)
+    ctx = pkg.Context(device_id=0)
+    ctx.set_option("overlap_exchange", overlap)
+    hc = strips.HostedCollectives(ctx, dist)
+    assert ctx.comm_info() == (rank, world)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    en = ctx.execute_sharded(0)                         # the loop of SRPS.cu:272-335 inside the library, to the reference's stop rule
+    assert not hc.errors, hc.errors
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), en=np.array(en), z=ctx.get("z"), rho=ctx.get("rho"), s=ctx.get("s"), fb=ctx.get_option("persistent_fallbacks"))
+    dist.barrier()
+    hc.remove()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("h,w,sf,n_img,kind,world,overlap", [(96, 80, 2, 5, "ragged", 2, 0), (256, 320, 4, 7, "ellipse", 3, 1)])
+def test_sharded_loop_inside_the_library_over_two_and_three_processes(pkg, tmp_path, h, w, sf, n_img, kind, world, overlap):
+    """srps_execute_sharded with MORE than one rank: the library's own loop -- its all-reduces, the compact q buffer, the flags that
+    travel with the energy term, the stop decision every rank takes for itself -- over collectives supplied by the caller
+    (srps_set_host_collectives: torch.distributed / gloo between processes that share the GPU, which RCCL cannot do), against the
+    one-context solve; also with the exchange overlapped"""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    seed = h + 5 * w + world
+    mp.spawn(_hosted_sharded_worker, args=(world, port, h, w, sf, n_img, kind, seed, overlap, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{q}.npz") for q in range(world)]
+    for q in range(1, world):                                # replicas: the same bits on every rank
+        for k in ("en", "z", "rho", "s"):
+            np.testing.assert_array_equal(r[q][k], r[0][k])
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=seed, mask_kind=kind)
+    ctx = pkg.Context(device_id=0)
+    one = pkg.SRPS(pkg.DataHandler.from_scene(sc), ctx=ctx)
+    e1 = one.execute()
+    d_z = float(np.sqrt(np.mean((r[0]["z"] - one.z()) ** 2)))
+    print(f"{world} ranks, library loop over gloo: {len(r[0]['en'])} passes (one context: {len(e1)}), depth RMSE {d_z:.3e}")
+    assert len(r[0]["en"]) == len(e1)
+    np.testing.assert_allclose(r[0]["en"], e1, rtol=5e-4)
+    assert d_z < 3e-5 and np.abs(r[0]["rho"].reshape(one.rho().shape) - one.rho()).max() < 5e-4
+    ctx.close()
