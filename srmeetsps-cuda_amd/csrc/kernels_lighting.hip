@@ -23,8 +23,9 @@ struct EnergyArgs {
     int img_offset;
     float* part_e;
     // the fused energy + lighting sweep forms the normals of the depth just solved in registers anyway: with these set it also
-    // stores them (N0, N1, N2; N3 == 1 stays from the set-up) and the new dz -- into a SECOND dz array, the sweep's other blocks
-    // still read the dz the system was built from -- and srps_normals has no kernel to launch (null: nothing is stored)
+    // stores them (N0, N1, N2; N3 == 1 stays from the set-up) and the new dz -- into a SECOND set of arrays: the sweep's other
+    // blocks still read the dz the system was built from, and until srps_normals every reader is to see the normals and dz of ONE
+    // depth, the previous one -- and srps_normals swaps the sets instead of launching a kernel (null: nothing is stored)
     float* N_out;
     float* dz_out;
 };
@@ -609,8 +610,8 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
     EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part, nullptr, nullptr};
     // the channel-inner sweep (the one the pipeline runs for 1 and 3 channels) can leave the normals and dz of the new depth
     const bool ci = ctx->light_grouped && L.V == 4 && ctx->light_channel_inner && (C == 1 || C == 3);
-    const bool write_normals = ci && ctx->fuse_normals && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && n_local > 0;
-    if (write_normals) { ea.N_out = ctx->Nrm; ea.dz_out = ctx->dz2; }
+    const bool write_normals = ci && ctx->fuse_normals && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && ctx->Nrm2 != nullptr && n_local > 0;
+    if (write_normals) { ea.N_out = ctx->Nrm2; ea.dz_out = ctx->dz2; }
     SRPS_TRY(light_partial_launch<true>(ctx, L, d_rho, nullptr, d_I, P, n_local, C, ea));
     SRPS_TRY(launch_final_sum(ctx->stream, G.d_misc_part, L.n_epart, d_out));
     ctx->normals_pending = write_normals;      // srps_normals only has to make dz2 the current dz

@@ -107,7 +107,7 @@ static void grid_free(Grid& G) {
 
 static void state_release(srps_ctx* c) {
     c->i8_state = 0;                       // I8 (its own allocation, made when the images turn out to be bytes) is kept for the next set-up
-    c->s = c->rho = c->z = c->Nrm = c->dz = c->dz2 = c->zx = c->zy = c->xx = c->yy = c->z0s = c->I = c->albedo_ex = c->q_ex = nullptr;      // carved out of state_arena
+    c->s = c->rho = c->z = c->Nrm = c->Nrm2 = c->dz = c->dz2 = c->zx = c->zy = c->xx = c->yy = c->z0s = c->I = c->albedo_ex = c->q_ex = nullptr;      // carved out of state_arena
     c->normals_pending = false;
     c->q_in_exchange = false; c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
@@ -299,16 +299,6 @@ static int persistent_sync_check(srps_ctx* ctx, int* flags_out) {
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     albedo_iters_collect(ctx);
     return persistent_aborts(ctx, flags_out);
-}
-
-// Option "fuse_normals": the energy + lighting sweep has already stored the normals of the new depth (Nrm) and its dz (dz2).  Whoever
-// reads Nrm or dz next -- a phase, a getter -- must see the pair of ONE depth: completing the update (what srps_normals does) is a
-// pointer swap.
-static inline void normals_flush(srps_ctx* ctx) {
-    if (!ctx->normals_pending) return;
-    std::swap(ctx->dz, ctx->dz2);
-    ctx->normals_pending = false;
-    ctx->light_cache_normals = true;
 }
 
 }  // namespace srps
@@ -826,14 +816,15 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     // ---- state arena ----
     {
         const size_t fP = al256((size_t)P * sizeof(float));
-        size_t need = al256((size_t)NT * C * 4 * sizeof(float)) + al256((size_t)C * P * sizeof(float)) + al256(4 * (size_t)P * sizeof(float)) + 8 * fP +
+        size_t need = al256((size_t)NT * C * 4 * sizeof(float)) + al256((size_t)C * P * sizeof(float)) + 2 * al256(4 * (size_t)P * sizeof(float)) + 8 * fP +
                       al256((size_t)std::max(G.Ps, 1) * sizeof(float)) + al256((size_t)std::max(NL, 1) * C * P * sizeof(float)) + al256(2 * (size_t)C * P * sizeof(float)) +
                       (NL != NT ? al256(3 * (size_t)P * sizeof(float)) : 0) + 256;
         SRPS_TRY(ensure(ctx->state_arena, need));                    // grows only when this problem is larger than every earlier one
         size_t used = 0;
         auto carve = [&](size_t bytes) -> float* { float* p = (float*)((char*)ctx->state_arena.p + used); used += al256(bytes); return p; };
         ctx->s = carve((size_t)NT * C * 4 * sizeof(float)); ctx->rho = carve((size_t)C * P * sizeof(float)); ctx->z = carve((size_t)P * sizeof(float));
-        ctx->Nrm = carve(4 * (size_t)P * sizeof(float)); ctx->dz = carve((size_t)P * sizeof(float)); ctx->dz2 = carve((size_t)P * sizeof(float));
+        ctx->Nrm = carve(4 * (size_t)P * sizeof(float)); ctx->Nrm2 = carve(4 * (size_t)P * sizeof(float));
+        ctx->dz = carve((size_t)P * sizeof(float)); ctx->dz2 = carve((size_t)P * sizeof(float));
         ctx->zx = carve((size_t)P * sizeof(float));
         ctx->zy = carve((size_t)P * sizeof(float)); ctx->xx = carve((size_t)P * sizeof(float)); ctx->yy = carve((size_t)P * sizeof(float));
         ctx->z0s = carve((size_t)std::max(G.Ps, 1) * sizeof(float));
@@ -846,6 +837,7 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     hipLaunchKernelGGL(k_init_s, dim3(std::max(1, std::min(cdiv((long long)NT * C * 4, 256), 1024))), dim3(256), 0, ax, ctx->s, NT * C * 4);      // SRPS.cu:209-217
     SRPS_LAUNCH_CHECK();
     SRPS_TRY(launch_fill(ax, ctx->rho, (size_t)C * P, 0.5f));                               // SRPS.cu:220
+    SRPS_TRY(launch_fill(ax, ctx->Nrm2 + 3 * (size_t)P, (size_t)P, 1.f));                   // N3 == 1 (dc.cu:175) in the second set of normals too
     // masked LR depth and initial HR depth (copy_if SRPS.cu:237-246): uploaded whole into the scratch the mask came through,
     // compacted with the index lists
     {
@@ -951,7 +943,6 @@ int srps_dims(srps_ctx* ctx, int* npix, int* npixs, int* grid_h, int* grid_w, in
 int srps_lighting_local(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_LIGHTING);
-    normals_flush(ctx);
     ctx->ssum_valid = false;             // s changes
     ctx->depth_assembled = false;
     return lighting(ctx, ctx->s, ctx->rho, ctx->Nrm, ctx->I, ctx->grid.P, ctx->N_local, ctx->C, ctx->N_total, ctx->img_offset,
@@ -966,7 +957,6 @@ int srps_lighting(srps_ctx* ctx) {
 int srps_albedo_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SWEEP);
-    normals_flush(ctx);
     float* ssum = nullptr;
     ctx->ssum_valid = false;
     ctx->depth_assembled = false;
@@ -1017,7 +1007,6 @@ int srps_depth_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     if (ctx->depth_assembled) { ctx->depth_assembled = false; ctx->q_in_exchange = false; return SRPS_OK; }      // SRPS_ALBEDO_FUSED: g and q are on the grid
     PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
-    normals_flush(ctx);
     const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
     ctx->q_in_exchange = ctx->q_ex != nullptr;
     return depth_assemble(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->fx, ctx->fy, ctx->grid.P, ctx->N_local, ctx->C,
@@ -1147,8 +1136,10 @@ int srps_normals(srps_ctx* ctx) {
     PhaseSpan span(ctx, SRPS_PHASE_NORMALS);
     Grid& G = ctx->grid;
     if (ctx->normals_pending && ctx->grad_current) {
-        // the fused energy + lighting sweep of this pass has stored the normals of the new depth and its dz (option
-        // "fuse_normals"): the second dz array becomes the current one, nothing is launched
+        // the fused energy + lighting sweep of this pass has stored the normals of the new depth and its dz in the SECOND set of
+        // arrays (option "fuse_normals"; until this call every reader sees the normals and dz of the previous depth, as with the
+        // kernel): the two sets swap roles, nothing is launched
+        std::swap(ctx->Nrm, ctx->Nrm2);
         std::swap(ctx->dz, ctx->dz2);
         ctx->normals_pending = false;
         ctx->light_cache_normals = true;
@@ -1213,7 +1204,6 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
 // computed.  Same kernels, same sums, same bits; what changes is when the bytes travel.
 static int sharded_albedo_partial_overlapped(srps_ctx* ctx) {
     PhaseSpan span(ctx, SRPS_PHASE_ALBEDO_SWEEP);
-    normals_flush(ctx);
     Grid& G = ctx->grid;
     const int P = G.P, C = ctx->C, K = 4;
     float* ssum = nullptr;
@@ -1241,7 +1231,6 @@ static int sharded_albedo_partial_overlapped(srps_ctx* ctx) {
 }
 static int sharded_depth_partial_overlapped(srps_ctx* ctx) {
     PhaseSpan span(ctx, SRPS_PHASE_DEPTH_ASSEMBLY);
-    normals_flush(ctx);
     Grid& G = ctx->grid;
     const int P = G.P, K = 4;
     const float* ssum = (ctx->assemble_from_sums && ctx->ssum_valid) ? (const float*)ctx->ws_ssum.p : nullptr;
@@ -1318,7 +1307,6 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
 
 static int lookup(srps_ctx* ctx, const char* name, float** p, size_t* n) {
     Grid& G = ctx->grid;
-    normals_flush(ctx);                  // "N" and "dz" of one depth
     const size_t P = G.P;
     if (!strcmp(name, "z")) { *p = ctx->z; *n = P; }
     else if (!strcmp(name, "rho")) { *p = ctx->rho; *n = P * ctx->C; }

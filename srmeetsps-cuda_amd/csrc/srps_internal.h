@@ -151,9 +151,10 @@ struct srps_ctx {
     bool op_pp_set = false;
     float *s = nullptr, *rho = nullptr, *z = nullptr, *Nrm = nullptr, *dz = nullptr;
     float *zx = nullptr, *zy = nullptr, *xx = nullptr, *yy = nullptr, *z0s = nullptr, *I = nullptr;
-    float* dz2 = nullptr;            // the fused energy + lighting sweep writes the dz of the new depth here (it still reads the old one); srps_normals swaps
+    float *Nrm2 = nullptr, *dz2 = nullptr;   // the fused energy + lighting sweep writes the normals and dz of the new depth here (the old ones stay current
+                                     // until srps_normals, which swaps the two sets)
     int fuse_normals = 1;            // option: that sweep also stores the normals and dz of the new depth (no k_normals launch per pass)
-    bool normals_pending = false;    // Nrm holds the normals of the current depth and dz2 its dz, left by the sweep
+    bool normals_pending = false;    // Nrm2 / dz2 hold the normals and dz of the current depth, left by the sweep
     float* albedo_ex = nullptr;      // [2][C][P]  num, den
     float* q_ex = nullptr;           // [3][P] q of a shard in the compact layout: what travels in the all-reduce (allocated for shards only)
     bool q_in_exchange = false;      // srps_depth_partial left q in q_ex: srps_depth_solve scatters it onto the grid planes first

@@ -492,6 +492,6 @@ def test_normals_stored_by_the_energy_sweep_equal_the_normals_kernel(pkg, h, w, 
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
     for a, b in zip(out[0][1], out[1][1]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    # read between the sweep and srps_normals: with the option the pair is already that of the new depth (N and dz of ONE depth
-    # either way); after srps_normals both agree (asserted above)
-    np.testing.assert_array_equal(out[0][2][0], out[0][1][-3]); np.testing.assert_array_equal(out[0][2][1], out[0][1][-2])
+    # read between the sweep and srps_normals: the normals and dz of the PREVIOUS depth, with or without the option
+    np.testing.assert_array_equal(out[0][2][0], out[1][2][0]); np.testing.assert_array_equal(out[0][2][1], out[1][2][1])
+    np.testing.assert_array_equal(out[0][2][0], out[0][1][3]); np.testing.assert_array_equal(out[0][2][1], out[0][1][4])
