@@ -366,6 +366,8 @@ int srps_destroy(srps_ctx* ctx) {
     if (!ctx) return SRPS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    if (ctx->gather_stream) (void)hipStreamSynchronize(ctx->gather_stream);
     if (ctx->device >= 0 && ctx->device < 64) g_live_contexts[ctx->device].fetch_sub(1);
     comm_release(ctx);
     state_release(ctx);
