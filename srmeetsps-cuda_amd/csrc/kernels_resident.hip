@@ -120,6 +120,13 @@ __device__ __forceinline__ v4i as_v4i(const F4& a) {
     return v;
 }
 
+// The timing-experiment switch (option "cg_resident_debug": no grid-wide sums, no ring polls, wrong results) is compiled in only
+// with -DSRPS_RES_DEBUG: in the shipped kernel it cost scalar registers -- which the CG loop is short of -- and a test per use.
+#ifdef SRPS_RES_DEBUG
+#define SRPS_RES_DEBUG_ON(A) ((A).debug & 1)
+#else
+#define SRPS_RES_DEBUG_ON(A) false
+#endif
 struct ResidentArgs {
     const float* G;            // [NC][plane]
     const uint8_t* flags;      // [plane]
@@ -689,14 +696,14 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         auto request_ring = [&]() {
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
-                hv[q] = (hoff[q] >= 0 && !(a.debug & 1))
+                hv[q] = (hoff[q] >= 0 && !(SRPS_RES_DEBUG_ON(a)))
                             ? __hip_atomic_load(a.halo + hoff[q] + (hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         };
         auto await_ring = [&](float (&val)[RPT]) {
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 val[q] = 0.f;
-                if (hoff[q] >= 0 && !(a.debug & 1)) {
+                if (hoff[q] >= 0 && !(SRPS_RES_DEBUG_ON(a))) {
                     const unsigned long long* s = a.halo + hoff[q] + (hgen & 1u) * HALO_N;
                     while ((unsigned)(hv[q] >> 32) != hgen) {
                         // the clock is read by the scalar unit (no counter register); uniform for the lanes still waiting
@@ -730,7 +737,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 ++gen;
                 grid_sum_publish(red, a.ent, gen, sm);
                 request_ring();
-                r1 = (a.debug & 1) ? 1.f : grid_sum_collect(a.ent, gen, sm);
+                r1 = (SRPS_RES_DEBUG_ON(a)) ? 1.f : grid_sum_collect(a.ent, gen, sm);
                 r1_anchor = r1;
                 await_ring(wr);
 #pragma unroll
@@ -741,7 +748,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 request_ring();
                 SRPS_STAMP(5);
                 double pw, rw, ww;
-                if (a.debug & 1) { pw = 1e30; rw = 0.0; ww = 0.0; }
+                if (SRPS_RES_DEBUG_ON(a)) { pw = 1e30; rw = 0.0; ww = 0.0; }
                 else grid_sum3_collect<true>(a.ent3, gen, pw, rw, ww, SRPS_STAMP_PTR);
                 SRPS_STAMP(6);
                 alpha = r1 / (float)pw;                    // dc.cu:269
@@ -771,8 +778,8 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 //    and at every 16th step (relative drift below 1e-5; about one step in 16 at the metric's size).
                 // Otherwise the direct sum, one more wait.  Every block holds the same numbers: the decision is uniform.
                 // (A step counter kept in a register instead of k & 15 cost 1.4 us per step in code generation.)
-                if ((a.debug & 1) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
-                    r1 = (a.debug & 1) ? 1.f : (float)pred;
+                if ((SRPS_RES_DEBUG_ON(a)) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
+                    r1 = (SRPS_RES_DEBUG_ON(a)) ? 1.f : (float)pred;
                 else { r1 = grid_sum(red, a.ent, ++gen, sm); r1_anchor = r1; }
             }
         } else {
@@ -787,7 +794,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                         red = fmaf(r[c].e[e], r[c].e[e], red);
                     }
             } else {
-                const float dot = (a.debug & 1) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
+                const float dot = (SRPS_RES_DEBUG_ON(a)) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
                 alpha = r1 / dot;                              // dc.cu:269
                 asm volatile("" : "+v"(alpha));
                 // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
@@ -805,7 +812,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             if (!pass0) r0 = r1;
             // r.r, and r on the ring (the neighbours' edges of this generation): the ring granules are requested before
             // the wait for the partial sums, so that both arrive within one round trip
-            if (a.debug & 1) r1 = fminf(fmaxf(block_sum(red, sm), 1.f), 2.f);
+            if (SRPS_RES_DEBUG_ON(a)) r1 = fminf(fmaxf(block_sum(red, sm), 1.f), 2.f);
             else {
                 ++gen;
                 grid_sum_publish(red, a.ent, gen, sm);
