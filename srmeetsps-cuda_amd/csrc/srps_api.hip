@@ -275,6 +275,7 @@ static int persistent_aborts(srps_ctx* ctx, int* flags_out, int others = 0) {
     // wait gave up during the last step, or a solve on the albedo of an aborted albedo launch), the plane it started from is
     // intact -- make it the current one again; the caller repeats the phase from it.
     if (swapped) std::swap(ctx->grid.d_x, ctx->grid.d_x2);
+    ctx->plane_restored = swapped;       // else no depth solve ran since the last look: the plane holds whatever it held before
     ++ctx->persistent_fallbacks;
     if (flags & ABORT_DEPTH) ctx->cg_resident = 0;
     if (flags & ABORT_ALBEDO) ctx->albedo_persistent = 0;
@@ -1083,6 +1084,8 @@ static int redo_pass_tail(srps_ctx* ctx, int aborted) {
     Grid& G = ctx->grid;
     const bool sharded = ctx->N_local != ctx->N_total || (ctx->defer_shard_checks && comm_bound(ctx));
     ctx->normals_pending = false;
+    if (!ctx->plane_restored) SRPS_TRY(grid_scatter(ctx, ctx->z, G.d_x));      // no solve touched z or the plane in this pass: z itself is the pass's depth
+    ctx->plane_restored = false;
     SRPS_TRY(grid_gradient(ctx, G.d_x, ctx->zx, ctx->zy, ctx->z));
     SRPS_TRY(launch_normals(ctx->stream, ctx->z, ctx->zx, ctx->zy, ctx->xx, ctx->yy, G.P, ctx->fx, ctx->fy, ctx->Nrm, ctx->dz));
     ctx->grad_current = true; ctx->plane_holds_z = true;

@@ -199,6 +199,7 @@ struct srps_ctx {
     int overlap_exchange = 0;        // option: srps_execute_sharded cuts the two sweeps that feed an all-reduce into pixel ranges and reduces a range
                                      // (on a second stream) while the next one is computed
     bool defer_shard_checks = false; // srps_execute_sharded: a shard's phases do not look at the abort flags themselves; the ranks decide together at the end of the pass
+    bool plane_restored = false;     // the last look at the abort flags made the depth plane of the pass's start current again
     bool x_swapped = false;          // the resident CG launched since the abort flags were last looked at swapped grid.d_x and grid.d_x2
     int persistent_inflight = 0;     // ABORT_* bits of the persistent kernels launched since the abort flags were last looked at
     int cg_one_sync = 1;             // resident CG: r.r from r.r - 2 alpha r.w + alpha^2 w.w (one grid-wide wait per step)
