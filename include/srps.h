@@ -284,6 +284,11 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
  * stand-in for n ranks -- the collectives are device copies, the arithmetic is the multi-GPU path's.  Every context must have
  * gone through srps_depth_partial on the same problem; afterwards each holds the new depth as after srps_depth_solve. */
 int srps_strip_group_solve(srps_ctx* const* ctxs, int n);
+/* The two partitions as pure functions (no device needed): rank `rank` of `world` owns the grid columns [*c0, *c0 + *width)
+ * (multiples of sf; sizes differ by at most one block column) resp. the images [*begin, *begin + *count) (contiguous; sizes differ
+ * by at most one). */
+int srps_strip_range(int grid_cols, int sf, int world, int rank, int* c0, int* width);
+int srps_shard_range(int n_images, int world, int rank, int* begin, int* count);
 /* The strips over a transport of the caller's instead of RCCL (MPI, gloo, shared memory ...): three host functions that work on
  * DEVICE pointers.  srps_depth_solve calls them between the launches with the context's stream drained; each returns 0 after
  * its reads and writes are complete.

@@ -138,6 +138,8 @@ def load():
         "srps_all_reduce": (i, [vp, C.c_char_p]),
         "srps_set_host_collectives": (i, [vp, i, i, HOST_ALLREDUCE_FN, HOST_BROADCAST_FN, vp]),
         "srps_strip_group_solve": (i, [C.POINTER(vp), i]),
+        "srps_strip_range": (i, [i, i, i, i, ip, ip]),
+        "srps_shard_range": (i, [i, i, i, ip, ip]),
         "srps_set_strip_transport": (i, [vp, i, i, STRIP_ALLREDUCE_FN, STRIP_EXCHANGE_FN, STRIP_ALLGATHER_FN, vp]),
         "srps_get": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_set": (i, [vp, C.c_char_p, fp, C.c_size_t]),

@@ -256,6 +256,23 @@ int srps_strip_group_solve(srps_ctx* const* ctxs, int n) {
 }
 
 
+// The partitions themselves, as pure functions (no device): the columns [*c0, *c0 + *width) of a grid of `grid_cols` columns that rank
+// `rank` of `world` owns (multiples of sf, sizes differ by at most one block column), and the images [*begin, *begin + *count)
+// of a shard (contiguous, sizes differ by at most one) -- what srps_depth_solve / the C++ host / api.shard_range use.
+int srps_strip_range(int grid_cols, int sf, int world, int rank, int* c0, int* width) {
+    SRPS_REQUIRE(c0 && width && sf >= 1 && grid_cols > 0 && grid_cols % sf == 0 && world >= 1 && rank >= 0 && rank < world, SRPS_ERR_INVALID, "strip_range: bad arguments");
+    const Range rg = strip_range(grid_cols, sf, world, rank);
+    *c0 = rg.c0; *width = rg.w;
+    return SRPS_OK;
+}
+int srps_shard_range(int n_images, int world, int rank, int* begin, int* count) {
+    SRPS_REQUIRE(begin && count && n_images >= 0 && world >= 1 && rank >= 0 && rank < world, SRPS_ERR_INVALID, "shard_range: bad arguments");
+    const int base = n_images / world, rem = n_images % world;
+    *begin = rank * base + std::min(rank, rem);
+    *count = base + (rank < rem ? 1 : 0);
+    return SRPS_OK;
+}
+
 // The caller's own transport for the strip-partitioned CG (instead of RCCL): three host functions on DEVICE pointers, called
 // from srps_depth_solve with the context's stream drained; each must have completed its reads and writes when it returns.
 int srps_set_strip_transport(srps_ctx* ctx, int rank, int world, srps_strip_allreduce_fn allreduce, srps_strip_exchange_fn exchange,

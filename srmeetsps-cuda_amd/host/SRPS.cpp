@@ -149,8 +149,8 @@ void SRPS::execute_sharded(const std::vector<float>& zs, const std::vector<float
     auto rank_main = [&](int r) {
         srps_ctx* c = shard_ctx[r];
         // contiguous shards whose sizes differ by at most one (api.py shard_range)
-        const int base = dh->I_n / n_gpus, rem = dh->I_n % n_gpus;
-        const int lo = r * base + std::min(r, rem), cnt = base + (r < rem ? 1 : 0);
+        int lo = 0, cnt = 0;
+        srps_check(srps_shard_range(dh->I_n, n_gpus, r, &lo, &cnt));
         srps_problem pr{};
         pr.h = dh->I_h; pr.w = dh->I_w; pr.n_channels = dh->I_c; pr.n_images = cnt; pr.n_images_total = dh->I_n;
         pr.image_offset = lo; pr.sf = (int)dh->sf;

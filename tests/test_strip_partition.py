@@ -141,3 +141,40 @@ def test_strip_partitioned_cg_equals_serial_cg(tmp_path, pkg, oracle, world, kin
         got[d["own"]] = d["x"]; seen[d["own"]] = True; steps.add(int(d["steps"]))
     assert seen.all() and steps == {it} and it == 101               # every pixel owned once; the same truncated 101 steps
     assert np.sqrt(np.mean((got - x) ** 2)) < 2e-5                  # dot products are summed in another order, nothing else differs
+
+
+def test_partitions_of_the_library_equal_the_python_ones():
+    """srps_strip_range / srps_shard_range (the C side: srps_depth_solve with cg_partition, the C++ host's --gpus) against
+    strips.strip_ranges / api.shard_range (the Python side) -- pure functions, no device -- and their invariants: the ranks'
+    pieces tile the whole range in order, strips are cut at multiples of sf, sizes differ by at most one block / one image"""
+    import ctypes as C
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    lib = pkg.load()
+    a, b = C.c_int(0), C.c_int(0)
+    for sf in (1, 2, 3, 4):
+        for blocks in (1, 2, 7, 8, 64, 1023, 2048):
+            cols = blocks * sf
+            for world in (1, 2, 3, 4, 8, 16):
+                if world > blocks:
+                    continue
+                ref = strips.strip_ranges(cols, sf, world)
+                got = []
+                for r in range(world):
+                    assert lib.srps_strip_range(cols, sf, world, r, C.byref(a), C.byref(b)) == 0
+                    got.append((a.value, a.value + b.value))
+                assert got == ref
+                assert got[0][0] == 0 and got[-1][1] == cols and all(x[1] == y[0] for x, y in zip(got, got[1:]))
+                assert all((e - s) % sf == 0 and e > s for s, e in got)
+                assert max(e - s for s, e in got) - min(e - s for s, e in got) <= sf
+    for n in (0, 1, 5, 8, 20, 40, 64, 65):
+        for world in (1, 2, 3, 4, 8):
+            got = []
+            for r in range(world):
+                assert lib.srps_shard_range(n, world, r, C.byref(a), C.byref(b)) == 0
+                got.append((a.value, a.value + b.value))
+                assert got[-1] == pkg.shard_range(n, world, r)
+            assert got[0][0] == 0 and got[-1][1] == n and all(x[1] == y[0] for x, y in zip(got, got[1:]))
+            assert max(e - s for s, e in got) - min(e - s for s, e in got) <= 1
+    assert lib.srps_strip_range(10, 4, 2, 0, C.byref(a), C.byref(b)) == 1          # columns not a multiple of sf
+    assert lib.srps_shard_range(5, 2, 2, C.byref(a), C.byref(b)) == 1               # rank out of range
