@@ -499,7 +499,10 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                         const v2f gb = xv - xlv;
                         gx.x = selm(m_right, gb.x, gx.x); gx.y = selm(m_right, gb.y, gx.y);
                     }
-                    gy = dn - xv;
+                    // row by row: the pair below (rows 1, 2 / row 3 and the next lane's row 0) is not a register pair, and a packed
+                    // subtraction costs what two plain ones do (tools/valu_issue_bench.hip) -- without the moves that align its operand
+                    gy.x = dn.x - xv.x; gy.y = dn.y - xv.y;
+                    asm("" : "+v"(gy.x), "+v"(gy.y));
                     if (h == 1) gy.y = selm(m_bot, gy.x, gy.y);      // the mask's last row: backward = the forward difference of the row above
                 } else {
                     mfx = (v2i){SRPS_MSK(B_FX, e0, FL), SRPS_MSK(B_FX, e1, FL)}; mbx = (v2i){SRPS_MSK(B_BX, e0, FL), SRPS_MSK(B_BX, e1, FL)};
@@ -530,7 +533,15 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                     fxU = andm2(U, mfx); bxU = andm2(U, mbx);
                     fyV = andm2(V, mfy); byV = andm2(V, mby);
                 }
-                const v2f own = W + (bxU - fxU) + (byV - fyV);        // A'(u, v, w) at the pixel itself
+                v2f own;                                              // A'(u, v, w) at the pixel itself
+                if constexpr (RECT) {
+                    // where no backward difference can occur (compile-time: every column but the last, every row but the thread's
+                    // last) bxU = byV = 0 and 0 - u = -u: two additions instead of four (the sign of a zero result aside, as
+                    // between the two bodies anyway)
+                    if (c < CPT - 1) own = W - fxU; else own = W + (bxU - fxU);
+                    if (h == 0) own = own - fyV;
+                    else { own.x = own.x - fyV.x; own.y = own.y + (byV.y - fyV.y); }
+                } else own = W + (bxU - fxU) + (byV - fyV);
                 w[c].e[e0] += own.x; w[c].e[e1] += own.y;
                 if (c < CPT - 1) { w[c < CPT - 1 ? c + 1 : CPT - 1].e[e0] += fxU.x; w[c < CPT - 1 ? c + 1 : CPT - 1].e[e1] += fxU.y; }      // Dx': +u right of a forward pixel
                 else { u3.e[e0] = fxU.x; u3.e[e1] = fxU.y; }
