@@ -81,6 +81,9 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {      // lane i <-
 }
 // bit BIT of the structure word as an all-ones / all-zeros mask. Written in assembly: the compiler turns the
 // portable forms into and + compare + select (three instructions and a scalar register pair per use).
+// a value every lane holds alike (read from LDS after a barrier), told to the compiler: in a scalar register the CG loop's exit test is
+// uniform -- as a vector value the loop counts as divergent, and everything live behind it (x, 32 registers) is copied aside and back every step
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 // lane l of `old` replaced by the (wave-uniform) value s: v_writelane_b32 -- no lane mask, no select
 template <int L>
@@ -370,8 +373,9 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
     // The CG steps k = 1.. follow (dc.cu:252: while r1 > tol^2 and k <= max_iter, max_steps = max_iter + 1).
 #pragma unroll
     for (int c = 0; c < CPT; ++c) p[c] = x[c];
-    bool pass0 = true;
-    while (pass0 || (r1 > a.tol2 && k < a.max_steps)) {
+    // The pass is written once, as a function of "pass 0 or a CG step" -- a compile-time constant or a run-time flag (below).
+    auto cg_pass = [&](auto pass0_c) __attribute__((always_inline)) {
+        const bool pass0 = pass0_c.value;
         if (!pass0) ++k;
         SRPS_STAMP(0);
         const bool first = pass0 || k == 1;               // p is taken as it is (x, or r), not updated
@@ -400,8 +404,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
 
         SRPS_STAMP(1);
         // ---- omega = A_ p ------------------------------------------------------------------------------------
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) w[c] = zero4();
+        w[0] = zero4();                                    // the other columns start from the u of the column to their left
         F4 u3 = zero4();                                   // forward-x u of the last column: goes to the next wave
         F4 u0 = zero4();                                   // backward-x u of the first column: goes to the previous wave
         float ksum[CPT >= 4 ? CPT / 4 : 1] = {};           // SF == 4: sums of the thread's 4 x 4 blocks (CPT = 2 is not built for sf 4)
@@ -543,7 +546,8 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                     else { own.x = own.x - fyV.x; own.y = own.y + (byV.y - fyV.y); }
                 } else own = W + (bxU - fxU) + (byV - fyV);
                 w[c].e[e0] += own.x; w[c].e[e1] += own.y;
-                if (c < CPT - 1) { w[c < CPT - 1 ? c + 1 : CPT - 1].e[e0] += fxU.x; w[c < CPT - 1 ? c + 1 : CPT - 1].e[e1] += fxU.y; }      // Dx': +u right of a forward pixel
+                // Dx': +u right of a forward pixel -- the first term of the next column's omega: set, not added to a zero
+                if (c < CPT - 1) { w[c < CPT - 1 ? c + 1 : CPT - 1].e[e0] = fxU.x; w[c < CPT - 1 ? c + 1 : CPT - 1].e[e1] = fxU.y; }
                 else { u3.e[e0] = fxU.x; u3.e[e1] = fxU.y; }
                 if (!RECT || c == CPT - 1) {
                     if (c > 0) { w[c > 0 ? c - 1 : 0].e[e0] -= bxU.x; w[c > 0 ? c - 1 : 0].e[e1] -= bxU.y; }                              //      -u left of a backward pixel
@@ -748,7 +752,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 ++gen;
                 grid_sum_publish(red, a.ent, gen, sm);
                 request_ring();
-                r1 = (SRPS_RES_DEBUG_ON(a)) ? 1.f : grid_sum_collect(a.ent, gen, sm);
+                r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : grid_sum_collect(a.ent, gen, sm));
                 r1_anchor = r1;
                 await_ring(wr);
 #pragma unroll
@@ -790,8 +794,8 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 // Otherwise the direct sum, one more wait.  Every block holds the same numbers: the decision is uniform.
                 // (A step counter kept in a register instead of k & 15 cost 1.4 us per step in code generation.)
                 if ((SRPS_RES_DEBUG_ON(a)) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
-                    r1 = (SRPS_RES_DEBUG_ON(a)) ? 1.f : (float)pred;
-                else { r1 = grid_sum(red, a.ent, ++gen, sm); r1_anchor = r1; }
+                    r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : (float)pred);
+                else { r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm)); r1_anchor = r1; }
             }
         } else {
             if (pass0) {
@@ -823,12 +827,12 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             if (!pass0) r0 = r1;
             // r.r, and r on the ring (the neighbours' edges of this generation): the ring granules are requested before
             // the wait for the partial sums, so that both arrive within one round trip
-            if (SRPS_RES_DEBUG_ON(a)) r1 = fminf(fmaxf(block_sum(red, sm), 1.f), 2.f);
+            if (SRPS_RES_DEBUG_ON(a)) r1 = uniform_f(fminf(fmaxf(block_sum(red, sm), 1.f), 2.f));
             else {
                 ++gen;
                 grid_sum_publish(red, a.ent, gen, sm);
                 request_ring();
-                r1 = grid_sum_collect(a.ent, gen, sm);
+                r1 = uniform_f(grid_sum_collect(a.ent, gen, sm));
                 float rv[RPT];
                 await_ring(rv);
 #pragma unroll
@@ -837,7 +841,21 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             }
         }
         SRPS_STAMP(7);
-        pass0 = false;
+    };
+    // The exit test goes through a scalar register: every lane holds the same r1 and k, but the compiler cannot know that of a
+    // value read from LDS, and counts the loop as divergent.
+    // General body: pass 0 instantiated ahead of the loop, the CG step inside it.  With pass 0 as a branch inside the loop its two
+    // routes deliver r and x in different registers -- 48 64-bit moves per step to bring them together, the loop carries the
+    // pass-0 code along, and the body spills (64 bytes of scratch per lane, 12 this way): 10.5 -> 9.9 us per step on one box.
+    // RECT body: the one loop with the run-time flag; it does not spill either way, and instantiated twice it measured 8.67
+    // against 8.52 us per step (same box, tools/ab_variants.sh), although its loop is 12 % shorter in issue clocks.
+    if constexpr (RECT) {
+        struct RtBool { bool value; };
+        bool pass0 = true;
+        while (__builtin_amdgcn_readfirstlane((int)(pass0 || (r1 > a.tol2 && k < a.max_steps)))) { cg_pass(RtBool{pass0}); pass0 = false; }
+    } else {
+        cg_pass(std::true_type{});
+        while (__builtin_amdgcn_readfirstlane((int)(r1 > a.tol2 && k < a.max_steps))) cg_pass(std::false_type{});
     }
     // ---- results ---------------------------------------------------------------------------------------------
     // a block one of whose waits gave up stores nothing: x keeps the iterate the launch started from
