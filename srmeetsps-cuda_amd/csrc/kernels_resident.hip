@@ -114,6 +114,37 @@ __device__ __forceinline__ v2f mul2(v2f a, v2f b) {
     return a * b;
 }
 __device__ __forceinline__ v2f andm2(v2f v, v2i m) { return __builtin_bit_cast(v2f, __builtin_bit_cast(v2i, v) & m); }
+// The column body's pair arithmetic: packed (two rows per v_pk_* instruction, the default) or row by row (-DSRPS_RES_UNPACKED=1, an
+// experiment that stays for the record).  Two waves share a SIMD here; the issue microbenchmark (tools/valu_issue_bench.hip) has
+// v_fma_f32 at 4.56 clocks per instruction with one wave per SIMD and 2.29 with two, v_pk_fma_f32 at 5.5 and 4.67 -- two plain
+// instructions of two waves pair up, two packed ones do not -- and the per-wave stamps (tools/resident_wave_stamps.py) show waves
+// 0 - 3 through their columns 1.6 us before waves 4 - 7 of the same SIMDs: the older wave runs at its solo speed, the younger one in
+// its gaps.  If plain instructions paired up in this kernel as they do in the microbenchmark, a body of plain instructions (except
+// where a scalar register is read: the tensor rebuild) would let both waves advance together.  Measured on one box: 8.97 against
+// 8.58 us per step (general body 10.35 against 9.90) -- they do not; the packed body stays.
+#ifndef SRPS_RES_UNPACKED
+#define SRPS_RES_UNPACKED 0
+#endif
+struct r2f { float x, y; };
+struct r2i { int x, y; };
+__device__ __forceinline__ r2f operator+(r2f a, r2f b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ r2f operator-(r2f a, r2f b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ r2f operator-(r2f a) { return {-a.x, -a.y}; }
+__device__ __forceinline__ r2f fma2(r2f a, r2f b, r2f c) { return {__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ r2f mul2(r2f a, r2f b) {
+#pragma clang fp contract(off)
+    return {a.x * b.x, a.y * b.y};
+}
+__device__ __forceinline__ r2f andm2(r2f v, r2i m) { return {andm(v.x, m.x), andm(v.y, m.y)}; }
+__device__ __forceinline__ void pin2(v2f& a, v2f& b) { asm("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void pin2(r2f& a, r2f& b) { asm("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y)); }
+#if SRPS_RES_UNPACKED
+typedef r2f B2;
+typedef r2i B2i;
+#else
+typedef v2f B2;
+typedef v2i B2i;
+#endif
 __device__ __forceinline__ F4 as_f4(v4i v) {
     F4 r; r.e[0] = __int_as_float(v.x); r.e[1] = __int_as_float(v.y); r.e[2] = __int_as_float(v.z); r.e[3] = __int_as_float(v.w);
     return r;
@@ -166,7 +197,11 @@ struct TensorConsts {
 // taken by thread 0 of every block at the phase boundaries of every CG step, [step][block][16]; stamps 8..10 come from
 // inside the three-value reduction.  Costs ~0.7 us per step; never part of the shipped build.
 __device__ unsigned long long g_stamps[128 * 256 * 16];
-#define SRPS_STAMP(ID) do { if (tid == 0 && k < 128) g_stamps[((size_t)k * 256 + blockIdx.x) * 16 + (ID)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per wave as well (lane 0 of every wave, the first 64 steps of the first 64 blocks): where the waves of a block are at the barriers
+__device__ unsigned long long g_wstamps[64 * 64 * 8 * 16];
+#define SRPS_STAMP(ID) do { \
+    if (tid == 0 && k < 128) g_stamps[((size_t)k * 256 + blockIdx.x) * 16 + (ID)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((tid & 63) == 0 && k < 64 && blockIdx.x < 64) g_wstamps[(((size_t)k * 64 + blockIdx.x) * 8 + (tid >> 6)) * 16 + (ID)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SRPS_STAMP(ID) do { } while (0)
 #endif
@@ -186,7 +221,7 @@ __device__ unsigned long long g_stamps[128 * 256 * 16];
 template <int SF, int NC, bool ONE_SYNC, bool RECT>
 __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int tile, const unsigned cls) {
     extern __shared__ float4 lds4[];
-    // LDS map: [NC==3: g0, g1 as float4 [CPT][NT]] | ex, ex2 (float4 [NT]) | ring (floats): hp, hg[NC], hfl
+    // LDS map: [NC==3: g0, g1 as float4 [CPT][NT]] | ex, ex2 (float4 [NT]) | ring (floats): hp, hg[NC], hfl | sm, sflag | ucol
     constexpr int GL = (NC == 3) ? 2 : 0;                 // g planes kept in LDS
     float4* lg = lds4;                                    // [GL][CPT][NT]
     float4* ex = lds4 + GL * CPT * NT;                    // [NT]
@@ -196,6 +231,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
     unsigned* hfl = reinterpret_cast<unsigned*>(hg + NC * RING);   // [RING]
     float* sm = reinterpret_cast<float*>(hfl + RING);     // [40]
     int* sflag = reinterpret_cast<int*>(sm + 40);         // [4] block-wide structure summary
+    float* ucol = reinterpret_cast<float*>(sflag + 4);    // [2][TR] what the ring columns add to the tile's first / last column
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -399,7 +435,9 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 hp[ri] = first ? rh[q] : scal_then_axpy(beta, hp[ri], rh[q]);
             }
         ex[tid] = make_float4(p[0].e[0], p[0].e[1], p[0].e[2], p[0].e[3]);
-        ex2[tid] = make_float4(p[CPT - 1].e[0], p[CPT - 1].e[1], p[CPT - 1].e[2], p[CPT - 1].e[3]);
+        // (a RECT tile reads no column to the left across a wave boundary -- backward differences occur in its last column only,
+        // whose left neighbour is the thread's own -- : its ex2 carries u below, without a barrier in between)
+        if (!RECT) ex2[tid] = make_float4(p[CPT - 1].e[0], p[CPT - 1].e[1], p[CPT - 1].e[2], p[CPT - 1].e[3]);
         __syncthreads();
 
         SRPS_STAMP(1);
@@ -441,7 +479,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 const float* src = (wave < NWV - 1) ? reinterpret_cast<const float*>(ex + tid + 64) : hp + ring_colR(4 * lane);
                 pedge = ld4(src);
             }
-            if (c == 0) {                                      // only backward differences read the column to the left
+            if (c == 0 && !RECT) {                             // only backward differences read the column to the left
                 const float* src = (wave > 0) ? reinterpret_cast<const float*>(ex2 + tid - 64) : hp + ring_colL(4 * lane);
                 pedge = ld4(src);
             }
@@ -489,17 +527,17 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                         asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(P22) : "v"(g), "s"(TP[ch][2]));
                     }
                 }
-                const v2f xv = {xc.e[e0], xc.e[e1]};
-                const v2f up = {(h == 0) ? x_up : xc.e[1], (h == 0) ? xc.e[0] : xc.e[2]};
-                const v2f dn = {(h == 0) ? xc.e[1] : xc.e[3], (h == 0) ? xc.e[2] : x_dn};
-                const v2f xrv = {xr.e[e0], xr.e[e1]}, xlv = {xl.e[e0], xl.e[e1]};
+                const B2 xv = {xc.e[e0], xc.e[e1]};
+                const B2 up = {(h == 0) ? x_up : xc.e[1], (h == 0) ? xc.e[0] : xc.e[2]};
+                const B2 dn = {(h == 0) ? xc.e[1] : xc.e[3], (h == 0) ? xc.e[2] : x_dn};
+                const B2 xrv = {xr.e[e0], xr.e[e1]}, xlv = {xl.e[e0], xl.e[e1]};
                 // forward / backward are exclusive (SRPS.cu:39-46, 31-38)
-                v2i mfx, mbx, mfy, mby;
-                v2f gx, gy;
+                B2i mfx, mbx, mfy, mby;
+                B2 gx, gy;
                 if constexpr (RECT) {
                     gx = xrv - xv;
                     if (c == CPT - 1) {                        // the mask's last column: backward (the wave is uniform)
-                        const v2f gb = xv - xlv;
+                        const B2 gb = xv - xlv;
                         gx.x = selm(m_right, gb.x, gx.x); gx.y = selm(m_right, gb.y, gx.y);
                     }
                     // row by row: the pair below (rows 1, 2 / row 3 and the next lane's row 0) is not a register pair, and a packed
@@ -508,27 +546,28 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                     asm("" : "+v"(gy.x), "+v"(gy.y));
                     if (h == 1) gy.y = selm(m_bot, gy.x, gy.y);      // the mask's last row: backward = the forward difference of the row above
                 } else {
-                    mfx = (v2i){SRPS_MSK(B_FX, e0, FL), SRPS_MSK(B_FX, e1, FL)}; mbx = (v2i){SRPS_MSK(B_BX, e0, FL), SRPS_MSK(B_BX, e1, FL)};
-                    mfy = (v2i){SRPS_MSK(B_FY, e0, FL), SRPS_MSK(B_FY, e1, FL)}; mby = (v2i){SRPS_MSK(B_BY, e0, FL), SRPS_MSK(B_BY, e1, FL)};
+                    mfx = B2i{SRPS_MSK(B_FX, e0, FL), SRPS_MSK(B_FX, e1, FL)}; mbx = B2i{SRPS_MSK(B_BX, e0, FL), SRPS_MSK(B_BX, e1, FL)};
+                    mfy = B2i{SRPS_MSK(B_FY, e0, FL), SRPS_MSK(B_FY, e1, FL)}; mby = B2i{SRPS_MSK(B_BY, e0, FL), SRPS_MSK(B_BY, e1, FL)};
                     gx = andm2(xrv - xv, mfx) + andm2(xv - xlv, mbx);
                     gy = andm2(dn - xv, mfy) + andm2(xv - up, mby);
                 }
                 // every multiply-add spelled out (see uv_pixel)
-                const v2f xs2 = {xs, xs};
-                const v2f t2 = -fma2(gx, xs2, fma2(gy, ys, xv));         // E'(gx, gy, x)
-                const v2f Y0 = fma2(P02, t2, fma2(P00, gx, mul2(P01, gy)));      // the t2 term last: shortest dependent chain
-                const v2f Y1 = fma2(P12, t2, fma2(P01, gx, mul2(P11, gy)));
-                const v2f Y2 = fma2(P22, t2, fma2(P02, gx, mul2(P12, gy)));
-                const v2f U = fma2(-Y2, xs2, Y0);
-                const v2f V = fma2(-Y2, ys, Y1);
-                const v2f W = -Y2;
-                v2f fxU, bxU, fyV, byV;
+                const B2 xs2 = {xs, xs}, ysb = {ys.x, ys.y};
+                const B2 Q00 = {P00.x, P00.y}, Q01 = {P01.x, P01.y}, Q02 = {P02.x, P02.y}, Q11 = {P11.x, P11.y}, Q12 = {P12.x, P12.y}, Q22 = {P22.x, P22.y};
+                const B2 t2 = -fma2(gx, xs2, fma2(gy, ysb, xv));         // E'(gx, gy, x)
+                const B2 Y0 = fma2(Q02, t2, fma2(Q00, gx, mul2(Q01, gy)));      // the t2 term last: shortest dependent chain
+                const B2 Y1 = fma2(Q12, t2, fma2(Q01, gx, mul2(Q11, gy)));
+                const B2 Y2 = fma2(Q22, t2, fma2(Q02, gx, mul2(Q12, gy)));
+                const B2 U = fma2(-Y2, xs2, Y0);
+                const B2 V = fma2(-Y2, ysb, Y1);
+                const B2 W = -Y2;
+                B2 fxU, bxU, fyV, byV;
                 if constexpr (RECT) {
-                    const v2f zero = {0.f, 0.f};
+                    const B2 zero = {0.f, 0.f};
                     // u and v as values of their own, as in the general body (whose bit masks see them): without this the compiler
                     // fuses the multiply-adds that make them into the sums below (aggressive FMA fusion) and rounds differently
-                    v2f Uo = U, Vo = V;
-                    asm("" : "+v"(Uo), "+v"(Vo));
+                    B2 Uo = U, Vo = V;
+                    pin2(Uo, Vo);
                     fxU = Uo; bxU = zero; fyV = Vo; byV = zero;
                     if (c == CPT - 1) { fxU.x = andm(Uo.x, ~m_right); fxU.y = andm(Uo.y, ~m_right); bxU.x = andm(Uo.x, m_right); bxU.y = andm(Uo.y, m_right); }
                     if (h == 1) { fyV.y = andm(Vo.y, ~m_bot); byV.y = andm(Vo.y, m_bot); }
@@ -536,7 +575,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                     fxU = andm2(U, mfx); bxU = andm2(U, mbx);
                     fyV = andm2(V, mfy); byV = andm2(V, mby);
                 }
-                v2f own;                                              // A'(u, v, w) at the pixel itself
+                B2 own;                                              // A'(u, v, w) at the pixel itself
                 if constexpr (RECT) {
                     // where no backward difference can occur (compile-time: every column but the last, every row but the thread's
                     // last) bxU = byV = 0 and 0 - u = -u: two additions instead of four (the sign of a zero result aside, as
@@ -622,54 +661,56 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 w[c].e[3] -= andm(tb, m_l63);
             }
         }
-        // ring columns: the pixels left of column 0 (forward in x) and right of column 63 (backward in x)
-        if (wave == 0) {
-            const float xs = xs_of(bc * TC - 1 + oz);
+        // ring columns: the pixels left of column 0 (they act on column 0 when forward in x) and right of the last column (on it,
+        // when backward in x).  One pixel per lane, spread over the waves -- left ring rows 0..255 on threads 0..255, the right
+        // ring on the next 256 (a second round where the block has only 256 threads) -- instead of four pixels per lane on the
+        // wave that owns the column: that wave's SIMD was the last to reach the barrier below by three evaluations.  The values
+        // reach the owner through LDS (ucol), behind that barrier; the owner's p comes from the columns in ex / ex2.
+        {
+            const float* pL = reinterpret_cast<const float*>(ex);                        // p of column 0, rows 0..255 (wave 0's entries)
+            const float* pR = reinterpret_cast<const float*>(ex2 + 64 * (NWV - 1));      // p of the last column (last wave's entries)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int il = ring_colL(4 * lane + e);
-                const unsigned f = hfl[il];
+            for (int rr0 = 0; rr0 < 2 * TR; rr0 += NT) {
+                const int side = __builtin_amdgcn_readfirstlane((rr0 + 64 * wave) >= TR ? 1 : 0);      // uniform per wave: 0 left, 1 right
+                if (side == 1 && !any_bx) continue;
+                const int row = rr0 + tid - side * TR;
+                const int ir = side ? ring_colR(row) : ring_colL(row);
+                const unsigned f = hfl[ir];
                 float g[NC];
-                const float ys = ys_of(grow0 + e + oz);
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + il];
-                const float xv = hp[il];
-                const float gx = p[0].e[e] - xv;                       // used only if the ring pixel is forward in x
-                const float gy = if_bit_rt(hp[il + 1] - xv, f, B_FY) + if_bit_rt(xv - hp[il - 1], f, B_BY);
+                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + ir];
+                const float xs = xs_of((side ? bc * TC + TC : bc * TC - 1) + oz), ys = ys_of(br * TR + row + oz);
+                const float xv = hp[ir];
+                const float gx = side ? xv - pR[row] : pL[row] - xv;      // left: used only if the ring pixel is forward in x; right: backward
+                const float gy = if_bit_rt(hp[ir + 1] - xv, f, B_FY) + if_bit_rt(xv - hp[ir - 1], f, B_BY);
                 const float U = uv_pixel(std::true_type{}, g, xs, ys, gx, gy, xv);
-                w[0].e[e] += if_bit_rt(U, f, B_FX);
-            }
-        }
-        if (any_bx && wave == NWV - 1) {
-            const float xs = xs_of(bc * TC + TC + oz);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int irr = ring_colR(4 * lane + e);
-                const unsigned f = hfl[irr];
-                float g[NC];
-                const float ys = ys_of(grow0 + e + oz);
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch) g[ch] = hg[ch * RING + irr];
-                const float xv = hp[irr];
-                const float gx = xv - p[CPT - 1].e[e];                 // backward in x
-                const float gy = if_bit_rt(hp[irr + 1] - xv, f, B_FY) + if_bit_rt(xv - hp[irr - 1], f, B_BY);
-                const float U = uv_pixel(std::true_type{}, g, xs, ys, gx, gy, xv);
-                w[CPT - 1].e[e] -= if_bit_rt(U, f, B_BX);
+                ucol[side * TR + row] = side ? if_bit_rt(U, f, B_BX) : if_bit_rt(U, f, B_FX);
             }
         }
         SRPS_STAMP(3);
         // u across the wave boundaries
-        __syncthreads();                                   // every wave has read the p columns in ex / ex2
-        ex[tid] = make_float4(u3.e[0], u3.e[1], u3.e[2], u3.e[3]);
+        float4* uex = RECT ? ex2 : ex;                     // RECT: ex2 is free (above) -- one barrier instead of two
+        if (!RECT) __syncthreads();                        // every wave has read the p columns in ex / ex2
+        SRPS_STAMP(14);
+        uex[tid] = make_float4(u3.e[0], u3.e[1], u3.e[2], u3.e[3]);
         if (any_bx) ex2[tid] = make_float4(u0.e[0], u0.e[1], u0.e[2], u0.e[3]);
         __syncthreads();
+        SRPS_STAMP(15);
         if (wave > 0) {
-            const float4 t = ex[tid - 64];
+            const float4 t = uex[tid - 64];
+            w[0].e[0] += t.x; w[0].e[1] += t.y; w[0].e[2] += t.z; w[0].e[3] += t.w;
+        } else {                                               // the left ring column acts on column 0
+            const float4 t = reinterpret_cast<const float4*>(ucol)[lane];
             w[0].e[0] += t.x; w[0].e[1] += t.y; w[0].e[2] += t.z; w[0].e[3] += t.w;
         }
-        if (any_bx && wave < NWV - 1) {
-            const float4 t = ex2[tid + 64];
-            w[CPT - 1].e[0] -= t.x; w[CPT - 1].e[1] -= t.y; w[CPT - 1].e[2] -= t.z; w[CPT - 1].e[3] -= t.w;
+        if (any_bx) {
+            if (wave < NWV - 1) {
+                const float4 t = ex2[tid + 64];
+                w[CPT - 1].e[0] -= t.x; w[CPT - 1].e[1] -= t.y; w[CPT - 1].e[2] -= t.z; w[CPT - 1].e[3] -= t.w;
+            } else {                                           // the right ring column on the last column
+                const float4 t = reinterpret_cast<const float4*>(ucol + TR)[lane];
+                w[CPT - 1].e[0] -= t.x; w[CPT - 1].e[1] -= t.y; w[CPT - 1].e[2] -= t.z; w[CPT - 1].e[3] -= t.w;
+            }
         }
         // omega = lambda * (...) + KT'KT p ; partial p.omega (and, one-sync form, r.omega and omega.omega)
         float red = 0.f, red_rw = 0.f, red_ww = 0.f;
@@ -891,12 +932,15 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
 
 size_t resident_lds_bytes(int NC) {
     const size_t gl = (NC == 3) ? 2 : 0;
-    return (gl * CPT * NT + 2 * NT) * sizeof(float4) + (size_t)RING * sizeof(float) * (1 + NC + 1) + 40 * sizeof(float) + 16;
+    return (gl * CPT * NT + 2 * NT) * sizeof(float4) + (size_t)RING * sizeof(float) * (1 + NC + 1) + 40 * sizeof(float) + 16 + 2 * TR * sizeof(float);
 }
 
 }  // namespace
 
 #if defined(SRPS_STAMPS) && SRPS_RES_NT == 512 && SRPS_RES_CPT == 8
+extern "C" int srps_debug_read_wave_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), sizeof(g_wstamps));
+}
 extern "C" int srps_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
