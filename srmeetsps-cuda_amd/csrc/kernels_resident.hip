@@ -415,25 +415,28 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         if (!pass0) ++k;
         SRPS_STAMP(0);
         const bool first = pass0 || k == 1;               // p is taken as it is (x, or r), not updated
-        float beta = first ? 0.f : r1 / r0;               // dc.cu:262
+        float beta = (ONE_SYNC || first) ? 0.f : r1 / r0;      // dc.cu:262
         asm volatile("" : "+v"(beta));                     // a vector register: see the lane masks above
         // An opaque zero added to every coordinate: without it the compiler hoists the (step-invariant) tensor terms
         // and the LDS reads of g out of the CG loop and keeps ~100 more values per thread alive than there are registers.
         int oz = 0;
         asm volatile("" : "+s"(oz));
         // ---- p = beta p + r, own pixels and ring (pass 0: p = x, set before the loop) ----------------------------------
-        if (!pass0) {
+        // (one-wait form: the previous pass has formed this step's p at its end, where r.r -- and with it beta -- is first known)
+        if (!ONE_SYNC) {
+            if (!pass0) {
 #pragma unroll
-            for (int c = 0; c < CPT; ++c)
+                for (int c = 0; c < CPT; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p[c].e[e] = scal_then_axpy(beta, p[c].e[e], r[c].e[e]);      // k == 1: beta = 0, p = 0 p + r = r (dc.cu:258)
-        }
-#pragma unroll
-        for (int q = 0; q < RPT; ++q)
-            if (tid + q * NT < NRING && !(ONE_SYNC && pass0)) {
-                const int ri = ring_index(tid + q * NT);
-                hp[ri] = first ? rh[q] : scal_then_axpy(beta, hp[ri], rh[q]);
+                    for (int e = 0; e < 4; ++e) p[c].e[e] = scal_then_axpy(beta, p[c].e[e], r[c].e[e]);      // k == 1: beta = 0, p = 0 p + r = r (dc.cu:258)
             }
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+                if (tid + q * NT < NRING) {
+                    const int ri = ring_index(tid + q * NT);
+                    hp[ri] = first ? rh[q] : scal_then_axpy(beta, hp[ri], rh[q]);
+                }
+        }
         ex[tid] = make_float4(p[0].e[0], p[0].e[1], p[0].e[2], p[0].e[3]);
         // (a RECT tile reads no column to the left across a wave boundary -- backward differences occur in its last column only,
         // whose left neighbour is the thread's own -- : its ex2 carries u below, without a barrier in between)
@@ -837,6 +840,22 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 if ((SRPS_RES_DEBUG_ON(a)) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
                     r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : (float)pred);
                 else { r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm)); r1_anchor = r1; }
+            }
+            // ---- the next step's p = beta p + r, own pixels and ring (dc.cu:256-264), here, where r.r has just become known: at the
+            // top of the next pass it cost a phase of its own behind the loop's turn.  After pass 0: beta = 0, p = 0 p + r = r.
+            {
+                float beta_n = pass0 ? 0.f : r1 / r0;      // dc.cu:262
+                asm volatile("" : "+v"(beta_n));
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[c].e[e] = scal_then_axpy(beta_n, p[c].e[e], r[c].e[e]);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q)
+                    if (tid + q * NT < NRING) {
+                        const int ri = ring_index(tid + q * NT);
+                        hp[ri] = pass0 ? rh[q] : scal_then_axpy(beta_n, hp[ri], rh[q]);
+                    }
             }
         } else {
             if (pass0) {
