@@ -733,21 +733,24 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         const unsigned hgen = (unsigned)k + 1u;           // edge generation: k + 1 (0 means "never written"), slot (k + 1) & 1
         // the tile's edges of `src` as generation-tagged granules
         auto publish_edges = [&](const F4 (&src)[CPT]) {
+            // two granules {value, generation} per 16-byte store (each granule is read on its own, as 8 bytes): half the store
+            // instructions of one per granule, and every store with data registers of its own
             unsigned long long* hb = a.halo + ((size_t)tile * 2 + (hgen & 1u)) * HALO_N;
-            const unsigned long long tag = (unsigned long long)hgen << 32;
+            auto store2 = [&](unsigned long long* d, float v0, float v1) {
+                const srps_v4u g = {__float_as_uint(v0), hgen, __float_as_uint(v1), hgen};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(d), "v"(g) : "memory");
+            };
             if (wave == 0 || wave == NWV - 1) {
                 const F4& rc = (wave == 0) ? src[0] : src[CPT - 1];
                 unsigned long long* d = hb + (wave == 0 ? 0 : TR) + 4 * lane;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    __hip_atomic_store(d + e, tag | (unsigned long long)__float_as_uint(rc.e[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                store2(d, rc.e[0], rc.e[1]);
+                store2(d + 2, rc.e[2], rc.e[3]);
             }
             if (lane == 0 || lane == 63) {
                 unsigned long long* d = hb + 2 * TR + (lane == 0 ? 0 : TC) + CPT * wave;
 #pragma unroll
-                for (int c = 0; c < CPT; ++c)
-                    __hip_atomic_store(d + c, tag | (unsigned long long)__float_as_uint(lane == 0 ? src[c].e[0] : src[c].e[3]),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int c = 0; c < CPT; c += 2)
+                    store2(d + c, lane == 0 ? src[c].e[0] : src[c].e[3], lane == 0 ? src[c + 1].e[0] : src[c + 1].e[3]);
             }
         };
         // the ring values of this generation: requested early (request), waited for late (await)
