@@ -282,7 +282,7 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
                 const srps_v4u g = {gen, __float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2])};
                 const int nbr = (nb + 255) & ~255;
                 const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(g) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
                 if (st) st[0] = __builtin_amdgcn_s_memrealtime();
             }
         }
@@ -312,9 +312,9 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
         const srps_v4u g = {gen, __float_as_uint((float)tot[0]), __float_as_uint((float)tot[1]), __float_as_uint((float)tot[2])};
         const int nbr = (nb + 255) & ~255;
         const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
-        // s_nop: a store of more than 8 bytes must not be followed directly by a write of its data registers (the compiler
-        // inserts this wait state for its own stores, it cannot see into the asm)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(g) : "memory");
+        // s_nop 1: a store of more than 8 bytes must not be followed within two wait states by a write of its data registers
+        // (gfx940 and later; the compiler inserts them for its own stores, it cannot see into the asm)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
         if (st) st[0] = __builtin_amdgcn_s_memrealtime();
     }
 }
@@ -409,7 +409,7 @@ __device__ __forceinline__ void grid_sum9_publish(const float (&v)[3][3], unsign
         const srps_v4u g = {gen, __float_as_uint((float)tot[0]), __float_as_uint((float)tot[1]), __float_as_uint((float)tot[2])};
         const int nbr = (nb + 255) & ~255;
         const char* dst = reinterpret_cast<const char*>(ent9) + (((size_t)(gen & 1u) * 3 + tid) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(g) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
     }
 }
 __device__ __forceinline__ void grid_sum9_collect(unsigned long long* ent9, unsigned gen, double (&o)[3][3]) {

@@ -738,7 +738,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             unsigned long long* hb = a.halo + ((size_t)tile * 2 + (hgen & 1u)) * HALO_N;
             auto store2 = [&](unsigned long long* d, float v0, float v1) {
                 const srps_v4u g = {__float_as_uint(v0), hgen, __float_as_uint(v1), hgen};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(d), "v"(g) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(d), "v"(g) : "memory");
             };
             if (wave == 0 || wave == NWV - 1) {
                 const F4& rc = (wave == 0) ? src[0] : src[CPT - 1];
