@@ -274,11 +274,27 @@ void oc_csr_spmv(int n, const int* rowptr, const int* col, const float* val, con
     }
 }
 
+/* cublasSdot (dc.cu:251, 268, 274).  The library's summation order is not specified; what a GPU BLAS does is a tree over blocks.
+ * Restated so that the result does NOT depend on the number of host threads: float sums over fixed blocks of 256 elements (a
+ * thread block's share), the block sums added in double in index order.  (One float accumulator per OpenMP thread, as this
+ * function had it first, made the truncated 101-step solve -- and the energy after it -- move with the thread count: 38 560 on 8
+ * threads, 38 522 on 64, 38 487 on 256 for the 1024 x 1024 scene whose energy is 38 487.29 on the GPU, and from run to run with
+ * the order in which OpenMP combined the threads' sums.) */
 static float sdot(int n, const float* a, const float* b) {
-    float acc = 0.f;
-#pragma omp parallel for schedule(static) reduction(+ : acc)
-    for (int i = 0; i < n; ++i) acc += a[i] * b[i];
-    return acc;
+    enum { BLK = 256 };
+    const int nblk = (n + BLK - 1) / BLK;
+    double* part = (double*)malloc((size_t)(nblk > 0 ? nblk : 1) * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nblk; ++q) {
+        const int i0 = q * BLK, i1 = i0 + BLK < n ? i0 + BLK : n;
+        float acc = 0.f;
+        for (int i = i0; i < i1; ++i) acc += a[i] * b[i];
+        part[q] = (double)acc;
+    }
+    double tot = 0.0;
+    for (int q = 0; q < nblk; ++q) tot += part[q];
+    free(part);
+    return (float)tot;
 }
 
 /* cuda_based_conjugate_gradient, devicecalls.cu:229-279, statement by statement (BLAS-1 ops unfused).

@@ -147,7 +147,7 @@ def _one_pass_vs_oracle(pkg, oracle, coracle, sc, expect_resident=True, e_tol=2e
     assert np.abs(rho - rho_ref).max() < 1e-4
     # first pass.  Measured (round 3): 4.3e-6 at 1024 x 1024 x 20 images, 2.1e-4 at 2048 x 2048 x 40, 3.1e-4 at
     # 512 x 384 x 45 images, 2.4e-6 and 4.2e-5 at 4096 x 4096 x 64 on two boxes -- the GPU's energy was the same bits both times, the
-    # ORACLE's moved (its fp32 sums are formed by however many host threads the box has); the callers allow about three times
+    # ORACLE's moved (its dot products were float sums per host thread then; since they are sums over fixed blocks the oracle gives the same energy on 8 and on 256 threads); the callers allow about three times
     # the largest value seen
     print("first-pass energy, relative deviation", abs(en[0] - e_ref) / abs(e_ref), "allowed", e_tol)
     assert abs(en[0] - e_ref) <= e_tol * abs(e_ref)
