@@ -33,6 +33,9 @@ def main():
     # gpurun merges every call's output into the same directory: the newest file of a kind is the one of the last run
     newest = lambda pattern: sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime, reverse=True)
     stats = newest(os.path.join(src, "bench", "**", "*kernel_stats.csv"))
+    # (bench.py's legs start child processes -- tools/hbm_ceiling_bench.bin -- which the profiler follows and gives statistics files
+    # of their own: the bench's is the newest one that holds the library's kernels)
+    stats = [f for f in stats if "srps::" in open(f).read()]
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{rnd}_bench_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "bench.json")):
