@@ -40,15 +40,15 @@ def seg(a, b, name):
 if t[:, :, 8].any():
     seg(4, 11, "edges published (4->11)")
     seg(11, 8, "sums: totals+barrier+store (11->8)")
-    if t[:, :, 14].any():
-        seg(11, 14, "  wave totals (11->14)"); seg(14, 15, "  LDS + barrier (14->15)"); seg(15, 8, "  thread-0 sum + store (15->8)")
     seg(8, 5, "ring requested (8->5)")
     seg(5, 9, "first poll round returned (5->9)")
     seg(9, 10, "retries (9->10)")
     seg(10, 6, "totals + barrier (10->6)")
     seg(6, 12, "x, r update (6->12)")
     seg(12, 13, "ring await, thread 0 (12->13)")
-    seg(13, 7, "rest (13->7)")
+    seg(13, 7, "r.r, beta, next p, ring p (13->7)")
+    if t[:, :, 14].any():
+        seg(3, 14, "barrier behind the ring (general body only) (3->14)"); seg(14, 15, "u to LDS + barrier (14->15)"); seg(15, 4, "u in, finalize (15->4)")
     t8 = t[:, :, 8]; t9 = t[:, :, 9]; t10 = t[:, :, 10]
     print("last store issue -> median retries-done", (np.median(t10, axis=1) - t8.max(axis=1)).mean(), " -> first", (t10.min(axis=1) - t8.max(axis=1)).mean(), " -> last", (t10.max(axis=1) - t8.max(axis=1)).mean())
     print("spread of store issue (max-min)", (t8.max(axis=1) - t8.min(axis=1)).mean(), "(max-median)", (t8.max(axis=1) - np.median(t8, axis=1)).mean())
