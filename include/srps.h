@@ -89,7 +89,9 @@ int srps_synchronize(srps_ctx* ctx);
  * "cg_fused_step" (0|1: streaming depth CG with the whole step in one launch instead of operator + update kernel),
  * "exclusive_device" (0|1: the caller states that nothing else uses the device: plain instead of cooperative launches of the
  *  persistent kernels), "spin_budget_ms" (a persistent launch whose grid-wide waits are not served within this time aborts and the
- *  phase is repeated by the streaming kernels; default 200), "phase_timing", "roctx" (see srps_get_timings),
+ *  phase is repeated by the streaming kernels; default 200), "host_wait_spin" (0|1, default 1: the one wait of a pass for the
+ *  device -- the energy of the stop rule -- polls the stream instead of sleeping on it: the result is picked up ~10 - 20 us earlier,
+ *  the calling thread is busy meanwhile), "phase_timing", "roctx" (see srps_get_timings),
  * "overlap_exchange" (0|1, default 0: srps_execute_sharded cuts the albedo sweep and the depth assembly into four pixel ranges and
  *  all-reduces a range on a second stream while the next is computed -- same bits, the bytes travel under the sweeps; off until a
  *  multi-GPU run has timed it),

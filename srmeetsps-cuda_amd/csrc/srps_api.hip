@@ -432,6 +432,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "exclusive_device")) {
         // the caller states that no other process or context uses the device: plain launches of the persistent kernels
         ctx->coop_launch = value ? 0 : 1;
+    } else if (!strcmp(name, "host_wait_spin")) {
+        ctx->host_wait_spin = value ? 1 : 0;
     } else if (!strcmp(name, "spin_budget_ms")) {
         SRPS_REQUIRE(value >= 1 && value <= 600000, SRPS_ERR_INVALID, "spin_budget_ms: 1 .. 600000");
         ctx->spin_budget_ms = value;
@@ -551,6 +553,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "num_cus")) *value = ctx->num_cus;
     else if (!strcmp(name, "coop_launch")) *value = ctx->coop_launch;
     else if (!strcmp(name, "exclusive_device")) *value = ctx->coop_launch == 0 ? 1 : 0;
+    else if (!strcmp(name, "host_wait_spin")) *value = ctx->host_wait_spin;
     else if (!strcmp(name, "spin_budget_ms")) *value = ctx->spin_budget_ms;
     else if (!strcmp(name, "persistent_fallbacks")) *value = ctx->persistent_fallbacks;
     else if (!strcmp(name, "cg_resident_active")) *value = (ctx->grid.bound && resident_supported(ctx)) ? 1 : 0;
@@ -1106,7 +1109,16 @@ int srps_energy_finish(srps_ctx* ctx, float* energy) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(energy != nullptr, SRPS_ERR_INVALID, "energy_finish: energy is NULL");
     SRPS_TRY(report_fetch(ctx));
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    // The host's one wait per pass -- the stop rule needs the energy (SRPS.cu:318-331) -- and the only stretch of a pass in which
+    // the device has nothing queued: hipStreamSynchronize puts the thread to sleep on the completion signal and wakes it ~20 us
+    // late; polling the stream picks the result up within a few microseconds (option "host_wait_spin", on by default: the caller is
+    // waiting for this result and nothing else).
+    if (ctx->host_wait_spin) {
+        hipError_t q;
+        while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady) { }
+        if (q != hipSuccess) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+    } else
+        SRPS_HIP(hipStreamSynchronize(ctx->stream));
     albedo_iters_collect(ctx);
     // The one place a pass waits for the device: were the persistent kernels of this pass served?  If not (nothing was stored by
     // them), the part of the pass that followed is repeated with the streaming kernels -- on one GPU only: a shard has looked

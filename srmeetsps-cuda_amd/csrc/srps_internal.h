@@ -176,6 +176,7 @@ struct srps_ctx {
                                      // check -- the caller states that the device is exclusive to this context (option
                                      // "exclusive_device"), 2 = plain while this is the only live context of the process on its device.
                                      // Whatever the launch, every wait inside the kernels is bounded (spin_budget_ms).
+    int host_wait_spin = 1;          // the pass's one wait for the device (srps_energy_finish) polls the stream instead of sleeping on it
     int spin_budget_ms = 200;        // a persistent launch whose waits are not all served within this time aborts (device_utils.h
                                      // SpinState); the host then repeats the phase with the streaming kernels
     int persistent_fallbacks = 0;    // aborted persistent launches so far (option "persistent_fallbacks", read-only)

@@ -119,4 +119,21 @@ def test_spin_budget_option_range(pkg):
         ctx.set_option("spin_budget_ms", 0)
     ctx.set_option("exclusive_device", 1)
     assert ctx.get_option("coop_launch") == 0
+    assert ctx.get_option("host_wait_spin") == 1
+    ctx.set_option("host_wait_spin", 0)
+    assert ctx.get_option("host_wait_spin") == 0
     ctx.close()
+
+
+def test_host_wait_sleeping_or_polling_same_results(pkg):
+    """option host_wait_spin: how the host waits for the pass's energy does not touch the results"""
+    sc = pkg.synth.make_scene(256, 192, 2, 4, seed=77, mask_kind="ellipse")
+    out = []
+    for spin in (1, 0):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("host_wait_spin", spin)
+        srps = pkg.SRPS(pkg.DataHandler.from_scene(sc), ctx=ctx)
+        en = srps.execute(max_outer=3)
+        out.append((np.array(en, np.float32), srps.z()))
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
