@@ -2,7 +2,11 @@
 """bench.py -- CG iterations/sec of the SRPS hot path on synthetic data (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 runs one process per GPU.  Started under torch.distributed.run (WORLD_SIZE in the environment) this process IS a rank;
+    started bare (`python bench.py --gpus 2`) it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+    bench.py <same arguments>` as a CHILD before anything here touches the GPU (no torch import in the parent), relays the
+    ranks' output -- rank 0's JSON line -- and exits with the child's code.  The seam in the reference: Main.cpp:29 / SRPS.cu:88
+    (`cudaSetDevice(Preferences::deviceId)`, its only device selection).
 
 Workload (config.workload): synthetic full-mask HR grid 2048x2048, sf 4, 20 images per GPU, 3 channels,
 seed 1234+3.  One "step" = one pass of the alternating loop of SRPS.cu:276-315:
@@ -117,7 +121,16 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
     P = ctx.dims()["npix"]
     resident = bool(ctx.get_option("cg_resident_active"))
     assert resident == resident_expected or not resident_expected, "the resident CG kernel was expected to run"
-    tj = _profile("r03_traffic.json") or _profile("r02_traffic.json") or {}
+    tj, tj_name = {}, None
+    for tj_name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+        tj = _profile(tj_name)
+        if tj:
+            break
+    tj = tj or {}
+    # `traffic` is NOT measured by this process: PMC counters need a profiler pass of their own (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # tools/profile_round.sh + tools/pmc_traffic.py); the line replays the committed summary of that pass and says so
+    traffic_source = (f"replayed from profiles/{tj_name}: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes) of tools/cg_prof.py on another "
+                      "run and box, 2 x FETCH_SIZE + WRITE_SIZE per launch, median; not measured by this process") if tj else None
     key = f"{H}x{W}_sf{sf}"
     if resident:
         # ONE launch runs the residual pass and all 101 steps with the CG state in registers + LDS (kernels_resident.hip).
@@ -141,7 +154,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         out["roofline"] = {"bound": "valu", "kernel": "k_cg_resident (" + ("mask-free body: every tile lies inside the mask" if rect else "general body") +
                                                       "): residual pass + the whole truncated CG (101 steps) in one persistent launch",
                            "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
-                           "traffic": (tj.get(key) or {}).get("resident"), "avg_launch_us": launch_us, "steps_per_launch": 101,
+                           "traffic": (tj.get(key) or {}).get("resident"), "traffic_source": traffic_source, "avg_launch_us": launch_us, "steps_per_launch": 101,
                            "flops_per_launch": flops, "flops_per_unknown_and_step": FLOPS_PER_UNKNOWN_STEP, "issue": issue,
                            # what a CG that streams its vectors would have to move for the same work, as a bandwidth -- NOT a roofline fraction
                            "hbm_equivalent": {"algorithmic_bytes_per_launch": loop_bytes * 101, "GBs": loop_bytes * 101 / (1e3 * launch_us),
@@ -155,14 +168,46 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         share = b["apply_us"] / (b["apply_us"] + b["update_us"]) if b["update_bytes"] > 0 else 1.0      # one launch per step: no update kernel
         apply_us = us_iter * share
         ach = b["apply_bytes"] / (1e3 * apply_us)
-        out["roofline"] = {"bound": "hbm", "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial dot products, deferred x / r updates)",
+        # the CG's working set: g (3) + q-free vectors x, r (2), p (2), omega (2) planes + structure bytes -- at 2048^2 it lies INSIDE the
+        # 256 MiB Infinity Cache (MALL), whose hits FETCH_SIZE counts: such a leg prices the cache, not HBM (MI355X_MICROARCH.md)
+        ws_bytes = b["apply_bytes"] + b["update_bytes"]          # every byte of a step is touched once: its working set
+        in_mall = ws_bytes < 256 * 2**20
+        out["roofline"] = {"bound": "infinity_cache" if in_mall else "hbm",
+                           "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial dot products, deferred x / r updates)",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": (tj.get(key) or {}).get("apply"), "avg_launch_us": apply_us,
+                           "traffic": (tj.get(key) or {}).get("apply"), "traffic_source": traffic_source, "avg_launch_us": apply_us,
                            "algorithmic_bytes_per_launch": b["apply_bytes"]}
+        if in_mall:
+            out["roofline"]["note"] = (f"the step's {ws_bytes / 2**20:.0f} MiB fit the 256 MiB Infinity Cache: `frac` is against the 8 TB/s HBM peak by the contract of this "
+                                       "line, but the bytes come from the cache; the HBM-side figure is the 4096^2 leg")
         if b["update_bytes"] > 0:
             out["roofline"]["update_kernel_us"] = us_iter - apply_us
             out["roofline"]["update_kernel_GBs"] = b["update_bytes"] / (1e3 * (us_iter - apply_us))
     return out
+
+
+def launch_ranks(n_gpus):
+    """`bench.py --gpus N` without a launcher around it: the N ranks as children of this process, which has made no GPU call
+    (and never replaces itself: an exec from a process that has initialised the GPU takes these machines down)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: what RCCL needs on these hosts
+    env["SRPS_BENCH_SELF_LAUNCHED"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith("{"):
+            lines += 1
+        sys.stdout.write(line); sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks printed {lines} JSON lines, expected one (rank 0's)", file=sys.stderr)
+        rc = 1
+    return rc
 
 
 def main():
@@ -185,17 +230,23 @@ def main():
                     help="N > 1: the all-reduces of a pass as ncclAllReduce inside libsrps_hip.so (srps_execute_sharded; default) or as "
                          "torch.distributed.all_reduce on views of the library's exchange buffers")
     args = ap.parse_args()
+    assert args.gpus >= 1, "--gpus must be at least 1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     # Dry-run hook for a one-GPU box (tests/test_gpu_distributed.py::test_bench_two_ranks_on_one_gpu): all ranks share device 0 and
     # the process group is gloo, because RCCL refuses two ranks on one device.  Never set on a multi-GPU node.
     shared_gpu = os.environ.get("SRPS_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
+    elif torch.cuda.device_count() < world:                       # counting devices initialises nothing
+        sys.exit(f"bench.py: --gpus {world} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -292,6 +343,11 @@ def main():
                    "exclusive_device": ctx.get_option("exclusive_device"),       # 1: plain launches of the persistent kernels (the library's default is the cooperative launch: ~26 us per pass more)
                    "comm": {"none": "none (1 GPU)", "library": "ncclAllReduce inside libsrps_hip.so (srps_execute_sharded), communicator from srps_comm_init_rank",
                             "torch": "torch.distributed.all_reduce on views of the library's exchange buffers"}[comm_kind],
+                   # what the LIBRARY's communicator says of itself (ncclCommCount through srps_comm_info; 0: none bound) and who holds what
+                   "ncclCommCount": ctx.comm_info()[1] if comm_kind == "library" else 0,
+                   "partition": args.partition if world > 1 else "none",
+                   "images_per_rank": [pkg.shard_range(n_total, world, r)[1] - pkg.shard_range(n_total, world, r)[0] for r in range(world)],
+                   "launched_by": "bench.py itself (child torch.distributed.run)" if os.environ.get("SRPS_BENCH_SELF_LAUNCHED") == "1" else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
                    "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, "
                                    + ("depth CG partitioned into column strips (4-double all-reduce + edge-column exchange per step)" if ctx.get_option("cg_partition_active") else "replicated CG")
                                    + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},

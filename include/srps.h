@@ -65,6 +65,10 @@ const char* srps_version(void);
  * (Main.cpp:27-28, Preferences Utilities.h:224-230); they are accepted and advisory. */
 int srps_create(int device_id, int block_x, int block_y, srps_ctx** out);
 int srps_destroy(srps_ctx* ctx);
+/* The number of HIP devices this process sees (0 without a device; never an error for "no device").  The reference passes
+ * --device straight to cudaSetDevice (Main.cpp:29, SRPS.cu:88) and lets the runtime fail; a host that spreads a job over
+ * --gpus N devices asks first. */
+int srps_device_count(int* n);
 int srps_set_stream(srps_ctx* ctx, void* hip_stream);      /* NULL = the context's own stream */
 int srps_synchronize(srps_ctx* ctx);
 /* options: "albedo_mode" (SRPS_ALBEDO_*), "apply_mode" (SRPS_APPLY_*), "cg_max_iter", "march_strip" (0 = automatic,
@@ -79,12 +83,21 @@ int srps_synchronize(srps_ctx* ctx);
  * "assemble_from_sums" (0|1: depth right-hand side from image sums left by the albedo sweep; no second pass over I),
  * "albedo_one_sync" (0|1: persistent albedo CG with one grid-wide wait per step),
  * "albedo_channels_together" (0|1: persistent albedo CG of 3 channels on masks up to 1 M pixels: the channels share the grid-wide waits),
- * "cg_one_sync" (0|1: resident CG with one grid-wide wait per step),
+ * "cg_one_sync" (0|1, default 1: resident CG with one grid-wide wait per step, see DESIGN.md section 4.  A DELIBERATE DEPARTURE from
+ *  devicecalls.cu:274, where r1 is the direct dot product of the updated residual (cublasSdot): with 1 the kernel takes beta from a
+ *  PREDICTED r.r = r.r - 2 alpha r.w + alpha^2 w.w, whose three products are summed together with p.w before alpha is known
+ *  (kernels_resident.hip "one wait"; kernels_march.hip MODE 3 does the same for the streaming step); the prediction is re-anchored on a
+ *  direct sum every 16th step, whenever r.r has fallen to a quarter of the anchor, and whenever its terms cancel more than two digits.
+ *  Measured against 0 (two waits, the reference's direct dot in every step): depth RMSE 3e-7 ... 6e-6 on unit-scale depth, bounded
+ *  at 2e-5 by tests/test_gpu_edge_and_scale.py::test_one_wait_per_cg_step_equals_two and tests/test_gpu_full_size.py -- inside the
+ *  1e-4 of north_star, but not the reference's arithmetic: set 0 to have the reference's),
  * "cg_resident_tile" (0|2|16|32|256|512: tile shape of the resident CG; 0 = 256 x 16 tiles while the grid has few of them (512
  *  threads and 2 columns per thread for sf 1 and 2, up to 240 tiles; 256 threads and 4 columns per thread for sf 4, up to 96),
  *  else 256 x 32 tiles (512 threads, 4 columns per thread) wherever the device has a CU for each of them, else 256 x 64 (512
  *  threads, 8 columns per thread); 2 | 16 | 32 | 512 force one of these, 256 the 256 x 32 tiles with 256 threads),
  * "cg_resident_debug" (timing experiments only: wrong results),
+ * "debug_inject_abort" (test hook, 0..3: the pass's next look at the persistent kernels' abort flags finds bit 1 (depth CG) / bit 2
+ *  (albedo CG) set, as if another rank of a sharded job had reported an abort -- the pass's tail is then repeated by the streaming kernels),
  * "cg_resident_rect" (0|1: tiles wholly inside the mask run the resident CG's body without structure bits),
  * "cg_fused_step" (0|1: streaming depth CG with the whole step in one launch instead of operator + update kernel),
  * "exclusive_device" (0|1: the caller states that nothing else uses the device: plain instead of cooperative launches of the
@@ -320,7 +333,9 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n);
 int srps_array_size(srps_ctx* ctx, const char* name, size_t* n_floats);
 /* The device array itself. The call drops the partial sums cached between phases ("fuse_energy_lighting"); a caller
  * that keeps the pointer and writes through it later must call this again (or srps_set) before the next phase.  Asking for
- * "I" also ends the use of the 8-bit image store (option "image_store") until the images are set again. */
+ * "I" also ends the use of the 8-bit image store (option "image_store") until the images are set again.  Asking for "N" or "dz"
+ * ends the double-buffering of the normals ("fuse_normals" swaps two sets of arrays per pass): the pointer stays THE normals / dz of
+ * the context until the next srps_setup, which invalidates every pointer obtained here. */
 int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n_floats);
 int srps_last_cg_iterations(srps_ctx* ctx, int* depth_iters, int* albedo_iters /*[8]*/, int* lighting_iters_max);
 

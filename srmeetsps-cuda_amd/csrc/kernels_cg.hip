@@ -547,22 +547,33 @@ int cg_flush_x(srps_ctx* ctx) {
 
 // the residual of devicecalls.cu:758 (G.d_r: b -> b - A_ x) and the loop of devicecalls.cu:252-275: "while (r1 > tol^2 && k <= max_iter)" => up to max_iter+1 steps.
 // Convergence is tested on the device by every kernel; the host just enqueues the steps.
-int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
-    if (strips_active(ctx)) return strips_cg(ctx, max_steps, fixed_steps);      // this rank's columns only, RCCL between the steps
-    if (resident_supported(ctx)) {                 // residual and CG in one persistent launch
-        const int rc = resident_cg(ctx, max_steps, fixed_steps);
-        if (rc != SRPS_ERR_UNSUPPORTED) return rc;
-        ctx->cg_resident = 0;                      // the device refused the launch: stream from now on
-    }
-    // A persistent kernel of this pass (the albedo CG) has not been looked at yet: should it turn out to have given up, this
-    // solve ran on an albedo that was never finished and the pass's tail is repeated -- from the iterate this solve starts
-    // from, which the streaming kernels update in place.  Keep a copy (one plane: 0.3 % of the solve's traffic); the abort
-    // check makes it the current plane again (persistent_aborts).
+// A persistent kernel of this pass (the albedo CG) has not been looked at yet: should it turn out to have given up -- on this rank
+// or on another one, reported through the energy all-reduce --, the solve ran on an albedo that was never finished and the pass's
+// tail is repeated -- from the iterate this solve starts from, which the streaming kernels (and the strips) update in place.
+// Keep a copy (one plane: 0.3 % of the solve's traffic); the abort check makes it the current plane again (persistent_aborts).
+static int keep_start_plane(srps_ctx* ctx, bool fixed_steps) {
     if (ctx->persistent_inflight && !ctx->x_swapped && !fixed_steps) {
         Grid& G = ctx->grid;
         SRPS_HIP(hipMemcpyAsync(G.d_x2, G.d_x, G.plane * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         ctx->x_swapped = true;
     }
+    return SRPS_OK;
+}
+
+int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
+    // the strips update x in place like the streaming kernels below: the copy of the start plane comes first (round-3 advisor
+    // finding: with cg_partition = 1 an aborted albedo launch of the same pass found no plane to go back to and the repeat
+    // rebuilt normals and dz around the discarded solve's depth)
+    if (strips_active(ctx)) {
+        SRPS_TRY(keep_start_plane(ctx, fixed_steps));
+        return strips_cg(ctx, max_steps, fixed_steps);      // this rank's columns only, RCCL between the steps
+    }
+    if (resident_supported(ctx)) {                 // residual and CG in one persistent launch
+        const int rc = resident_cg(ctx, max_steps, fixed_steps);
+        if (rc != SRPS_ERR_UNSUPPORTED) return rc;
+        ctx->cg_resident = 0;                      // the device refused the launch: stream from now on
+    }
+    SRPS_TRY(keep_start_plane(ctx, fixed_steps));
     SRPS_TRY(grid_residual(ctx));                  // dc.cu:758
     ctx->cg_fixed = fixed_steps;                   // bench: never stop early (tol^2 := -1)
     for (int k = 1; k <= max_steps; ++k) {

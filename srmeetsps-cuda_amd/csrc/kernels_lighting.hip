@@ -610,7 +610,7 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
     EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part, nullptr, nullptr};
     // the channel-inner sweep (the one the pipeline runs for 1 and 3 channels) can leave the normals and dz of the new depth
     const bool ci = ctx->light_grouped && L.V == 4 && ctx->light_channel_inner && (C == 1 || C == 3);
-    const bool write_normals = ci && ctx->fuse_normals && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && ctx->Nrm2 != nullptr && n_local > 0;
+    const bool write_normals = ci && ctx->fuse_normals && !ctx->nd_ptr_out && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && ctx->Nrm2 != nullptr && n_local > 0;
     if (write_normals) { ea.N_out = ctx->Nrm2; ea.dz_out = ctx->dz2; }
     SRPS_TRY(light_partial_launch<true>(ctx, L, d_rho, nullptr, d_I, P, n_local, C, ea));
     SRPS_TRY(launch_final_sum(ctx->stream, G.d_misc_part, L.n_epart, d_out));

@@ -400,7 +400,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
     float lambda_v = a.lambda, inv_sf4_v = a.inv_sf4;
     asm volatile("" : "+v"(lambda_v), "+v"(inv_sf4_v));
 
-    // the plane sizes of the bench shapes stay far below the 4 GiB a descriptor can address
+    // num_records in bytes as an int: the host refuses planes of 2 GiB and more before the launch (resident_cg)
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
     unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
     float r1 = 0.f, r0 = 0.f, alpha = 0.f, r1_anchor = 0.f;
@@ -989,6 +989,9 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
     SRPS_TRY(ensure(ctx->ws_resident, need));
     SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));
+    // the kernel addresses the streamed g plane through a buffer descriptor whose num_records is an int of BYTES
+    SRPS_REQUIRE((unsigned long long)G.plane * sizeof(float) < (1ull << 31), SRPS_ERR_UNSUPPORTED,
+                 "resident CG: a plane of %zu floats does not fit the kernel's buffer descriptor (2 GiB)", (size_t)G.plane);
     ResidentArgs a;
     memset(&a, 0, sizeof(a));
     a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.x_out = G.d_x2; a.r = G.d_r;

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <dlfcn.h>
 #include "srps_internal.h"
 
@@ -40,24 +41,26 @@ typedef int (*roctx_push_t)(const char*);
 typedef int (*roctx_pop_t)(void);
 static roctx_push_t g_roctx_push = nullptr;
 static roctx_pop_t g_roctx_pop = nullptr;
+static bool g_roctx_ok = false;
+static std::once_flag g_roctx_once;
+// resolved once, whichever thread comes first (srps --gpus N runs one host thread per context; round-3 advisor finding: an
+// unsynchronised state flag let a second thread skip a push whose pop it then issued)
 static bool roctx_resolve() {
-    static int state = 0;      // 0 not tried, 1 found, -1 absent
-    if (state == 0) {
-        state = -1;
+    std::call_once(g_roctx_once, [] {
         for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
             void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
             if (!h) continue;
-            g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
-            g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
-            if (g_roctx_push && g_roctx_pop) { state = 1; break; }
+            roctx_push_t push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+            roctx_pop_t pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+            if (push && pop) { g_roctx_push = push; g_roctx_pop = pop; g_roctx_ok = true; break; }
         }
-    }
-    return state == 1;
+    });
+    return g_roctx_ok;
 }
 static const char* const kPhaseNames[SRPS_N_PHASES] = {"srps:lighting", "srps:albedo_sweep", "srps:albedo_solve", "srps:depth_assembly",
                                                        "srps:depth_solve", "srps:energy", "srps:normals"};
 PhaseSpan::PhaseSpan(srps_ctx* ctx, int ph) : c(ctx), phase(ph) {
-    if (c->roctx && roctx_resolve()) g_roctx_push(kPhaseNames[phase]);
+    if (c->roctx && roctx_resolve()) { g_roctx_push(kPhaseNames[phase]); pushed = true; }
     if (c->phase_timing) {
         if (!c->ev_created) {
             for (int i = 0; i < SRPS_N_PHASES; ++i) { (void)hipEventCreate(&c->ev_begin[i]); (void)hipEventCreate(&c->ev_end[i]); }
@@ -69,7 +72,7 @@ PhaseSpan::PhaseSpan(srps_ctx* ctx, int ph) : c(ctx), phase(ph) {
 }
 PhaseSpan::~PhaseSpan() {
     if (c->phase_timing && c->ev_created) { (void)hipEventRecord(c->ev_end[phase], c->stream); c->ev_mask |= 1u << phase; }
-    if (c->roctx && g_roctx_pop) g_roctx_pop();
+    if (pushed) g_roctx_pop();                        // only the range this span opened itself
 }
 
 template <typename T>
@@ -109,6 +112,7 @@ static void state_release(srps_ctx* c) {
     c->i8_state = 0;                       // I8 (its own allocation, made when the images turn out to be bytes) is kept for the next set-up
     c->s = c->rho = c->z = c->Nrm = c->Nrm2 = c->dz = c->dz2 = c->zx = c->zy = c->xx = c->yy = c->z0s = c->I = c->albedo_ex = c->q_ex = nullptr;      // carved out of state_arena
     c->normals_pending = false;
+    c->nd_ptr_out = false;                 // every pointer handed out is void with the arrays
     c->q_in_exchange = false; c->energy_ex = nullptr;      // energy_ex lives in the report record
     c->have_state = false;
 }
@@ -129,6 +133,18 @@ int grid_need_M(srps_ctx* ctx) {
 // bounding box, a compact->grid index map and one byte per pixel -- built on the device (kernels_structure.hip) on the context's
 // auxiliary stream.  after_release (may be null) runs first, once the old grid has been released and the arguments have been
 // checked: srps_setup starts its image uploads there, so that the DMA runs while the structure is built.
+// what the arrays carved out of the grid arena take together (build_grid), from the grid's dimensions, tile counts and plan
+static size_t grid_arena_bytes(const Grid& G) {
+    const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
+    const size_t pl = al256(G.plane * sizeof(float));
+    size_t need = 2 * al256((size_t)G.P * sizeof(int)) + al256((size_t)std::max(G.Ps, 1) * sizeof(int)) + al256(G.plane) + al256((size_t)G.Hl * G.Wl * sizeof(int) + 4);
+    for (int shape = 0; shape < 3; ++shape) need += al256((size_t)G.n_tiles[shape]) + al256((size_t)G.n_tiles[shape] * sizeof(int));
+    need += (3 + 3 + 9) * pl + 256;                       // q [3], g [3], x, x2, r, r2, p [2], w, w2, save
+    need += al256(128 * sizeof(float)) + al256(2 * 4 * (size_t)G.n_part4 * sizeof(float)) + al256(n_pw * sizeof(float)) +
+            al256(2 * (size_t)G.nb_update * sizeof(float)) + al256(4096 * sizeof(float));
+    return need;
+}
+
 static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, const std::function<int()>* after_release = nullptr) {
     Grid& G = ctx->grid;
     grid_release(G);
@@ -141,6 +157,30 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     // scratch first (growing it frees the old one, and hipFree waits for the device: not while the images are in flight)
     const size_t mask_bytes = al256(hw * sizeof(float));
     SRPS_TRY(ensure(ctx->ws_struct, mask_bytes + struct_scratch_bytes(h, w, sf) + 256));
+    // The grid arena's exact size is known only after the structure kernels have run -- while the images are in flight -- and growing
+    // it means hipFree, which waits for the device, i.e. for the whole DMA (round-3 advisor finding).  So an arena that exists and is
+    // smaller than what a FULL-frame mask of this h x w would need is replaced now, before the copies are queued; the exact size
+    // below can then only be smaller (a plan with more partial sums than the full frame's is the one exception and still grows it).
+    if (G.arena) {
+        Grid ub;
+        ub.h = h; ub.w = w; ub.sf = sf; ub.Hg = h; ub.Wg = w; ub.P = (int)hw; ub.Ps = (int)(hw / ((size_t)sf * sf));
+        ub.Hs = ((ub.Hg + 2 * PAD + 31) / 32) * 32; ub.Ws = ub.Wg + 512 + 2 * PAD; ub.plane = (size_t)ub.Hs * ub.Ws;
+        ub.Hl = h / sf; ub.Wl = w / sf;
+        if (ub.plane < ((size_t)1 << 31) - 8 * (size_t)ub.Hs) {
+            ub.used = (size_t)ub.Hs * (ub.Wg + 2 * PAD);
+            ub.nb_update = std::max(1, std::min(cdiv((long long)ub.used / 4, 256 * 4), 1024));
+            march_plan(ub, ctx->march_tj, ctx->num_cus);
+            ub.n_part4 = std::max(4096, march_blocks(ub) + 8);
+            for (int shape = 0; shape < 3; ++shape) ub.n_tiles[shape] = cdiv(ub.Hg, 256) * cdiv(ub.Wg, shape == 0 ? 32 : shape == 1 ? 64 : 16);
+            const size_t need_ub = grid_arena_bytes(ub);
+            if (G.arena_bytes < need_ub) {
+                SRPS_HIP(hipFree(G.arena));
+                G.arena = nullptr; G.arena_bytes = 0;
+                SRPS_HIP(hipMalloc(&G.arena, need_ub));
+                G.arena_bytes = need_ub;
+            }
+        }
+    }
     if (after_release) SRPS_TRY((*after_release)());
     float* d_mask = (float*)ctx->ws_struct.p;
     const StructScratch sc = struct_scratch((char*)ctx->ws_struct.p + mask_bytes, h, w, sf);
@@ -177,12 +217,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     const size_t n_pw = (size_t)std::max(4096, march_blocks(G) + 8);
     for (int shape = 0; shape < 3; ++shape) G.n_tiles[shape] = cdiv(G.Hg, 256) * cdiv(G.Wg, shape == 0 ? 32 : shape == 1 ? 64 : 16);
     // ---- one arena for every array of the grid ----
-    const size_t pl = al256(G.plane * sizeof(float));
-    size_t need = 2 * al256((size_t)G.P * sizeof(int)) + al256((size_t)std::max(G.Ps, 1) * sizeof(int)) + al256(G.plane) + al256((size_t)G.Hl * G.Wl * sizeof(int) + 4);
-    for (int shape = 0; shape < 3; ++shape) need += al256((size_t)G.n_tiles[shape]) + al256((size_t)G.n_tiles[shape] * sizeof(int));
-    need += (3 + 3 + 9) * pl + 256;                       // q [3], g [3], x, x2, r, r2, p [2], w, w2, save
-    need += al256(128 * sizeof(float)) + al256(2 * 4 * (size_t)G.n_part4 * sizeof(float)) + al256(n_pw * sizeof(float)) +
-            al256(2 * (size_t)G.nb_update * sizeof(float)) + al256(4096 * sizeof(float));
+    const size_t need = grid_arena_bytes(G);
     if (G.arena_bytes < need) {
         if (G.arena) SRPS_HIP(hipFree(G.arena));
         G.arena = nullptr; G.arena_bytes = 0;
@@ -266,7 +301,8 @@ static int report_fetch(srps_ctx* ctx) {
 static int persistent_aborts(srps_ctx* ctx, int* flags_out, int others = 0) {
     *flags_out = 0;
     const CgScalars* hs = (const CgScalars*)(ctx->h_pinned + 64);
-    const int flags = hs->abort_flags | others;
+    const int flags = hs->abort_flags | others | ctx->debug_inject_abort;
+    ctx->debug_inject_abort = 0;
     ctx->persistent_inflight = 0;
     const bool swapped = ctx->x_swapped;
     ctx->x_swapped = false;
@@ -325,6 +361,14 @@ extern "C" {
 const char* srps_last_error(void) { return g_err.c_str(); }
 const char* srps_version(void) { return "srps-hip 0.1 (gfx950)"; }
 
+int srps_device_count(int* n) {
+    SRPS_REQUIRE(n != nullptr, SRPS_ERR_INVALID, "device_count: n is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+    *n = ndev;
+    return SRPS_OK;
+}
+
 int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     SRPS_REQUIRE(out != nullptr, SRPS_ERR_INVALID, "srps_create: out is NULL");
     *out = nullptr;
@@ -344,19 +388,32 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
         c->num_cus = cus > 0 ? cus : 1;
         if (!coop) { c->albedo_persistent = 0; c->cg_resident = 0; }
     }
+    // every handle made so far is released by ONE helper on each failure path (round-3 advisor finding: aux / gather streams and
+    // the event used to leak)
+    auto fail = [c](hipError_t err, const char* what, int line) {
+        if (c->d_report) (void)hipFree(c->d_report);
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        if (c->aux_event) (void)hipEventDestroy(c->aux_event);
+        if (c->gather_stream) (void)hipStreamDestroy(c->gather_stream);
+        if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return hip_fail(err, what, __FILE__, line);
+    };
     hipError_t e = hipStreamCreate(&c->own_stream);
-    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    if (e != hipSuccess) return fail(e, "hipStreamCreate", __LINE__);
     c->stream = c->own_stream;
     e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->gather_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux_event, hipEventDisableTiming);
-    if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__); }
+    if (e != hipSuccess) return fail(e, "hipStreamCreateWithFlags", __LINE__);
+    e = hipEventCreateWithFlags(&c->aux_event, hipEventDisableTiming);
+    if (e != hipSuccess) return fail(e, "hipEventCreateWithFlags", __LINE__);
     e = hipHostMalloc((void**)&c->h_pinned, 256 * sizeof(float));
-    if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
+    if (e != hipSuccess) return fail(e, "hipHostMalloc", __LINE__);
     memset(c->h_pinned, 0, 256 * sizeof(float));
     e = hipMalloc((void**)&c->d_report, 256 * sizeof(float));
     if (e == hipSuccess) e = hipMemset(c->d_report, 0, 256 * sizeof(float));
-    if (e != hipSuccess) { (void)hipHostFree(c->h_pinned); (void)hipStreamDestroy(c->own_stream); delete c; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    if (e != hipSuccess) return fail(e, "hipMalloc", __LINE__);
     if (device_id < 64) g_live_contexts[device_id].fetch_add(1);
     if (const char* e = getenv("SRPS_ROCTX")) c->roctx = atoi(e) != 0;
     *out = c;
@@ -458,6 +515,10 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->cg_resident_rect = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident_debug")) {
         ctx->cg_resident_debug = value;
+    } else if (!strcmp(name, "debug_inject_abort")) {
+        // test hook: the next look at the abort flags finds these bits (1 depth, 2 albedo) as if ANOTHER rank had reported them
+        SRPS_REQUIRE(value >= 0 && value <= 3, SRPS_ERR_INVALID, "debug_inject_abort: 0..3, got %d", value);
+        ctx->debug_inject_abort = value;
     } else if (!strcmp(name, "light_blocks")) {
         SRPS_REQUIRE(value >= 0 && value <= 2016, SRPS_ERR_INVALID, "light_blocks: 0 (automatic) .. 2016, got %d", value);
         ctx->light_blocks = value;
@@ -1276,9 +1337,41 @@ static int sharded_depth_partial_overlapped(srps_ctx* ctx) {
 }
 
 // SRPS.cu:272-335 on a context that holds a shard of the images and an RCCL communicator
+// Do the ranks' image ranges [img_offset, img_offset + N_local) tile [0, N_total) -- every image on exactly one rank?  Two ranks that
+// both hold all images would silently double s, num and q (round-3 advisor finding).  Every rank marks its images with 1 in a
+// vector of N_total floats, the vectors are all-reduced, and every entry must come back as exactly 1; the first entry that does not
+// names the image.  One tiny collective per solve, before the first pass.
+__global__ void k_mark_images(float* __restrict__ cover, int n_total, int lo, int n_local) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += gridDim.x * blockDim.x) cover[i] = (i >= lo && i < lo + n_local) ? 1.f : 0.f;
+}
+static int sharded_ranges_tile(srps_ctx* ctx) {
+    const int n = ctx->N_total;
+    SRPS_TRY(ensure(ctx->ws_misc, (size_t)n * sizeof(float)));
+    float* cover = (float*)ctx->ws_misc.p;
+    hipLaunchKernelGGL(k_mark_images, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, cover, n, ctx->img_offset, ctx->N_local);
+    SRPS_LAUNCH_CHECK();
+    SRPS_TRY(comm_all_reduce_sum(ctx, cover, (size_t)n));
+    std::vector<float> h((size_t)n);
+    SRPS_HIP(hipMemcpyAsync(h.data(), cover, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i)
+        SRPS_REQUIRE(h[i] == 1.f, SRPS_ERR_INVALID,
+                     "execute_sharded: image %d of %d is held by %d ranks (this rank %d of %d holds [%d, %d)): the ranks' image ranges must tile the image set",
+                     i, n, (int)h[i], ctx->comm_rank, ctx->comm_world, ctx->img_offset, ctx->img_offset + ctx->N_local);
+    return SRPS_OK;
+}
+
 int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(comm_bound(ctx), SRPS_ERR_STATE, "execute_sharded: no communicator bound to the context (srps_comm_init_rank / srps_comm_init_all / srps_set_comm)");
+    SRPS_TRY(sharded_ranges_tile(ctx));
+    if (ctx->comm != nullptr && ctx->comm_world > 1) {
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true) && !getenv("SRPS_QUIET"))
+            fprintf(stderr, "srps: note: the RCCL paths with more than one rank (all-reduce of s / num / q, strip exchange, srps --gpus N) were developed on "
+                            "one-GPU boxes; tests/test_multi_gpu.py exercises them wherever two devices exist -- run it on this node before relying on them "
+                            "(SRPS_QUIET=1 silences this note)\n");
+    }
     const float TOLERANCE = 5e-3f;         // SRPS.cu:85
     const int MAX_ITERATIONS = 10;         // SRPS.cu:86
     float last_error = NAN;                // SRPS.cu:273
@@ -1382,6 +1475,10 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
         // the caller may write the images through the pointer at any later time: the byte copy cannot follow that
         ctx->i8_state = 2;
     }
+    // "N" / "dz": with fuse_normals the energy sweep stores the next normals into a SECOND set of arrays and srps_normals swaps the
+    // sets -- a pointer handed out would point at the non-current set from the next pass on (round-3 advisor finding).  From here on
+    // this context keeps ONE set (the normals kernel writes it in place, as before round 3) until the next srps_setup.
+    if (p == ctx->Nrm || p == ctx->dz) ctx->nd_ptr_out = true;
     ctx->light_cache_valid = false;      // the caller may write through the pointer
     ctx->depth_assembled = false;
     ctx->normals_pending = false;

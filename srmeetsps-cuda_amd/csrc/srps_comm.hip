@@ -241,6 +241,14 @@ int srps_comm_release(srps_ctx* ctx) {
 int srps_comm_info(srps_ctx* ctx, int* rank, int* world) {
     SRPS_REQUIRE(ctx != nullptr, SRPS_ERR_INVALID, "comm_info: null context");
     const bool any = ctx->comm != nullptr || ctx->host_allreduce != nullptr;
+    if (ctx->comm != nullptr) {
+        // what the communicator says about itself (ncclCommCount / ncclCommUserRank), not what the context was told
+        int cw = 0, cr = -1;
+        SRPS_RCCL(g_rccl.CommCount((ncclComm_t)ctx->comm, &cw));
+        SRPS_RCCL(g_rccl.CommUserRank((ncclComm_t)ctx->comm, &cr));
+        SRPS_REQUIRE(cw == ctx->comm_world && cr == ctx->comm_rank, SRPS_ERR_STATE,
+                     "comm_info: the communicator is rank %d of %d, the context holds %d of %d", cr, cw, ctx->comm_rank, ctx->comm_world);
+    }
     if (rank) *rank = any ? ctx->comm_rank : 0;
     if (world) *world = any ? ctx->comm_world : 0;      // 0: no communicator bound
     return SRPS_OK;

@@ -153,6 +153,7 @@ struct srps_ctx {
     float *zx = nullptr, *zy = nullptr, *xx = nullptr, *yy = nullptr, *z0s = nullptr, *I = nullptr;
     float *Nrm2 = nullptr, *dz2 = nullptr;   // the fused energy + lighting sweep writes the normals and dz of the new depth here (the old ones stay current
                                      // until srps_normals, which swaps the two sets)
+    bool nd_ptr_out = false;         // srps_get_device_ptr("N" | "dz") has handed out a pointer: no swapping of the two sets until the next set-up
     int fuse_normals = 1;            // option: that sweep also stores the normals and dz of the new depth (no k_normals launch per pass)
     bool normals_pending = false;    // Nrm2 / dz2 hold the normals and dz of the current depth, left by the sweep
     float* albedo_ex = nullptr;      // [2][C][P]  num, den
@@ -208,6 +209,7 @@ struct srps_ctx {
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
+    int debug_inject_abort = 0;      // test hook: ABORT_* bits the next persistent_aborts finds, as reported by another rank
     int cg_resident_tile = 0;        // 0: the smallest tile shape that fits the device, 256 | 512: threads per block of the forced shape
     int cg_resident_rect = 1;        // tiles inside the mask take the body without structure bits (0: every tile the general body)
     int albedo_channels_together = 1;   // persistent albedo CG, 3 channels, small masks: the channels share the grid-wide waits
@@ -244,6 +246,7 @@ namespace srps {
 struct PhaseSpan {
     srps_ctx* c;
     int phase;
+    bool pushed = false;
     PhaseSpan(srps_ctx* ctx, int ph);
     ~PhaseSpan();
 };

@@ -4,7 +4,7 @@
 //
 // Every rank holds the whole grid (planes, structure, the assembled g_c and q: 1 GB at 4096 x 4096 -- nothing on a 288 GB device)
 // and OWNS the bounding-box columns [c0, c1), cut at multiples of sf so that no sf x sf block of KT straddles two ranks
-// (srmeetsps-cuda_amd/strips.py: strip_ranges; tests/test_strip_partition.py asserts on the assembled matrix that a row of A_ at
+// (tests/_strip_protocol.py: strip_ranges; tests/test_strip_partition.py asserts on the assembled matrix that a row of A_ at
 // an owned pixel references nothing further away than ONE column).  The marching kernel runs on a VIEW of the grid -- the
 // planes' base pointers moved by c0 columns, width c1 - c0 -- so its halo columns are the neighbours' edge columns.  Per step:
 //
@@ -28,7 +28,7 @@ namespace srps {
 namespace {
 
 struct Range { int c0, w; };
-// strips.py: strip_ranges -- multiples of sf, sizes differ by at most one block column
+// tests/_strip_protocol.py: strip_ranges -- multiples of sf, sizes differ by at most one block column
 Range strip_range(int Wg, int sf, int world, int rank) {
     const int blocks = Wg / sf, base = blocks / world, rem = blocks % world;
     const int b = rank * base + std::min(rank, rem), e = b + base + (rank < rem ? 1 : 0);

@@ -1,6 +1,7 @@
 // Main.cpp -- command line of the reference (Main.cpp:9-44): --dstype|-t, --dsloc|-d, --device|-g,
 // --blockx|-x, --blocky|-y, --help|-h|--usage; plus --outdir|-o and --no-output for the result dumps, --images, --exclusive,
-// --gpus|-n N (images sharded over N devices of this node, RCCL inside the library) and --sharded.
+// --gpus|-n N (images sharded over N devices of this node, RCCL inside the library), --partition images|strips (strips: the depth CG
+// is also cut into column strips over the N devices, library option "cg_partition") and --sharded.
 #include <algorithm>
 #include <cstring>
 #include <iostream>
@@ -21,13 +22,16 @@ static void print_message() {
                  "\t--images\n\t\twrite the reference's three views (normals initial/current, albedo) and the depth map as PNG\n"
                  "\t--exclusive\n\t\tnothing else uses the device: plain instead of cooperative launches of the persistent kernels\n"
                  "\t-n, --gpus (value:1)\n\t\tshard the images over this many devices of the node, starting at --device (RCCL all-reduce of the partial sums)\n"
+                 "\t--partition (value:images)\n\t\twith --gpus N: images = shard the images, every device runs the whole depth CG; strips = the depth CG is also\n"
+                 "\t\tpartitioned into column strips over the devices (4-double all-reduce + edge-column exchange per CG step)\n"
                  "\t--sharded\n\t\ttake the communicator path even with one GPU (diagnostic)\n";
 }
 
 int main(int argc, char* argv[]) {
     static const std::map<std::string, std::string> alias = {{"h", "help"}, {"usage", "help"}, {"t", "dstype"}, {"d", "dsloc"}, {"g", "device"},
                                                             {"x", "blockx"}, {"y", "blocky"}, {"o", "outdir"}, {"n", "gpus"}};
-    std::map<std::string, std::string> opt = {{"dstype", "matlab"}, {"device", "0"}, {"blockx", "256"}, {"blocky", "4"}, {"outdir", "."}, {"gpus", "1"}};   // Main.cpp:11-16
+    std::map<std::string, std::string> opt = {{"dstype", "matlab"}, {"device", "0"}, {"blockx", "256"}, {"blocky", "4"}, {"outdir", "."}, {"gpus", "1"},
+                                               {"partition", "images"}};   // Main.cpp:11-16
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a.rfind("--", 0) == 0) a = a.substr(2); else if (a.rfind("-", 0) == 0) a = a.substr(1); else continue;
@@ -46,24 +50,54 @@ int main(int argc, char* argv[]) {
         print_message();
         return 0;
     }
-    Preferences::blockX = std::stoi(opt["blockx"]);                 // Main.cpp:27-29
-    Preferences::blockY = std::stoi(opt["blocky"]);
-    Preferences::deviceId = std::stoi(opt["device"]);
+    // every number of the command line is parsed where a bad one ends in the usage text and exit code 1, not in std::terminate
+    // (round-3 advisor finding: --gpus x)
+    auto number = [&](const char* key) {
+        const std::string& v = opt[key];
+        size_t used = 0;
+        int n = 0;
+        try { n = std::stoi(v, &used); } catch (const std::exception&) { used = 0; }
+        if (used == 0 || used != v.size()) throw std::invalid_argument(std::string("--") + key + ": '" + v + "' is not a number");
+        return n;
+    };
+    try {
+        Preferences::blockX = number("blockx");                     // Main.cpp:27-29
+        Preferences::blockY = number("blocky");
+        Preferences::deviceId = number("device");
+        Preferences::numGpus = number("gpus");
+        if (Preferences::numGpus < 1) throw std::invalid_argument("--gpus: at least 1");
+        if (opt["partition"] != "images" && opt["partition"] != "strips") throw std::invalid_argument("--partition: images or strips, got '" + opt["partition"] + "'");
+        Preferences::partitionStrips = opt["partition"] == "strips";
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << std::endl;
+        print_message();
+        return 1;
+    }
     Preferences::outDir = opt["outdir"];
     Preferences::writeOutputs = !opt.count("no-output");
     Preferences::writeImages = opt.count("images") > 0;
     Preferences::exclusiveDevice = opt.count("exclusive") > 0;
-    Preferences::numGpus = std::max(1, std::stoi(opt["gpus"]));
     Preferences::forceSharded = opt.count("sharded") > 0;
+    // the devices the job names must exist -- asked after the data set has loaded (a bad path fails without touching a device) and
+    // before any context is made
+    auto check_devices = [] {
+        int ndev = 0;
+        srps_check(srps_device_count(&ndev));
+        if (Preferences::deviceId < 0 || Preferences::deviceId + Preferences::numGpus > ndev)
+            throw std::invalid_argument("--device " + std::to_string(Preferences::deviceId) + " --gpus " + std::to_string(Preferences::numGpus) + ": this node shows " +
+                                        std::to_string(ndev) + " HIP device(s)");
+    };
     try {
         if (opt["dstype"] == "matlab") {                            // Main.cpp:31-36
             MatFileDataHandler dh;
             dh.loadDataFromMatFiles(opt["dsloc"].c_str());
+            check_devices();
             SRPS srps(dh);
             srps.execute();
         } else if (opt["dstype"] == "images") {                     // Main.cpp:37-42
             ImageDataHandler dh;
             dh.loadDataFromImages(opt["dsloc"].c_str());
+            check_devices();
             SRPS srps(dh);
             srps.execute();
         }

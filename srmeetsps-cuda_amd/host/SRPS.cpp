@@ -135,11 +135,13 @@ void SRPS::execute_sharded(const std::vector<float>& zs, const std::vector<float
     for (int r = 0; r < n_gpus; ++r) {
         srps_check(srps_create(Preferences::deviceId + r, Preferences::blockX, Preferences::blockY, &shard_ctx[r]));
         srps_check(srps_set_option(shard_ctx[r], "exclusive_device", Preferences::exclusiveDevice ? 1 : 0));
+        if (Preferences::partitionStrips) srps_check(srps_set_option(shard_ctx[r], "cg_partition", 1));      // --partition strips
     }
     ctx = shard_ctx[0];
     srps_check(srps_comm_init_all(shard_ctx.data(), n_gpus));                  // ncclCommInitAll over the job's devices
-    printf("Images sharded over %d GPU%s (devices %d..%d), RCCL all-reduce of the partial sums\n", n_gpus, n_gpus > 1 ? "s" : "",
-           Preferences::deviceId, Preferences::deviceId + n_gpus - 1);
+    printf("Images sharded over %d GPU%s (devices %d..%d), RCCL all-reduce of the partial sums%s\n", n_gpus, n_gpus > 1 ? "s" : "",
+           Preferences::deviceId, Preferences::deviceId + n_gpus - 1,
+           Preferences::partitionStrips ? (n_gpus > 1 ? "; depth CG partitioned into column strips" : "; --partition strips has no effect on one device") : "");
     const size_t per_image = (size_t)dh->I_c * dh->I_h * dh->I_w;
     std::vector<int> imask;
     if (Preferences::writeImages)

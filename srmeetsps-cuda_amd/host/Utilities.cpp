@@ -16,6 +16,7 @@ bool Preferences::writeImages = false;
 bool Preferences::exclusiveDevice = false;
 int Preferences::numGpus = 1;
 bool Preferences::forceSharded = false;
+bool Preferences::partitionStrips = false;
 std::string Preferences::outDir = ".";
 
 void DataHandler::freeMemory() {

@@ -27,6 +27,7 @@ struct Preferences {
     static int numGpus;           // new: --gpus N: the images are sharded over devices deviceId .. deviceId + N - 1 of this node (one
                                   // thread and one context per device, RCCL all-reduces inside the library); the seam is the reference's
                                   // cudaSetDevice(Preferences::deviceId), SRPS.cu:88
+    static bool partitionStrips;  // new: --partition strips: with --gpus N the depth CG is also cut into column strips over the devices (srps option "cg_partition")
     static bool forceSharded;     // new: --sharded: take the communicator path even on one GPU (a one-rank communicator; diagnostic)
     static std::string outDir;
 

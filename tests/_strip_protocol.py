@@ -1,4 +1,5 @@
-"""Strip-partitioned depth CG over several GPUs: host-side protocol (design for grids from 4096 x 4096 up, where the
+"""TEST INFRASTRUCTURE (moved out of the package in round 4: nothing in the product imports it -- the product's strip CG is
+csrc/srps_strips.hip).  Strip-partitioned depth CG over several GPUs: host-side protocol (design for grids from 4096 x 4096 up, where the
 replicated CG of the image-sharded mode is what bounds the pass).
 
 The reference's CG (devicecalls.cu:229-279) on A_ = KT'KT + lambda A'A is kept step for step; what is partitioned is the
@@ -23,6 +24,8 @@ device copies between several contexts of one process (srps_strip_group_solve), 
 the caller brings (srps_set_strip_transport): here torch.distributed, which lets two PROCESSES on one GPU run the strips over gloo.
 """
 from __future__ import annotations
+
+import importlib
 
 import numpy as np
 
@@ -117,7 +120,7 @@ class HostedTransport:
     def __init__(self, ctx, dist, device: str = "cuda:0"):
         import ctypes as C
         import torch
-        from . import _lib
+        _lib = importlib.import_module("srmeetsps-cuda_amd._lib")
         self.ctx, self.dist, self.torch, self.device = ctx, dist, torch, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.errors = []
@@ -182,7 +185,7 @@ class HostedTransport:
         _lib.check(ctx.lib.srps_set_strip_transport(ctx.h, self.rank, self.world, *self._fns, None))
 
     def remove(self):
-        from . import _lib
+        _lib = importlib.import_module("srmeetsps-cuda_amd._lib")
         _lib.check(self.ctx.lib.srps_set_strip_transport(self.ctx.h, 0, 1, _lib.STRIP_ALLREDUCE_FN(), _lib.STRIP_EXCHANGE_FN(), _lib.STRIP_ALLGATHER_FN(), None))
 
 
@@ -192,7 +195,7 @@ class HostedCollectives:
 
     def __init__(self, ctx, dist, device: str = "cuda:0"):
         import torch
-        from . import _lib
+        _lib = importlib.import_module("srmeetsps-cuda_amd._lib")
         self.ctx, self.errors = ctx, []
 
         def view(ptr, n, typestr):
@@ -230,5 +233,5 @@ class HostedCollectives:
         _lib.check(ctx.lib.srps_set_host_collectives(ctx.h, dist.get_rank(), dist.get_world_size(), *self._fns, None))
 
     def remove(self):
-        from . import _lib
+        _lib = importlib.import_module("srmeetsps-cuda_amd._lib")
         _lib.check(self.ctx.lib.srps_set_host_collectives(self.ctx.h, 0, 1, _lib.HOST_ALLREDUCE_FN(), _lib.HOST_BROADCAST_FN(), None))

@@ -1,0 +1,39 @@
+"""bench.py's own launcher for N > 1, as far as a box without a GPU can check it: started bare with
+--gpus 2 the parent must start the ranks as children (torch.distributed.run) WITHOUT importing torch itself -- a process that has
+initialised the GPU must never start or replace another -- and hand their exit code on.  The ranks themselves fail here (no GPU)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parent_starts_children_and_relays_their_failure(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    probe = tmp_path / "probe.py"
+    # run bench.main() in-process with subprocess.Popen replaced by a recorder: which command, and was torch imported before it?
+    probe.write_text(
+        "import sys, json, subprocess, runpy\n"
+        "rec = {}\n"
+        "class P:\n"
+        "    def __init__(self, cmd, **kw):\n"
+        "        rec['cmd'] = cmd; rec['torch_imported'] = 'torch' in sys.modules; rec['env_flag'] = kw['env'].get('SRPS_BENCH_SELF_LAUNCHED')\n"
+        "        self.stdout = iter(['{\"metric\": \"x\"}\\n'])\n"
+        "    def wait(self): return 7\n"
+        "subprocess.Popen = P\n"
+        f"sys.argv = [{str(os.path.join(ROOT, 'bench.py'))!r}, '--gpus', '2', '--steps', '3']\n"
+        "try:\n"
+        f"    runpy.run_path({str(os.path.join(ROOT, 'bench.py'))!r}, run_name='__main__')\n"
+        "except SystemExit as e:\n"
+        "    rec['exit'] = e.code\n"
+        "print('REC' + json.dumps(rec))\n")
+    out = subprocess.run([sys.executable, str(probe)], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("REC")][0][3:])
+    assert rec["torch_imported"] is False
+    assert rec["exit"] == 7 and rec["env_flag"] == "1"
+    cmd = rec["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert '{"metric": "x"}' in out.stdout                         # the ranks' line is relayed

@@ -209,7 +209,7 @@ def _hosted_sharded_worker(rank, world, port, h, w, sf, n_img, kind, seed, overl
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module("srmeetsps-cuda_amd")
-    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
     lo, hi = pkg.shard_range(n_img, world, rank)
     sc = pkg.synth.make_scene(h, w, sf, n_img, seed=seed, mask_kind=kind, img_begin=lo, img_end=hi)
     ctx = pkg.Context(device_id=0)
@@ -252,3 +252,51 @@ def test_sharded_loop_inside_the_library_over_two_and_three_processes(pkg, tmp_p
     np.testing.assert_allclose(r[0]["en"], e1, rtol=5e-4)
     assert d_z < 3e-5 and np.abs(r[0]["rho"].reshape(one.rho().shape) - one.rho()).max() < 5e-4
     ctx.close()
+
+
+def test_image_ranges_that_do_not_tile_the_image_set_are_refused(pkg):
+    """srps_execute_sharded checks, with one small all-reduce before its first pass, that every image is held by exactly one rank
+    (round-3 advisor finding: two ranks holding all images used to double s, num and q silently).  One rank, one-rank
+    communicator, a context that holds images [0, 3) of 5: images 3 and 4 are on no rank."""
+    sc = pkg.synth.make_scene(48, 40, 2, 5, seed=19, mask_kind="ragged", img_begin=0, img_end=3)
+    ctx = pkg.Context(device_id=0)
+    pkg.Context.comm_init_all([ctx])
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    with pytest.raises(Exception) as ei:
+        ctx.execute_sharded(1)
+    assert "image 3 of 5 is held by 0 ranks" in str(ei.value)
+    ctx.close()
+    # the whole set on the one rank is fine
+    sc = pkg.synth.make_scene(48, 40, 2, 5, seed=19, mask_kind="ragged")
+    ctx = pkg.Context(device_id=0)
+    pkg.Context.comm_init_all([ctx])
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    assert len(ctx.execute_sharded(1)) == 1
+    ctx.close()
+
+
+def test_device_pointers_to_normals_stay_current(pkg):
+    """srps_get_device_ptr("N" | "dz") hands out THE arrays: from then on the context stops double-buffering the normals
+    (option fuse_normals swaps two sets per pass), so a zero-copy view keeps showing the current pass's normals (round-3 advisor
+    finding: it showed the previous pass's)"""
+    import torch
+    from importlib import import_module
+    api = import_module("srmeetsps-cuda_amd.api")
+    sc = pkg.synth.make_scene(64, 48, 2, 4, seed=23, mask_kind="ellipse")
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    pkg.alternating_loop(ctx, None, max_outer=1)
+    ptr, n = ctx.device_ptr("N")
+    view = torch.as_tensor(api._DevView(ptr, n), device="cuda:0")
+    for _ in range(3):
+        pkg.alternating_loop(ctx, None, max_outer=1)
+        ctx.synchronize()
+        assert ctx.device_ptr("N")[0] == ptr
+        np.testing.assert_array_equal(view.cpu().numpy(), ctx.get("N"))
+    ctx.close()
+    # and the results are those of a context that was never asked
+    a = pkg.Context(device_id=0); a.setup(pkg.DataHandler.from_scene(sc)); ea = pkg.alternating_loop(a, None, max_outer=3)
+    b = pkg.Context(device_id=0); b.setup(pkg.DataHandler.from_scene(sc)); b.device_ptr("dz"); eb = pkg.alternating_loop(b, None, max_outer=3)
+    assert ea == eb
+    np.testing.assert_array_equal(a.get("z"), b.get("z")); np.testing.assert_array_equal(a.get("N"), b.get("N"))
+    a.close(); b.close()

@@ -115,6 +115,38 @@ def test_bench_two_ranks_on_one_gpu():
     assert two["total_solve_outer_iterations"] == ref["total_solve_outer_iterations"]
 
 
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (WORLD_SIZE unset: the form the driver's N = 1 command line takes
+    with another N): the parent starts the two ranks as children before it touches the GPU, relays rank 0's one line and exits
+    with the children's code.  Dry run on one GPU over gloo, like the test above; the line must be the one torch.distributed.run
+    around bench.py produces."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--size", "256", "--sf", "2", "--no-cpu-baseline", "--images", "3"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True,
+                         timeout=800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    two = json.loads(lines[0])
+    cfg = two["config"]
+    assert two["n_gpus"] == 2 and cfg["images_total"] == 6 and cfg["images_per_rank"] == [3, 3] and cfg["partition"] == "images"
+    assert cfg["launched_by"].startswith("bench.py itself") and "ncclCommCount" in cfg and two["value"] > 0
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env,
+                              capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    ref = json.loads([ln for ln in launched.stdout.splitlines() if ln.startswith("{")][0])
+    assert two["energies"] == ref["energies"]                     # the same job either way, bit for bit
+    # a launcher that started another number of ranks than --gpus says is an error with a message, not a traceback
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert bad.returncode != 0 and "--gpus 2 but the launcher started 1" in bad.stderr
+
+
 @pytest.mark.parametrize("bytes_store", [False, True])
 def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg, bytes_store):
     """srps_albedo_partial on a context that holds a shard of the images: den = sum_i (N . s_i)^2 does not involve the images, so it

@@ -126,7 +126,7 @@ def _hosted_worker(rank, world, port, h, w, sf, kind, seed, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module("srmeetsps-cuda_amd")
-    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
     sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
     ctx = pkg.Context(device_id=0)
     ctx.set_option("cg_resident", 0)
@@ -168,3 +168,63 @@ def test_strips_over_two_processes_and_the_callers_transport(pkg, tmp_path, h, w
     assert int(r[0]["it"]) == it1
     assert rmse(r[0]["z"], z1) < 2e-5
     assert abs(float(r[0]["e"]) - e1) <= 1e-3 * abs(e1)
+
+
+def _abort_worker(rank, world, port, inject, out_dir):
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
+    sc = pkg.synth.make_scene(128, 96, 2, 3, seed=91, mask_kind="ellipse")
+    ctx = pkg.Context(device_id=0)
+    ctx.set_option("cg_resident", 0)
+    ctx.set_option("cg_partition", 1)
+    ctx.set_option("albedo_persistent", 1 if inject else 0)
+    tr = strips.HostedTransport(ctx, dist)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    out = {}
+    for it in range(2):                                   # the second pass starts from a depth that differs from the first solve's start
+        ctx.lighting(); ctx.albedo()
+        if inject and it == 1:
+            assert ctx.get_option("albedo_persistent") == 1
+            ctx.set_option("debug_inject_abort", 2)        # "another rank's persistent albedo CG gave up": found at the pass's one wait
+        out[f"e{it}"] = ctx.depth()
+        ctx.normals()
+        out[f"z{it}"] = ctx.get("z"); out[f"rho{it}"] = ctx.get("rho")
+    out["fb"] = ctx.get_option("persistent_fallbacks")
+    assert not tr.errors, tr.errors
+    np.savez(os.path.join(out_dir, f"inj{inject}_rank{rank}.npz"), **out)
+    dist.barrier()
+    tr.remove()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_albedo_abort_with_strips_repeats_from_the_pass_start_plane(pkg, tmp_path):
+    """round-3 advisor finding: with cg_partition = 1 the strips update x in place, and an albedo abort found at the end of the pass
+    (here injected, as if reported by another rank) must repeat the solve from the iterate the pass STARTED with -- the copy of
+    that plane is now made before the strips run.  Two processes over gloo; the repeated pass must equal a pass that never used the
+    persistent albedo kernel (the albedo CG converges to the same fixed point from the aborted launch's values: 1e-6), where the
+    defect restarted the CG from the discarded solve's depth (1e-3 apart on this scene)."""
+    import socket
+    import torch.multiprocessing as mp
+    for inject in (0, 1):
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        mp.spawn(_abort_worker, args=(2, port, inject, str(tmp_path)), nprocs=2, join=True)
+    ref = np.load(tmp_path / "inj0_rank0.npz"); got = [np.load(tmp_path / f"inj1_rank{q}.npz") for q in range(2)]
+    assert int(got[0]["fb"]) == 1 and int(ref["fb"]) == 0
+    np.testing.assert_array_equal(got[0]["z1"], got[1]["z1"])                  # the ranks stay replicas
+    d_first = rmse(got[0]["z0"], ref["z0"]); d = rmse(got[0]["z1"], ref["z1"]); moved = rmse(ref["z1"], ref["z0"])
+    print(f"strips + injected albedo abort: pass 1 depth RMSE vs never-persistent {d:.3e} (pass 0: {d_first:.3e}; the pass moved the depth by {moved:.3e})")
+    assert d < 2e-6 and d < 0.05 * moved
+    assert np.abs(got[0]["rho1"] - ref["rho1"]).max() < 1e-5
+    assert abs(float(got[0]["e1"]) - float(ref["e1"])) <= 1e-5 * abs(float(ref["e1"]))

@@ -215,6 +215,14 @@ def test_cli_help_and_errors(host, pkg):
     assert out.returncode == 0 and "Usage" in out.stdout
     out = subprocess.run([cli, "-d", "/nonexistent.mat"], capture_output=True, text=True)
     assert out.returncode == 1 and "Failed opening MAT file" in out.stderr
+    # round 4: a --gpus / --device / --partition value that is no number (or no partition) ends in a message + usage + exit code 1
+    out = subprocess.run([cli, "--gpus", "x", "-d", "/nonexistent.mat"], capture_output=True, text=True)
+    assert out.returncode == 1 and "--gpus: 'x' is not a number" in out.stderr and "Usage" in out.stdout
+    out = subprocess.run([cli, "--gpus=", "-d", "/nonexistent.mat"], capture_output=True, text=True)
+    assert out.returncode == 1 and "is not a number" in out.stderr
+    out = subprocess.run([cli, "--partition", "rows", "-d", "/nonexistent.mat"], capture_output=True, text=True)
+    assert out.returncode == 1 and "--partition: images or strips" in out.stderr
+    assert "--partition" in subprocess.run([cli, "--help"], capture_output=True, text=True).stdout
     # round 3: the multi-GPU switches are part of the command line; a bad data set fails before any device is touched
     out = subprocess.run([cli, "--help"], capture_output=True, text=True)
     assert "--gpus" in out.stdout and "--sharded" in out.stdout

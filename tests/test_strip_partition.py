@@ -1,4 +1,4 @@
-"""The strip-partitioned depth CG (srmeetsps-cuda_amd/strips.py) under gloo, world sizes 2 and 3, on CPU: the protocol --
+"""The strip-partitioned depth CG (tests/_strip_protocol.py) under gloo, world sizes 2 and 3, on CPU: the protocol --
 column strips cut at multiples of sf, one-column halo of p per step, the step's dot products as all-reduces -- driven with an
 engine built from the oracle's ASSEMBLED system (A_ = KT'KT + A'A and the right-hand side of devicecalls.cu:734-745), against
 the oracle's serial CG.  Also the structural claim the design rests on: a row of A_ at an owned pixel references no column
@@ -98,7 +98,7 @@ def _worker(rank, world, port, kind, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
     synth = importlib.import_module("srmeetsps-cuda_amd.synth")
     import srps_oracle as O
     from test_strip_partition import StripEngine, _system
@@ -114,7 +114,7 @@ def _worker(rank, world, port, kind, out_dir):
 
 
 def test_strip_ranges(pkg):
-    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
     for n, sf, world in ((4096, 2, 8), (36, 2, 3), (2048, 4, 5), (8, 4, 2)):
         r = strips.strip_ranges(n, sf, world)
         assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
@@ -149,7 +149,7 @@ def test_partitions_of_the_library_equal_the_python_ones():
     pieces tile the whole range in order, strips are cut at multiples of sf, sizes differ by at most one block / one image"""
     import ctypes as C
     pkg = importlib.import_module("srmeetsps-cuda_amd")
-    strips = importlib.import_module("srmeetsps-cuda_amd.strips")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
     lib = pkg.load()
     a, b = C.c_int(0), C.c_int(0)
     for sf in (1, 2, 3, 4):
