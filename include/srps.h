@@ -96,6 +96,8 @@ int srps_synchronize(srps_ctx* ctx);
  *  else 256 x 32 tiles (512 threads, 4 columns per thread) wherever the device has a CU for each of them, else 256 x 64 (512
  *  threads, 8 columns per thread); 2 | 16 | 32 | 512 force one of these, 256 the 256 x 32 tiles with 256 threads),
  * "cg_resident_debug" (timing experiments only: wrong results),
+ * "shard_range_check" (0|1, default 1: srps_execute_sharded all-reduces an image-coverage vector before its first pass and refuses image
+ *  ranges that overlap or leave an image out; 0: the caller vouches for the partition -- kernel tests that run ONE shard alone),
  * "debug_inject_abort" (test hook, 0..3: the pass's next look at the persistent kernels' abort flags finds bit 1 (depth CG) / bit 2
  *  (albedo CG) set, as if another rank of a sharded job had reported an abort -- the pass's tail is then repeated by the streaming kernels),
  * "cg_resident_rect" (0|1: tiles wholly inside the mask run the resident CG's body without structure bits),

@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libsrps_hip.so")
+# SRPS_LIB_PATH: another build of the same library (development aid: same-box A/B of variants under srmeetsps-cuda_amd/variants/)
+LIB_PATH = os.environ.get("SRPS_LIB_PATH") or os.path.join(_HERE, "libsrps_hip.so")
 HEADER = os.path.join(ROOT, "include", "srps.h")
 
 SRPS_OK = 0

@@ -537,6 +537,38 @@ __device__ __forceinline__ Vec<2> ldv<2>(const float* __restrict__ p) {
     r.v[0] = t.x; r.v[1] = t.y;
     return r;
 }
+// V consecutive compact pixels onto a grid plane through the compact -> grid map: the V grid indices of a lane are consecutive and
+// 16-byte aligned wherever the lane's pixels lie in one column segment (everywhere in a full-frame mask, nearly everywhere in
+// any other) -- then ONE 16-byte store; else V scalar stores.  (One dword store per pixel makes every store instruction of a
+// wave write 64 x 4 bytes with a 16-byte stride: a quarter of the bytes per request.)
+template <int V>
+struct GridIdx {
+    int go[V];
+    bool vec;
+};
+template <int V>
+__device__ __forceinline__ GridIdx<V> grid_idx(const int* __restrict__ gofp, int q) {
+    GridIdx<V> r;
+    if constexpr (V == 4) {
+        const int4 t = *reinterpret_cast<const int4*>(gofp + q);
+        r.go[0] = t.x; r.go[1] = t.y; r.go[2] = t.z; r.go[3] = t.w;
+        r.vec = ((t.x & 3) == 0) && (t.y == t.x + 1) && (t.z == t.x + 2) && (t.w == t.x + 3);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) r.go[e] = gofp[q + e];
+        r.vec = false;
+    }
+    return r;
+}
+template <int V>
+__device__ __forceinline__ void scatter_store(float* __restrict__ plane, const GridIdx<V>& gi, const float (&val)[V]) {
+    if constexpr (V == 4) {
+        if (gi.vec) { *reinterpret_cast<float4*>(plane + gi.go[0]) = make_float4(val[0], val[1], val[2], val[3]); return; }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) plane[gi.go[e]] = val[e];
+}
+
 // Four image samples kept as bytes (the 8-bit image store, srps_api.hip: image_store_prepare): the float the reference's
 // loader forms from a byte is k / 255.f (Utilities.cpp:343).  The division is replaced by k R_hi + k R_lo with R_hi + R_lo =
 // 1/255 to 48 bits, the second product rounded, the sum formed by one fused multiply-add: the correctly rounded quotient for
@@ -556,13 +588,47 @@ __device__ __forceinline__ Vec<4> ld_img8(const unsigned char* __restrict__ p) {
     return r;
 }
 // the image samples of one (image, channel) row at pixel q: floats, or bytes when the context holds the 8-bit store
+// Cache policy of the streams (round 4).  tools/hbm_ceiling_bench.hip on the same box: a grid-stride float4 read reaches 5.3 - 6.4 TB/s
+// with the default policy and 6.5 - 7.15 with NON-TEMPORAL loads (`global_load_dwordx4 ... nt`: the lines are not kept in the L2 /
+// Infinity Cache, which a stream larger than the caches only thrashes); a copy 4.2 - 5.7 against 6.5 - 7.1.  The images (1 GB per
+// sweep at the metric's configuration, every byte read once per sweep) are such a stream: SRPS_NT_IMAGES.  Planes that one kernel
+// writes for the next (num, den, the image sums; N and dz of the next pass) are stored non-temporally under SRPS_NT_STORES.
+#ifndef SRPS_NT_IMAGES
+#define SRPS_NT_IMAGES 1
+#endif
+#ifndef SRPS_NT_STORES
+#define SRPS_NT_STORES 0
+#endif
+#ifndef SRPS_NT_NORMALS
+#define SRPS_NT_NORMALS 1
+#endif
+typedef float srps_vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Vec<4> ldv4_nt(const float* __restrict__ p) {
+    const srps_vf4 t = __builtin_nontemporal_load(reinterpret_cast<const srps_vf4*>(p));
+    Vec<4> r;
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    return r;
+}
+// a load of image samples (read once per sweep, never again before the caches have turned over)
+template <int V>
+__device__ __forceinline__ Vec<V> ldv_stream(const float* __restrict__ p) {
+    if constexpr (V == 4 && SRPS_NT_IMAGES) return ldv4_nt(p);
+    else return ldv<V>(p);
+}
 template <int V, bool U8>
 __device__ __forceinline__ Vec<V> ld_img(const float* __restrict__ I, const unsigned char* __restrict__ I8, size_t row, int P, int q) {
     if constexpr (U8) {
         static_assert(V == 4, "the 8-bit image store is read four pixels at a time");
-        return ld_img8(I8 + row * (size_t)P + q);
+        if constexpr (SRPS_NT_IMAGES) {
+            const unsigned w = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(I8 + row * (size_t)P + q));
+            Vec<4> r;
+            r.v[0] = unit_from_byte((float)(w & 0xffu)); r.v[1] = unit_from_byte((float)((w >> 8) & 0xffu));
+            r.v[2] = unit_from_byte((float)((w >> 16) & 0xffu)); r.v[3] = unit_from_byte((float)(w >> 24));
+            return r;
+        } else
+            return ld_img8(I8 + row * (size_t)P + q);
     } else {
-        return ldv<V>(I + row * (size_t)P + q);
+        return ldv_stream<V>(I + row * (size_t)P + q);
     }
 }
 template <int V>
@@ -572,6 +638,16 @@ __device__ __forceinline__ void stv<1>(float* __restrict__ p, const Vec<1>& a) {
 template <>
 __device__ __forceinline__ void stv<4>(float* __restrict__ p, const Vec<4>& a) {
     *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+// a store of a plane that the writing kernel does not read again.  Same-box A/B at 2048 x 2048, 20 images (gpurun_out/r04b): the normals
+// and dz the lighting sweep leaves for the next pass stored non-temporally: 0.284 -> 0.267 ms for that sweep (NT = SRPS_NT_NORMALS);
+// num / den / the image sums of the albedo sweep, which the next two kernels read back at once: 0.234 -> 0.253 ms (SRPS_NT_STORES, off).
+template <int V, bool NT = SRPS_NT_STORES>
+__device__ __forceinline__ void stv_stream(float* __restrict__ p, const Vec<V>& a) {
+    if constexpr (V == 4 && NT) {
+        srps_vf4 t; t.x = a.v[0]; t.y = a.v[1]; t.z = a.v[2]; t.w = a.v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<srps_vf4*>(p));
+    } else stv<V>(p, a);
 }
 
 }  // namespace srps

@@ -80,12 +80,12 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
                 }
             }
         }
-        stv<V>(num + (size_t)c * P + q, nu);
-        stv<V>(den + (size_t)c * P + q, de);
+        stv_stream<V>(num + (size_t)c * P + q, nu);
+        stv_stream<V>(den + (size_t)c * P + q, de);
         if (SUMS) {
-            stv<V>(ssum + ((size_t)c * 3 + 0) * P + q, sa);
-            stv<V>(ssum + ((size_t)c * 3 + 1) * P + q, sap);
-            stv<V>(ssum + ((size_t)c * 3 + 2) * P + q, sb);
+            stv_stream<V>(ssum + ((size_t)c * 3 + 0) * P + q, sa);
+            stv_stream<V>(ssum + ((size_t)c * 3 + 1) * P + q, sap);
+            stv_stream<V>(ssum + ((size_t)c * 3 + 2) * P + q, sb);
         }
     }
 }
@@ -106,9 +106,7 @@ __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
-    int go[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) go[e] = gofp[q + e];
+    const GridIdx<V> gi = grid_idx<V>(gofp, q);
     float qq[3][V];
 #pragma unroll
     for (int e = 0; e < V; ++e) qq[0][e] = qq[1][e] = qq[2][e] = 0.f;
@@ -138,9 +136,10 @@ __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ 
             if (de.v[e] > 0.f) vr.v[e] = nu.v[e] / de.v[e];                      // k_albedo_closed: pixels with a zero denominator keep their value
         stv<V>(rho + (size_t)c * P + q, vr);
         const float ca = qc[c * 4 + 0], cap = qc[c * 4 + 1], cb = qc[c * 4 + 2];
-        float g[V];
+        float g[V], g2[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) { g[e] = vr.v[e] / vdz.v[e]; Gp[(size_t)c * plane + go[e]] = g[e] * g[e]; }
+        for (int e = 0; e < V; ++e) { g[e] = vr.v[e] / vdz.v[e]; g2[e] = g[e] * g[e]; }
+        scatter_store<V>(Gp + (size_t)c * plane, gi, g2);
 #pragma unroll
         for (int e = 0; e < V; ++e) {                                            // k_depth_from_sums: the same expressions
             const float t0 = fmaf(-vxx.v[e], sb.v[e], sa.v[e]), t1 = fmaf(-vyy.v[e], sb.v[e], sap.v[e]), t2 = -sb.v[e];
@@ -151,9 +150,7 @@ __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ 
         }
     }
 #pragma unroll
-    for (int e = 0; e < V; ++e)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) Q[(size_t)t * plane + go[e]] = qq[t][e];
+    for (int t = 0; t < 3; ++t) scatter_store<V>(Q + (size_t)t * plane, gi, qq[t]);
 }
 int albedo_fused(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_img, int C, float* d_rho, const float* d_qc,
                  const float* d_xx, const float* d_yy, const float* d_dz, float fx, float fy) {

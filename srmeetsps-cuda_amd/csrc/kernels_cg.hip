@@ -14,21 +14,44 @@ namespace srps {
 // ---------------------------------------------------------------------------------------------
 // layout conversion
 // ---------------------------------------------------------------------------------------------
+// four consecutive compact pixels per thread: one 16-byte access on the grid side wherever they lie in one column segment
+// (device_utils.h grid_idx), which is nearly everywhere
+template <int V>
 __global__ void k_scatter(const float* __restrict__ compact, const int* __restrict__ gofp, int P, float* __restrict__ plane) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) plane[gofp[p]] = compact[p];
+    for (int p = (blockIdx.x * blockDim.x + threadIdx.x) * V; p < P; p += gridDim.x * blockDim.x * V) {
+        const GridIdx<V> gi = grid_idx<V>(gofp, p);
+        const Vec<V> v = ldv<V>(compact + p);
+        scatter_store<V>(plane, gi, v.v);
+    }
 }
+template <int V>
 __global__ void k_gather(const float* __restrict__ plane, const int* __restrict__ gofp, int P, float* __restrict__ compact) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) compact[p] = plane[gofp[p]];
+    for (int p = (blockIdx.x * blockDim.x + threadIdx.x) * V; p < P; p += gridDim.x * blockDim.x * V) {
+        const GridIdx<V> gi = grid_idx<V>(gofp, p);
+        Vec<V> v;
+        if (V == 4 && gi.vec) v = ldv<V>(plane + gi.go[0]);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v.v[e] = plane[gi.go[e]];
+        }
+        stv<V>(compact + p, v);
+    }
 }
 int grid_scatter(srps_ctx* ctx, const float* d_compact, float* d_plane) {
     Grid& G = ctx->grid;
-    hipLaunchKernelGGL(k_scatter, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_compact, G.d_gofp, G.P, d_plane);
+    if (G.P % 4 == 0 && (uintptr_t)d_compact % 16 == 0)
+        hipLaunchKernelGGL(k_scatter<4>, dim3(std::min(cdiv(G.P, 1024), 4096)), dim3(256), 0, ctx->stream, d_compact, G.d_gofp, G.P, d_plane);
+    else
+        hipLaunchKernelGGL(k_scatter<1>, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_compact, G.d_gofp, G.P, d_plane);
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
 }
 int grid_gather(srps_ctx* ctx, const float* d_plane, float* d_compact) {
     Grid& G = ctx->grid;
-    hipLaunchKernelGGL(k_gather, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_plane, G.d_gofp, G.P, d_compact);
+    if (G.P % 4 == 0 && (uintptr_t)d_compact % 16 == 0)
+        hipLaunchKernelGGL(k_gather<4>, dim3(std::min(cdiv(G.P, 1024), 4096)), dim3(256), 0, ctx->stream, d_plane, G.d_gofp, G.P, d_compact);
+    else
+        hipLaunchKernelGGL(k_gather<1>, dim3(std::min(cdiv(G.P, 256), 4096)), dim3(256), 0, ctx->stream, d_plane, G.d_gofp, G.P, d_compact);
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
 }

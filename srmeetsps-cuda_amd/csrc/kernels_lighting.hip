@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_light_partial(const float* __restrict__
                 // batch re-read the last image (cache hits) and their sums are simply not stored.
                 Vec<V> iv[IB];
 #pragma unroll
-                for (int ii = 0; ii < IB; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(b0 + ii, n_img - 1) * C + c) * P + q);
+                for (int ii = 0; ii < IB; ++ii) iv[ii] = ldv_stream<V>(I + ((size_t)min(b0 + ii, n_img - 1) * C + c) * P + q);
 #pragma unroll
                 for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_light_grouped(const float* __restrict__
                     for (int e = 0; e < V; ++e) a[k][e] = r.v[e] * nk[k].v[e];       // dc.cu:381
                 Vec<V> iv[IBW];                                      // images past the end re-read the last one
 #pragma unroll
-                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
+                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv_stream<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
 #pragma unroll
                 for (int ii = 0; ii < IBW; ++ii)
 #pragma unroll
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
                     T[2].v[e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
                 }
                 if (ea.N_out && grp == 0 && b0 == 0) {                       // block-uniform: one of the four image groups, its first round
-                    stv<V>(ea.N_out + q, nk[0]); stv<V>(ea.N_out + (size_t)P + q, nk[1]); stv<V>(ea.N_out + 2 * (size_t)P + q, nk[2]);
-                    stv<V>(ea.dz_out + q, vnrm);
+                    stv_stream<V, SRPS_NT_NORMALS>(ea.N_out + q, nk[0]); stv_stream<V, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, nk[1]); stv_stream<V, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, nk[2]);
+                    stv_stream<V, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
                 }
             }
 #pragma unroll
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
                 }
                 Vec<V> iv[IBW];                                      // images past the end re-read the last one
 #pragma unroll
-                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
+                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv_stream<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
 #pragma unroll
                 for (int ii = 0; ii < IBW; ++ii)
 #pragma unroll
@@ -423,6 +423,182 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
     if (tid == 0) ea.part_e[blockIdx.x] = t;
 }
 
+// Round 4: the same sweep with the geometry read ONCE per pixel.  The four image groups of a pixel range are the four WAVES of one
+// block instead of four blocks: per tile of 1024 pixels the block's 256 threads load the six geometry planes and the albedo (16 B per
+// lane), form the normal of the new depth once per pixel (perspective_normal: k_normals' instruction sequence), the channel-
+// independent factors of the residual and rho_c / dz, and leave them in LDS (6 + 2 NCH planes of 4 KiB); then wave g walks the
+// tile's four 256-pixel pieces for ITS images: 12 ds_read_b128 and NCH * IBW image loads of 16 B per lane and piece.  HBM traffic =
+// the algorithmic bytes (k_light_fused_ci fetched the geometry once per image group: 1.41 x the algorithmic bytes by the round-1
+// counters, and formed every normal four times).  Same expressions per pixel as k_light_fused_ci; the sums run over other
+// pixel subsets per lane, so results agree to rounding, not to the bit.
+template <int IBW, int NCH, bool TAIL>
+__global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, int P, int n_img,
+                                                            int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
+                                                            EnergyArgs ea) {
+    constexpr int C = NCH, TP = 1024, NQ = 3 + 4 * NCH;     // LDS planes: nk0 nk1 nk2 | rho_c | E0_c E1_c E2_c (the residual's factors of s0, s1, s2)
+    __shared__ float4 geo[NQ][TP / 4];
+    __shared__ float4 svs[4][NCH * IBW];                  // the lighting vectors of every wave's images: read as LDS broadcasts (the kernel also
+                                                           // stores, so the compiler would fetch them with a vector load per use)
+    __shared__ float sme[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x;
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
+    for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
+        const int ib = b0 + grp * IBW;                     // first image of this wave (may be past the end: nothing stored)
+        const int gram_c = (b0 == 0 && grp < NCH) ? grp : -1;      // the channel whose Gram matrix this wave accumulates
+        const bool active = ib < n_img || gram_c >= 0;     // wave-uniform
+        if (lane < NCH * IBW) {                            // (c, ii) = (lane / IBW, lane % IBW); images past the end: zeros, never used
+            const int c = lane / IBW, ii = lane - c * IBW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ib + ii < n_img) v = *reinterpret_cast<const float4*>(ea.s + ((size_t)(ea.img_offset + ib + ii) * C + c) * 4);
+            svs[grp][lane] = v;                            // visible after the first barrier of the tile loop
+        }
+        float acc[NCH][IBW][4];
+        float g[10];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c][ii][k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) g[t] = 0.f;
+        for (int t0 = p0; t0 < p1; t0 += TP) {
+            __syncthreads();                               // the previous tile has been read by every wave
+            {
+                const int q = t0 + tid * 4;
+                auto put = [&](int plane, const Vec<4>& v) { geo[plane][tid] = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); };
+                if (q < p1) {
+                    const Vec<4> vdz = ldv<4>(ea.dz + q), vxx = ldv<4>(ea.xx + q), vyy = ldv<4>(ea.yy + q);
+                    const Vec<4> vz = ldv<4>(ea.z + q), vzx = ldv<4>(ea.zx + q), vzy = ldv<4>(ea.zy + q);
+                    Vec<4> vnrm, n0, n1, n2;
+                    float T[3][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float nrm;
+                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], n0.v[e], n1.v[e], n2.v[e], nrm);
+                        vnrm.v[e] = nrm;
+                        T[0][e] = ea.fx * vzx.v[e];
+                        T[1][e] = ea.fy * vzy.v[e];
+                        T[2][e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                    }
+                    put(0, n0); put(1, n1); put(2, n2);
+                    if (ea.N_out && b0 == 0) {             // block-uniform: the first round of images
+                        stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + q, n0); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, n1); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, n2);
+                        stv_stream<4, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const Vec<4> r = ldv<4>(rho + (size_t)c * P + q);
+                        Vec<4> E0, E1, E2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float vg = r.v[e] / vdz.v[e];
+                            E0.v[e] = vg * T[0][e];
+                            E1.v[e] = vg * T[1][e];
+                            E2.v[e] = -vg * T[2][e];
+                        }
+                        put(3 + c, r); put(3 + NCH + 3 * c, E0); put(3 + NCH + 3 * c + 1, E1); put(3 + NCH + 3 * c + 2, E2);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) geo[k][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            __syncthreads();
+            if (!active) continue;
+#pragma unroll 1
+            for (int sub = 0; sub < 4; ++sub) {
+                const int li = sub * 64 + lane;
+                const int q = t0 + li * 4;
+                if (__builtin_amdgcn_readfirstlane(t0 + sub * 256) >= p1) break;      // wave-uniform: the tile's tail
+                const bool valid = q < p1;
+                const int ql = valid ? q : p1 - 4;
+                const bool ragged = __builtin_amdgcn_readfirstlane(t0 + sub * 256 + 256) > p1;      // wave-uniform: the range's last, partial piece
+                float4 nkq[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nkq[k] = geo[k][li];
+                const float (*nk)[4] = reinterpret_cast<const float (*)[4]>(nkq);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    Vec<4> ivc[IBW];                                   // images past the end re-read the last one
+#pragma unroll
+                    for (int ii = 0; ii < IBW; ++ii) ivc[ii] = ldv_stream<4>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + ql);
+                    const float4 rq = geo[3 + c][li];
+                    const float r[4] = {rq.x, rq.y, rq.z, rq.w};
+                    float a[4][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[0][e] = r[e] * nk[0][e]; a[1][e] = r[e] * nk[1][e]; a[2][e] = r[e] * nk[2][e];       // dc.cu:381
+                        a[3][e] = r[e] * 1.f;
+                    }
+                    if (ragged) {                                      // lanes past the range: rho, E and I are all zero there
+#pragma unroll
+                        for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) ivc[ii].v[e] = valid ? ivc[ii].v[e] : 0.f;
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[c][ii][k] = fmaf(a[k][e], ivc[ii].v[e], acc[c][ii][k]);
+                    float4 Eq[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) Eq[k] = geo[3 + NCH + 3 * c + k][li];
+                    const float (*E)[4] = reinterpret_cast<const float (*)[4]>(Eq);
+#pragma unroll
+                    for (int ii = 0; ii < IBW; ++ii) {
+                        if (!TAIL || ib + ii < n_img) {                          // wave-uniform; without TAIL every wave's images exist
+                            const float4 sv = svs[grp][c * IBW + ii];
+                            const float s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float res = fmaf(E[0][e], s0, fmaf(E[1][e], s1, fmaf(E[2][e], s2, fmaf(r[e], s3, -ivc[ii].v[e]))));
+                                e_acc = fmaf(res, res, e_acc);
+                            }
+                        }
+                    }
+                    if (c == gram_c) {                                           // wave-uniform
+                        int t = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int l = k; l < 4; ++l) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                                ++t;
+                            }
+                    }
+                }
+            }
+        }
+        // every wave holds the sums of ITS images: no cross-wave step
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = wave_sum(acc[c][ii][k]);
+                    if (lane == 0 && ib + ii < n_img) part_atb[(((size_t)blk * n_img + ib + ii) * C + c) * 4 + k] = v;
+                }
+        if (gram_c >= 0) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float v = wave_sum(g[t]);
+                if (lane == 0) part_g[((size_t)blk * C + gram_c) * 10 + t] = v;
+            }
+        }
+    }
+    const float t = block_sum(e_acc, sme);
+    if (tid == 0) ea.part_e[blk] = t;
+}
+
 // one wave per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
 // The 64 lanes add the per-block partial sums (fixed order, double), lane 0 runs the 4x4 CG.
 __global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
@@ -487,6 +663,7 @@ __global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ pa
 }
 
 struct LightPlan {
+    bool tiled = false;        // k_light_fused_tile: the four image groups of a pixel range are the waves of one block
     int V, IB, chunk, nblk;
     int n_epart;               // energy partial sums the fused sweep leaves (one per launched block)
     float *part_atb, *part_g;
@@ -508,6 +685,29 @@ static int fused_ci_blocks_per_cu(int ibw, int C) {
     }
     return v;
 }
+// images per wave of the tiled sweep: at most 5 (register budget); a count that divides the images into whole rounds of four waves
+// is preferred (no wave then ever holds an image that does not exist: the kernel without the per-image guards)
+static int tile_images_per_wave(int n_local) {
+    const int n = std::max(n_local, 1);
+    if (n <= 20) return std::min(5, cdiv(n, 4));
+    for (int cand : {5, 4, 3}) if (n % (4 * cand) == 0) return cand;
+    return 5;
+}
+static int fused_tile_blocks_per_cu(int ibw, int C) {
+    static int cache[6][4] = {};
+    int& v = cache[ibw][C];
+    if (v == 0) {
+        const void* fn = nullptr;
+#define SRPS_LT_PTR(BB, CC) fn = (const void*)k_light_fused_tile<BB, CC, true>
+        if (C == 3) { switch (ibw) { case 1: SRPS_LT_PTR(1, 3); break; case 2: SRPS_LT_PTR(2, 3); break; case 3: SRPS_LT_PTR(3, 3); break; case 4: SRPS_LT_PTR(4, 3); break; default: SRPS_LT_PTR(5, 3); } }
+        else { switch (ibw) { case 1: SRPS_LT_PTR(1, 1); break; case 2: SRPS_LT_PTR(2, 1); break; case 3: SRPS_LT_PTR(3, 1); break; case 4: SRPS_LT_PTR(4, 1); break; default: SRPS_LT_PTR(5, 1); } }
+#undef SRPS_LT_PTR
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        v = std::min(nb, 8);
+    }
+    return v;
+}
 static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightPlan& L, bool fused = false) {
     // images per register batch: the block re-reads rho and N once per batch, so one batch is best
     L.IB = 4;
@@ -515,7 +715,13 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     // the fused sweep holds 7 more planes per pixel: 2 pixels per thread keep it at 2 waves per SIMD
     // (334 us against 504 us at 2048^2, 20 images); alone the lighting sweep is faster with 4 (250 / 268 us)
     L.V = vec ? ((fused && !ctx->light_grouped) ? 2 : 4) : 1;
-    if (ctx->light_grouped && L.V == 4) {
+    L.tiled = fused && vec && ctx->light_grouped && ctx->light_channel_inner && ctx->light_tiled && (C == 1 || C == 3);
+    if (L.tiled) {
+        // one round of blocks, each a range of whole 1024-pixel tiles (k_light_fused_tile); one energy partial per block
+        const int per_cu = fused_tile_blocks_per_cu(tile_images_per_wave(n_local), C);
+        const int target = std::max(1, std::min(ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * per_cu, 2048));
+        L.chunk = std::max(1024, cdiv(cdiv(P, target), 1024) * 1024);
+    } else if (ctx->light_grouped && L.V == 4) {
         // one round of blocks: the sweep keeps 3 (fused, 135 registers) or 5 (96 registers) blocks per CU resident; with
         // 1024 blocks the last third of the kernel ran at a third of the occupancy
         // (the channel-inner fused kernel needs ~250 registers: 2 blocks per CU; 768 blocks were 1.5 rounds, the last half of
@@ -532,7 +738,7 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
         L.chunk = std::max(256 * L.V, cdiv(chunk, 256 * L.V) * 256 * L.V);
     }
     L.nblk = cdiv(P, L.chunk);
-    L.n_epart = (ctx->light_grouped && L.V == 4) ? cdiv(L.nblk, 8) * 32 : L.nblk;
+    L.n_epart = L.tiled ? L.nblk : (ctx->light_grouped && L.V == 4) ? cdiv(L.nblk, 8) * 32 : L.nblk;
     SRPS_REQUIRE(L.n_epart <= 2048, SRPS_ERR_UNSUPPORTED, "lighting sweep: %d energy partial sums do not fit their buffer", L.n_epart);
     const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4, n_g = (size_t)L.nblk * C * 10;
     SRPS_TRY(ensure(ctx->ws_light, (n_atb + n_g) * sizeof(float) + 64));
@@ -544,6 +750,17 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
 template <bool ENERGY>
 static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* d_rho, const float* d_N, const float* d_I,
                                 int P, int n_local, int C, const EnergyArgs& ea) {
+    if (ENERGY && L.tiled) {
+        const int ibw = tile_images_per_wave(n_local);
+        // (TAIL = false, the kernel without the per-image guards, is not used: hipcc 7.2 then hoists every load and LDS read of a piece
+        // to its top and spills 330 bytes; the guards are wave-uniform branches on a scalar compare)
+#define SRPS_LT(BB, CC) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, P, n_local, L.chunk, L.part_atb, L.part_g, ea)
+        if (C == 3) { switch (ibw) { case 1: SRPS_LT(1, 3); break; case 2: SRPS_LT(2, 3); break; case 3: SRPS_LT(3, 3); break; case 4: SRPS_LT(4, 3); break; default: SRPS_LT(5, 3); } }
+        else { switch (ibw) { case 1: SRPS_LT(1, 1); break; case 2: SRPS_LT(2, 1); break; case 3: SRPS_LT(3, 1); break; case 4: SRPS_LT(4, 1); break; default: SRPS_LT(5, 1); } }
+#undef SRPS_LT
+        SRPS_LAUNCH_CHECK();
+        return SRPS_OK;
+    }
     if (ctx->light_grouped && L.V == 4) {
         const int ibw = std::min(5, cdiv(n_local, 4));
         const int nb4 = cdiv(L.nblk, 8) * 8 * 4;            // four image groups per pixel range, ranges in sets of 8 (one per XCD)
@@ -578,7 +795,7 @@ int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, co
     const bool cached = use_cache && ctx->light_cache_valid && ctx->light_cache_normals;
     ctx->light_cache_valid = false;
     if (cached) {
-        L = LightPlan{ctx->light_cache_V, 0, 0, ctx->light_cache_nblk, 0, nullptr, nullptr, nullptr};
+        L = LightPlan{false, ctx->light_cache_V, 0, 0, ctx->light_cache_nblk, 0, nullptr, nullptr, nullptr};
         const size_t n_atb = (size_t)L.nblk * std::max(n_local, 1) * C * 4;
         L.part_atb = (float*)ctx->ws_light.p;
         L.part_g = L.part_atb + n_atb;

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
     if (q >= P) return;
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
+    const GridIdx<V> gi = grid_idx<V>(gofp, q);
     float m[6][V], qq[3][V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -246,8 +247,10 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < V; ++e) g[e] = vr.v[e] / vdz.v[e];
         if (Gp) {                                                            // g_c^2 for the tensor-recompute operator
+            float g2[V];
 #pragma unroll
-            for (int e = 0; e < V; ++e) Gp[(size_t)c * plane + gofp[q + e]] = g[e] * g[e];
+            for (int e = 0; e < V; ++e) g2[e] = g[e] * g[e];
+            scatter_store<V>(Gp + (size_t)c * plane, gi, g2);
         }
         // M needs the lighting of ALL images (no image data): skipped when the operator rebuilds it
         if (M) {
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
         for (int li = 0; li < n_local; ++li) {
             const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
-            const Vec<V> iv = ldv<V>(I + ((size_t)li * C + c) * P + q);
+            const Vec<V> iv = ldv_stream<V>(I + ((size_t)li * C + c) * P + q);
             const float fs0 = fx * s0, fs1 = fy * s1;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -288,18 +291,18 @@ __global__ __launch_bounds__(256) void k_depth_assemble(const float* __restrict_
             }
         }
     }
+    if (M) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-        const int go = gofp[q + e];
-        if (M) {
+        for (int t = 0; t < 6; ++t) scatter_store<V>(M + (size_t)t * plane, gi, m[t]);
+    }
 #pragma unroll
-            for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
-        }
+    for (int t = 0; t < 3; ++t) {
+        if (Qc) {                                              // sharded: compact [3][P] exchange buffer (scattered after the all-reduce)
+            Vec<V> o;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (Qc) Qc[(size_t)t * P + q + e] = qq[t][e];      // sharded: compact [3][P] exchange buffer (scattered after the all-reduce)
-            else Q[(size_t)t * plane + go] = qq[t][e];
-        }
+            for (int e = 0; e < V; ++e) o.v[e] = qq[t][e];
+            stv<V>(Qc + (size_t)t * P + q, o);
+        } else scatter_store<V>(Q + (size_t)t * plane, gi, qq[t]);
     }
 }
 
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict
     const int q = ((blockIdx.x + blk0) * 256 + threadIdx.x) * V;
     if (q >= P) return;
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
+    const GridIdx<V> gi = grid_idx<V>(gofp, q);
     float m[6][V], qq[3][V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -333,8 +337,10 @@ __global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict
 #pragma unroll
         for (int e = 0; e < V; ++e) g[e] = vr.v[e] / vdz.v[e];
         if (Gp) {                                                            // g_c^2 for the tensor-recompute operator
+            float g2[V];
 #pragma unroll
-            for (int e = 0; e < V; ++e) Gp[(size_t)c * plane + gofp[q + e]] = g[e] * g[e];
+            for (int e = 0; e < V; ++e) g2[e] = g[e] * g[e];
+            scatter_store<V>(Gp + (size_t)c * plane, gi, g2);
         }
         if (M) {                                                             // stored tensor (no image data), as in k_depth_assemble
             for (int i = 0; i < n_total; ++i) {
@@ -364,18 +370,18 @@ __global__ __launch_bounds__(256) void k_depth_from_sums(const float* __restrict
             qq[2][e] = fmaf(g[e], fmaf(-vr.v[e], u2, t2), qq[2][e]);
         }
     }
+    if (M) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-        const int go = gofp[q + e];
-        if (M) {
+        for (int t = 0; t < 6; ++t) scatter_store<V>(M + (size_t)t * plane, gi, m[t]);
+    }
 #pragma unroll
-            for (int t = 0; t < 6; ++t) M[(size_t)t * plane + go] = m[t][e];
-        }
+    for (int t = 0; t < 3; ++t) {
+        if (Qc) {                                              // sharded: compact [3][P] exchange buffer (scattered after the all-reduce)
+            Vec<V> o;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (Qc) Qc[(size_t)t * P + q + e] = qq[t][e];      // sharded: compact [3][P] exchange buffer (scattered after the all-reduce)
-            else Q[(size_t)t * plane + go] = qq[t][e];
-        }
+            for (int e = 0; e < V; ++e) o.v[e] = qq[t][e];
+            stv<V>(Qc + (size_t)t * P + q, o);
+        } else scatter_store<V>(Q + (size_t)t * plane, gi, qq[t]);
     }
 }
 
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(256) void k_energy_partial(const float* __restrict_
             for (int li = 0; li < n_local; ++li) {
                 const float* sv = s + ((size_t)(img_offset + li) * C + c) * 4;
                 const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
-                const Vec<V> iv = ldv<V>(I + ((size_t)li * C + c) * P + q);
+                const Vec<V> iv = ldv_stream<V>(I + ((size_t)li * C + c) * P + q);
                 const float fs0 = fx * s0, fs1 = fy * s1;
 #pragma unroll
                 for (int e = 0; e < V; ++e) {

@@ -515,6 +515,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->cg_resident_rect = value ? 1 : 0;
     } else if (!strcmp(name, "cg_resident_debug")) {
         ctx->cg_resident_debug = value;
+    } else if (!strcmp(name, "shard_range_check")) {
+        ctx->shard_range_check = value ? 1 : 0;
     } else if (!strcmp(name, "debug_inject_abort")) {
         // test hook: the next look at the abort flags finds these bits (1 depth, 2 albedo) as if ANOTHER rank had reported them
         SRPS_REQUIRE(value >= 0 && value <= 3, SRPS_ERR_INVALID, "debug_inject_abort: 0..3, got %d", value);
@@ -525,6 +527,12 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "light_channel_inner")) {
         ctx->light_channel_inner = value ? 1 : 0;
+        ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "march_nt")) {
+        SRPS_REQUIRE(value >= 0 && value <= 2, SRPS_ERR_INVALID, "march_nt: 0 (never), 1 (always) or 2 (automatic), got %d", value);
+        ctx->march_nt = value;
+    } else if (!strcmp(name, "light_tiled")) {
+        ctx->light_tiled = value ? 1 : 0;
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "light_grouped")) {
         ctx->light_grouped = value ? 1 : 0;
@@ -584,6 +592,8 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "keep_stored_tensor")) *value = ctx->keep_stored_tensor;
     else if (!strcmp(name, "fuse_energy_lighting")) *value = ctx->fuse_energy_lighting;
     else if (!strcmp(name, "fuse_normals")) *value = ctx->fuse_normals;
+    else if (!strcmp(name, "march_nt")) *value = ctx->march_nt;
+    else if (!strcmp(name, "light_tiled")) *value = ctx->light_tiled;
     else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
     else if (!strcmp(name, "cg_fused_step")) *value = ctx->cg_fused_step;
@@ -1364,7 +1374,7 @@ static int sharded_ranges_tile(srps_ctx* ctx) {
 int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(comm_bound(ctx), SRPS_ERR_STATE, "execute_sharded: no communicator bound to the context (srps_comm_init_rank / srps_comm_init_all / srps_set_comm)");
-    SRPS_TRY(sharded_ranges_tile(ctx));
+    if (ctx->shard_range_check) SRPS_TRY(sharded_ranges_tile(ctx));
     if (ctx->comm != nullptr && ctx->comm_world > 1) {
         static std::atomic<bool> warned{false};
         if (!warned.exchange(true) && !getenv("SRPS_QUIET"))

@@ -170,6 +170,8 @@ struct srps_ctx {
     int fuse_energy_lighting = 1;
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
     int light_channel_inner = 1;     // fused energy + lighting sweep with the channels in the inner loop (C in {1, 3})
+    int march_nt = 2;                // streaming CG step with non-temporal loads / stores: 0 never, 1 always, 2 when its vectors exceed the Infinity Cache
+    int light_tiled = 1;             // ... with the four image groups as the waves of one block and the geometry shared through LDS (k_light_fused_tile)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue
                                      // per device: two such kernels of this process cannot interleave their blocks and wait for each
@@ -209,6 +211,7 @@ struct srps_ctx {
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
+    int shard_range_check = 1;       // srps_execute_sharded verifies (one small all-reduce per call) that the ranks' image ranges tile the image set
     int debug_inject_abort = 0;      // test hook: ABORT_* bits the next persistent_aborts finds, as reported by another rank
     int cg_resident_tile = 0;        // 0: the smallest tile shape that fits the device, 256 | 512: threads per block of the forced shape
     int cg_resident_rect = 1;        // tiles inside the mask take the body without structure bits (0: every tile the general body)

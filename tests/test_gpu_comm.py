@@ -137,7 +137,13 @@ def test_command_line_program_sharded_path_equals_one_gpu_path(pkg, tmp_path):
     import torch
     n_dev = torch.cuda.device_count()
     bad = subprocess.run([pkg.host.CLI, f"--dsloc={path}", "--no-output", "--gpus", str(n_dev + 1)], capture_output=True, text=True)
-    assert bad.returncode == 1 and "out of range" in bad.stderr
+    assert bad.returncode == 1 and f"this node shows {n_dev} HIP device(s)" in bad.stderr and "Usage" not in bad.stdout
+    # with --partition strips (round 4) the one-rank path still equals the one-GPU path (a single strip is the whole grid)
+    (tmp_path / "c").mkdir()
+    st = subprocess.run([pkg.host.CLI, f"--dsloc={path}", "-o", str(tmp_path / "c"), "--sharded", "--gpus", "1", "--partition", "strips"], capture_output=True, text=True)
+    assert st.returncode == 0, st.stderr
+    assert "--partition strips has no effect on one device" in st.stdout
+    np.testing.assert_array_equal(scipy.io.loadmat(str(tmp_path / "a" / "z.mat"))["x"], scipy.io.loadmat(str(tmp_path / "c" / "z.mat"))["x"])
 
 
 def test_command_line_program_on_an_image_folder_hands_the_bytes_to_the_device(pkg, tmp_path):
@@ -187,6 +193,7 @@ def test_overlapped_exchange_gives_the_same_bits(pkg, h, w, sf, kind):
     for overlap in (0, 1):
         ctx = pkg.Context(device_id=0)
         ctx.set_option("overlap_exchange", overlap)
+        ctx.set_option("shard_range_check", 0)             # ONE shard alone on purpose (the SHARD kernels): no partition to verify
         pkg.Context.comm_init_all([ctx])
         ctx.setup(dh)
         en = ctx.execute_sharded(2)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Whole solves to the reference's stop rule with the albedo step as the reference's CG on the diagonal system (SRPS_ALBEDO_CG,
+devicecalls.cu:513-548) against its fixed point formed inside the albedo sweep (SRPS_ALBEDO_FUSED), on BASELINE.json's configurations
+(VERDICT round 3, next #3): final depth RMSE, albedo max-abs / RMSE, lighting, energies, pass counts; and WHERE the albedo differs
+(the denominators of the worst pixels).   python tools/albedo_mode_compare.py [mitten|1024|2048x40|2048|all] -> JSON lines"""
+import importlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("srmeetsps-cuda_amd")
+
+
+def mitten():
+    M = np.load(os.path.join(ROOT, "tests", "golden", "mitten_full.npz"))
+    mh, mw, msf = int(M["h"]), int(M["w"]), int(M["sf"])
+    mmask = np.unpackbits(M["mask_bits"])[: mh * mw].astype(np.float32)
+    mi = np.flatnonzero(mmask == 1)
+    mI = np.zeros((M["I_u8"].shape[0], 3, mh * mw), np.float32); mI[:, :, mi] = M["I_u8"].astype(np.float32) / np.float32(255)
+    mzs = np.zeros((mh // msf) * (mw // msf), np.float32); mzs[M["imasks"]] = M["zs_lr_masked"]
+    mzf = np.zeros(mh * mw, np.float32); mzf[mi] = M["z_full_masked"]
+    return pkg.DataHandler(I=mI, mask=mmask, K=M["K"], sf=msf, z0=mzs.reshape(1, -1), I_h=mh, I_w=mw, I_c=3, I_n=mI.shape[0],
+                           I_n_total=mI.shape[0], zs_lr=mzs, z_full=mzf)
+
+
+def solve(dh, mode, extra=()):
+    ctx = pkg.Context(device_id=0)
+    ctx.set_option("albedo_mode", mode)
+    for k, v in extra:
+        ctx.set_option(k, v)
+    ctx.setup(dh)
+    en = pkg.alternating_loop(ctx, None)
+    out = dict(en=np.array(en), z=ctx.get("z"), rho=ctx.get("rho"), s=ctx.get("s"), it=ctx.last_cg_iterations(), N=ctx.get("N"))
+    # the albedo system of the LAST pass as the CG saw it: one more sweep gives num / den of the final state
+    ctx.close()
+    return out
+
+
+def compare(name, dh):
+    a = solve(dh, 0); b = solve(dh, 2); c = solve(dh, 1)
+    scale = float(np.sqrt(np.mean(a["z"].astype(np.float64) ** 2)))
+    d = np.abs(a["rho"].astype(np.float64) - b["rho"])
+    worst = np.argsort(d)[-5:][::-1]
+    # the diagonal of the albedo system at the worst pixels: den_c[p] = sum_i (N[:, p] . s_ic)^2  (devicecalls.cu:395-406)
+    P = a["z"].size
+    Nn = a["N"].reshape(4, P).astype(np.float64); S = a["s"].reshape(-1, dh.I_c, 4).astype(np.float64)
+    def den_at(idx):
+        c, p = divmod(int(idx), P)
+        sh = S[:, c, :] @ Nn[:, p]
+        return float((sh ** 2).sum())
+    den_all = np.stack([((S[:, c, :] @ Nn) ** 2).sum(axis=0) for c in range(dh.I_c)]).reshape(-1)
+    big = d > 1e-5
+    res = {"scene": name, "passes": [len(a["en"]), len(b["en"]), len(c["en"])], "albedo_cg_steps_last_pass": a["it"]["albedo"][:3],
+           "depth_rmse_rel": float(np.sqrt(np.mean((a["z"].astype(np.float64) - b["z"]) ** 2))) / scale, "depth_scale": scale,
+           "albedo_max_abs": float(d.max()), "albedo_rmse": float(np.sqrt(np.mean(d ** 2))), "albedo_p9999": float(np.quantile(d, 0.9999)),
+           "pixels_above_1e-5": int((d > 1e-5).sum()), "pixels_above_1e-4": int((d > 1e-4).sum()), "n": int(d.size),
+           "lighting_max_abs": float(np.abs(a["s"] - b["s"]).max()),
+           "final_energy_rel": float(abs(a["en"][-1] - b["en"][-1]) / abs(a["en"][-1])) if len(a["en"]) == len(b["en"]) else None,
+           "worst_pixels_den": [den_at(i) for i in worst], "den_median": float(np.median(den_all)),
+           "max_den_where_albedo_differs_by_1e-5": float(den_all[big].max()) if big.any() else None,
+           "max_abs_diff_times_den": float((d * den_all).max()),
+           "worst_albedo_values_cg_fused": [[float(a["rho"][i]), float(b["rho"][i])] for i in worst],
+           "fused_equals_closed_form_bits": bool(np.array_equal(b["rho"], c["rho"]) and np.array_equal(b["z"], c["z"]))}
+    print(json.dumps(res), flush=True)
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("mitten", "all"):
+        compare("mitten_full_frame_sf2_8_images (config 2)", mitten())
+    if which in ("1024", "all"):
+        compare("synthetic_1024_sf4_20_images (config 3)", pkg.DataHandler.from_scene(pkg.synth.make_scene(1024, 1024, 4, 20, seed=1234 + 2, mask_kind="full")))
+    if which in ("2048", "all"):
+        compare("synthetic_2048_sf4_20_images (metric)", pkg.DataHandler.from_scene(pkg.synth.make_scene(2048, 2048, 4, 20, seed=1234 + 3, mask_kind="full")))
+    if which in ("2048x40", "all"):
+        compare("synthetic_2048_sf4_40_images (config 4 volume)", pkg.DataHandler.from_scene(pkg.synth.make_scene(2048, 2048, 4, 40, seed=1234 + 4, mask_kind="full")))
+    if which in ("ellipse", "all"):
+        compare("synthetic_1024_sf2_12_images_ellipse", pkg.DataHandler.from_scene(pkg.synth.make_scene(1024, 1024, 2, 12, seed=77, mask_kind="ellipse")))
+
+
+if __name__ == "__main__":
+    main()

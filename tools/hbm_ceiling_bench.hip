@@ -6,12 +6,13 @@
 //   march_paired                              same bytes, (p, r) and (x, omega) stored as interleaved pairs: 5 read + 2 write streams
 //   march_records                             same bytes, ONE 32-byte read record and ONE 16-byte write record per pixel: 1 + 1 streams
 // All at two waves per SIMD (the occupancy of k_apply_march<., 3, 3>), loads of column c+1 and c+2 in flight.
-//   hipcc -O3 --offload-arch=gfx950 tools/hbm_ceiling_bench.hip -o tools/hbm_ceiling_bench.bin ; tools/hbm_ceiling_bench.bin [rows=4096] [cols=4096] [reps=20]
+//   hipcc -O3 --offload-arch=gfx950 tools/hbm_ceiling_bench.hip -o tools/hbm_ceiling_bench.bin ; tools/hbm_ceiling_bench.bin [rows=4096] [cols=4096] [reps=20] [guide_sweep=0]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
 #define CHECK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
 
 __global__ __launch_bounds__(256) void k_linear_read(const float4* __restrict__ a, size_t n4, float* __restrict__ out) {
@@ -45,18 +46,57 @@ __global__ __launch_bounds__(256) void k_linear_rw21(const float4* __restrict__ 
     for (; i < n4; i += st) b[i] = a[i];
 }
 
+
+// ---- round 4: the guide's recipe, swept (MI355X_MICROARCH.md:36 "6.29 TB/s measured (float4 copy)", :351 "1.2 GB table swept in order
+// 6.0 - 6.1 TB/s"; cdna_hip_programming.md Guideline 11: 256 CUs x 8 blocks of 256 threads, grid-stride, 16 B per lane) ----
+// U loads of 16 B in flight per lane; NT: non-temporal loads / stores; CONTIG: every block sweeps one contiguous chunk instead of
+// striding over the whole array (the DRAM pages a block touches then stay its own).
+template <int U, bool NT, bool CONTIG, bool WRITE>
+__global__ __launch_bounds__(256) void k_stream(const float4* __restrict__ a_, float4* __restrict__ b_, size_t n4, float* __restrict__ out) {
+    const vf4* __restrict__ a = reinterpret_cast<const vf4*>(a_);
+    vf4* __restrict__ b = reinterpret_cast<vf4*>(b_);
+    size_t i, end, st;
+    if (CONTIG) {
+        const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+        i = blockIdx.x * per + threadIdx.x; end = min(n4, (blockIdx.x + 1) * per); st = 256;
+    } else { i = blockIdx.x * (size_t)256 + threadIdx.x; end = n4; st = (size_t)gridDim.x * 256; }
+    float s = 0.f;
+    for (; i + (U - 1) * st < end; i += U * st) {
+        vf4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(a + i + u * st) : a[i + u * st];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (WRITE) { if (NT) __builtin_nontemporal_store(v[u], b + i + u * st); else b[i + u * st] = v[u]; }
+            else s += v[u].x + v[u].w;
+        }
+    }
+    for (; i < end; i += st) { const vf4 v = a[i]; if (WRITE) b[i] = v; else s += v.x; }
+    if (!WRITE && s == 1.2345f) out[0] = s;
+}
+
 struct F4 { float e[4]; };
-__device__ __forceinline__ F4 ld4(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return F4{{t.x, t.y, t.z, t.w}}; }
-__device__ __forceinline__ void st4(float* p, const F4& a) { *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]); }
+template <bool NT = false>
+__device__ __forceinline__ F4 ld4(const float* p) {
+    if constexpr (NT) { const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p)); return F4{{t.x, t.y, t.z, t.w}}; }
+    else { const float4 t = *reinterpret_cast<const float4*>(p); return F4{{t.x, t.y, t.z, t.w}}; }
+}
+template <bool NT = false>
+__device__ __forceinline__ void st4(float* p, const F4& a) {
+    if constexpr (NT) { vf4 t; t.x = a.e[0]; t.y = a.e[1]; t.z = a.e[2]; t.w = a.e[3]; __builtin_nontemporal_store(t, reinterpret_cast<vf4*>(p)); }
+    else *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]);
+}
 
 // LAYOUT 0: 8 read planes, 4 write planes (element = float).  1: reads g0, g1, g2 (3 planes) + [p r] + [x w] (2 planes of pairs),
 // writes [p r] + [x w].  2: reads one plane of 8-float records, writes one plane of 4-float records.
 struct MArgs {
     const float* in[8];
     float* out[4];
-    int Hs, cols_per_wave, n_items, n_seg;
+    int Hs, cols_per_wave, n_items, n_seg, cols_total;
 };
-template <int LAYOUT>
+// LAYOUT 3 (round 4): the planar layout with every plane stored SEGMENT-major, [segment][column][256 rows]: a wave's march over its
+// columns is one contiguous run of 1 KiB x columns per plane instead of 1 KiB every Hs * 4 bytes.  NT: non-temporal loads and stores.
+template <int LAYOUT, bool NT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_march(MArgs a, float* chk_out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
@@ -67,37 +107,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float chk = 0.f;
     struct Raw { F4 v[8]; };
     auto issue = [&](Raw& r, int col) {
-        const size_t e = (size_t)(c0 + col) * a.Hs + row;      // element index of the lane's first row
-        if (LAYOUT == 0) {
+        const size_t e = LAYOUT == 3 ? ((size_t)seg * a.cols_total + (c0 + col)) * 256 + lane * 4 : (size_t)(c0 + col) * a.Hs + row;      // element index of the lane's first row
+        if (LAYOUT == 0 || LAYOUT == 3) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) r.v[p] = ld4(a.in[p] + e);
+            for (int p = 0; p < 8; ++p) r.v[p] = ld4<NT>(a.in[p] + e);
         } else if (LAYOUT == 1) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) r.v[p] = ld4(a.in[p] + e);
-            r.v[3] = ld4(a.in[3] + 2 * e); r.v[4] = ld4(a.in[3] + 2 * e + 4);
-            r.v[5] = ld4(a.in[4] + 2 * e); r.v[6] = ld4(a.in[4] + 2 * e + 4);
+            for (int p = 0; p < 3; ++p) r.v[p] = ld4<NT>(a.in[p] + e);
+            r.v[3] = ld4<NT>(a.in[3] + 2 * e); r.v[4] = ld4<NT>(a.in[3] + 2 * e + 4);
+            r.v[5] = ld4<NT>(a.in[4] + 2 * e); r.v[6] = ld4<NT>(a.in[4] + 2 * e + 4);
             r.v[7] = r.v[0];                                    // (the structure bytes: a quarter plane, left out)
         } else {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) r.v[p] = ld4(a.in[0] + 8 * e + 4 * p);
+            for (int p = 0; p < 8; ++p) r.v[p] = ld4<NT>(a.in[0] + 8 * e + 4 * p);
         }
     };
     auto consume = [&](const Raw& r, int col) {
-        const size_t e = (size_t)(c0 + col) * a.Hs + row;
+        const size_t e = LAYOUT == 3 ? ((size_t)seg * a.cols_total + (c0 + col)) * 256 + lane * 4 : (size_t)(c0 + col) * a.Hs + row;
         F4 o[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w)
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[w].e[q] = fmaf(r.v[w].e[q], 0.5f, r.v[w + 4].e[q]);
-        if (LAYOUT == 0) {
+        if (LAYOUT == 0 || LAYOUT == 3) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) st4(a.out[w] + e, o[w]);
+            for (int w = 0; w < 4; ++w) st4<NT>(a.out[w] + e, o[w]);
         } else if (LAYOUT == 1) {
-            st4(a.out[0] + 2 * e, o[0]); st4(a.out[0] + 2 * e + 4, o[1]);
-            st4(a.out[1] + 2 * e, o[2]); st4(a.out[1] + 2 * e + 4, o[3]);
+            st4<NT>(a.out[0] + 2 * e, o[0]); st4<NT>(a.out[0] + 2 * e + 4, o[1]);
+            st4<NT>(a.out[1] + 2 * e, o[2]); st4<NT>(a.out[1] + 2 * e + 4, o[3]);
         } else {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) st4(a.out[0] + 4 * e + 4 * w, o[w]);
+            for (int w = 0; w < 4; ++w) st4<NT>(a.out[0] + 4 * e + 4 * w, o[w]);
         }
         chk += o[0].e[0];
     };
@@ -108,6 +148,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         { const Raw cur = b1; issue(b1, min(c + 3, a.cols_per_wave - 1)); consume(cur, c + 1); }
     }
     if (chk == 1.2345f) chk_out[0] = chk;
+}
+
+
+// ---- round 4: the image sweeps' shape.  A block of 256 threads owns 1024 consecutive pixels and reads them from NP planes (the
+// (image, channel) rows of I[n][c][P], P * 4 bytes apart), four loads in flight per lane (k_albedo_numden) -- against the same bytes
+// stored TILE-major, [tile][plane][1024 pixels]: the block's NP x 4 KiB are one contiguous run.
+template <bool NT, bool TILED>
+__global__ __launch_bounds__(256) void k_sweep(const float* __restrict__ I, size_t P, int NP, float* __restrict__ out) {
+    const size_t q = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q >= P) return;
+    float s = 0.f;
+#pragma unroll 4
+    for (int pl = 0; pl < NP; ++pl) {
+        const float* src = TILED ? I + ((size_t)blockIdx.x * NP + pl) * 1024 + threadIdx.x * 4 : I + (size_t)pl * P + q;
+        const F4 v = ld4<NT>(src);
+        s = fmaf(v.e[0], v.e[1], s) + v.e[2] * v.e[3];
+    }
+    if (s == 1.2345f) out[0] = s;
 }
 
 int main(int argc, char** argv) {
@@ -145,6 +203,9 @@ int main(int argc, char** argv) {
     CHECK(hipFuncSetAttribute((const void*)k_march<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     CHECK(hipFuncSetAttribute((const void*)k_march<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     CHECK(hipFuncSetAttribute((const void*)k_march<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_march<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_march<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    CHECK(hipFuncSetAttribute((const void*)k_march<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     for (int waves_target : {2048, 1024}) {
         int strips = waves_target / a.n_seg; if (strips < 1) strips = 1;
         while (cols % strips) --strips;
@@ -153,13 +214,48 @@ int main(int argc, char** argv) {
         printf("march: rows %d cols %d: %d waves, %d columns each, %.1f MB per pass\n", rows, cols, a.n_items, a.cols_per_wave, bytes * 1e-6);
         for (int p = 0; p < 8; ++p) a.in[p] = arena + (size_t)p * pl;
         for (int w = 0; w < 4; ++w) a.out[w] = arena + (size_t)(8 + w) * pl;
+        a.cols_total = cols;
         timeit("march_planar_8r_4w", bytes, [&] { hipLaunchKernelGGL((k_march<0>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
+        timeit("march_planar_nt", bytes, [&] { hipLaunchKernelGGL((k_march<0, true>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
+        timeit("march_segmajor", bytes, [&] { hipLaunchKernelGGL((k_march<3>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
+        timeit("march_segmajor_nt", bytes, [&] { hipLaunchKernelGGL((k_march<3, true>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
         // pairs: g0 g1 g2 | [p r] (2 planes) | [x w] (2 planes) read; [p r] | [x w] written
         a.in[0] = arena; a.in[1] = arena + pl; a.in[2] = arena + 2 * pl; a.in[3] = arena + 3 * pl; a.in[4] = arena + 5 * pl;
         a.out[0] = arena + 7 * pl; a.out[1] = arena + 9 * pl;
         timeit("march_paired_5r_2w", bytes * 11.0 / 12.0, [&] { hipLaunchKernelGGL((k_march<1>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
         a.in[0] = arena; a.out[0] = arena + 8 * pl;
         timeit("march_records_1r_1w", bytes, [&] { hipLaunchKernelGGL((k_march<2>), dim3(nb), dim3(256), LDSB, 0, a, chk); });
+    }
+    // the guide's recipe swept: blocks x loads in flight x cache policy x block-contiguous chunks; read of 1.2 GB (guide :351) and
+    // copy of 2 x 0.6 GB; also what the runtime's own device-to-device copy and memset reach
+    if (argc > 4 && atoi(argv[4]) != 0) {
+        const size_t big4 = ((size_t)1200 << 20) / 16;
+        float4* big; CHECK(hipMalloc(&big, big4 * 16));
+        CHECK(hipMemset(big, 0, big4 * 16));
+#define SWEEP(U, NT, CONTIG)                                                                                                       \
+        for (int nb : {1024, 2048, 4096, 16384}) {                                                                                   \
+            char nm[96];                                                                                                           \
+            snprintf(nm, sizeof nm, "guide_read_u%d%s%s_%dblk", U, NT ? "_nt" : "", CONTIG ? "_contig" : "", nb);                  \
+            timeit(nm, 16.0 * big4, [&] { hipLaunchKernelGGL((k_stream<U, NT, CONTIG, false>), dim3(nb), dim3(256), 0, 0, (const float4*)big, (float4*)nullptr, big4, chk); });   \
+            snprintf(nm, sizeof nm, "guide_copy_u%d%s%s_%dblk", U, NT ? "_nt" : "", CONTIG ? "_contig" : "", nb);                  \
+            timeit(nm, 16.0 * big4, [&] { hipLaunchKernelGGL((k_stream<U, NT, CONTIG, true>), dim3(nb), dim3(256), 0, 0, (const float4*)big, big + big4 / 2, big4 / 2, chk); });  \
+        }
+        SWEEP(1, false, false) SWEEP(4, false, false) SWEEP(8, false, false) SWEEP(4, true, false) SWEEP(8, true, false)
+        SWEEP(4, false, true) SWEEP(8, true, true)
+#undef SWEEP
+        {
+            const size_t Pp = (size_t)2048 * 2048; const int NP = 60;          // 1.0066 GB: the images of the metric's configuration
+            float* img; CHECK(hipMalloc(&img, Pp * NP * 4)); CHECK(hipMemset(img, 0, Pp * NP * 4));
+            const int nbs = (int)(Pp / 1024);
+            timeit("sweep_60planes", 4.0 * Pp * NP, [&] { hipLaunchKernelGGL((k_sweep<false, false>), dim3(nbs), dim3(256), 0, 0, img, Pp, NP, chk); });
+            timeit("sweep_60planes_nt", 4.0 * Pp * NP, [&] { hipLaunchKernelGGL((k_sweep<true, false>), dim3(nbs), dim3(256), 0, 0, img, Pp, NP, chk); });
+            timeit("sweep_tilemajor", 4.0 * Pp * NP, [&] { hipLaunchKernelGGL((k_sweep<false, true>), dim3(nbs), dim3(256), 0, 0, img, Pp, NP, chk); });
+            timeit("sweep_tilemajor_nt", 4.0 * Pp * NP, [&] { hipLaunchKernelGGL((k_sweep<true, true>), dim3(nbs), dim3(256), 0, 0, img, Pp, NP, chk); });
+            CHECK(hipFree(img));
+        }
+        timeit("hipMemcpyDtoD_600MB", 16.0 * big4, [&] { CHECK(hipMemcpyAsync(big + big4 / 2, big, big4 / 2 * 16, hipMemcpyDeviceToDevice, 0)); });
+        timeit("hipMemset_1200MB", 16.0 * big4, [&] { CHECK(hipMemsetAsync(big, 0, big4 * 16, 0)); });
+        CHECK(hipFree(big));
     }
     CHECK(hipFree(arena));
     return 0;
