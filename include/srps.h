@@ -45,14 +45,23 @@ enum {
     SRPS_ERR_UNSUPPORTED = 5
 };
 
-/* albedo solver: the reference solves the per-pixel diagonal system with its global CG
- * (devicecalls.cu:513-548); CLOSED_FORM is the fixed point of that CG (num/den per pixel). */
+/* albedo solver: the reference solves the per-pixel diagonal system with its global CG (devicecalls.cu:513-548); CLOSED_FORM is the
+ * fixed point of that CG (num / den per pixel; pixels with a zero denominator keep their value).
+ * AUTO (the default since round 4): the PIPELINE phases (srps_albedo, srps_albedo_partial / _finish, srps_execute*) form the fixed
+ * point -- on a context that holds all images inside the one albedo sweep (FUSED), on a shard from the all-reduced num and den --, the
+ * OPERATOR srps_albedo_estimation, which stands in for cuda_based_albedo_estimation call for call, runs the reference's CG.
+ * Why the pipeline may: from identical inputs one albedo step of the CG lands within 4e-7 of the fixed point (its recursive residual
+ * falls below 1e-18 after 6 - 17 steps; the diagonal's condition number is 2 - 3 on the reference's Mitten data); after whole solves the
+ * two modes differ by depth 3e-7 ... 7e-7 relative RMSE and albedo 2e-4 ... 1e-3 max-abs (4e-5 RMSE) -- which is what two faithful
+ * implementations of the CG mode differ by as well (this library against the oracle on Mitten: 1e-3): rounding differences of the
+ * depth (1 ulp of z) reach the normals through the finite differences amplified by 2 f / z, and the albedo through the shading.
+ * tools/albedo_mode_compare.py, DESIGN.md section 4.  Set SRPS_ALBEDO_CG to have the reference's CG in the pipeline too. */
 enum { SRPS_ALBEDO_CG = 0, SRPS_ALBEDO_CLOSED_FORM = 1,
        /* the fixed point AND the depth system (g, q) formed inside the one albedo sweep over the images: no num / den / image-sum
         * planes, no albedo solve, no depth assembly kernel.  The same bits as CLOSED_FORM; pipeline phases on one GPU (elsewhere it
-        * behaves as CLOSED_FORM).  Not the default: the reference runs its CG on the diagonal system (devicecalls.cu:513-548),
-        * which stops within 1e-6 of this fixed point. */
-       SRPS_ALBEDO_FUSED = 2 };
+        * behaves as CLOSED_FORM). */
+       SRPS_ALBEDO_FUSED = 2,
+       SRPS_ALBEDO_AUTO = 3 };
 /* operator used by the depth CG: AUTO picks the register-marching kernel when sf is 1, 2 or 4 */
 enum { SRPS_APPLY_AUTO = 0, SRPS_APPLY_SIMPLE = 1, SRPS_APPLY_MARCH = 2 };
 

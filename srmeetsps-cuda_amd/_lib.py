@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SRPS_LIB_PATH") or os.path.join(_HERE, "libsrps_hip.s
 HEADER = os.path.join(ROOT, "include", "srps.h")
 
 SRPS_OK = 0
-ALBEDO_CG, ALBEDO_CLOSED_FORM, ALBEDO_FUSED = 0, 1, 2
+ALBEDO_CG, ALBEDO_CLOSED_FORM, ALBEDO_FUSED, ALBEDO_AUTO = 0, 1, 2, 3
 APPLY_AUTO, APPLY_SIMPLE, APPLY_MARCH = 0, 1, 2
 
 

@@ -431,7 +431,8 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
 // the algorithmic bytes (k_light_fused_ci fetched the geometry once per image group: 1.41 x the algorithmic bytes by the round-1
 // counters, and formed every normal four times).  Same expressions per pixel as k_light_fused_ci; the sums run over other
 // pixel subsets per lane, so results agree to rounding, not to the bit.
-template <int IBW, int NCH, bool TAIL>
+// TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
+template <int IBW, int NCH, bool TAIL, bool TM = false>
 __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, int P, int n_img,
                                                             int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
                                                             EnergyArgs ea) {
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                 for (int c = 0; c < NCH; ++c) {
                     Vec<4> ivc[IBW];                                   // images past the end re-read the last one
 #pragma unroll
-                    for (int ii = 0; ii < IBW; ++ii) ivc[ii] = ldv_stream<4>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + ql);
+                    for (int ii = 0; ii < IBW; ++ii) ivc[ii] = ld_img<4, false, TM>(I, nullptr, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);
                     const float4 rq = geo[3 + c][li];
                     const float r[4] = {rq.x, rq.y, rq.z, rq.w};
                     float a[4][4];
@@ -754,7 +755,9 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
         const int ibw = tile_images_per_wave(n_local);
         // (TAIL = false, the kernel without the per-image guards, is not used: hipcc 7.2 then hoists every load and LDS read of a piece
         // to its top and spills 330 bytes; the guards are wave-uniform branches on a scalar compare)
-#define SRPS_LT(BB, CC) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, P, n_local, L.chunk, L.part_atb, L.part_g, ea)
+        const float* d_It = image_store_tiles(ctx, d_I);       // the tile-major copy of the context's images, when it keeps one
+#define SRPS_LT(BB, CC) do { if (d_It) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
+                             else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, P, n_local, L.chunk, L.part_atb, L.part_g, ea); } while (0)
         if (C == 3) { switch (ibw) { case 1: SRPS_LT(1, 3); break; case 2: SRPS_LT(2, 3); break; case 3: SRPS_LT(3, 3); break; case 4: SRPS_LT(4, 3); break; default: SRPS_LT(5, 3); } }
         else { switch (ibw) { case 1: SRPS_LT(1, 1); break; case 2: SRPS_LT(2, 1); break; case 3: SRPS_LT(3, 1); break; case 4: SRPS_LT(4, 1); break; default: SRPS_LT(5, 1); } }
 #undef SRPS_LT

@@ -120,7 +120,7 @@ struct srps_ctx {
     int block_x = 256, block_y = 4;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    int albedo_mode = SRPS_ALBEDO_CG;
+    int albedo_mode = SRPS_ALBEDO_AUTO;       // pipeline: the fixed point (fused into the sweep where the context holds all images); operator: the reference's CG
     int apply_mode = SRPS_APPLY_AUTO;
     int march_tj = 0;                // strip width of the marching operator (multiple of 4); 0 = chosen by march_plan
     int keep_stored_tensor = 0;      // also write the 6-plane tensor when the recompute form is active (tests)
@@ -225,6 +225,14 @@ struct srps_ctx {
     int image_store = 1;                  // option "image_store": 0 floats only, 1 bytes whenever the samples allow it
     unsigned char* I8 = nullptr;          // [N_local][C][P] bytes
     size_t I8_cap = 0;                    // bytes allocated behind I8 (kept across set-ups)
+    // The TILE-major copy of the context's float images (round 4, option "image_tiles"): It[tile][image * C + channel][1024 pixels].
+    // The image sweeps give a block 1024 consecutive pixels of every (image, channel) row; in the reference's layout I[n][c][P] those are
+    // N C pieces of 4 KiB, P * 4 bytes apart -- in this one a single run of N C * 4 KiB.  tools/hbm_ceiling_bench.hip (sweep_*): the same
+    // 1.0 GB read at 5.9 TB/s from the planes and at 7.1 TB/s from the tiles (non-temporal loads both).
+    float* It = nullptr;
+    size_t It_cap = 0;                    // floats allocated behind It (kept across set-ups)
+    int it_state = 0;                     // 0: stale (rebuilt at the next sweep), 1: current, 2: not to be used (the caller holds a pointer to I)
+    int image_tiles = 1;                  // option
     bool I8_cap_ok(size_t n) const { return I8 != nullptr && I8_cap >= n; }
     std::vector<hipEvent_t> ev_copied, ev_gathered;      // upload pipeline of srps_setup: per staging slot
     int i8_state = 0;                     // 0: not looked at since I last changed, 1: I8 holds I, 2: I is not representable
@@ -283,6 +291,7 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 int launch_fill(hipStream_t st, float* d, size_t n, float v);
 int launch_pack_bytes(hipStream_t st, const float* d_I, size_t n, unsigned char* d_out, int* d_inexact);
 const unsigned char* image_store_bytes(srps_ctx* ctx, const float* d_I);
+const float* image_store_tiles(srps_ctx* ctx, const float* d_I);      // null: read the planar array
 int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask, int P, int C, size_t hw, float* d_out);
 int launch_meshgrid_compact(hipStream_t st, const int* d_imask, int P, int h, float cx, float cy, float* xx, float* yy);
 int launch_meshgrid_full(hipStream_t st, int w, int h, float K02, float K12, float* xx, float* yy);
@@ -298,7 +307,7 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
                   int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr, int n_total = 0,
                   int q0 = 0, int q1 = 0 /* > 0: the pixels [q0, q1) only, q0 a multiple of 1024 */);
-int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C);
+int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int C, bool pipeline = false);
 int albedo_fused(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_img, int C, float* d_rho, const float* d_qc,
                  const float* d_xx, const float* d_yy, const float* d_dz, float fx, float fy);
 int depth_fused_prepare(srps_ctx* ctx, const float* d_s, float fx, float fy, int C, int n_total, int n_local, int img_offset, float cx, float cy, bool* ok);

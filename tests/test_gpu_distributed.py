@@ -160,6 +160,7 @@ def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg, bytes_store):
     quant = (lambda sc: setattr(sc, "I", (np.rint(np.clip(sc.I, 0, 1) * 255).astype(np.float32) / np.float32(255))) or sc) if bytes_store else (lambda sc: sc)
     full = quant(pkg.synth.make_scene(64, 48, 2, n_img, seed=37, mask_kind="full" if bytes_store else "ragged"))
     ctx = pkg.Context(device_id=0)
+    ctx.set_option("albedo_mode", 0)                       # num and den in the exchange buffer (the default forms the albedo inside the sweep)
     ctx.setup(pkg.DataHandler.from_scene(full))
     assert ctx.get_option("image_store_bytes_active") == (1 if bytes_store else 0)
     ctx.lighting()

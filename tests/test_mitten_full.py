@@ -63,5 +63,20 @@ def test_hip_full_mitten_solve_to_convergence(pkg, oracle):
     np.testing.assert_allclose(en, G["energies"], rtol=8e-5)
     assert rel_rmse(srps.z(), G["final_z"]) < 1e-4                        # north_star's bar; relative: depth ~ 700, ulp(700) = 6e-5
     assert rel_rmse(srps.z(), G["final_z"]) < 6e-6                        # ... and what a regression would have to stay under
-    assert np.abs(srps.rho() - G["final_rho"]).max() < 3e-3
+    # WHY the albedo is only good to 1e-3 here when the depth agrees to 2e-6 (round-3 review, weak 1b) -- found in round 4
+    # (tools/albedo_mode_compare.py): not the albedo solve (the diagonal system's condition number is 2 - 3 on this data; CG and
+    # fixed point agree to 4e-7 per step), and not a scale exchanged between albedo and lighting (the fitted scale is 1 to 1e-7).
+    # It is the DEPTH's rounding reaching the normals: N = (fx zx, fy zy, ...) / dz takes finite differences of z (~ 550 here,
+    # 1 ulp = 6e-5) and multiplies them by the focal length (1217): two runs whose depths differ by d differ in the normals by up to
+    # 2 fx d / dz, in the shading by about as much, and in the albedo by that times rho.  So the albedo's tolerance FOLLOWS from the
+    # depth's deviation:
+    dzn = ctx.get("dz")
+    d_abs = float(np.abs(srps.z().astype(np.float64) - G["final_z"]).max())
+    amp = 2.0 * float(K[0]) * d_abs / float(dzn.min())
+    alb = float(np.abs(srps.rho() - G["final_rho"]).max())
+    print(f"Mitten: depth max-abs deviation {d_abs:.3e} (z ~ {float(np.median(srps.z())):.0f}), fx {float(K[0]):.1f}, min dz {float(dzn.min()):.1f}: normals may differ by "
+          f"{amp:.3e}; albedo max-abs {alb:.3e} = {alb / (amp * float(srps.rho().max())):.2f} x that bound x max rho, RMSE {float(np.sqrt(np.mean((srps.rho() - G['final_rho']) ** 2))):.2e}")
+    assert alb < 3e-3
+    assert alb <= 2.0 * amp * float(srps.rho().max())                      # the albedo deviates no more than the depth's deviation explains
+    assert float(np.sqrt(np.mean((srps.rho() - G["final_rho"]) ** 2))) < 2e-4
     ctx.close()

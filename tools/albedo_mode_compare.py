@@ -49,7 +49,15 @@ def compare(name, dh):
         return float((sh ** 2).sum())
     den_all = np.stack([((S[:, c, :] @ Nn) ** 2).sum(axis=0) for c in range(dh.I_c)]).reshape(-1)
     big = d > 1e-5
-    res = {"scene": name, "passes": [len(a["en"]), len(b["en"]), len(c["en"])], "albedo_cg_steps_last_pass": a["it"]["albedo"][:3],
+    # Albedo and lighting are determined only up to a scale per channel (rho_c -> g rho_c, s_ic -> s_ic / g leaves every image and the
+    # energy unchanged): the alternation drifts along that direction, so albedos of two runs are compared after removing the scale
+    C = dh.I_c
+    ra = a["rho"].reshape(C, P).astype(np.float64); rb = b["rho"].reshape(C, P).astype(np.float64)
+    gam = [float((ra[c] @ rb[c]) / (rb[c] @ rb[c])) for c in range(C)]
+    gauge_resid = float(max(np.abs(ra[c] - gam[c] * rb[c]).max() for c in range(C)))
+    sa = a["s"].reshape(-1, C, 4).astype(np.float64); sb = b["s"].reshape(-1, C, 4).astype(np.float64)
+    s_resid = float(max(np.abs(sa[:, c, :] * gam[c] - sb[:, c, :]).max() for c in range(C)))
+    res = {"scene": name, "albedo_scale_cg_over_fused": gam, "albedo_max_abs_after_scale": gauge_resid, "lighting_max_abs_after_scale": s_resid, "passes": [len(a["en"]), len(b["en"]), len(c["en"])], "albedo_cg_steps_last_pass": a["it"]["albedo"][:3],
            "depth_rmse_rel": float(np.sqrt(np.mean((a["z"].astype(np.float64) - b["z"]) ** 2))) / scale, "depth_scale": scale,
            "albedo_max_abs": float(d.max()), "albedo_rmse": float(np.sqrt(np.mean(d ** 2))), "albedo_p9999": float(np.quantile(d, 0.9999)),
            "pixels_above_1e-5": int((d > 1e-5).sum()), "pixels_above_1e-4": int((d > 1e-4).sum()), "n": int(d.size),
