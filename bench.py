@@ -101,6 +101,10 @@ FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X peak fp32 vector rate, /opt/skills/g
 # p = beta p + r 2, x += alpha p and r -= alpha omega 4, r.r 2
 FLOPS_PER_UNKNOWN_STEP = 82
 FLOPS_PER_UNKNOWN_RESIDUAL_PASS = 71
+# ... of which 36 rebuild the step-INVARIANT tensor P = sum_c g_c T_c every step because six values per unknown have nowhere to live on
+# the chip: a CG step that could keep P would need 46 (the round-3 review's "minimal" count); both fractions are reported
+FLOPS_PER_UNKNOWN_STEP_MINIMAL = 46
+FLOPS_PER_UNKNOWN_RESIDUAL_PASS_MINIMAL = 35
 
 
 def _profile(name):
@@ -156,6 +160,9 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
                            "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
                            "traffic": (tj.get(key) or {}).get("resident"), "traffic_source": traffic_source, "avg_launch_us": launch_us, "steps_per_launch": 101,
                            "flops_per_launch": flops, "flops_per_unknown_and_step": FLOPS_PER_UNKNOWN_STEP, "issue": issue,
+                           "minimal_flop_count": {"flops_per_unknown_and_step": FLOPS_PER_UNKNOWN_STEP_MINIMAL,
+                                                  "frac": float(P) * (101 * FLOPS_PER_UNKNOWN_STEP_MINIMAL + FLOPS_PER_UNKNOWN_RESIDUAL_PASS_MINIMAL) / (launch_us * 1e6) / FP32_VALU_PEAK_TFLOPS,
+                                                  "note": "the executed form rebuilds the step-invariant 3 x 3 tensor P = sum_c g_c T_c (36 flops per unknown and step); counted without it"},
                            # what a CG that streams its vectors would have to move for the same work, as a bandwidth -- NOT a roofline fraction
                            "hbm_equivalent": {"algorithmic_bytes_per_launch": loop_bytes * 101, "GBs": loop_bytes * 101 / (1e3 * launch_us),
                                               "x_hbm_peak": loop_bytes * 101 / (1e3 * launch_us) / HBM_PEAK_GBS}}
@@ -340,6 +347,7 @@ def main():
         "config": {"workload": f"synthetic full-mask HR grid {H}x{W}, sf {args.sf}, {args.images} images/GPU x {world} GPU, 3 channels",
                    "hr_grid": [H, W], "sf": args.sf, "images_per_gpu": args.images, "images_total": n_total,
                    "unknowns": dims["npix"], "cg_steps_per_solve": depth_steps, "persistent_fallbacks": fallbacks,
+                   "albedo_mode": {0: "SRPS_ALBEDO_CG", 1: "SRPS_ALBEDO_CLOSED_FORM", 2: "SRPS_ALBEDO_FUSED", 3: "SRPS_ALBEDO_AUTO (pipeline: the albedo CG's fixed point formed inside the sweep)"}[ctx.get_option("albedo_mode")],
                    "exclusive_device": ctx.get_option("exclusive_device"),       # 1: plain launches of the persistent kernels (the library's default is the cooperative launch: ~26 us per pass more)
                    "comm": {"none": "none (1 GPU)", "library": "ncclAllReduce inside libsrps_hip.so (srps_execute_sharded), communicator from srps_comm_init_rank",
                             "torch": "torch.distributed.all_reduce on views of the library's exchange buffers"}[comm_kind],
@@ -451,13 +459,13 @@ def main():
                                    "workload": "the headline workload with 8-bit images (k / 255.f, the reference's image-folder input): image sweeps read bytes"}
             c8.close()
             sc.I = I_keep
-            # The headline workload with albedo_mode = SRPS_ALBEDO_FUSED (not the default: the reference runs its CG on the diagonal
-            # albedo system; this is that CG's fixed point, formed together with the depth system inside the albedo sweep -- no
-            # num / den / image-sum planes, no albedo solve, no assembly kernel).  Reported next to the headline, never as it.
+            # The headline workload with the reference's albedo CG in the pipeline (albedo_mode = SRPS_ALBEDO_CG; the default since round 4
+            # is the CG's fixed point formed inside the albedo sweep, SRPS_ALBEDO_AUTO -- include/srps.h has the measurements behind that):
+            # num / den / image-sum planes, the persistent albedo CG, the depth assembly from the sums.
             cf = pkg.Context(device_id=local_rank)
             cf.set_stream(stream.cuda_stream)
             cf.set_option("exclusive_device", 1)
-            cf.set_option("albedo_mode", 2)
+            cf.set_option("albedo_mode", 0)
             cf.setup(dh)
             for _ in range(max(args.warmup, 1)):
                 pkg.alternating_loop(cf, None, max_outer=1)
@@ -467,10 +475,10 @@ def main():
                 pkg.alternating_loop(cf, None, max_outer=1)
             torch.cuda.synchronize()
             df = time.perf_counter() - tf
-            itf = cf.last_cg_iterations()["depth"]
-            assert itf == 101 and cf.get_option("persistent_fallbacks") == 0
-            legs["albedo_fused_closed_form"] = {"cg_iterations_per_sec": itf * args.steps / df, "ms_per_step": 1e3 * df / args.steps,
-                                                "workload": "the headline workload with albedo_mode = SRPS_ALBEDO_FUSED (the albedo CG's fixed point and the depth system formed inside the albedo sweep; not the default)"}
+            itf = cf.last_cg_iterations()
+            assert itf["depth"] == 101 and cf.get_option("persistent_fallbacks") == 0
+            legs["albedo_reference_cg"] = {"cg_iterations_per_sec": itf["depth"] * args.steps / df, "ms_per_step": 1e3 * df / args.steps, "albedo_cg_steps": list(itf["albedo"][:3]),
+                                           "workload": "the headline workload with albedo_mode = SRPS_ALBEDO_CG (the reference's CG on the diagonal albedo system in the pipeline; not the default)"}
             cf.close()
             mitten = os.path.join(ROOT, "tests", "golden", "mitten_full.npz")
             if os.path.exists(mitten):
@@ -506,13 +514,16 @@ def main():
                 try:
                     import subprocess
                     torch.cuda.synchronize()
-                    res = subprocess.run([ceil_bin, "4096", "4096", "10"], capture_output=True, text=True, timeout=120)
+                    res = subprocess.run([ceil_bin, "4096", "4096", "10", "1"], capture_output=True, text=True, timeout=300)
                     rows = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
                     best = {}
                     for r in rows:
-                        name = r["variant"].split("_blk")[0].rstrip("0123456789").rstrip("_") if r["variant"].startswith("linear") else r["variant"]
+                        v = r["variant"]
+                        name = v.rsplit("_", 1)[0] if v.endswith("blk") else v         # best over the block counts tried
                         best[name] = max(best.get(name, 0.0), r["GBs"])
-                    legs["hbm_ceiling_this_box"] = {"GBs": best, "workload": "tools/hbm_ceiling_bench.bin 4096 4096 10: pure float4 streams over 813 MB and the CG step's access shape (8 planes read, 4 written, marching), best of the block / wave counts tried"}
+                    fam = lambda pre: max([g for n, g in best.items() if n.startswith(pre)] or [0.0])
+                    legs["hbm_ceiling_this_box"] = {"GBs": best, "best_read_GBs": fam("guide_read"), "best_copy_GBs": fam("guide_copy"),
+                                                    "workload": "tools/hbm_ceiling_bench.bin 4096 4096 10 1: float4 streams (grid-stride and block-contiguous, default and non-temporal policy, 1 - 8 loads in flight), the CG step's access shape (8 planes read, 4 written, marching) and the image sweeps' shape (60 planes / tile-major)"}
                     march = best.get("march_planar_8r_4w")
                     if march:
                         for key in ("largest_grid_4096_sf2",):

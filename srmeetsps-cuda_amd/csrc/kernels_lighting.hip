@@ -431,6 +431,12 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
 // the algorithmic bytes (k_light_fused_ci fetched the geometry once per image group: 1.41 x the algorithmic bytes by the round-1
 // counters, and formed every normal four times).  Same expressions per pixel as k_light_fused_ci; the sums run over other
 // pixel subsets per lane, so results agree to rounding, not to the bit.
+#ifndef SRPS_LIGHT_SV_REGS
+#define SRPS_LIGHT_SV_REGS 1
+#endif
+#ifndef SRPS_LIGHT_PREFETCH
+#define SRPS_LIGHT_PREFETCH 1
+#endif
 // TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
 template <int IBW, int NCH, bool TAIL, bool TM = false>
 __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, int P, int n_img,
@@ -467,6 +473,10 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                 for (int k = 0; k < 4; ++k) acc[c][ii][k] = 0.f;
 #pragma unroll
         for (int t = 0; t < 10; ++t) g[t] = 0.f;
+#if SRPS_LIGHT_SV_REGS
+        float4 svr[NCH][IBW];                              // ... and kept in registers for the round: an LDS read per use cost a wait each
+        bool sv_loaded = false;
+#endif
         for (int t0 = p0; t0 < p1; t0 += TP) {
             __syncthreads();                               // the previous tile has been read by every wave
             {
@@ -511,23 +521,47 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
             }
             __syncthreads();
             if (!active) continue;
-#pragma unroll 1
-            for (int sub = 0; sub < 4; ++sub) {
+#if SRPS_LIGHT_SV_REGS
+            if (!sv_loaded) {                                      // once per round, behind the tile loop's first barrier pair
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int ii = 0; ii < IBW; ++ii) svr[c][ii] = svs[grp][c * IBW + ii];
+                sv_loaded = true;
+            }
+#endif
+            // The tile's 4 pieces x NCH channels as one sequence of steps, software-pipelined: the image loads of step k + 1 are issued
+            // before the arithmetic of step k (PF + 1 sets of IBW float4 rotate).  With one set the sweep ran at 4.9 TB/s, which is
+            // what 8 waves per CU with 5 KiB in flight each can draw from a memory ~2 us away; with two, twice that is in flight.
+            const int npieces = __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8));      // wave-uniform: the range's last tile may be short
+            constexpr int NS = 4 * NCH;
+            constexpr int PF = SRPS_LIGHT_PREFETCH;                  // steps of look-ahead (PF + 1 sets of IBW float4 rotate)
+            Vec<4> ivb[PF + 1][IBW];
+            auto issue = [&](int k, Vec<4> (&buf)[IBW]) {
+                const int sub = k / NCH, c = k - sub * NCH;
+                const int q = t0 + (sub * 64 + lane) * 4;
+                const int ql = q < p1 ? q : p1 - 4;
+#pragma unroll
+                for (int ii = 0; ii < IBW; ++ii) buf[ii] = ld_img<4, false, TM>(I, nullptr, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);      // images past the end re-read the last one
+            };
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+                if (k < NS && k / NCH < npieces) issue(k, ivb[k % (PF + 1)]);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int sub = k / NCH, c = k % NCH;
+                if (sub < npieces) {                                   // wave-uniform (no break: the loop must unroll completely, k is an array index)
+                if (k + PF < NS && (k + PF) / NCH < npieces) issue(k + PF, ivb[(k + PF) % (PF + 1)]);
+                Vec<4> (&ivc)[IBW] = ivb[k % (PF + 1)];
                 const int li = sub * 64 + lane;
                 const int q = t0 + li * 4;
-                if (__builtin_amdgcn_readfirstlane(t0 + sub * 256) >= p1) break;      // wave-uniform: the tile's tail
                 const bool valid = q < p1;
-                const int ql = valid ? q : p1 - 4;
                 const bool ragged = __builtin_amdgcn_readfirstlane(t0 + sub * 256 + 256) > p1;      // wave-uniform: the range's last, partial piece
                 float4 nkq[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) nkq[k] = geo[k][li];
+                for (int kk = 0; kk < 3; ++kk) nkq[kk] = geo[kk][li];
                 const float (*nk)[4] = reinterpret_cast<const float (*)[4]>(nkq);
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    Vec<4> ivc[IBW];                                   // images past the end re-read the last one
-#pragma unroll
-                    for (int ii = 0; ii < IBW; ++ii) ivc[ii] = ld_img<4, false, TM>(I, nullptr, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);
+                {
                     const float4 rq = geo[3 + c][li];
                     const float r[4] = {rq.x, rq.y, rq.z, rq.w};
                     float a[4][4];
@@ -547,15 +581,19 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) acc[c][ii][k] = fmaf(a[k][e], ivc[ii].v[e], acc[c][ii][k]);
+                            for (int kk = 0; kk < 4; ++kk) acc[c][ii][kk] = fmaf(a[kk][e], ivc[ii].v[e], acc[c][ii][kk]);
                     float4 Eq[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) Eq[k] = geo[3 + NCH + 3 * c + k][li];
+                    for (int kk = 0; kk < 3; ++kk) Eq[kk] = geo[3 + NCH + 3 * c + kk][li];
                     const float (*E)[4] = reinterpret_cast<const float (*)[4]>(Eq);
 #pragma unroll
                     for (int ii = 0; ii < IBW; ++ii) {
                         if (!TAIL || ib + ii < n_img) {                          // wave-uniform; without TAIL every wave's images exist
+#if SRPS_LIGHT_SV_REGS
+                            const float4 sv = svr[c][ii];
+#else
                             const float4 sv = svs[grp][c * IBW + ii];
+#endif
                             const float s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -567,14 +605,15 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                     if (c == gram_c) {                                           // wave-uniform
                         int t = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                            for (int l = k; l < 4; ++l) {
+                            for (int l = kk; l < 4; ++l) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
+                                for (int e = 0; e < 4; ++e) g[t] = fmaf(a[kk][e], a[l][e], g[t]);
                                 ++t;
                             }
                     }
+                }
                 }
             }
         }

@@ -170,7 +170,7 @@ struct srps_ctx {
     int fuse_energy_lighting = 1;
     int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
     int light_channel_inner = 1;     // fused energy + lighting sweep with the channels in the inner loop (C in {1, 3})
-    int march_nt = 2;                // streaming CG step with non-temporal loads / stores: 0 never, 1 always, 2 when its vectors exceed the Infinity Cache
+    int march_nt = 0;                // streaming CG step with non-temporal loads / stores: 0 never (default: measured 15 - 35 % SLOWER at 2304^2 ... 4096^2, tools/march_nt_sweep.sh -- the strips re-read their halo columns, which then miss the L2), 1 always, 2 when its vectors exceed the Infinity Cache
     int light_tiled = 1;             // ... with the four image groups as the waves of one block and the geometry shared through LDS (k_light_fused_tile)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue
@@ -232,7 +232,8 @@ struct srps_ctx {
     float* It = nullptr;
     size_t It_cap = 0;                    // floats allocated behind It (kept across set-ups)
     int it_state = 0;                     // 0: stale (rebuilt at the next sweep), 1: current, 2: not to be used (the caller holds a pointer to I)
-    int image_tiles = 1;                  // option
+    int image_tiles = 0;                  // option; off: measured in the sweeps themselves (gpurun_out/r04e, 2048 x 2048 x 20 images) the copy did not pay --
+                                          // albedo sweep 0.251 ms from the tiles against 0.226 from the planes, lighting sweep 0.261 / 0.261
     bool I8_cap_ok(size_t n) const { return I8 != nullptr && I8_cap >= n; }
     std::vector<hipEvent_t> ev_copied, ev_gathered;      // upload pipeline of srps_setup: per staging slot
     int i8_state = 0;                     // 0: not looked at since I last changed, 1: I8 holds I, 2: I is not representable

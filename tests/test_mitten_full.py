@@ -77,6 +77,7 @@ def test_hip_full_mitten_solve_to_convergence(pkg, oracle):
     print(f"Mitten: depth max-abs deviation {d_abs:.3e} (z ~ {float(np.median(srps.z())):.0f}), fx {float(K[0]):.1f}, min dz {float(dzn.min()):.1f}: normals may differ by "
           f"{amp:.3e}; albedo max-abs {alb:.3e} = {alb / (amp * float(srps.rho().max())):.2f} x that bound x max rho, RMSE {float(np.sqrt(np.mean((srps.rho() - G['final_rho']) ** 2))):.2e}")
     assert alb < 3e-3
-    assert alb <= 2.0 * amp * float(srps.rho().max())                      # the albedo deviates no more than the depth's deviation explains
+    # (measured, round 4: depth max-abs 6.8e-3 -> the normals may differ by 3.1e-2; the albedo's 1.15e-3 is 3 % of that worst case)
+    assert alb <= 0.25 * amp * float(srps.rho().max())                     # the albedo deviates no more than the depth's deviation explains
     assert float(np.sqrt(np.mean((srps.rho() - G["final_rho"]) ** 2))) < 2e-4
     ctx.close()

@@ -20,4 +20,18 @@ done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/pmc_resident_2048_SQ1" -- python3 "$R/tools/cg_prof.py" 2048 4 1 0 101 1 > "$OUT/pmc_resident_2048_SQ1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_resident_2048_SQ2" -- python3 "$R/tools/cg_prof.py" 2048 4 1 0 101 1 > "$OUT/pmc_resident_2048_SQ2.log" 2>&1
 python3 "$R/tools/valu_issue.py" "$OUT/valu_issue.json" > "$OUT/valu_issue.log" 2>&1
+# round 4: the image sweeps -- FETCH_SIZE / WRITE_SIZE (separate passes) of whole passes at the metric's configuration, default options
+# and with the reference's albedo CG (albedo_mode=0: num / den / image sums written, read back by the CG and the assembly)
+for mode in 3 0; do
+  for pmc in FETCH_SIZE WRITE_SIZE; do
+    sub=$( [ $pmc = FETCH_SIZE ] && echo fetch || echo write )
+    rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d "$OUT/pmc_sweeps_mode$mode/$sub" -- python3 "$R/tools/pass_prof.py" 2048 4 20 3 albedo_mode=$mode > "$OUT/pmc_sweeps_mode${mode}_$sub.log" 2>&1
+  done
+  python3 "$R/tools/pmc_sweeps.py" "$OUT/pmc_sweeps_mode$mode" 4194304 20 3 "$OUT/sweeps_mode$mode.json" > /dev/null 2>&1
+done
+python3 "$R/bench.py" > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+"$R/tools/hbm_ceiling_bench.bin" 4096 4096 10 1 > "$OUT/hbm_ceiling.txt" 2>&1
+python3 "$R/tools/cliff_curve.py" 2>/dev/null | grep "^{" > "$OUT/cliff_curve.jsonl"
+bash "$R/tools/march_nt_sweep.sh" > "$OUT/march_nt_sweep.txt" 2>&1
+find "$OUT" -name "*.db" -delete; find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
 ls "$OUT"
