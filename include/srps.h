@@ -310,6 +310,14 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
  * stand-in for n ranks -- the collectives are device copies, the arithmetic is the multi-GPU path's.  Every context must have
  * gone through srps_depth_partial on the same problem; afterwards each holds the new depth as after srps_depth_solve. */
 int srps_strip_group_solve(srps_ctx* const* ctxs, int n);
+/* The same group with the RESIDENT depth-CG kernel on every strip (round 4): ranges of 256 x 64 tile columns, one persistent launch per
+ * context on the context's OWN stream (the launches must run side by side: the contexts must not share a stream), sums and border
+ * edges exchanged through each other's memory while the kernels run -- no host step between the 101 CG steps (devicecalls.cu:252-275
+ * unchanged; the grid-wide sums are added in the single launch's order: the same bits as srps_depth_solve on one context).  The
+ * contexts share a device (one-GPU test bed: all occupied tiles together <= its CUs) or sit on peer devices of this process (xGMI;
+ * not exercised yet).  SRPS_ERR_UNSUPPORTED: does not fit, or the launches could not become resident together within spin_budget_ms
+ * (nothing stored; use srps_strip_group_solve). */
+int srps_strip_group_solve_resident(srps_ctx* const* ctxs, int n);
 /* The two partitions as pure functions (no device needed): rank `rank` of `world` owns the grid columns [*c0, *c0 + *width)
  * (multiples of sf; sizes differ by at most one block column) resp. the images [*begin, *begin + *count) (contiguous; sizes differ
  * by at most one). */

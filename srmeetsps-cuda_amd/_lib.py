@@ -139,6 +139,7 @@ def load():
         "srps_all_reduce": (i, [vp, C.c_char_p]),
         "srps_set_host_collectives": (i, [vp, i, i, HOST_ALLREDUCE_FN, HOST_BROADCAST_FN, vp]),
         "srps_strip_group_solve": (i, [C.POINTER(vp), i]),
+        "srps_strip_group_solve_resident": (i, [C.POINTER(vp), i]),
         "srps_strip_range": (i, [i, i, i, i, ip, ip]),
         "srps_shard_range": (i, [i, i, i, ip, ip]),
         "srps_device_count": (i, [ip]),

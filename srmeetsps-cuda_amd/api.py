@@ -301,6 +301,13 @@ class Context:
         arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
         check(_lib.load().srps_strip_group_solve(arr, len(contexts)))
 
+    @staticmethod
+    def strip_group_solve_resident(contexts):
+        """the same with the resident CG kernel on every strip: one persistent launch per context, each on its own stream, sums and
+        border edges exchanged through each other's memory while the kernels run"""
+        arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+        check(_lib.load().srps_strip_group_solve_resident(arr, len(contexts)))
+
     def comm_release(self):
         check(self.lib.srps_comm_release(self.h))
 

@@ -168,6 +168,20 @@ __device__ __forceinline__ bool spin_block_dead() {
     return spin_state()->dead != 0;
 }
 
+// Several launches as ONE grid (round 4: the resident depth CG on the column strips of a multi-GPU partition, kernels_resident.hip): the
+// granule arrays of the exchange exist once per launch ("rank"), every block publishes its granule into ITS slot of every rank's
+// array -- its own and, through peer pointers, the others' -- and polls its own rank's array only.  nb slots for the blocks of the
+// whole group, in the order a single launch over all tiles would give them: the sums are added in that order, bit for bit as there.
+// Stores and polls are system scope then (the arrays may sit in another device's memory).  A null pointer where the functions below take
+// a GridPeers means: one launch, slots = blocks, device scope -- and folds away at compile time.
+struct GridPeers {
+    int nb;                              // granule slots = blocks of the whole group
+    int slot;                            // this block's slot
+    int n_peers;                         // the OTHER ranks
+    unsigned long long* ent[7];          // their 8-byte granule arrays [2][nb]
+    unsigned long long* ent3[7];         // their 16-byte granule arrays [2][nb rounded up to 256]
+};
+
 // ---- grid-wide sum of a persistent (cooperative) launch: blocks of up to 1024 threads (a multiple of 64) ----
 // No read-modify-write atomics (256 device-scope atomics on one address serialise in the fabric: the library's grid
 // barrier costs 33 us on 256 CUs).  Every block publishes {generation, partial sum} as one 64-bit device-scope store;
@@ -175,7 +189,7 @@ __device__ __forceinline__ bool spin_block_dead() {
 // generation; more polling waves cost fabric bandwidth: 8 per block made the step 15 % slower) and adds them in a fixed
 // order, in double: all blocks obtain the same bits.  Nothing but these entries travels between blocks, so no other fences are needed.  Two slots per
 // block: a block can be at most one reduction ahead of the slowest one.  sm: 40 floats (blocks of at most 16 waves).
-__device__ __forceinline__ void grid_sum_publish(float v, unsigned long long* ent, unsigned gen, float* sm) {
+__device__ __forceinline__ void grid_sum_publish(float v, unsigned long long* ent, unsigned gen, float* sm, const GridPeers* gp = nullptr) {
     const int tid = threadIdx.x, nw = (int)blockDim.x >> 6;
     float* s = sm + (gen & 1u) * 16;                       // alternating: the previous reduction may still be read
     const float t = wave_total(v);
@@ -184,13 +198,17 @@ __device__ __forceinline__ void grid_sum_publish(float v, unsigned long long* en
     if (tid == 0) {
         float tot = 0.f;
         for (int i = 0; i < nw; ++i) tot += s[i];
-        __hip_atomic_store(&ent[(size_t)(gen & 1u) * gridDim.x + blockIdx.x],
-                           ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(tot), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long g = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(tot);
+        if (gp) {
+            const size_t at = (size_t)(gen & 1u) * gp->nb + gp->slot;
+            __hip_atomic_store(&ent[at], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int q = 0; q < gp->n_peers; ++q) __hip_atomic_store(&gp->ent[q][at], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else
+            __hip_atomic_store(&ent[(size_t)(gen & 1u) * gridDim.x + blockIdx.x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsigned gen, float* sm) {
-    const int nb = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsigned gen, float* sm, const GridPeers* gp = nullptr) {
+    const int nb = gp ? gp->nb : (int)gridDim.x, tid = threadIdx.x, lane = tid & 63;
     const unsigned long long* slot = ent + (size_t)(gen & 1u) * nb;
     float* res = sm + 32 + (gen & 1u);                     // behind the two sets of wave partials
     if (tid < 64) {                                        // one polling wave per block: pollers cost fabric bandwidth
@@ -202,7 +220,8 @@ __device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsig
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = base + 4 * lane + i;
-                w[i] = (idx < nb) ? __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)gen << 32);
+                w[i] = (idx < nb) ? (gp ? __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                  : ((unsigned long long)gen << 32);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -210,7 +229,7 @@ __device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsig
                 while (!gave_up && (unsigned)(w[i] >> 32) != gen) {
                     if (spin_expired(polls)) { gave_up = true; break; }
                     __builtin_amdgcn_s_sleep(SRPS_POLL_SLEEP);
-                    w[i] = __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w[i] = gp ? __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(&slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 a += (double)__uint_as_float((unsigned)w[i]);
             }
@@ -226,9 +245,9 @@ __device__ __forceinline__ float grid_sum_collect(unsigned long long* ent, unsig
     __syncthreads();
     return *res;
 }
-__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm) {
-    grid_sum_publish(v, ent, gen, sm);
-    return grid_sum_collect(ent, gen, sm);
+__device__ __forceinline__ float grid_sum(float v, unsigned long long* ent, unsigned gen, float* sm, const GridPeers* gp = nullptr) {
+    grid_sum_publish(v, ent, gen, sm, gp);
+    return grid_sum_collect(ent, gen, sm, gp);
 }
 
 // Three sums in one exchange. A block publishes ONE 16-byte granule {generation, v0, v1, v2} (partial sums float per
@@ -256,8 +275,25 @@ __device__ __forceinline__ void grid_sum3_prepare() {
     if (threadIdx.x < 2) grid_sum3_arrived()[threadIdx.x] = 0u;
 }
 template <int NW = 0, bool FLOAT32 = false>      // NW: waves per block when known at compile time (the cross-wave sum is then one LDS round trip)
-__device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen, unsigned long long* st = nullptr) {
-    const int tid = threadIdx.x, nw = NW ? NW : (int)blockDim.x >> 6, nb = gridDim.x;
+__device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, unsigned long long* ent3, unsigned gen, unsigned long long* st = nullptr,
+                                                  const GridPeers* gp = nullptr) {
+    const int tid = threadIdx.x, nw = NW ? NW : (int)blockDim.x >> 6, nb = gp ? gp->nb : (int)gridDim.x, myslot = gp ? gp->slot : (int)blockIdx.x;
+    // the granule into this block's slot of the rank's own array and, in a group, of every other rank's
+    auto store_granule = [&](const srps_v4u& g) {
+        const int nbr = (nb + 255) & ~255;
+        const size_t at = ((size_t)(gen & 1u) * nbr + myslot) * SRPS_G3_STRIDE;
+        const char* dst = reinterpret_cast<const char*>(ent3) + at;
+        // s_nop 1: a store of more than 8 bytes must not be followed within two wait states by a write of its data registers
+        // (gfx940 and later; the compiler inserts them for its own stores, it cannot see into the asm)
+        if (gp) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
+            for (int q = 0; q < gp->n_peers; ++q) {
+                const char* d2 = reinterpret_cast<const char*>(gp->ent3[q]) + at;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(d2), "v"(g) : "memory");
+            }
+        } else
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
+    };
     if constexpr (NW > 0 && FLOAT32) {
         // Every wave leaves its three totals in LDS and counts itself in; the wave that arrives LAST adds the NW entries in
         // their fixed order and publishes the granule -- the block's sums leave as soon as its slowest wave is done, without
@@ -280,9 +316,7 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
 #pragma unroll
                 for (int i = 0; i < NW; ++i) { const float* e = sf[gen & 1u][i]; f[0] += e[0]; f[1] += e[1]; f[2] += e[2]; }
                 const srps_v4u g = {gen, __float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2])};
-                const int nbr = (nb + 255) & ~255;
-                const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
+                store_granule(g);
                 if (st) st[0] = __builtin_amdgcn_s_memrealtime();
             }
         }
@@ -310,17 +344,14 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
             for (int i = 0; i < nw; ++i) { const double* d = sd[gen & 1u][i]; tot[0] += d[0]; tot[1] += d[1]; tot[2] += d[2]; }
         }
         const srps_v4u g = {gen, __float_as_uint((float)tot[0]), __float_as_uint((float)tot[1]), __float_as_uint((float)tot[2])};
-        const int nbr = (nb + 255) & ~255;
-        const char* dst = reinterpret_cast<const char*>(ent3) + ((size_t)(gen & 1u) * nbr + blockIdx.x) * SRPS_G3_STRIDE;
-        // s_nop 1: a store of more than 8 bytes must not be followed within two wait states by a write of its data registers
-        // (gfx940 and later; the compiler inserts them for its own stores, it cannot see into the asm)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
+        store_granule(g);
         if (st) st[0] = __builtin_amdgcn_s_memrealtime();
     }
 }
 template <bool FLOAT32 = false>
-__device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsigned gen, double& o0, double& o1, double& o2, unsigned long long* st = nullptr) {
-    const int nb = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsigned gen, double& o0, double& o1, double& o2, unsigned long long* st = nullptr,
+                                                  const GridPeers* gp = nullptr) {
+    const int nb = gp ? gp->nb : (int)gridDim.x, tid = threadIdx.x, lane = tid & 63;
     __shared__ double res3[2][3];
     if (tid < 64) {                                        // one polling wave per block
         double acc[3] = {0.0, 0.0, 0.0};
@@ -338,6 +369,14 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
             const unsigned want2 = (base + lane + 128 < nb) ? gen : 0u, want3 = (base + lane + 192 < nb) ? gen : 0u;
             bool first = true;
             for (;;) {
+                if (gp)
+                    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                                 "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+                                 "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+                                 "s_waitcnt vmcnt(0)"
+                                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(src), "v"(s1), "v"(s2), "v"(s3) : "memory");
+                else
                 asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
                              "global_load_dwordx4 %1, %5, off sc1\n\t"
                              "global_load_dwordx4 %2, %6, off sc1\n\t"

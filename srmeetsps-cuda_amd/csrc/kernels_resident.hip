@@ -184,6 +184,12 @@ struct ResidentArgs {
     const uint8_t* tile_cls;   // [tiles] TILE_* bits per tile (kernels_structure.hip), nullptr: every tile takes the general body
     const uint8_t* tile_occ;   // [tiles] the same array, always: TILE_OCCUPIED says whether a neighbouring tile has a block at all
     const int* tile_list;      // [blocks] the occupied tiles, ascending: block b works on tile tile_list[b]
+    // ---- several launches as one grid (GROUP kernels: the ranks of a strip partition, srps_strip_group_solve_resident) ----
+    GridPeers grp;             // slots of the whole group's blocks, the other ranks' granule arrays (grp.slot is set per block)
+    int grp_list_base;         // index of this rank's first tile in the GROUP's ascending tile list (tile_list holds the rank's own tiles)
+    int grp_bc_first, grp_bc_last;       // the rank's first / last column of tiles
+    unsigned long long* grp_halo_left;   // the edge-granule arrays of the ranks to the left / right (null: none): same layout, global tile numbers
+    unsigned long long* grp_halo_right;
 };
 
 // per-channel constants of the tensor-recompute form (uniform)
@@ -218,8 +224,8 @@ __device__ unsigned long long g_wstamps[64 * 64 * 8 * 16];
 // column (SRPS.cu:35-38, 43-46).  No structure bits are decoded: the two edge cases are selects on loop-invariant lane
 // masks.  The arithmetic per pixel is that of the general body (the masked-out terms there are additions of 0), so the two
 // bodies agree bit for bit up to the sign of zeros.
-template <int SF, int NC, bool ONE_SYNC, bool RECT>
-__device__ __forceinline__ void resident_body(const ResidentArgs& a, const int tile, const unsigned cls) {
+template <int SF, int NC, bool ONE_SYNC, bool RECT, bool GROUP = false>
+__device__ __forceinline__ void resident_body(const ResidentArgs& a, const int tile, const unsigned cls, const GridPeers* gp = nullptr) {
     extern __shared__ float4 lds4[];
     // LDS map: [NC==3: g0, g1 as float4 [CPT][NT]] | ex, ex2 (float4 [NT]) | ring (floats): hp, hg[NC], hfl | sm, sflag | ucol
     constexpr int GL = (NC == 3) ? 2 : 0;                 // g planes kept in LDS
@@ -743,8 +749,25 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             if (wave == 0 || wave == NWV - 1) {
                 const F4& rc = (wave == 0) ? src[0] : src[CPT - 1];
                 unsigned long long* d = hb + (wave == 0 ? 0 : TR) + 4 * lane;
+                if constexpr (GROUP) {
+                    // a tile in the strip's first / last column of tiles: its first / last column is the ring column of a tile on the
+                    // neighbouring rank -- the same granules, also into that rank's array (system scope: it may be another device's memory)
+                    auto store2s = [&](unsigned long long* dd, float v0, float v1) {
+                        const srps_v4u g = {__float_as_uint(v0), hgen, __float_as_uint(v1), hgen};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(dd), "v"(g) : "memory");
+                    };
+                    store2s(d, rc.e[0], rc.e[1]);
+                    store2s(d + 2, rc.e[2], rc.e[3]);
+                    unsigned long long* peer = (wave == 0) ? ((bc == a.grp_bc_first) ? a.grp_halo_left : nullptr) : ((bc == a.grp_bc_last) ? a.grp_halo_right : nullptr);
+                    if (peer) {                                            // wave-uniform
+                        unsigned long long* d2 = peer + (d - a.halo);
+                        store2s(d2, rc.e[0], rc.e[1]);
+                        store2s(d2 + 2, rc.e[2], rc.e[3]);
+                    }
+                } else {
                 store2(d, rc.e[0], rc.e[1]);
                 store2(d + 2, rc.e[2], rc.e[3]);
+                }
             }
             if (lane == 0 || lane == 63) {
                 unsigned long long* d = hb + 2 * TR + (lane == 0 ? 0 : TC) + CPT * wave;
@@ -759,7 +782,8 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
                 hv[q] = (hoff[q] >= 0 && !(SRPS_RES_DEBUG_ON(a)))
-                            ? __hip_atomic_load(a.halo + hoff[q] + (hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                            ? (GROUP ? __hip_atomic_load(a.halo + hoff[q] + (hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                     : __hip_atomic_load(a.halo + hoff[q] + (hgen & 1u) * HALO_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0ull;
         };
         auto await_ring = [&](float (&val)[RPT]) {
 #pragma unroll
@@ -771,7 +795,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                         // the clock is read by the scalar unit (no counter register); uniform for the lanes still waiting
                         if (spin_deadline_passed()) { spin_give_up(-1, hgen); break; }
                         __builtin_amdgcn_s_sleep(1);
-                        hv[q] = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hv[q] = GROUP ? __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     val[q] = __uint_as_float((unsigned)hv[q]);
                 }
@@ -797,21 +821,21 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                         red = fmaf(r[c].e[e], r[c].e[e], red);
                     }
                 ++gen;
-                grid_sum_publish(red, a.ent, gen, sm);
+                grid_sum_publish(red, a.ent, gen, sm, gp);
                 request_ring();
-                r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : grid_sum_collect(a.ent, gen, sm));
+                r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : grid_sum_collect(a.ent, gen, sm, gp));
                 r1_anchor = r1;
                 await_ring(wr);
 #pragma unroll
                 for (int q = 0; q < RPT; ++q) rh[q] -= wr[q];
             } else {
                 ++gen;
-                grid_sum3_publish<NWV, true>(red, red_rw, red_ww, a.ent3, gen, SRPS_STAMP_PTR);
+                grid_sum3_publish<NWV, true>(red, red_rw, red_ww, a.ent3, gen, SRPS_STAMP_PTR, gp);
                 request_ring();
                 SRPS_STAMP(5);
                 double pw, rw, ww;
                 if (SRPS_RES_DEBUG_ON(a)) { pw = 1e30; rw = 0.0; ww = 0.0; }
-                else grid_sum3_collect<true>(a.ent3, gen, pw, rw, ww, SRPS_STAMP_PTR);
+                else grid_sum3_collect<true>(a.ent3, gen, pw, rw, ww, SRPS_STAMP_PTR, gp);
                 SRPS_STAMP(6);
                 alpha = r1 / (float)pw;                    // dc.cu:269
                 asm volatile("" : "+v"(alpha));
@@ -842,7 +866,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 // (A step counter kept in a register instead of k & 15 cost 1.4 us per step in code generation.)
                 if ((SRPS_RES_DEBUG_ON(a)) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
                     r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : (float)pred);
-                else { r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm)); r1_anchor = r1; }
+                else { r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm, gp)); r1_anchor = r1; }
             }
             // ---- the next step's p = beta p + r, own pixels and ring (dc.cu:256-264), here, where r.r has just become known: at the
             // top of the next pass it cost a phase of its own behind the loop's turn.  After pass 0: beta = 0, p = 0 p + r = r.
@@ -872,7 +896,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                         red = fmaf(r[c].e[e], r[c].e[e], red);
                     }
             } else {
-                const float dot = (SRPS_RES_DEBUG_ON(a)) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm);
+                const float dot = (SRPS_RES_DEBUG_ON(a)) ? fmaxf(block_sum(red, sm), 1e30f) : grid_sum(red, a.ent, ++gen, sm, gp);
                 alpha = r1 / dot;                              // dc.cu:269
                 asm volatile("" : "+v"(alpha));
                 // ---- x += alpha p ; r -= alpha omega ; r.r ------------------------------------------------------------
@@ -893,9 +917,9 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             if (SRPS_RES_DEBUG_ON(a)) r1 = uniform_f(fminf(fmaxf(block_sum(red, sm), 1.f), 2.f));
             else {
                 ++gen;
-                grid_sum_publish(red, a.ent, gen, sm);
+                grid_sum_publish(red, a.ent, gen, sm, gp);
                 request_ring();
-                r1 = uniform_f(grid_sum_collect(a.ent, gen, sm));
+                r1 = uniform_f(grid_sum_collect(a.ent, gen, sm, gp));
                 float rv[RPT];
                 await_ring(rv);
 #pragma unroll
@@ -950,6 +974,33 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     tile = a.tile_list[tile];                              // one block per occupied tile
     const unsigned cls = RECT ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.tile_cls[tile]) : 0u;
     resident_body<SF, NC, ONE_SYNC, RECT>(a, tile, cls);
+}
+
+// The same body as one RANK of a group of launches that together cover the grid (srps_strip_group_solve_resident): the rank's blocks
+// work on its own tiles (a.tile_list, a column range of tiles), publish their sums into the slot a single launch over the whole
+// grid would give them -- in every rank's array -- and the tiles on the strip's border also leave their edge columns with the
+// neighbouring rank.  Same arithmetic per block, same order of the grid-wide sums: the same bits as the single launch.
+template <int SF, int NC, bool ONE_SYNC, bool RECT>
+__global__ __launch_bounds__(NT) void k_cg_resident_group(ResidentArgs a) {
+    __shared__ GridPeers gps;
+    int li = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = li & 7, kk = li >> 3;
+        li = xcd * q + min(xcd, rem) + kk;                 // XCD-aware order inside the rank's own launch
+    }
+    const int tile = a.tile_list[li];
+    if (threadIdx.x == 0) {
+        // the block index that the single launch's XCD-aware order (k_cg_resident) maps onto entry L of the group's tile list
+        const int L = a.grp_list_base + li, NB = a.grp.nb, q = NB >> 3, rem = NB & 7;
+        int xcd, kk;
+        if (L < rem * (q + 1)) { xcd = L / (q + 1); kk = L - xcd * (q + 1); }
+        else { const int L2 = L - rem * (q + 1); xcd = rem + L2 / q; kk = L2 - (L2 / q) * q; }
+        gps = a.grp;
+        gps.slot = kk * 8 + xcd;
+    }
+    __syncthreads();
+    const unsigned cls = RECT ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.tile_cls[tile]) : 0u;
+    resident_body<SF, NC, ONE_SYNC, RECT, true>(a, tile, cls, &gps);
 }
 
 size_t resident_lds_bytes(int NC) {
@@ -1031,6 +1082,157 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
 }
 
 #if SRPS_RES_NT == 512 && SRPS_RES_CPT == 8
+// ---- the resident CG on the column strips of a group of contexts ----------------------------------------
+// n contexts that hold the SAME assembled depth system (replicated state, as after srps_depth_partial on every one) each run the
+// resident kernel on a range of tile columns; together the launches cover the grid.  What crosses the ranks inside a CG step is what
+// crosses the blocks of the single launch: the 16-byte granules of the three sums (every block into every rank's array) and the
+// 8-byte edge granules of the tiles on a strip's border (into the neighbouring rank's array) -- plain stores through pointers into
+// the other rank's memory: the same device (several contexts of one process: the test bed of a one-GPU box) or a peer device over
+// xGMI (hipDeviceEnablePeerAccess; not run anywhere yet).  No host step between the 101 CG steps.  All launches must be resident
+// TOGETHER: plain launches on the contexts' own streams (cooperative launches of one device queue one behind the other), the bounded
+// waits of device_utils.h end a group that cannot be (SRPS_ERR_UNSUPPORTED after the budget; nothing is stored).
+int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_steps) {
+    SRPS_REQUIRE(n >= 1 && n <= 8, SRPS_ERR_INVALID, "resident strip group: 1 .. 8 ranks");
+    srps_ctx* c0 = ctxs[0];
+    const Grid& G0 = c0->grid;
+    const int nc = march_recompute_channels(c0);
+    SRPS_REQUIRE((nc == 1 || nc == 3) && (G0.sf == 1 || G0.sf == 2 || G0.sf == 4) && use_march(c0), SRPS_ERR_UNSUPPORTED,
+                 "resident strip group: needs the tensor-recompute operator (1 or 3 channels, sf 1, 2 or 4)");
+    const int nbr = cdiv(G0.Hg, TR), nbc = cdiv(G0.Wg, TC), tiles = nbr * nbc, shape = 1;      // 256 x 64 tiles
+    SRPS_REQUIRE(nbc >= n, SRPS_ERR_INVALID, "resident strip group: %d ranks for %d columns of tiles", n, nbc);
+    const int NB = G0.n_occ[shape];
+    SRPS_REQUIRE(NB > 0 && G0.n_tiles[shape] == tiles, SRPS_ERR_STATE, "resident strip group: no tile list for the 256 x 64 tiling");
+    // the group's ascending tile list (the same on every rank): tiles are numbered column by column, so a range of tile columns is
+    // a contiguous piece of it
+    std::vector<int> list((size_t)NB);
+    SRPS_HIP(hipSetDevice(c0->device));
+    SRPS_HIP(hipMemcpy(list.data(), G0.d_tile_list[shape], (size_t)NB * sizeof(int), hipMemcpyDeviceToHost));
+    const bool rect = c0->cg_resident_rect && G0.n_rect_tiles[shape] == NB;
+    std::vector<int> tc0(n + 1), lbase(n + 1);
+    for (int r = 0; r <= n; ++r) tc0[r] = (int)((long long)nbc * r / n);
+    for (int r = 0, i = 0; r <= n; ++r) {
+        while (i < NB && list[(size_t)i] / nbr < tc0[r]) ++i;
+        lbase[r] = i;
+    }
+    bool one_device = true;
+    for (int r = 0; r < n; ++r) {
+        srps_ctx* c = ctxs[r];
+        SRPS_REQUIRE(c->grid.Hg == G0.Hg && c->grid.Wg == G0.Wg && c->grid.sf == G0.sf && c->grid.Hs == G0.Hs && c->grid.n_occ[shape] == NB, SRPS_ERR_INVALID,
+                     "resident strip group: rank %d holds another grid", r);
+        SRPS_REQUIRE(march_recompute_channels(c) == nc, SRPS_ERR_INVALID, "resident strip group: rank %d has another operator form", r);
+        for (int q = 0; q < r; ++q)
+            SRPS_REQUIRE(ctxs[q]->stream != c->stream, SRPS_ERR_INVALID, "resident strip group: ranks %d and %d share a stream (their launches must run side by side)", q, r);
+        SRPS_REQUIRE(lbase[r + 1] - lbase[r] <= c->num_cus, SRPS_ERR_UNSUPPORTED, "resident strip group: rank %d has %d tiles for %d CUs", r, lbase[r + 1] - lbase[r], c->num_cus);
+        one_device = one_device && c->device == c0->device;
+    }
+    SRPS_REQUIRE(!one_device || NB <= c0->num_cus, SRPS_ERR_UNSUPPORTED, "resident strip group: %d tiles on one device of %d CUs", NB, c0->num_cus);
+    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
+    const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
+    const size_t lds = resident_lds_bytes(nc);
+    std::vector<ResidentArgs> args((size_t)n);
+    std::vector<hipEvent_t> ready((size_t)n, nullptr), done((size_t)n, nullptr);
+    auto cleanup = [&]() { for (auto e : ready) if (e) (void)hipEventDestroy(e); for (auto e : done) if (e) (void)hipEventDestroy(e); };
+    int rc = SRPS_OK;
+    for (int r = 0; r < n && rc == SRPS_OK; ++r) {
+        srps_ctx* c = ctxs[r];
+        Grid& G = c->grid;
+        if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+        if (!one_device)
+            for (int q = 0; q < n; ++q)
+                if (ctxs[q]->device != c->device) { (void)hipDeviceEnablePeerAccess(ctxs[q]->device, 0); (void)hipGetLastError(); }
+        if ((rc = ensure(c->ws_resident, need)) != SRPS_OK) break;
+        if (hipMemsetAsync(c->ws_resident.p, 0, need, c->stream) != hipSuccess || hipEventCreateWithFlags(&ready[(size_t)r], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&done[(size_t)r], hipEventDisableTiming) != hipSuccess || hipEventRecord(ready[(size_t)r], c->stream) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+        ResidentArgs& a = args[(size_t)r];
+        memset(&a, 0, sizeof(a));
+        a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.x_out = G.d_x2; a.r = G.d_r;
+        a.ent = (unsigned long long*)c->ws_resident.p; a.ent3 = a.ent + ent_n; a.halo = a.ent3 + ent3_n;
+        a.scal = G.d_scal;
+        a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = nbr; a.nbc = nbc;
+        a.lambda = c->lambda; a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
+        a.tol2 = fixed_steps ? -1.f : c->cg_tol * c->cg_tol; a.max_steps = max_steps;
+        a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
+        a.spin_ticks = (unsigned long long)c->spin_budget_ms * 100000ull;
+        a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr; a.tile_occ = G.d_tile_cls[shape];
+        a.tile_list = G.d_tile_list[shape] + lbase[r];
+        a.grp.nb = NB; a.grp.slot = 0; a.grp_list_base = lbase[r];
+        a.grp_bc_first = tc0[r]; a.grp_bc_last = tc0[r + 1] - 1;
+    }
+    // every rank's arrays are known now: the peers' pointers
+    for (int r = 0; r < n && rc == SRPS_OK; ++r) {
+        ResidentArgs& a = args[(size_t)r];
+        int np = 0;
+        for (int q = 0; q < n; ++q)
+            if (q != r) { a.grp.ent[np] = args[(size_t)q].ent; a.grp.ent3[np] = args[(size_t)q].ent3; ++np; }
+        a.grp.n_peers = np;
+        a.grp_halo_left = r > 0 ? args[(size_t)r - 1].halo : nullptr;
+        a.grp_halo_right = r + 1 < n ? args[(size_t)r + 1].halo : nullptr;
+    }
+    // launches: every rank waits until ALL granule arrays are zeroed, then runs on its own stream, plain launch
+    for (int r = 0; r < n && rc == SRPS_OK; ++r) {
+        srps_ctx* c = ctxs[r];
+        if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+        for (int q = 0; q < n; ++q)
+            if (q != r && hipStreamWaitEvent(c->stream, ready[(size_t)q], 0) != hipSuccess) rc = SRPS_ERR_HIP;
+        if (rc != SRPS_OK) break;
+        const int blocks = lbase[r + 1] - lbase[r];
+        if (blocks == 0) { (void)hipEventRecord(done[(size_t)r], c->stream); continue; }      // a strip without a masked pixel
+        const void* fn = nullptr;
+        const int sf = c->grid.sf;
+#define SRPS_RESG(SFV, NCV) fn = rect ? (const void*)k_cg_resident_group<SFV, NCV, true, true> : (const void*)k_cg_resident_group<SFV, NCV, true, false>
+        if (sf == 4) { if (nc == 3) SRPS_RESG(4, 3); else SRPS_RESG(4, 1); }
+        else if (sf == 2) { if (nc == 3) SRPS_RESG(2, 3); else SRPS_RESG(2, 1); }
+        else { if (nc == 3) SRPS_RESG(1, 3); else SRPS_RESG(1, 1); }
+#undef SRPS_RESG
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); rc = SRPS_ERR_UNSUPPORTED; break; }
+        c->persistent_inflight = 1;
+        void* kargs[] = {&args[(size_t)r]};
+        if (hipLaunchKernel(fn, dim3(blocks), dim3(NT), kargs, lds, c->stream) != hipSuccess) { (void)hipGetLastError(); rc = SRPS_ERR_HIP; break; }
+        (void)hipEventRecord(done[(size_t)r], c->stream);
+    }
+    // wait for all of them; did every wait get served?
+    bool aborted = false;
+    for (int r = 0; r < n; ++r) {
+        srps_ctx* c = ctxs[r];
+        (void)hipSetDevice(c->device);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = rc == SRPS_OK ? SRPS_ERR_HIP : rc;
+        CgScalars hs;
+        if (hipMemcpy(&hs, c->grid.d_scal, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess && hs.abort_flags) {
+            aborted = true;
+            (void)hipMemset(&c->grid.d_scal->abort_flags, 0, 3 * sizeof(int));
+        }
+        c->persistent_inflight = 0;
+    }
+    if (rc == SRPS_OK && aborted) {
+        cleanup();
+        set_error("resident strip group: the %d launches did not become resident together within %d ms (shared device?); nothing was stored", n, c0->spin_budget_ms);
+        return SRPS_ERR_UNSUPPORTED;
+    }
+    // the result: every rank's strip is in its second plane; the planes swap roles and the strips travel to the other ranks
+    for (int r = 0; r < n && rc == SRPS_OK; ++r) {
+        srps_ctx* c = ctxs[r];
+        Grid& G = c->grid;
+        if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+        // the columns of the other strips in the result plane: they arrive below; until then the plane must not be read
+        std::swap(G.d_x, G.d_x2);
+    }
+    for (int r = 0; r < n && rc == SRPS_OK; ++r) {
+        srps_ctx* c = ctxs[r];
+        if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+        for (int q = 0; q < n; ++q) {
+            if (q == r) continue;
+            const int cb = tc0[q] * TC, ce = std::min(tc0[q + 1] * TC, G0.Wg);
+            if (ce <= cb) continue;
+            const size_t off = (size_t)(cb + PAD) * G0.Hs, cnt = (size_t)(ce - cb) * G0.Hs;
+            if (hipMemcpyAsync(c->grid.d_x + off, ctxs[q]->grid.d_x + off, cnt * sizeof(float), hipMemcpyDefault, c->stream) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+        }
+    }
+    for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); (void)hipStreamSynchronize(ctxs[r]->stream); }
+    cleanup();
+    if (rc != SRPS_OK) set_error("resident strip group: a HIP call failed (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 // the smallest tile that still gives every tile a CU (more CUs at work, less arithmetic per CU and step);
 // cg_resident_tile = 16 | 256 | 512 forces the 256 x 16, 256 x 32 or 256 x 64 shape
 static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 4: 256 x 16 with 512 threads, 3: 256 x 32 with 512 threads, 0: 256 x 32 with 256, 1: 256 x 64, -1: none fits

@@ -330,6 +330,7 @@ int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, vo
 bool resident_supported(const srps_ctx* ctx);
 bool resident_rect_active(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
+int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_steps);      // the resident kernel on column strips of several contexts
 bool resident_supported_n512(const srps_ctx* ctx);       // the three tile shapes (kernels_resident.hip, kernels_resident_n256.hip, kernels_resident_n256c4.hip)
 bool resident_supported_n256(const srps_ctx* ctx);
 bool resident_supported_n256c4(const srps_ctx* ctx);

@@ -256,6 +256,26 @@ int srps_strip_group_solve(srps_ctx* const* ctxs, int n) {
 }
 
 
+// The same group with the RESIDENT kernel on every strip (kernels_resident.hip: resident_cg_group): the strips are ranges of
+// 256 x 64 tile columns, every context launches the persistent CG kernel on its own tiles, on its OWN stream, and the launches
+// exchange their sums and border edges through each other's memory while they run -- no host step, no collective between the
+// 101 CG steps.  The contexts may share a device (all tiles together must then fit its CUs: the one-GPU test bed) or sit on peer
+// devices of one process.  Results: those of the single resident launch, bit for bit (tests/test_gpu_strips.py).
+// SRPS_ERR_UNSUPPORTED: the grid does not fit this form, or the launches could not be resident together (nothing stored: call
+// srps_strip_group_solve, the streaming strips, instead).
+int srps_strip_group_solve_resident(srps_ctx* const* ctxs, int n) {
+    SRPS_REQUIRE(ctxs != nullptr && n >= 1 && n <= 8, SRPS_ERR_INVALID, "strip_group_solve_resident: 1 .. 8 contexts");
+    for (int i = 0; i < n; ++i) {
+        SRPS_REQUIRE(ctxs[i] != nullptr && ctxs[i]->have_state && ctxs[i]->tensor_valid, SRPS_ERR_STATE, "strip_group_solve_resident: context %d has no assembled depth system (srps_depth_partial)", i);
+        strips_clear_view(ctxs[i]);
+    }
+    int rc = SRPS_OK;
+    for (int i = 0; i < n && rc == SRPS_OK; ++i) { (void)hipSetDevice(ctxs[i]->device); rc = depth_solve_prepare(ctxs[i]); }
+    if (rc == SRPS_OK) rc = resident_cg_group(ctxs, n, ctxs[0]->cg_max_iter + 1, false);
+    for (int i = 0; i < n && rc == SRPS_OK; ++i) { (void)hipSetDevice(ctxs[i]->device); rc = depth_solve_finish(ctxs[i]); }
+    return rc;
+}
+
 // The partitions themselves, as pure functions (no device): the columns [*c0, *c0 + *width) of a grid of `grid_cols` columns that rank
 // `rank` of `world` owns (multiples of sf, sizes differ by at most one block column), and the images [*begin, *begin + *count)
 // of a shard (contiguous, sizes differ by at most one) -- what srps_depth_solve / the C++ host / api.shard_range use.

@@ -231,3 +231,82 @@ def test_albedo_abort_with_strips_repeats_from_the_pass_start_plane(pkg, tmp_pat
     # focal length -- tests/test_mitten_full.py; measured 1.1e-4 on the worst pixel)
     assert np.abs(got[0]["rho1"] - ref["rho1"]).max() < 5e-4
     assert abs(float(got[0]["e1"]) - float(ref["e1"])) <= 1e-5 * abs(float(ref["e1"]))
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: the RESIDENT kernel on the strips (srps_strip_group_solve_resident)
+# ------------------------------------------------------------------------------------------------
+def _resident_single(pkg, dh):
+    c = pkg.Context(device_id=0)
+    c.set_option("cg_resident_tile", 512)                  # 256 x 64 tiles: the shape the strip group runs
+    c.setup(dh)
+    c.lighting(); c.albedo()
+    e = c.depth()
+    assert c.get_option("cg_resident_active") == 1 and c.get_option("persistent_fallbacks") == 0
+    out = (e, c.get("z"), c.last_cg_iterations()["depth"], c.get_option("cg_resident_rect_active"))
+    c.close()
+    return out
+
+
+def _resident_group(pkg, dh, world):
+    ctxs = []
+    for _ in range(world):
+        c = pkg.Context(device_id=0)                       # every context keeps its OWN stream: the launches must run side by side
+        c.set_option("cg_resident_tile", 512)
+        c.setup(dh)
+        ctxs.append(c)
+    for c in ctxs:
+        c.lighting(); c.albedo(); c.depth_partial()
+    for c in ctxs:
+        c.synchronize()
+    pkg.Context.strip_group_solve_resident(ctxs)
+    out = []
+    for c in ctxs:
+        c.energy_partial(); c.normals()
+        e = c.energy_finish()
+        out.append((e, c.get("z"), c.last_cg_iterations()["depth"]))
+        c.close()
+    return out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("h,w,sf,kind,world", [(1024, 2048, 4, "full", 1), (1024, 2048, 4, "full", 2), (1024, 2048, 4, "full", 4), (1024, 1536, 2, "ellipse", 3),
+                                               (2048, 2048, 4, "full", 2), (768, 1280, 1, "ragged", 2)])
+def test_resident_kernel_on_strips_equals_the_single_resident_launch_bit_for_bit(pkg, h, w, sf, kind, world):
+    """The resident depth CG as `world` launches, one per context, each on its own range of 256 x 64 tile columns, side by side on this
+    one device and exchanging the three sums of a step and the border tiles' edge columns through each other's memory while they run
+    (the multi-GPU form of the kernel, with ordinary device memory in the place of peer memory): every block computes what it
+    computes in the single launch and the grid-wide sums are added in the single launch's order -- the depth, the energy and the
+    step count are those of srps_depth_solve on one context, bit for bit, on every rank."""
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=h + 3 * w + sf, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    e1, z1, it1, rect1 = _resident_single(pkg, dh)
+    group = _resident_group(pkg, dh, world)
+    for e, z, it in group:
+        assert it == it1 == 101
+        np.testing.assert_array_equal(z, z1)
+        assert e == e1
+    print(f"{h}x{w} sf {sf} {kind}: {world} resident strips == the single resident launch (rect body {rect1})")
+
+
+def test_resident_strip_group_refuses_what_it_cannot_run(pkg):
+    sc = pkg.synth.make_scene(256, 256, 2, 2, seed=3, mask_kind="full")
+    dh = pkg.DataHandler.from_scene(sc)
+    import torch
+    stream = torch.cuda.Stream()
+    ctxs = []
+    for _ in range(2):
+        c = pkg.Context(device_id=0); c.set_stream(stream.cuda_stream); c.setup(dh); c.lighting(); c.albedo(); c.depth_partial(); ctxs.append(c)
+    with pytest.raises(Exception) as ei:                    # a shared stream: the two launches could never run side by side
+        pkg.Context.strip_group_solve_resident(ctxs)
+    assert "share a stream" in str(ei.value)
+    for c in ctxs:
+        c.close()
+    ctxs = []
+    for _ in range(5):                                      # 4 columns of tiles cannot be dealt to 5 ranks
+        c = pkg.Context(device_id=0); c.setup(dh); c.lighting(); c.albedo(); c.depth_partial(); ctxs.append(c)
+    with pytest.raises(Exception) as ei:
+        pkg.Context.strip_group_solve_resident(ctxs)
+    assert "columns of tiles" in str(ei.value)
+    for c in ctxs:
+        c.close()
