@@ -305,7 +305,9 @@ def main():
             elif ok:
                 ctx.comm_release()
     if args.partition == "strips" and comm_kind == "library":
-        ctx.set_option("cg_partition", 1)
+        # 2: the resident kernel on every rank's strip of tile columns where the strips fit (<= one 256 x 64 tile per CU and rank), the ranks'
+        # kernels talking through hipIpc-mapped exchange buffers; the library falls back to 1 (streaming strips, collectives per step)
+        ctx.set_option("cg_partition", 2)
     ctx.setup(dh)
     dims = ctx.dims()
 
@@ -357,7 +359,8 @@ def main():
                    "images_per_rank": [pkg.shard_range(n_total, world, r)[1] - pkg.shard_range(n_total, world, r)[0] for r in range(world)],
                    "launched_by": "bench.py itself (child torch.distributed.run)" if os.environ.get("SRPS_BENCH_SELF_LAUNCHED") == "1" else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
                    "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, "
-                                   + ("depth CG partitioned into column strips (4-double all-reduce + edge-column exchange per step)" if ctx.get_option("cg_partition_active") else "replicated CG")
+                                   + ("depth CG as the resident kernel on strips of tile columns (sums and border edges through hipIpc-mapped buffers, no collective between the steps)" if ctx.get_option("cg_partition_resident_active")
+                                      else "depth CG partitioned into column strips (4-double all-reduce + edge-column exchange per step)" if ctx.get_option("cg_partition_active") else "replicated CG")
                                    + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},
         "energies": energies,
     }

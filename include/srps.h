@@ -119,7 +119,12 @@ int srps_synchronize(srps_ctx* ctx);
  * "overlap_exchange" (0|1, default 0: srps_execute_sharded cuts the albedo sweep and the depth assembly into four pixel ranges and
  *  all-reduces a range on a second stream while the next is computed -- same bits, the bytes travel under the sweeps; off until a
  *  multi-GPU run has timed it),
- * "cg_partition" (0|1: the depth CG as column strips over the ranks of the context's communicator, see srps_strip_group_solve),
+ * "cg_partition" (0|1|2: the depth CG over the ranks of the context's communicator -- 1: column strips with the streaming step and a
+ *  4-double all-reduce + edge-column exchange per step, see srps_strip_group_solve; 2 (round 4): the RESIDENT kernel on strips of
+ *  256 x 64 tile columns, the ranks' kernels side by side for the whole solve, exchanging their sums and border edges through
+ *  exchange buffers mapped into each other with hipIpc (handles travel through the context's all-reduce) -- no collective between the
+ *  101 steps; falls back to 1 / to the replicated CG where the grid does not fit or the mapping fails; "cg_partition_resident_active"
+ *  tells.  Exercised on one device with two PROCESSES (tests/test_gpu_strips.py); across devices not yet),
  * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader
  *  produces, Utilities.cpp:343 -- the context also keeps the images as bytes and the two image sweeps of a pass read those:
  *  the same floats, the same results bit for bit, a quarter of the traffic; other images are read as floats) */

@@ -587,6 +587,12 @@ int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     // the strips update x in place like the streaming kernels below: the copy of the start plane comes first (round-3 advisor
     // finding: with cg_partition = 1 an aborted albedo launch of the same pass found no plane to go back to and the repeat
     // rebuilt normals and dz around the discarded solve's depth)
+    // cg_partition = 2: the resident kernel on this rank's strip of tile columns, side by side with the other ranks' (kernels_resident.hip:
+    // resident_cg_rank); where that does not fit or could not be set up: the streaming strips (1) or the replicated CG
+    if (ctx->cg_strips == 2 && comm_bound(ctx) && ctx->comm_world > 1) {
+        const int rc = resident_cg_rank(ctx, max_steps, fixed_steps);
+        if (rc != SRPS_ERR_UNSUPPORTED) return rc;
+    }
     if (strips_active(ctx)) {
         SRPS_TRY(keep_start_plane(ctx, fixed_steps));
         return strips_cg(ctx, max_steps, fixed_steps);      // this rank's columns only, RCCL between the steps

@@ -1233,6 +1233,149 @@ int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_st
     return rc;
 }
 
+// ---- the same, as ONE RANK of a communicator (cg_partition = 2): the other ranks are other processes, on other devices or on this one ----
+// Every rank keeps its granule arrays (ent | ent3 | halo, for the tiles of the WHOLE grid) in one fine-grained buffer, exports it
+// with hipIpcGetMemHandle and opens the others' (the 64-byte handles travel through the context's all-reduce, one float per byte:
+// any collective the context has -- RCCL or the caller's -- will do).  A solve: zero the own buffer, all-reduce one float (a barrier:
+// nobody publishes into a buffer that is not zeroed yet), launch the group kernel on the own strip of tile columns, then the strips
+// of x travel (one broadcast per rank).  The kernels of the ranks run side by side for the whole solve and talk through the mapped
+// buffers; nothing else happens between the 101 steps.
+void resident_rank_release(srps_ctx* ctx) {
+    for (int q = 0; q < 8; ++q) {
+        if (ctx->xg_peer[q] && ctx->xg_peer[q] != ctx->xg_buf) (void)hipIpcCloseMemHandle(ctx->xg_peer[q]);
+        ctx->xg_peer[q] = nullptr;
+    }
+    ctx->xg_world = 0;
+    if (ctx->xg_buf) (void)hipFree(ctx->xg_buf);
+    ctx->xg_buf = nullptr; ctx->xg_bytes = 0;
+    (void)hipGetLastError();
+}
+static int resident_rank_open(srps_ctx* ctx, size_t need) {
+    const int world = ctx->comm_world, rank = ctx->comm_rank;
+    if (ctx->xg_world == world && ctx->xg_bytes >= need) return SRPS_OK;
+    // (re)allocation is collective: every rank gets here in the same solve -- the grid, and with it `need`, is the same on all
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    resident_rank_release(ctx);
+    if (hipExtMallocWithFlags(&ctx->xg_buf, need, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        SRPS_HIP(hipMalloc(&ctx->xg_buf, need));           // same-device groups work with ordinary memory too
+    }
+    ctx->xg_bytes = need;
+    hipIpcMemHandle_t mine;
+    SRPS_HIP(hipIpcGetMemHandle(&mine, ctx->xg_buf));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
+    const size_t nf = (size_t)world * 64;
+    std::vector<float> h(nf, 0.f);
+    for (int b = 0; b < 64; ++b) h[(size_t)rank * 64 + b] = (float)((const unsigned char*)&mine)[b];
+    SRPS_TRY(ensure(ctx->ws_misc, nf * sizeof(float)));
+    float* d = (float*)ctx->ws_misc.p;
+    SRPS_HIP(hipMemcpyAsync(d, h.data(), nf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SRPS_TRY(comm_all_reduce_sum(ctx, d, nf));             // every rank's 64 bytes, one float each
+    SRPS_HIP(hipMemcpyAsync(h.data(), d, nf * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < world; ++q) {
+        if (q == rank) { ctx->xg_peer[q] = ctx->xg_buf; continue; }
+        hipIpcMemHandle_t hq;
+        for (int b = 0; b < 64; ++b) ((unsigned char*)&hq)[b] = (unsigned char)h[(size_t)q * 64 + b];
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, hq, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("resident strips: hipIpcOpenMemHandle of rank %d's exchange buffer failed (%s)", q, hipGetErrorString(e));
+            return SRPS_ERR_UNSUPPORTED;
+        }
+        ctx->xg_peer[q] = p;
+    }
+    ctx->xg_world = world;
+    return SRPS_OK;
+}
+int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps) {
+    Grid& G = ctx->grid;
+    const int n = ctx->comm_world, rank = ctx->comm_rank;
+    if (ctx->xg_failed || n < 2 || n > 8 || !comm_bound(ctx) || !ctx->cg_resident || !ctx->cg_one_sync) return SRPS_ERR_UNSUPPORTED;
+    const int nc = march_recompute_channels(ctx);
+    if (!((nc == 1 || nc == 3) && (G.sf == 1 || G.sf == 2 || G.sf == 4) && use_march(ctx))) return SRPS_ERR_UNSUPPORTED;
+    const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc, shape = 1;
+    const int NB = G.n_occ[shape];
+    if (nbc < n || NB <= 0 || G.n_tiles[shape] != tiles) return SRPS_ERR_UNSUPPORTED;
+    // the rank's piece of the ascending tile list (a range of tile columns); the list itself is the same on every rank
+    if ((int)G.h_tile_list1.size() != NB) {
+        G.h_tile_list1.resize((size_t)NB);
+        SRPS_HIP(hipMemcpy(G.h_tile_list1.data(), G.d_tile_list[shape], (size_t)NB * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    std::vector<int> tc0(n + 1), lbase(n + 1);
+    for (int r = 0; r <= n; ++r) tc0[r] = (int)((long long)nbc * r / n);
+    for (int r = 0, i = 0; r <= n; ++r) {
+        while (i < NB && G.h_tile_list1[(size_t)i] / nbr < tc0[r]) ++i;
+        lbase[r] = i;
+    }
+    for (int r = 0; r < n; ++r)
+        if (lbase[r + 1] - lbase[r] > ctx->num_cus) return SRPS_ERR_UNSUPPORTED;      // (the same decision on every rank: same list, same CU count assumed)
+    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
+    const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
+    {
+        const int rc = resident_rank_open(ctx, need);
+        if (rc != SRPS_OK) { ctx->xg_failed = 1; return rc == SRPS_ERR_UNSUPPORTED ? rc : SRPS_ERR_UNSUPPORTED; }
+    }
+    SRPS_HIP(hipMemsetAsync(ctx->xg_buf, 0, need, ctx->stream));
+    // barrier: every rank's buffer is zeroed before any rank's kernel publishes into it
+    SRPS_TRY(ensure(ctx->ws_misc, 64));
+    SRPS_HIP(hipMemsetAsync(ctx->ws_misc.p, 0, sizeof(float), ctx->stream));
+    SRPS_TRY(comm_all_reduce_sum(ctx, (float*)ctx->ws_misc.p, 1));
+    ResidentArgs a;
+    memset(&a, 0, sizeof(a));
+    auto carve = [&](void* base, unsigned long long*& ent, unsigned long long*& ent3, unsigned long long*& halo) {
+        ent = (unsigned long long*)base; ent3 = ent + ent_n; halo = ent3 + ent3_n;
+    };
+    a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.x_out = G.d_x2; a.r = G.d_r;
+    carve(ctx->xg_buf, a.ent, a.ent3, a.halo);
+    a.scal = G.d_scal;
+    a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = nbr; a.nbc = nbc;
+    a.lambda = ctx->lambda; a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
+    a.tol2 = fixed_steps ? -1.f : ctx->cg_tol * ctx->cg_tol; a.max_steps = max_steps;
+    a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
+    a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;
+    const bool rect = ctx->cg_resident_rect && G.n_rect_tiles[shape] == NB;
+    a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr; a.tile_occ = G.d_tile_cls[shape];
+    a.tile_list = G.d_tile_list[shape] + lbase[rank];
+    a.grp.nb = NB; a.grp_list_base = lbase[rank];
+    a.grp_bc_first = tc0[rank]; a.grp_bc_last = tc0[rank + 1] - 1;
+    int np = 0;
+    for (int q = 0; q < n; ++q) {
+        if (q == rank) continue;
+        unsigned long long *e, *e3, *hl;
+        carve(ctx->xg_peer[q], e, e3, hl);
+        a.grp.ent[np] = e; a.grp.ent3[np] = e3; ++np;
+        if (q == rank - 1) a.grp_halo_left = hl;
+        if (q == rank + 1) a.grp_halo_right = hl;
+    }
+    a.grp.n_peers = np;
+    const int blocks = lbase[rank + 1] - lbase[rank];
+    if (blocks > 0) {
+        const void* fn = nullptr;
+#define SRPS_RESG(SFV, NCV) fn = rect ? (const void*)k_cg_resident_group<SFV, NCV, true, true> : (const void*)k_cg_resident_group<SFV, NCV, true, false>
+        if (G.sf == 4) { if (nc == 3) SRPS_RESG(4, 3); else SRPS_RESG(4, 1); }
+        else if (G.sf == 2) { if (nc == 3) SRPS_RESG(2, 3); else SRPS_RESG(2, 1); }
+        else { if (nc == 3) SRPS_RESG(1, 3); else SRPS_RESG(1, 1); }
+#undef SRPS_RESG
+        const size_t lds = resident_lds_bytes(nc);
+        SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->persistent_inflight = 1;
+        void* kargs[] = {&a};
+        // a plain launch: the ranks' kernels must run side by side, and a cooperative launch of another process on the same device
+        // would queue behind this one
+        SRPS_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(NT), kargs, lds, ctx->stream));
+    }
+    std::swap(G.d_x, G.d_x2); ctx->x_swapped = true;      // the rank's strip of the result is in the other plane (see persistent_aborts)
+    // the other strips: one broadcast per rank, in place in the result plane
+    for (int q = 0; q < n; ++q) {
+        const int cb = tc0[q] * TC, ce = std::min(tc0[q + 1] * TC, G.Wg);
+        if (ce <= cb) continue;
+        SRPS_TRY(comm_broadcast(ctx, G.d_x + (size_t)(cb + PAD) * G.Hs, (size_t)(ce - cb) * G.Hs, q));
+    }
+    return SRPS_OK;
+}
+
 // the smallest tile that still gives every tile a CU (more CUs at work, less arithmetic per CU and step);
 // cg_resident_tile = 16 | 256 | 512 forces the 256 x 16, 256 x 32 or 256 x 64 shape
 static int resident_shape(const srps_ctx* ctx) {      // 2: 256 x 16, 4: 256 x 16 with 512 threads, 3: 256 x 32 with 512 threads, 0: 256 x 32 with 256, 1: 256 x 64, -1: none fits

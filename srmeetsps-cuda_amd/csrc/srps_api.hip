@@ -267,6 +267,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
         for (int t = 0; t < G.n_tiles[shape]; ++t)
             if (h_cls[shape][t] & TILE_OCCUPIED) h_list[shape].push_back(t);
         G.n_occ[shape] = (int)h_list[shape].size();
+        if (shape == 1) G.h_tile_list1 = h_list[shape];      // the resident strips cut this list into ranges of tile columns
         if (G.n_occ[shape]) SRPS_HIP(hipMemcpyAsync(G.d_tile_list[shape], h_list[shape].data(), (size_t)G.n_occ[shape] * sizeof(int), hipMemcpyHostToDevice, ax));
     }
     SRPS_HIP(hipEventRecord(ctx->aux_event, ax));
@@ -433,6 +434,7 @@ int srps_destroy(srps_ctx* ctx) {
     grid_free(ctx->grid);
     dfree(ctx->I8);
     dfree(ctx->It);
+    resident_rank_release(ctx);
     dfree(ctx->d_strip_tot);
     if (ctx->state_arena.p) (void)hipFree(ctx->state_arena.p);
     if (ctx->ws_struct.p) (void)hipFree(ctx->ws_struct.p);
@@ -579,7 +581,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "overlap_exchange")) {
         ctx->overlap_exchange = value ? 1 : 0;
     } else if (!strcmp(name, "cg_partition")) {
-        SRPS_REQUIRE(value == 0 || value == 1, SRPS_ERR_INVALID, "cg_partition: 0 (every rank runs the whole depth CG) or 1 (column strips over the communicator's ranks)");
+        SRPS_REQUIRE(value >= 0 && value <= 2, SRPS_ERR_INVALID, "cg_partition: 0 (every rank runs the whole depth CG), 1 (column strips over the communicator's ranks, streaming step) or 2 (the resident kernel on strips of tile columns)");
+        if (value != 2) ctx->xg_failed = 0;
         ctx->cg_strips = value;
     } else if (!strcmp(name, "cg_max_iter")) {
         SRPS_REQUIRE(value >= 0, SRPS_ERR_INVALID, "cg_max_iter: bad value %d", value);
@@ -629,6 +632,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "cg_partition")) *value = ctx->cg_strips;
     else if (!strcmp(name, "overlap_exchange")) *value = ctx->overlap_exchange;
     else if (!strcmp(name, "cg_partition_active")) *value = strips_active(ctx) ? 1 : 0;
+    else if (!strcmp(name, "cg_partition_resident_active")) *value = (ctx->cg_strips == 2 && ctx->xg_world > 1 && !ctx->xg_failed && ctx->cg_resident) ? 1 : 0;      // the last solve ran as resident strips
     else if (!strcmp(name, "cg_resident_tile")) *value = ctx->cg_resident_tile;
     else if (!strcmp(name, "albedo_channels_together")) *value = ctx->albedo_channels_together;
     else if (!strcmp(name, "albedo_one_sync")) *value = ctx->albedo_one_sync;

@@ -71,6 +71,7 @@ struct Grid {
     int tensor_channels = 0;      // channels of the last assembly
     bool M_valid = false;         // d_M holds the tensor of the last assembly
     float cx = 0.f, cy = 0.f;     // principal point used by the last assembly (xx = j - cx, yy = i - cy)
+    std::vector<int> h_tile_list1;   // host copy of d_tile_list[1] (the 256 x 64 tiling), made when the resident strips first ask for it
     float* d_x = nullptr;         // [plane] z on the grid
     float* d_x2 = nullptr;        // [plane] the resident CG stores its result here and the two planes swap roles: the iterate a persistent
                                   // launch started from survives it (an aborted launch is repeated by the streaming kernels from exactly that iterate)
@@ -188,6 +189,15 @@ struct srps_ctx {
     bool comm_owned = false;         // created by srps_comm_init_rank / srps_comm_init_all (destroyed with the context), not borrowed (srps_set_comm)
     int comm_rank = 0, comm_world = 1;
     int cg_strips = 0;               // option "cg_partition": 1 = the depth CG partitioned into column strips over the communicator's ranks
+                                     // (streaming step + collectives per step); 2 = the RESIDENT kernel on strips of tile columns, sums and border
+                                     // edges through the ranks' shared exchange buffers (hipIpc), falling back to 1 / the replicated CG
+    // the exchange buffer of the resident strips (cg_partition = 2): fine-grained device memory, exported to the other ranks of the
+    // communicator by hipIpc handle; peer_base[q] = rank q's buffer as mapped into this process (own rank: the buffer itself)
+    void* xg_buf = nullptr;
+    size_t xg_bytes = 0;
+    void* xg_peer[8] = {};
+    int xg_world = 0;                // ranks the peers were opened for (0: not open)
+    int xg_failed = 0;               // the handshake or a launch failed once: not tried again on this context
     double* d_strip_tot = nullptr;   // [12]: [0..3] this rank's sums of a launch, [4..7] / [8..11] the sums over all ranks of the launches of even / odd
                                      // parity (Grid::d_totals4 points at [4])
     // the caller's collectives for the image-sharded pass (srps_set_host_collectives) instead of an RCCL communicator
@@ -330,7 +340,9 @@ int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, vo
 bool resident_supported(const srps_ctx* ctx);
 bool resident_rect_active(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
-int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_steps);      // the resident kernel on column strips of several contexts
+int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_steps);
+int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps);      // one RANK of such a group: the other ranks are other processes / devices (cg_partition = 2); SRPS_ERR_UNSUPPORTED: use another path
+void resident_rank_release(srps_ctx* ctx);                                 // closes the peers' mappings, frees the exchange buffer      // the resident kernel on column strips of several contexts
 bool resident_supported_n512(const srps_ctx* ctx);       // the three tile shapes (kernels_resident.hip, kernels_resident_n256.hip, kernels_resident_n256c4.hip)
 bool resident_supported_n256(const srps_ctx* ctx);
 bool resident_supported_n256c4(const srps_ctx* ctx);

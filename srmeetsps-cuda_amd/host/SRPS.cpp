@@ -135,7 +135,9 @@ void SRPS::execute_sharded(const std::vector<float>& zs, const std::vector<float
     for (int r = 0; r < n_gpus; ++r) {
         srps_check(srps_create(Preferences::deviceId + r, Preferences::blockX, Preferences::blockY, &shard_ctx[r]));
         srps_check(srps_set_option(shard_ctx[r], "exclusive_device", Preferences::exclusiveDevice ? 1 : 0));
-        if (Preferences::partitionStrips) srps_check(srps_set_option(shard_ctx[r], "cg_partition", 1));      // --partition strips
+        // --partition strips: 2 = the resident kernel on strips of tile columns where they fit (exchange buffers mapped with hipIpc),
+        // else the library falls back to the streaming strips (1) by itself
+        if (Preferences::partitionStrips) srps_check(srps_set_option(shard_ctx[r], "cg_partition", 2));
     }
     ctx = shard_ctx[0];
     srps_check(srps_comm_init_all(shard_ctx.data(), n_gpus));                  // ncclCommInitAll over the job's devices

@@ -310,3 +310,68 @@ def test_resident_strip_group_refuses_what_it_cannot_run(pkg):
     assert "columns of tiles" in str(ei.value)
     for c in ctxs:
         c.close()
+
+
+def _ipc_worker(rank, world, port, h, w, sf, kind, seed, out_dir):
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("srmeetsps-cuda_amd")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
+    ctx = pkg.Context(device_id=0)
+    ctx.set_option("cg_resident_tile", 512)
+    ctx.set_option("cg_partition", 2)                      # the resident kernel on this rank's strip of tile columns
+    ctx.set_option("spin_budget_ms", 2000)                 # two processes start their launches a few milliseconds apart
+    hc = strips.HostedCollectives(ctx, dist)               # all-reduce / broadcast over gloo: carries the hipIpc handles, the barrier, the strips of x
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    out = {}
+    for it in range(2):                                    # the second solve reuses the mapped buffers
+        ctx.lighting(); ctx.albedo()
+        out[f"e{it}"] = ctx.depth()
+        ctx.normals()
+        out[f"z{it}"] = ctx.get("z")
+    out["resident"] = ctx.get_option("cg_partition_resident_active"); out["fb"] = ctx.get_option("persistent_fallbacks")
+    out["it"] = ctx.last_cg_iterations()["depth"]
+    assert not hc.errors, hc.errors
+    np.savez(os.path.join(out_dir, f"ipc_rank{rank}.npz"), **out)
+    dist.barrier()
+    hc.remove()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("h,w,sf,kind,world", [(1024, 2048, 4, "full", 2), (1024, 1536, 2, "ellipse", 3)])
+def test_resident_strips_between_processes_through_ipc_mapped_buffers(pkg, tmp_path, h, w, sf, kind, world):
+    """cg_partition = 2 as a multi-GPU job would run it -- one PROCESS per rank, every rank's exchange buffer exported with
+    hipIpcGetMemHandle and mapped by the others (the handles travel through the context's all-reduce), the ranks' resident kernels side
+    by side for the whole solve, the strips of x broadcast afterwards -- with the ranks sharing this one device: two passes, the results
+    of the single resident launch bit for bit on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    seed = h + 3 * w + sf
+    mp.spawn(_ipc_worker, args=(world, port, h, w, sf, kind, seed, str(tmp_path)), nprocs=world, join=True)
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
+    c = pkg.Context(device_id=0)
+    c.set_option("cg_resident_tile", 512)
+    c.setup(pkg.DataHandler.from_scene(sc))
+    ref = {}
+    for it in range(2):
+        c.lighting(); c.albedo(); ref[f"e{it}"] = c.depth(); c.normals(); ref[f"z{it}"] = c.get("z")
+    c.close()
+    for q in range(world):
+        r = np.load(tmp_path / f"ipc_rank{q}.npz")
+        assert int(r["resident"]) == 1 and int(r["fb"]) == 0 and int(r["it"]) == 101, (int(r["resident"]), int(r["fb"]), int(r["it"]))
+        for it in range(2):
+            np.testing.assert_array_equal(r[f"z{it}"], ref[f"z{it}"])
+            assert float(r[f"e{it}"]) == ref[f"e{it}"]
+    print(f"{h}x{w} sf {sf} {kind}: {world} processes, resident strips through hipIpc-mapped buffers == the single resident launch")

@@ -47,8 +47,10 @@ def _rank(rank, world, port, h, w, sf, n_img, kind, seed, overlap, strips, out_d
     sc = pkg.synth.make_scene(h, w, sf, n_img, seed=seed, mask_kind=kind, img_begin=lo, img_end=hi)
     ctx = pkg.Context(device_id=rank)
     ctx.set_option("overlap_exchange", overlap)
-    if strips:
+    if strips == 1:
         ctx.set_option("cg_resident", 0); ctx.set_option("cg_partition", 1)
+    if strips == 2:
+        ctx.set_option("cg_resident_tile", 512); ctx.set_option("cg_partition", 2)      # the resident kernel on strips, peer memory through hipIpc
     uid = [pkg.Context.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     ctx.comm_init_rank(uid[0], rank, world)
@@ -56,7 +58,7 @@ def _rank(rank, world, port, h, w, sf, n_img, kind, seed, overlap, strips, out_d
     ctx.setup(pkg.DataHandler.from_scene(sc))
     en = ctx.execute_sharded(0)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), en=np.array(en), z=ctx.get("z"), rho=ctx.get("rho"), s=ctx.get("s"),
-             strips=ctx.get_option("cg_partition_active"), it=ctx.last_cg_iterations()["depth"])
+             strips=2 if ctx.get_option("cg_partition_resident_active") else ctx.get_option("cg_partition_active"), it=ctx.last_cg_iterations()["depth"])
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -64,7 +66,7 @@ def _rank(rank, world, port, h, w, sf, n_img, kind, seed, overlap, strips, out_d
 
 @needs_two
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("overlap,strips", [(0, 0), (1, 0), (0, 1)])
+@pytest.mark.parametrize("overlap,strips", [(0, 0), (1, 0), (0, 1), (0, 2)])
 def test_two_ranks_over_rccl_equal_one_gpu(pkg, tmp_path, overlap, strips):
     import torch.multiprocessing as mp
     h, w, sf, n_img, kind, seed = (512, 384, 2, 5, "ellipse", 71)
@@ -75,8 +77,10 @@ def test_two_ranks_over_rccl_equal_one_gpu(pkg, tmp_path, overlap, strips):
     assert int(r[0]["strips"]) == strips
     sc = pkg.synth.make_scene(h, w, sf, n_img, seed=seed, mask_kind=kind)
     ctx = pkg.Context(device_id=0)
-    if strips:
+    if strips == 1:
         ctx.set_option("cg_resident", 0)
+    if strips == 2:
+        ctx.set_option("cg_resident_tile", 512)
     one = pkg.SRPS(pkg.DataHandler.from_scene(sc), ctx=ctx)
     e1 = one.execute()
     assert len(e1) == len(r[0]["en"])
