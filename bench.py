@@ -287,8 +287,15 @@ def main():
     # carries its 128 bytes to the other ranks (and the timing barrier); every rank joins with its context.  Should that fail on
     # any rank (no librccl), all ranks fall back to torch.distributed's collectives together.
     comm_kind = "none"
+    hosted = None
     if world > 1:
         comm_kind = "torch"
+        if args.comm == "library" and shared_gpu:
+            # the dry run on one GPU: the library's own sharded loop (srps_execute_sharded) with torch.distributed (gloo) UNDER it as the
+            # context's collectives (srps_set_host_collectives) -- the code path of the RCCL run, with host functions for the collectives
+            hosted = pkg.TorchCollectives(ctx, dist)
+            ctx.set_option("spin_budget_ms", 2000)         # the ranks' persistent kernels share the device and start milliseconds apart
+            comm_kind = "hosted"
         if args.comm == "library" and not shared_gpu:
             ok = 1
             try:
@@ -304,7 +311,7 @@ def main():
                 comm_kind = "library"
             elif ok:
                 ctx.comm_release()
-    if args.partition == "strips" and comm_kind == "library":
+    if args.partition == "strips" and comm_kind in ("library", "hosted"):
         # 2: the resident kernel on every rank's strip of tile columns where the strips fit (<= one 256 x 64 tile per CU and rank), the ranks'
         # kernels talking through hipIpc-mapped exchange buffers; the library falls back to 1 (streaming strips, collectives per step)
         ctx.set_option("cg_partition", 2)
@@ -316,7 +323,7 @@ def main():
     ar = all_reduce if (world > 1 and comm_kind == "torch") else None
 
     def solve(max_outer=None):
-        if comm_kind == "library":
+        if comm_kind in ("library", "hosted"):
             return ctx.execute_sharded(max_outer or 0)
         return pkg.alternating_loop(ctx, ar, max_outer=max_outer)
 
@@ -352,9 +359,11 @@ def main():
                    "albedo_mode": {0: "SRPS_ALBEDO_CG", 1: "SRPS_ALBEDO_CLOSED_FORM", 2: "SRPS_ALBEDO_FUSED", 3: "SRPS_ALBEDO_AUTO (pipeline: the albedo CG's fixed point formed inside the sweep)"}[ctx.get_option("albedo_mode")],
                    "exclusive_device": ctx.get_option("exclusive_device"),       # 1: plain launches of the persistent kernels (the library's default is the cooperative launch: ~26 us per pass more)
                    "comm": {"none": "none (1 GPU)", "library": "ncclAllReduce inside libsrps_hip.so (srps_execute_sharded), communicator from srps_comm_init_rank",
+                            "hosted": "srps_execute_sharded with torch.distributed (gloo) under it as the context's collectives (srps_set_host_collectives) [dry run]",
                             "torch": "torch.distributed.all_reduce on views of the library's exchange buffers"}[comm_kind],
                    # what the LIBRARY's communicator says of itself (ncclCommCount through srps_comm_info; 0: none bound) and who holds what
                    "ncclCommCount": ctx.comm_info()[1] if comm_kind == "library" else 0,
+                   "ranks_seen_by_the_library": ctx.comm_info()[1] if comm_kind in ("library", "hosted") else 0,
                    "partition": args.partition if world > 1 else "none",
                    "images_per_rank": [pkg.shard_range(n_total, world, r)[1] - pkg.shard_range(n_total, world, r)[0] for r in range(world)],
                    "launched_by": "bench.py itself (child torch.distributed.run)" if os.environ.get("SRPS_BENCH_SELF_LAUNCHED") == "1" else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
@@ -364,11 +373,16 @@ def main():
                                    + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},
         "energies": energies,
     }
-    if rank == 0:
+    # the isolated CG loop: with the depth CG partitioned over the ranks (strips) a solve is a collective -- every rank takes part, rank 0 reports
+    cg_collective = world > 1 and (ctx.get_option("cg_partition_active") == 1 or ctx.get_option("cg_partition_resident_active") == 1)
+    if rank == 0 or cg_collective:
         # the resident kernel runs where the grid has at most one 256 x 64 tile per CU (2048 x 2048 on 256 CUs); it must then
         # really have run -- a persistent launch that gave up a wait would have switched the context to the streaming kernels
         tiles = -(-dims["grid_h"] // 256) * -(-dims["grid_w"] // 64)
-        out.update(cg_legs(pkg, ctx, H, W, args.sf, resident_expected=tiles <= ctx.get_option("num_cus")))
+        legs_cg = cg_legs(pkg, ctx, H, W, args.sf, resident_expected=(tiles <= ctx.get_option("num_cus")) and not cg_collective)
+        if rank == 0:
+            out.update(legs_cg)
+    if rank == 0:
         if not args.no_legs and world == 1:
             # the two HBM-bound legs of north_star, driver-timed with the headline: the streaming CG on the metric's grid
             # (">= 60 % of the HBM roofline on the CG SpMV + axpy loop at 2048 x 2048") and on the largest single-GPU grid
@@ -578,6 +592,9 @@ def main():
             if mit:
                 out["cpu_baseline"]["mitten_full_frame"] = mit
         print(json.dumps(out))
+    if hosted is not None:
+        assert not hosted.errors, hosted.errors
+        hosted.remove()
     ctx.close()
     if dist:
         dist.destroy_process_group()

@@ -5,7 +5,7 @@ The directory name contains a hyphen (it is fixed by the project layout); import
 ``importlib.import_module("srmeetsps-cuda_amd")``.
 """
 from ._lib import SRPSError, build, load, declared_symbols, LIB_PATH  # noqa: F401
-from .api import (Context, DataHandler, Preferences, SRPS, alternating_loop, shard_range)  # noqa: F401
+from .api import (Context, DataHandler, Preferences, SRPS, TorchCollectives, alternating_loop, shard_range)  # noqa: F401
 from . import synth  # noqa: F401
 
 

@@ -464,3 +464,51 @@ class SRPS:
     def rho(self): return self.ctx.get("rho").reshape(self.dh.I_c, -1)
     def s(self): return self.ctx.get("s").reshape(-1, self.dh.I_c, 4)
     def N(self): return self.ctx.get("N").reshape(4, -1)
+
+
+class TorchCollectives:
+    """The two host functions of srps_set_host_collectives on torch.distributed (any backend, e.g. gloo): the library's own sharded loop
+    (srps_execute_sharded), the hipIpc handshake and the barrier of the resident strips (cg_partition = 2) then run over the caller's
+    process group -- between processes that share one GPU (where RCCL refuses a second rank) as between GPUs.  Host functions on device
+    pointers: every call drains the stream; a dry-run / portability path, not the fast one (that is RCCL inside the library)."""
+
+    def __init__(self, ctx, dist, device: str = "cuda:0"):
+        import torch
+        self.ctx, self.errors = ctx, []
+
+        def view(ptr, n, typestr):
+            class V:
+                pass
+            v = V()
+            v.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(v, device=device)
+
+        def allreduce(user, d_buf, n, f64):
+            try:
+                g = view(d_buf, n, "<f8" if f64 else "<f4")
+                t = g.cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                g.copy_(t)
+                torch.cuda.synchronize()
+                return 0
+            except Exception as exc:
+                self.errors.append(repr(exc))
+                return 1
+
+        def broadcast(user, d_buf, n, root):
+            try:
+                g = view(d_buf, n, "<f4")
+                t = g.cpu()
+                dist.broadcast(t, src=root)
+                g.copy_(t)
+                torch.cuda.synchronize()
+                return 0
+            except Exception as exc:
+                self.errors.append(repr(exc))
+                return 1
+
+        self._fns = (_lib.HOST_ALLREDUCE_FN(allreduce), _lib.HOST_BROADCAST_FN(broadcast))
+        check(ctx.lib.srps_set_host_collectives(ctx.h, dist.get_rank(), dist.get_world_size(), *self._fns, None))
+
+    def remove(self):
+        check(self.ctx.lib.srps_set_host_collectives(self.ctx.h, 0, 1, _lib.HOST_ALLREDUCE_FN(), _lib.HOST_BROADCAST_FN(), None))

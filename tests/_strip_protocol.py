@@ -189,49 +189,7 @@ class HostedTransport:
         _lib.check(self.ctx.lib.srps_set_strip_transport(self.ctx.h, 0, 1, _lib.STRIP_ALLREDUCE_FN(), _lib.STRIP_EXCHANGE_FN(), _lib.STRIP_ALLGATHER_FN(), None))
 
 
-class HostedCollectives:
-    """The two host functions of srps_set_host_collectives on torch.distributed: the image-sharded loop INSIDE the library
-    (srps_execute_sharded) over gloo between processes that share one GPU -- what RCCL runs between GPUs."""
-
-    def __init__(self, ctx, dist, device: str = "cuda:0"):
-        import torch
-        _lib = importlib.import_module("srmeetsps-cuda_amd._lib")
-        self.ctx, self.errors = ctx, []
-
-        def view(ptr, n, typestr):
-            class V:
-                pass
-            v = V()
-            v.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
-            return torch.as_tensor(v, device=device)
-
-        def allreduce(user, d_buf, n, f64):
-            try:
-                g = view(d_buf, n, "<f8" if f64 else "<f4")
-                t = g.cpu()
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                g.copy_(t)
-                torch.cuda.synchronize()
-                return 0
-            except Exception as exc:
-                self.errors.append(repr(exc))
-                return 1
-
-        def broadcast(user, d_buf, n, root):
-            try:
-                g = view(d_buf, n, "<f4")
-                t = g.cpu()
-                dist.broadcast(t, src=root)
-                g.copy_(t)
-                torch.cuda.synchronize()
-                return 0
-            except Exception as exc:
-                self.errors.append(repr(exc))
-                return 1
-
-        self._fns = (_lib.HOST_ALLREDUCE_FN(allreduce), _lib.HOST_BROADCAST_FN(broadcast))
-        _lib.check(ctx.lib.srps_set_host_collectives(ctx.h, dist.get_rank(), dist.get_world_size(), *self._fns, None))
-
-    def remove(self):
-        _lib = importlib.import_module("srmeetsps-cuda_amd._lib")
-        _lib.check(self.ctx.lib.srps_set_host_collectives(self.ctx.h, 0, 1, _lib.HOST_ALLREDUCE_FN(), _lib.HOST_BROADCAST_FN(), None))
+def HostedCollectives(ctx, dist, device: str = "cuda:0"):
+    """moved into the package in round 4 (api.TorchCollectives: bench.py's one-GPU dry run of the sharded loop uses it too)"""
+    api = importlib.import_module("srmeetsps-cuda_amd.api")
+    return api.TorchCollectives(ctx, dist, device)

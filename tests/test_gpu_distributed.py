@@ -147,6 +147,28 @@ def test_bench_starts_its_own_ranks():
     assert bad.returncode != 0 and "--gpus 2 but the launcher started 1" in bad.stderr
 
 
+@pytest.mark.timeout(900)
+def test_bench_dry_run_with_the_resident_kernel_on_strips():
+    """`bench.py --gpus 2 --partition strips` on one GPU: the images sharded 3 + 3, the library's sharded loop over gloo host collectives,
+    and the depth CG as the resident kernel on two strips of tile columns -- two PROCESSES whose kernels run side by side and talk
+    through hipIpc-mapped exchange buffers (cg_partition = 2).  The line says which form ran; the energies are those of the one-GPU job."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--size", "1024", "--sf", "4", "--no-cpu-baseline", "--no-legs", "--option", "cg_resident_tile=512"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "3", "--partition", "strips"] + common, env=env,
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert "resident kernel on strips" in two["config"]["parallelism"], two["config"]["parallelism"]
+    assert two["config"]["persistent_fallbacks"] == 0 and two["config"]["cg_steps_per_solve"] == 101 and two["config"]["ranks_seen_by_the_library"] == 2
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--images", "6"] + common, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    np.testing.assert_allclose(two["energies"], ref["energies"], rtol=1e-4)
+
+
 @pytest.mark.parametrize("bytes_store", [False, True])
 def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg, bytes_store):
     """srps_albedo_partial on a context that holds a shard of the images: den = sum_i (N . s_i)^2 does not involve the images, so it
