@@ -438,8 +438,10 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
 #define SRPS_LIGHT_PREFETCH 1
 #endif
 // TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
-template <int IBW, int NCH, bool TAIL, bool TM = false>
-__global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, int P, int n_img,
+// U8: the images from the context's 8-bit store (bytes, k / 255.f formed in registers: device_utils.h unit_from_byte -- the same floats);
+// the sweep's vector pipes are a third busy, the bytes are a quarter of the floats.
+template <int IBW, int NCH, bool TAIL, bool TM = false, bool U8 = false>
+__global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img,
                                                             int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
                                                             EnergyArgs ea) {
     constexpr int C = NCH, TP = 1024, NQ = 3 + 4 * NCH;     // LDS planes: nk0 nk1 nk2 | rho_c | E0_c E1_c E2_c (the residual's factors of s0, s1, s2)
@@ -533,6 +535,10 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
             // The tile's 4 pieces x NCH channels as one sequence of steps, software-pipelined: the image loads of step k + 1 are issued
             // before the arithmetic of step k (PF + 1 sets of IBW float4 rotate).  With one set the sweep ran at 4.9 TB/s, which is
             // what 8 waves per CU with 5 KiB in flight each can draw from a memory ~2 us away; with two, twice that is in flight.
+            // (Round-4 timing experiments on one box, 2048^2 x 20 images: the sweep 0.271 ms; WITHOUT its image loads 0.149 ms -- the
+            // floor of its arithmetic, LDS traffic and barriers --; with the loads and one add per value instead of the arithmetic
+            // 0.245 ms: the loads alone run at 5.0 TB/s, the arithmetic hides under them.  A wave reads 1 KiB runs of five image planes;
+            // the albedo sweep, whose block reads 4 KiB runs, draws 6.1 TB/s.)
             const int npieces = __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8));      // wave-uniform: the range's last tile may be short
             constexpr int NS = 4 * NCH;
             constexpr int PF = SRPS_LIGHT_PREFETCH;                  // steps of look-ahead (PF + 1 sets of IBW float4 rotate)
@@ -542,7 +548,9 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                 const int q = t0 + (sub * 64 + lane) * 4;
                 const int ql = q < p1 ? q : p1 - 4;
 #pragma unroll
-                for (int ii = 0; ii < IBW; ++ii) buf[ii] = ld_img<4, false, TM>(I, nullptr, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);      // images past the end re-read the last one
+                for (int ii = 0; ii < IBW; ++ii) {
+                    buf[ii] = ld_img<4, U8, TM>(I, I8, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);      // images past the end re-read the last one
+                }
             };
 #pragma unroll
             for (int k = 0; k < PF; ++k)
@@ -552,6 +560,9 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                 const int sub = k / NCH, c = k % NCH;
                 if (sub < npieces) {                                   // wave-uniform (no break: the loop must unroll completely, k is an array index)
                 if (k + PF < NS && (k + PF) / NCH < npieces) issue(k + PF, ivb[(k + PF) % (PF + 1)]);
+                // pinned: the compiler otherwise clusters the loads of two steps, consumes both sets and only then issues the next two --
+                // the memory pipe ran dry every second step (s_waitcnt vmcnt(0) in the middle of the sequence)
+                __builtin_amdgcn_sched_barrier(0);
                 Vec<4> (&ivc)[IBW] = ivb[k % (PF + 1)];
                 const int li = sub * 64 + lane;
                 const int q = t0 + li * 4;
@@ -795,8 +806,10 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
         // (TAIL = false, the kernel without the per-image guards, is not used: hipcc 7.2 then hoists every load and LDS read of a piece
         // to its top and spills 330 bytes; the guards are wave-uniform branches on a scalar compare)
         const float* d_It = image_store_tiles(ctx, d_I);       // the tile-major copy of the context's images, when it keeps one
-#define SRPS_LT(BB, CC) do { if (d_It) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
-                             else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, P, n_local, L.chunk, L.part_atb, L.part_g, ea); } while (0)
+        const unsigned char* d_I8 = ctx->light_bytes ? image_store_bytes(ctx, d_I) : nullptr;      // byte images: the sweep reads the bytes (option "light_bytes")
+#define SRPS_LT(BB, CC) do { if (d_I8) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
+                             else if (d_It) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
+                             else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); } while (0)
         if (C == 3) { switch (ibw) { case 1: SRPS_LT(1, 3); break; case 2: SRPS_LT(2, 3); break; case 3: SRPS_LT(3, 3); break; case 4: SRPS_LT(4, 3); break; default: SRPS_LT(5, 3); } }
         else { switch (ibw) { case 1: SRPS_LT(1, 1); break; case 2: SRPS_LT(2, 1); break; case 3: SRPS_LT(3, 1); break; case 4: SRPS_LT(4, 1); break; default: SRPS_LT(5, 1); } }
 #undef SRPS_LT

@@ -541,6 +541,9 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "march_nt")) {
         SRPS_REQUIRE(value >= 0 && value <= 2, SRPS_ERR_INVALID, "march_nt: 0 (never), 1 (always) or 2 (automatic), got %d", value);
         ctx->march_nt = value;
+    } else if (!strcmp(name, "light_bytes")) {
+        ctx->light_bytes = value ? 1 : 0;
+        ctx->light_cache_valid = false;
     } else if (!strcmp(name, "light_tiled")) {
         ctx->light_tiled = value ? 1 : 0;
         ctx->light_cache_valid = false;
@@ -606,6 +609,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "fuse_normals")) *value = ctx->fuse_normals;
     else if (!strcmp(name, "march_nt")) *value = ctx->march_nt;
     else if (!strcmp(name, "light_tiled")) *value = ctx->light_tiled;
+    else if (!strcmp(name, "light_bytes")) *value = ctx->light_bytes;
     else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
     else if (!strcmp(name, "cg_fused_step")) *value = ctx->cg_fused_step;
