@@ -253,6 +253,7 @@ def _resident_group(pkg, dh, world):
     for _ in range(world):
         c = pkg.Context(device_id=0)                       # every context keeps its OWN stream: the launches must run side by side
         c.set_option("cg_resident_tile", 512)
+        c.set_option("spin_budget_ms", 1000)               # the launches start one after the other: the first waits for the last
         c.setup(dh)
         ctxs.append(c)
     for c in ctxs:
