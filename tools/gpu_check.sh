@@ -1,7 +1,8 @@
 #!/bin/bash
+# The round-end check on a GPU box: the whole GPU suite, smoke(), the bench line.   gpurun --timeout 2700 -- bash tools/gpu_check.sh
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/r04z
+OUT=$R/gpurun_out/check
 mkdir -p "$OUT"
 cd "$R"
 timeout 1500 python -m pytest tests -m gpu -q > "$OUT/pytest.log" 2>&1
