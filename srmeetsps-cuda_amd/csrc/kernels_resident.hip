@@ -1250,20 +1250,24 @@ void resident_rank_release(srps_ctx* ctx) {
     ctx->xg_buf = nullptr; ctx->xg_bytes = 0;
     (void)hipGetLastError();
 }
+// Collective: every rank of the communicator calls it in the same solve (the grid, and with it `need`, is the same on all).  Whatever
+// goes wrong locally, the rank still takes part in the exchange of the handles (with zeros) -- the others must not be left waiting --
+// and reports failure; resident_cg_rank then lets all ranks decide together.
 static int resident_rank_open(srps_ctx* ctx, size_t need) {
     const int world = ctx->comm_world, rank = ctx->comm_rank;
     if (ctx->xg_world == world && ctx->xg_bytes >= need) return SRPS_OK;
-    // (re)allocation is collective: every rank gets here in the same solve -- the grid, and with it `need`, is the same on all
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
     resident_rank_release(ctx);
-    if (hipExtMallocWithFlags(&ctx->xg_buf, need, hipDeviceMallocFinegrained) != hipSuccess) {
+    if (ok && hipExtMallocWithFlags(&ctx->xg_buf, need, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
-        SRPS_HIP(hipMalloc(&ctx->xg_buf, need));           // same-device groups work with ordinary memory too
+        ctx->xg_buf = nullptr;
+        ok = hipMalloc(&ctx->xg_buf, need) == hipSuccess;      // same-device groups work with ordinary memory too
     }
-    ctx->xg_bytes = need;
+    if (ok) ctx->xg_bytes = need; else { ctx->xg_buf = nullptr; (void)hipGetLastError(); }
     hipIpcMemHandle_t mine;
-    SRPS_HIP(hipIpcGetMemHandle(&mine, ctx->xg_buf));
+    memset(&mine, 0, sizeof(mine));
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
+    if (ok && hipIpcGetMemHandle(&mine, ctx->xg_buf) != hipSuccess) { (void)hipGetLastError(); ok = false; memset(&mine, 0, sizeof(mine)); }
     const size_t nf = (size_t)world * 64;
     std::vector<float> h(nf, 0.f);
     for (int b = 0; b < 64; ++b) h[(size_t)rank * 64 + b] = (float)((const unsigned char*)&mine)[b];
@@ -1273,15 +1277,17 @@ static int resident_rank_open(srps_ctx* ctx, size_t need) {
     SRPS_TRY(comm_all_reduce_sum(ctx, d, nf));             // every rank's 64 bytes, one float each
     SRPS_HIP(hipMemcpyAsync(h.data(), d, nf * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ok) { set_error("resident strips: this rank could not allocate or export its exchange buffer"); return SRPS_ERR_UNSUPPORTED; }
     for (int q = 0; q < world; ++q) {
         if (q == rank) { ctx->xg_peer[q] = ctx->xg_buf; continue; }
         hipIpcMemHandle_t hq;
-        for (int b = 0; b < 64; ++b) ((unsigned char*)&hq)[b] = (unsigned char)h[(size_t)q * 64 + b];
+        bool any = false;
+        for (int b = 0; b < 64; ++b) { ((unsigned char*)&hq)[b] = (unsigned char)h[(size_t)q * 64 + b]; any = any || h[(size_t)q * 64 + b] != 0.f; }
         void* p = nullptr;
-        const hipError_t e = hipIpcOpenMemHandle(&p, hq, hipIpcMemLazyEnablePeerAccess);
+        const hipError_t e = any ? hipIpcOpenMemHandle(&p, hq, hipIpcMemLazyEnablePeerAccess) : hipErrorInvalidValue;
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            set_error("resident strips: hipIpcOpenMemHandle of rank %d's exchange buffer failed (%s)", q, hipGetErrorString(e));
+            set_error("resident strips: rank %d's exchange buffer could not be mapped (%s)", q, any ? hipGetErrorString(e) : "that rank exported none");
             return SRPS_ERR_UNSUPPORTED;
         }
         ctx->xg_peer[q] = p;
@@ -1313,15 +1319,19 @@ int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps) {
         if (lbase[r + 1] - lbase[r] > ctx->num_cus) return SRPS_ERR_UNSUPPORTED;      // (the same decision on every rank: same list, same CU count assumed)
     const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
     const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
-    {
-        const int rc = resident_rank_open(ctx, need);
-        if (rc != SRPS_OK) { ctx->xg_failed = 1; return rc == SRPS_ERR_UNSUPPORTED ? rc : SRPS_ERR_UNSUPPORTED; }
-    }
-    SRPS_HIP(hipMemsetAsync(ctx->xg_buf, 0, need, ctx->stream));
-    // barrier: every rank's buffer is zeroed before any rank's kernel publishes into it
+    const bool opened = resident_rank_open(ctx, need) == SRPS_OK;
+    if (opened) SRPS_HIP(hipMemsetAsync(ctx->xg_buf, 0, need, ctx->stream));
+    // One float through the all-reduce: the barrier (every rank's buffer is zeroed before any rank's kernel publishes into it) AND the
+    // decision -- a rank whose mapping failed says so, and ALL ranks leave this path together (a rank that went its own way would meet
+    // the others in different collectives)
     SRPS_TRY(ensure(ctx->ws_misc, 64));
-    SRPS_HIP(hipMemsetAsync(ctx->ws_misc.p, 0, sizeof(float), ctx->stream));
+    const float mine_failed = opened ? 0.f : 1.f;
+    float failed = 0.f;
+    SRPS_HIP(hipMemcpyAsync(ctx->ws_misc.p, &mine_failed, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SRPS_TRY(comm_all_reduce_sum(ctx, (float*)ctx->ws_misc.p, 1));
+    SRPS_HIP(hipMemcpyAsync(&failed, ctx->ws_misc.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    if (failed != 0.f) { ctx->xg_failed = 1; return SRPS_ERR_UNSUPPORTED; }
     ResidentArgs a;
     memset(&a, 0, sizeof(a));
     auto carve = [&](void* base, unsigned long long*& ent, unsigned long long*& ent3, unsigned long long*& halo) {
