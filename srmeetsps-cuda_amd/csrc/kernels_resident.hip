@@ -1233,6 +1233,10 @@ int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_st
     return rc;
 }
 
+// a rank whose strip holds no masked pixel launches nothing: its report record says what the other ranks' kernels will say of a full solve
+__global__ void k_report_empty_rank(CgScalars* scal, int steps) {
+    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = 0.f; scal->iters = steps; scal->active = 0; scal->alpha = 0.f; }
+}
 // ---- the same, as ONE RANK of a communicator (cg_partition = 2): the other ranks are other processes, on other devices or on this one ----
 // Every rank keeps its granule arrays (ent | ent3 | halo, for the tiles of the WHOLE grid) in one fine-grained buffer, exports it
 // with hipIpcGetMemHandle and opens the others' (the 64-byte handles travel through the context's all-reduce, one float per byte:
@@ -1375,6 +1379,9 @@ int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps) {
         // a plain launch: the ranks' kernels must run side by side, and a cooperative launch of another process on the same device
         // would queue behind this one
         SRPS_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(NT), kargs, lds, ctx->stream));
+    } else {
+        hipLaunchKernelGGL(k_report_empty_rank, dim3(1), dim3(64), 0, ctx->stream, G.d_scal, max_steps);
+        SRPS_LAUNCH_CHECK();
     }
     std::swap(G.d_x, G.d_x2); ctx->x_swapped = true;      // the rank's strip of the result is in the other plane (see persistent_aborts)
     // the other strips: one broadcast per rank, in place in the result plane
