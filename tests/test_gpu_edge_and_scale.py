@@ -499,3 +499,36 @@ def test_normals_stored_by_the_energy_sweep_equal_the_normals_kernel(pkg, h, w, 
     # read between the sweep and srps_normals: the normals and dz of the PREVIOUS depth, with or without the option
     np.testing.assert_array_equal(out[0][2][0], out[1][2][0]); np.testing.assert_array_equal(out[0][2][1], out[1][2][1])
     np.testing.assert_array_equal(out[0][2][0], out[0][1][3]); np.testing.assert_array_equal(out[0][2][1], out[0][1][4])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: the tiled energy + lighting sweep (k_light_fused_tile) against round 3's four blocks per pixel range (k_light_fused_ci)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w,sf,n_img,n_ch,kind,bytes_in", [(96, 80, 2, 5, 3, "ragged", False), (512, 384, 4, 23, 3, "ellipse", False), (300, 200, 1, 2, 1, "ragged", False),
+                                                             (1024, 1024, 4, 20, 3, "full", False), (256, 128, 4, 20, 3, "full", True), (320, 240, 2, 45, 3, "ellipse", False)])
+def test_tiled_lighting_sweep_equals_the_sweep_of_four_blocks_per_range(pkg, h, w, sf, n_img, n_ch, kind, bytes_in):
+    """option light_tiled: the four image groups of a pixel range as the four waves of one block, geometry and normals once per pixel
+    through LDS, image loads prefetched (and, with byte images, from the 8-bit store: light_bytes) -- the same expressions per pixel as
+    k_light_fused_ci, other pixel subsets per lane: energies, lighting, albedo and depth agree to rounding over three passes; masks whose
+    pixel count is no multiple of the 1 024-pixel tile, image counts with partial rounds (23, 45) and one channel included"""
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img + 1, n_ch=n_ch, mask_kind=kind)
+    if bytes_in:
+        sc.I = (np.rint(np.clip(sc.I, 0, 1) * 255).astype(f32) / f32(255)).astype(f32)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for tiled, lbytes in ((0, 0), (1, 0), (1, 1)):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("light_tiled", tiled); ctx.set_option("light_bytes", lbytes)
+        srps = pkg.SRPS(dh, ctx=ctx)
+        en = srps.execute(max_outer=3)
+        out[(tiled, lbytes)] = (np.array(en, f32), srps.z(), srps.rho(), ctx.get("s"), ctx.get("N"), ctx.get_option("image_store_bytes_active"))
+        ctx.close()
+    a, b, c = out[(0, 0)], out[(1, 0)], out[(1, 1)]
+    assert c[5] == (1 if (bytes_in and dh.mask.sum() % 4 == 0) else 0)
+    # floats or bytes: the same floats reach the same arithmetic
+    for x, y in zip(b[:5], c[:5]):
+        assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-3)                      # first-pass energies answer rounding with up to 1e-3 (DESIGN.md section 6)
+    assert abs(float(b[0][-1]) - float(a[0][-1])) <= 2e-4 * abs(float(a[0][-1]))
+    assert rmse(b[1], a[1]) < 2e-5
+    assert rmse(b[2], a[2]) < 2e-4 and np.abs(b[3] - a[3]).max() < 5e-3
