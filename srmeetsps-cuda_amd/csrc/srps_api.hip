@@ -539,7 +539,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->light_channel_inner = value ? 1 : 0;
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "march_nt")) {
-        SRPS_REQUIRE(value >= 0 && value <= 2, SRPS_ERR_INVALID, "march_nt: 0 (never), 1 (always) or 2 (automatic), got %d", value);
+        SRPS_REQUIRE(value >= 0 && value <= 3, SRPS_ERR_INVALID, "march_nt: 0 (never), 1 (always), 2 (automatic) or 3 (stores only), got %d", value);
         ctx->march_nt = value;
     } else if (!strcmp(name, "light_bytes")) {
         ctx->light_bytes = value ? 1 : 0;
