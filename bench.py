@@ -436,6 +436,33 @@ def main():
             except Exception as exc:                      # a side measurement: never fail the bench line because of it
                 legs["strip_cg_4096_sf2_8_ranks_on_one_device"] = {"error": str(exc)}
             del sc4
+            # The RESIDENT kernel on strips (round 4): the headline's grid as two launches of 128 blocks each, side by side on this one
+            # device, exchanging their sums and border edges through each other's memory -- the multi-GPU form of the kernel with ordinary
+            # device memory in the place of peer memory.  Host clock around the whole group solve (events, synchronisations and the gather
+            # of the strips included): an upper bound of the step; the depth must be the single launch's, bit for bit.
+            try:
+                def prep():
+                    cq = pkg.Context(device_id=local_rank)         # its OWN stream: the launches must run side by side
+                    cq.set_option("exclusive_device", 1); cq.set_option("cg_resident_tile", 512); cq.set_option("spin_budget_ms", 1000)
+                    cq.setup(dh); cq.lighting(); cq.albedo(); cq.depth_partial(); cq.synchronize()
+                    return cq
+                one = prep(); one.depth_solve(); one.synchronize(); z_one = one.get("z"); one.close()
+                grp = [prep() for _ in range(2)]
+                pkg.Context.strip_group_solve_resident(grp)
+                same = all(np.array_equal(cq.get("z"), z_one) for cq in grp)
+                tsg = []
+                for _ in range(5):
+                    for cq in grp:
+                        cq.depth_partial(); cq.synchronize()
+                    tg0 = time.perf_counter(); pkg.Context.strip_group_solve_resident(grp); tsg.append(time.perf_counter() - tg0)
+                legs["resident_strips_2048_2_ranks_on_one_device"] = {
+                    "group_solve_ms": 1e3 * sorted(tsg)[len(tsg) // 2], "us_per_step_upper_bound": 1e6 * sorted(tsg)[len(tsg) // 2] / 102,
+                    "bit_identical_to_the_single_launch": bool(same), "ranks": 2, "blocks_per_rank": 128,
+                    "workload": f"depth CG of the headline workload ({H}x{W}, sf {args.sf}) as two resident launches on two strips of tile columns, both on this device (srps_strip_group_solve_resident)"}
+                for cq in grp:
+                    cq.close()
+            except Exception as exc:                      # a side measurement: never fail the bench line because of it
+                legs["resident_strips_2048_2_ranks_on_one_device"] = {"error": str(exc)}
             # the headline's mask is the best case of the resident kernel (every tile inside the mask: the body without structure
             # bits); any other mask -- the reference's own data -- takes the general body.  An ellipse in the same frame:
             scg = pkg.synth.make_scene(H, W, args.sf, 2, seed=1234 + 6, mask_kind="ellipse")
