@@ -1081,6 +1081,63 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     return rc;
 }
 
+// ---- one rank of a GROUP of resident launches in this unit's tile shape (drivers: resident_cg_group / resident_cg_rank below) --------
+size_t SRPS_RES_NAME(resident_group_bytes)(int tiles) {
+    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
+    return (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
+}
+int SRPS_RES_NAME(resident_group_launch)(srps_ctx* ctx, const ResidentGroupSpec& sp) {
+    Grid& G = ctx->grid;
+    const int nc = march_recompute_channels(ctx);
+    const int shape = TC == 64 ? 1 : (TC == 32 ? 0 : 2);
+    const size_t ent_n = ((size_t)sp.tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((sp.tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
+    auto carve = [&](void* base, unsigned long long*& ent, unsigned long long*& ent3, unsigned long long*& halo) {
+        ent = (unsigned long long*)base; ent3 = ent + ent_n; halo = ent3 + ent3_n;
+    };
+    ResidentArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.x_out = G.d_x2; a.r = G.d_r;
+    carve(sp.exch, a.ent, a.ent3, a.halo);
+    a.scal = G.d_scal;
+    a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = sp.nbr; a.nbc = sp.nbc;
+    a.lambda = ctx->lambda; a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
+    a.tol2 = sp.fixed_steps ? -1.f : ctx->cg_tol * ctx->cg_tol; a.max_steps = sp.max_steps;
+    a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
+    a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;
+    a.tile_cls = sp.rect ? G.d_tile_cls[shape] : nullptr; a.tile_occ = G.d_tile_cls[shape];
+    a.tile_list = G.d_tile_list[shape] + sp.list_base;
+    a.grp.nb = sp.nb_total; a.grp.slot = 0; a.grp.n_peers = sp.n_peers; a.grp_list_base = sp.list_base;
+    a.grp_bc_first = sp.bc_first; a.grp_bc_last = sp.bc_last;
+    for (int q = 0; q < sp.n_peers; ++q) {
+        unsigned long long *e, *e3, *hl;
+        carve(sp.peer_exch[q], e, e3, hl);
+        a.grp.ent[q] = e; a.grp.ent3[q] = e3;
+        if (q == sp.left_peer) a.grp_halo_left = hl;
+        if (q == sp.right_peer) a.grp_halo_right = hl;
+    }
+    if (sp.blocks == 0) {      // a strip without a masked pixel launches nothing: its report record says what the others' kernels say of a full solve
+        SRPS_HIP(hipMemsetAsync(G.d_scal, 0, 5 * sizeof(int), ctx->stream));
+        const int steps = sp.max_steps;
+        SRPS_HIP(hipMemcpyAsync(&G.d_scal->iters, &steps, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        return SRPS_OK;
+    }
+    const void* fn = nullptr;
+#define SRPS_RESG(SFV, NCV) fn = sp.rect ? (const void*)k_cg_resident_group<SFV, NCV, true, true> : (const void*)k_cg_resident_group<SFV, NCV, true, false>
+    if (G.sf == 4) {
+        if constexpr (CPT >= 4) { if (nc == 3) SRPS_RESG(4, 3); else SRPS_RESG(4, 1); }
+        else return SRPS_ERR_UNSUPPORTED;
+    } else if (nc == 3) { if (G.sf == 1) SRPS_RESG(1, 3); else SRPS_RESG(2, 3); }
+    else { if (G.sf == 1) SRPS_RESG(1, 1); else SRPS_RESG(2, 1); }
+#undef SRPS_RESG
+    const size_t lds = resident_lds_bytes(nc);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return SRPS_ERR_UNSUPPORTED; }
+    ctx->persistent_inflight = 1;
+    void* kargs[] = {&a};
+    // a PLAIN launch: the ranks' kernels must run side by side, and cooperative launches of one device queue one behind the other
+    SRPS_HIP(hipLaunchKernel(fn, dim3(sp.blocks), dim3(NT), kargs, lds, ctx->stream));
+    return SRPS_OK;
+}
+
 #if SRPS_RES_NT == 512 && SRPS_RES_CPT == 8
 // ---- the resident CG on the column strips of a group of contexts ----------------------------------------
 // n contexts that hold the SAME assembled depth system (replicated state, as after srps_depth_partial on every one) each run the
@@ -1089,106 +1146,135 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
 // 8-byte edge granules of the tiles on a strip's border (into the neighbouring rank's array) -- plain stores through pointers into
 // the other rank's memory: the same device (several contexts of one process: the test bed of a one-GPU box) or a peer device over
 // xGMI (hipDeviceEnablePeerAccess; not run anywhere yet).  No host step between the 101 CG steps.  All launches must be resident
-// TOGETHER: plain launches on the contexts' own streams (cooperative launches of one device queue one behind the other), the bounded
-// waits of device_utils.h end a group that cannot be (SRPS_ERR_UNSUPPORTED after the budget; nothing is stored).
+// TOGETHER: plain launches on the contexts' own streams, the bounded waits of device_utils.h end a group that cannot be
+// (SRPS_ERR_UNSUPPORTED after the budget; nothing is stored).
+namespace {
+// the tile shapes a group can run in (one compile unit each): columns per tile, threads, columns per thread, index of the tiling
+struct GroupUnit {
+    int tc, nt, cpt, shape, option;      // option: the value of "cg_resident_tile" that forces the unit
+    size_t (*bytes)(int);
+    int (*launch)(srps_ctx*, const ResidentGroupSpec&);
+};
+const GroupUnit kGroupUnits[] = {
+    {16, 512, 2, 2, 2, resident_group_bytes_n512c2, resident_group_launch_n512c2},
+    {16, 256, 4, 2, 16, resident_group_bytes_n256c4, resident_group_launch_n256c4},
+    {32, 512, 4, 0, 32, resident_group_bytes_n512c4, resident_group_launch_n512c4},
+    {32, 256, 8, 0, 256, resident_group_bytes_n256, resident_group_launch_n256},
+    {64, 512, 8, 1, 512, resident_group_bytes_n512, resident_group_launch_n512},
+};
+struct GroupPlan {
+    const GroupUnit* unit = nullptr;
+    int nbr = 0, nbc = 0, tiles = 0, NB = 0;
+    bool rect = false;
+    std::vector<int> tc0, lbase;         // per rank: first column of tiles, first entry of the tile list ([n] = end)
+};
+// ranges of tile columns for n ranks in unit u's tiling, and whether every rank's tiles get a CU each (all of them together when the
+// ranks share a device)
+bool group_partition(const srps_ctx* ctx, const GroupUnit& u, int n, bool one_device, GroupPlan& pl) {
+    const Grid& G = ctx->grid;
+    if (G.sf > u.cpt || (G.sf == 4 && u.cpt < 4)) return false;      // a thread's columns hold whole sf x sf blocks of KT
+    pl.nbr = cdiv(G.Hg, 256); pl.nbc = cdiv(G.Wg, u.tc); pl.tiles = pl.nbr * pl.nbc; pl.NB = G.n_occ[u.shape];
+    const std::vector<int>& list = G.h_tile_list[u.shape];
+    if (pl.nbc < n || pl.NB <= 0 || G.n_tiles[u.shape] != pl.tiles || (int)list.size() != pl.NB) return false;
+    pl.tc0.assign(n + 1, 0); pl.lbase.assign(n + 1, 0);
+    for (int r = 0; r <= n; ++r) pl.tc0[r] = (int)((long long)pl.nbc * r / n);
+    for (int r = 0, i = 0; r <= n; ++r) {
+        while (i < pl.NB && list[(size_t)i] / pl.nbr < pl.tc0[r]) ++i;      // tiles are numbered column by column
+        pl.lbase[r] = i;
+    }
+    for (int r = 0; r < n; ++r)
+        if (pl.lbase[r + 1] - pl.lbase[r] > ctx->num_cus) return false;
+    if (one_device && pl.NB > ctx->num_cus) return false;
+    pl.rect = ctx->cg_resident_rect && G.n_rect_tiles[u.shape] == pl.NB;
+    pl.unit = &u;
+    return true;
+}
+// the unit of a group: the one "cg_resident_tile" forces, else the smallest tiles that still give every tile of every rank a CU --
+// with the single launch's preferences (resident_shape below): 256 x 16 while a rank has few of them, then 256 x 32, then 256 x 64
+bool group_plan(const srps_ctx* ctx, int n, bool one_device, GroupPlan& pl) {
+    const int nc = march_recompute_channels(ctx);
+    const Grid& G = ctx->grid;
+    if (!((nc == 1 || nc == 3) && (G.sf == 1 || G.sf == 2 || G.sf == 4) && use_march(ctx))) return false;
+    const int want = ctx->cg_resident_tile;
+    for (const GroupUnit& u : kGroupUnits) {
+        if (want != 0 && u.option != want) continue;
+        GroupPlan cand;
+        if (!group_partition(ctx, u, n, one_device, cand)) continue;
+        if (want == 0) {
+            int most = 0;
+            for (int r = 0; r < n; ++r) most = std::max(most, cand.lbase[r + 1] - cand.lbase[r]);
+            if (u.option == 2 && most > 240) continue;
+            if (u.option == 16 && most > 96) continue;
+            if (u.option == 256) continue;                 // 256 x 32 with 256 threads: only when asked for
+        }
+        pl = cand;
+        return true;
+    }
+    return false;
+}
+}  // namespace
+
 int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_steps) {
     SRPS_REQUIRE(n >= 1 && n <= 8, SRPS_ERR_INVALID, "resident strip group: 1 .. 8 ranks");
     srps_ctx* c0 = ctxs[0];
     const Grid& G0 = c0->grid;
-    const int nc = march_recompute_channels(c0);
-    SRPS_REQUIRE((nc == 1 || nc == 3) && (G0.sf == 1 || G0.sf == 2 || G0.sf == 4) && use_march(c0), SRPS_ERR_UNSUPPORTED,
-                 "resident strip group: needs the tensor-recompute operator (1 or 3 channels, sf 1, 2 or 4)");
-    const int nbr = cdiv(G0.Hg, TR), nbc = cdiv(G0.Wg, TC), tiles = nbr * nbc, shape = 1;      // 256 x 64 tiles
-    SRPS_REQUIRE(nbc >= n, SRPS_ERR_INVALID, "resident strip group: %d ranks for %d columns of tiles", n, nbc);
-    const int NB = G0.n_occ[shape];
-    SRPS_REQUIRE(NB > 0 && G0.n_tiles[shape] == tiles, SRPS_ERR_STATE, "resident strip group: no tile list for the 256 x 64 tiling");
-    // the group's ascending tile list (the same on every rank): tiles are numbered column by column, so a range of tile columns is
-    // a contiguous piece of it
-    std::vector<int> list((size_t)NB);
-    SRPS_HIP(hipSetDevice(c0->device));
-    SRPS_HIP(hipMemcpy(list.data(), G0.d_tile_list[shape], (size_t)NB * sizeof(int), hipMemcpyDeviceToHost));
-    const bool rect = c0->cg_resident_rect && G0.n_rect_tiles[shape] == NB;
-    std::vector<int> tc0(n + 1), lbase(n + 1);
-    for (int r = 0; r <= n; ++r) tc0[r] = (int)((long long)nbc * r / n);
-    for (int r = 0, i = 0; r <= n; ++r) {
-        while (i < NB && list[(size_t)i] / nbr < tc0[r]) ++i;
-        lbase[r] = i;
-    }
     bool one_device = true;
     for (int r = 0; r < n; ++r) {
         srps_ctx* c = ctxs[r];
-        SRPS_REQUIRE(c->grid.Hg == G0.Hg && c->grid.Wg == G0.Wg && c->grid.sf == G0.sf && c->grid.Hs == G0.Hs && c->grid.n_occ[shape] == NB, SRPS_ERR_INVALID,
+        SRPS_REQUIRE(c->grid.Hg == G0.Hg && c->grid.Wg == G0.Wg && c->grid.sf == G0.sf && c->grid.Hs == G0.Hs && c->grid.P == G0.P, SRPS_ERR_INVALID,
                      "resident strip group: rank %d holds another grid", r);
-        SRPS_REQUIRE(march_recompute_channels(c) == nc, SRPS_ERR_INVALID, "resident strip group: rank %d has another operator form", r);
+        SRPS_REQUIRE(march_recompute_channels(c) == march_recompute_channels(c0), SRPS_ERR_INVALID, "resident strip group: rank %d has another operator form", r);
         for (int q = 0; q < r; ++q)
             SRPS_REQUIRE(ctxs[q]->stream != c->stream, SRPS_ERR_INVALID, "resident strip group: ranks %d and %d share a stream (their launches must run side by side)", q, r);
-        SRPS_REQUIRE(lbase[r + 1] - lbase[r] <= c->num_cus, SRPS_ERR_UNSUPPORTED, "resident strip group: rank %d has %d tiles for %d CUs", r, lbase[r + 1] - lbase[r], c->num_cus);
         one_device = one_device && c->device == c0->device;
     }
-    SRPS_REQUIRE(!one_device || NB <= c0->num_cus, SRPS_ERR_UNSUPPORTED, "resident strip group: %d tiles on one device of %d CUs", NB, c0->num_cus);
-    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
-    const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
-    const size_t lds = resident_lds_bytes(nc);
-    std::vector<ResidentArgs> args((size_t)n);
-    std::vector<hipEvent_t> ready((size_t)n, nullptr), done((size_t)n, nullptr);
-    auto cleanup = [&]() { for (auto e : ready) if (e) (void)hipEventDestroy(e); for (auto e : done) if (e) (void)hipEventDestroy(e); };
+    GroupPlan pl;
+    SRPS_REQUIRE(cdiv(G0.Wg, 16) >= n, SRPS_ERR_INVALID, "resident strip group: %d ranks for %d columns of tiles", n, cdiv(G0.Wg, 16));
+    if (one_device) {
+        // streams of one process share the runtime's hardware queues (GPU_MAX_HW_QUEUES, 4 by default): a fifth launch would wait in a
+        // queue behind one of the first four, which wait for it -- found by a test that dealt a grid to five contexts
+        const char* e = getenv("GPU_MAX_HW_QUEUES");
+        const int queues = e ? atoi(e) : 4;
+        SRPS_REQUIRE(n <= std::max(queues, 1), SRPS_ERR_UNSUPPORTED,
+                     "resident strip group: %d launches of one process on one device need %d hardware queues (GPU_MAX_HW_QUEUES is %d): they could not run side by side", n, n, queues);
+    }
+    SRPS_REQUIRE(group_plan(c0, n, one_device, pl), SRPS_ERR_UNSUPPORTED,
+                 "resident strip group: no tile shape gives every tile of every rank a CU (%d ranks%s), or the operator is not the tensor-recompute form", n,
+                 one_device ? " on one device" : "");
+    const GroupUnit& U = *pl.unit;
+    const size_t need = U.bytes(pl.tiles);
+    std::vector<hipEvent_t> ready((size_t)n, nullptr);
+    auto cleanup = [&]() { for (auto e : ready) if (e) (void)hipEventDestroy(e); };
     int rc = SRPS_OK;
     for (int r = 0; r < n && rc == SRPS_OK; ++r) {
         srps_ctx* c = ctxs[r];
-        Grid& G = c->grid;
         if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
         if (!one_device)
             for (int q = 0; q < n; ++q)
                 if (ctxs[q]->device != c->device) { (void)hipDeviceEnablePeerAccess(ctxs[q]->device, 0); (void)hipGetLastError(); }
         if ((rc = ensure(c->ws_resident, need)) != SRPS_OK) break;
         if (hipMemsetAsync(c->ws_resident.p, 0, need, c->stream) != hipSuccess || hipEventCreateWithFlags(&ready[(size_t)r], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&done[(size_t)r], hipEventDisableTiming) != hipSuccess || hipEventRecord(ready[(size_t)r], c->stream) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
-        ResidentArgs& a = args[(size_t)r];
-        memset(&a, 0, sizeof(a));
-        a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.x_out = G.d_x2; a.r = G.d_r;
-        a.ent = (unsigned long long*)c->ws_resident.p; a.ent3 = a.ent + ent_n; a.halo = a.ent3 + ent3_n;
-        a.scal = G.d_scal;
-        a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = nbr; a.nbc = nbc;
-        a.lambda = c->lambda; a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
-        a.tol2 = fixed_steps ? -1.f : c->cg_tol * c->cg_tol; a.max_steps = max_steps;
-        a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
-        a.spin_ticks = (unsigned long long)c->spin_budget_ms * 100000ull;
-        a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr; a.tile_occ = G.d_tile_cls[shape];
-        a.tile_list = G.d_tile_list[shape] + lbase[r];
-        a.grp.nb = NB; a.grp.slot = 0; a.grp_list_base = lbase[r];
-        a.grp_bc_first = tc0[r]; a.grp_bc_last = tc0[r + 1] - 1;
+            hipEventRecord(ready[(size_t)r], c->stream) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
     }
-    // every rank's arrays are known now: the peers' pointers
-    for (int r = 0; r < n && rc == SRPS_OK; ++r) {
-        ResidentArgs& a = args[(size_t)r];
-        int np = 0;
-        for (int q = 0; q < n; ++q)
-            if (q != r) { a.grp.ent[np] = args[(size_t)q].ent; a.grp.ent3[np] = args[(size_t)q].ent3; ++np; }
-        a.grp.n_peers = np;
-        a.grp_halo_left = r > 0 ? args[(size_t)r - 1].halo : nullptr;
-        a.grp_halo_right = r + 1 < n ? args[(size_t)r + 1].halo : nullptr;
-    }
-    // launches: every rank waits until ALL granule arrays are zeroed, then runs on its own stream, plain launch
+    // launches: every rank waits until ALL granule arrays are zeroed, then runs on its own stream
     for (int r = 0; r < n && rc == SRPS_OK; ++r) {
         srps_ctx* c = ctxs[r];
         if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
         for (int q = 0; q < n; ++q)
             if (q != r && hipStreamWaitEvent(c->stream, ready[(size_t)q], 0) != hipSuccess) rc = SRPS_ERR_HIP;
         if (rc != SRPS_OK) break;
-        const int blocks = lbase[r + 1] - lbase[r];
-        if (blocks == 0) { (void)hipEventRecord(done[(size_t)r], c->stream); continue; }      // a strip without a masked pixel
-        const void* fn = nullptr;
-        const int sf = c->grid.sf;
-#define SRPS_RESG(SFV, NCV) fn = rect ? (const void*)k_cg_resident_group<SFV, NCV, true, true> : (const void*)k_cg_resident_group<SFV, NCV, true, false>
-        if (sf == 4) { if (nc == 3) SRPS_RESG(4, 3); else SRPS_RESG(4, 1); }
-        else if (sf == 2) { if (nc == 3) SRPS_RESG(2, 3); else SRPS_RESG(2, 1); }
-        else { if (nc == 3) SRPS_RESG(1, 3); else SRPS_RESG(1, 1); }
-#undef SRPS_RESG
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); rc = SRPS_ERR_UNSUPPORTED; break; }
-        c->persistent_inflight = 1;
-        void* kargs[] = {&args[(size_t)r]};
-        if (hipLaunchKernel(fn, dim3(blocks), dim3(NT), kargs, lds, c->stream) != hipSuccess) { (void)hipGetLastError(); rc = SRPS_ERR_HIP; break; }
-        (void)hipEventRecord(done[(size_t)r], c->stream);
+        ResidentGroupSpec sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.exch = c->ws_resident.p; sp.left_peer = -1; sp.right_peer = -1;
+        for (int q = 0; q < n; ++q) {
+            if (q == r) continue;
+            if (q == r - 1) sp.left_peer = sp.n_peers;
+            if (q == r + 1) sp.right_peer = sp.n_peers;
+            sp.peer_exch[sp.n_peers++] = ctxs[q]->ws_resident.p;
+        }
+        sp.tiles = pl.tiles; sp.nbr = pl.nbr; sp.nbc = pl.nbc; sp.nb_total = pl.NB; sp.list_base = pl.lbase[r]; sp.blocks = pl.lbase[r + 1] - pl.lbase[r];
+        sp.bc_first = pl.tc0[r]; sp.bc_last = pl.tc0[r + 1] - 1; sp.rect = pl.rect; sp.max_steps = max_steps; sp.fixed_steps = fixed_steps;
+        rc = U.launch(c, sp);
     }
     // wait for all of them; did every wait get served?
     bool aborted = false;
@@ -1203,40 +1289,29 @@ int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_st
         }
         c->persistent_inflight = 0;
     }
+    cleanup();
     if (rc == SRPS_OK && aborted) {
-        cleanup();
         set_error("resident strip group: the %d launches did not become resident together within %d ms (shared device?); nothing was stored", n, c0->spin_budget_ms);
         return SRPS_ERR_UNSUPPORTED;
     }
     // the result: every rank's strip is in its second plane; the planes swap roles and the strips travel to the other ranks
-    for (int r = 0; r < n && rc == SRPS_OK; ++r) {
-        srps_ctx* c = ctxs[r];
-        Grid& G = c->grid;
-        if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
-        // the columns of the other strips in the result plane: they arrive below; until then the plane must not be read
-        std::swap(G.d_x, G.d_x2);
-    }
+    for (int r = 0; r < n && rc == SRPS_OK; ++r) std::swap(ctxs[r]->grid.d_x, ctxs[r]->grid.d_x2);
     for (int r = 0; r < n && rc == SRPS_OK; ++r) {
         srps_ctx* c = ctxs[r];
         if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
         for (int q = 0; q < n; ++q) {
             if (q == r) continue;
-            const int cb = tc0[q] * TC, ce = std::min(tc0[q + 1] * TC, G0.Wg);
+            const int cb = pl.tc0[q] * U.tc, ce = std::min(pl.tc0[q + 1] * U.tc, G0.Wg);
             if (ce <= cb) continue;
             const size_t off = (size_t)(cb + PAD) * G0.Hs, cnt = (size_t)(ce - cb) * G0.Hs;
             if (hipMemcpyAsync(c->grid.d_x + off, ctxs[q]->grid.d_x + off, cnt * sizeof(float), hipMemcpyDefault, c->stream) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
         }
     }
     for (int r = 0; r < n; ++r) { (void)hipSetDevice(ctxs[r]->device); (void)hipStreamSynchronize(ctxs[r]->stream); }
-    cleanup();
-    if (rc != SRPS_OK) set_error("resident strip group: a HIP call failed (%s)", hipGetErrorString(hipGetLastError()));
+    if (rc != SRPS_OK && rc != SRPS_ERR_UNSUPPORTED) set_error("resident strip group: a HIP call failed (%s)", hipGetErrorString(hipGetLastError()));
     return rc;
 }
 
-// a rank whose strip holds no masked pixel launches nothing: its report record says what the other ranks' kernels will say of a full solve
-__global__ void k_report_empty_rank(CgScalars* scal, int steps) {
-    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = 0.f; scal->iters = steps; scal->active = 0; scal->alpha = 0.f; }
-}
 // ---- the same, as ONE RANK of a communicator (cg_partition = 2): the other ranks are other processes, on other devices or on this one ----
 // Every rank keeps its granule arrays (ent | ent3 | halo, for the tiles of the WHOLE grid) in one fine-grained buffer, exports it
 // with hipIpcGetMemHandle and opens the others' (the 64-byte handles travel through the context's all-reduce, one float per byte:
@@ -1303,26 +1378,11 @@ int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     Grid& G = ctx->grid;
     const int n = ctx->comm_world, rank = ctx->comm_rank;
     if (ctx->xg_failed || n < 2 || n > 8 || !comm_bound(ctx) || !ctx->cg_resident || !ctx->cg_one_sync) return SRPS_ERR_UNSUPPORTED;
-    const int nc = march_recompute_channels(ctx);
-    if (!((nc == 1 || nc == 3) && (G.sf == 1 || G.sf == 2 || G.sf == 4) && use_march(ctx))) return SRPS_ERR_UNSUPPORTED;
-    const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc, shape = 1;
-    const int NB = G.n_occ[shape];
-    if (nbc < n || NB <= 0 || G.n_tiles[shape] != tiles) return SRPS_ERR_UNSUPPORTED;
-    // the rank's piece of the ascending tile list (a range of tile columns); the list itself is the same on every rank
-    if ((int)G.h_tile_list1.size() != NB) {
-        G.h_tile_list1.resize((size_t)NB);
-        SRPS_HIP(hipMemcpy(G.h_tile_list1.data(), G.d_tile_list[shape], (size_t)NB * sizeof(int), hipMemcpyDeviceToHost));
-    }
-    std::vector<int> tc0(n + 1), lbase(n + 1);
-    for (int r = 0; r <= n; ++r) tc0[r] = (int)((long long)nbc * r / n);
-    for (int r = 0, i = 0; r <= n; ++r) {
-        while (i < NB && G.h_tile_list1[(size_t)i] / nbr < tc0[r]) ++i;
-        lbase[r] = i;
-    }
-    for (int r = 0; r < n; ++r)
-        if (lbase[r + 1] - lbase[r] > ctx->num_cus) return SRPS_ERR_UNSUPPORTED;      // (the same decision on every rank: same list, same CU count assumed)
-    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
-    const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
+    // (every decision up to the handshake depends on replicated state only -- the grid, the options --: all ranks take the same way)
+    GroupPlan pl;
+    if (!group_plan(ctx, n, /*one_device=*/false, pl)) return SRPS_ERR_UNSUPPORTED;
+    const GroupUnit& U = *pl.unit;
+    const size_t need = U.bytes(pl.tiles);
     const bool opened = resident_rank_open(ctx, need) == SRPS_OK;
     if (opened) SRPS_HIP(hipMemsetAsync(ctx->xg_buf, 0, need, ctx->stream));
     // One float through the all-reduce: the barrier (every rank's buffer is zeroed before any rank's kernel publishes into it) AND the
@@ -1336,57 +1396,22 @@ int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     SRPS_HIP(hipMemcpyAsync(&failed, ctx->ws_misc.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SRPS_HIP(hipStreamSynchronize(ctx->stream));
     if (failed != 0.f) { ctx->xg_failed = 1; return SRPS_ERR_UNSUPPORTED; }
-    ResidentArgs a;
-    memset(&a, 0, sizeof(a));
-    auto carve = [&](void* base, unsigned long long*& ent, unsigned long long*& ent3, unsigned long long*& halo) {
-        ent = (unsigned long long*)base; ent3 = ent + ent_n; halo = ent3 + ent3_n;
-    };
-    a.G = G.d_G; a.flags = G.d_flags; a.consts = G.d_tconsts; a.x = G.d_x; a.x_out = G.d_x2; a.r = G.d_r;
-    carve(ctx->xg_buf, a.ent, a.ent3, a.halo);
-    a.scal = G.d_scal;
-    a.Hs = G.Hs; a.Ws = G.Ws; a.plane = G.plane; a.nbr = nbr; a.nbc = nbc;
-    a.lambda = ctx->lambda; a.inv_sf4 = 1.0f / ((float)(G.sf * G.sf) * (float)(G.sf * G.sf));
-    a.tol2 = fixed_steps ? -1.f : ctx->cg_tol * ctx->cg_tol; a.max_steps = max_steps;
-    a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
-    a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;
-    const bool rect = ctx->cg_resident_rect && G.n_rect_tiles[shape] == NB;
-    a.tile_cls = rect ? G.d_tile_cls[shape] : nullptr; a.tile_occ = G.d_tile_cls[shape];
-    a.tile_list = G.d_tile_list[shape] + lbase[rank];
-    a.grp.nb = NB; a.grp_list_base = lbase[rank];
-    a.grp_bc_first = tc0[rank]; a.grp_bc_last = tc0[rank + 1] - 1;
-    int np = 0;
+    ResidentGroupSpec sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.exch = ctx->xg_buf; sp.left_peer = -1; sp.right_peer = -1;
     for (int q = 0; q < n; ++q) {
         if (q == rank) continue;
-        unsigned long long *e, *e3, *hl;
-        carve(ctx->xg_peer[q], e, e3, hl);
-        a.grp.ent[np] = e; a.grp.ent3[np] = e3; ++np;
-        if (q == rank - 1) a.grp_halo_left = hl;
-        if (q == rank + 1) a.grp_halo_right = hl;
+        if (q == rank - 1) sp.left_peer = sp.n_peers;
+        if (q == rank + 1) sp.right_peer = sp.n_peers;
+        sp.peer_exch[sp.n_peers++] = ctx->xg_peer[q];
     }
-    a.grp.n_peers = np;
-    const int blocks = lbase[rank + 1] - lbase[rank];
-    if (blocks > 0) {
-        const void* fn = nullptr;
-#define SRPS_RESG(SFV, NCV) fn = rect ? (const void*)k_cg_resident_group<SFV, NCV, true, true> : (const void*)k_cg_resident_group<SFV, NCV, true, false>
-        if (G.sf == 4) { if (nc == 3) SRPS_RESG(4, 3); else SRPS_RESG(4, 1); }
-        else if (G.sf == 2) { if (nc == 3) SRPS_RESG(2, 3); else SRPS_RESG(2, 1); }
-        else { if (nc == 3) SRPS_RESG(1, 3); else SRPS_RESG(1, 1); }
-#undef SRPS_RESG
-        const size_t lds = resident_lds_bytes(nc);
-        SRPS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ctx->persistent_inflight = 1;
-        void* kargs[] = {&a};
-        // a plain launch: the ranks' kernels must run side by side, and a cooperative launch of another process on the same device
-        // would queue behind this one
-        SRPS_HIP(hipLaunchKernel(fn, dim3(blocks), dim3(NT), kargs, lds, ctx->stream));
-    } else {
-        hipLaunchKernelGGL(k_report_empty_rank, dim3(1), dim3(64), 0, ctx->stream, G.d_scal, max_steps);
-        SRPS_LAUNCH_CHECK();
-    }
+    sp.tiles = pl.tiles; sp.nbr = pl.nbr; sp.nbc = pl.nbc; sp.nb_total = pl.NB; sp.list_base = pl.lbase[rank]; sp.blocks = pl.lbase[rank + 1] - pl.lbase[rank];
+    sp.bc_first = pl.tc0[rank]; sp.bc_last = pl.tc0[rank + 1] - 1; sp.rect = pl.rect; sp.max_steps = max_steps; sp.fixed_steps = fixed_steps;
+    SRPS_TRY(U.launch(ctx, sp));
     std::swap(G.d_x, G.d_x2); ctx->x_swapped = true;      // the rank's strip of the result is in the other plane (see persistent_aborts)
     // the other strips: one broadcast per rank, in place in the result plane
     for (int q = 0; q < n; ++q) {
-        const int cb = tc0[q] * TC, ce = std::min(tc0[q + 1] * TC, G.Wg);
+        const int cb = pl.tc0[q] * U.tc, ce = std::min(pl.tc0[q + 1] * U.tc, G.Wg);
         if (ce <= cb) continue;
         SRPS_TRY(comm_broadcast(ctx, G.d_x + (size_t)(cb + PAD) * G.Hs, (size_t)(ce - cb) * G.Hs, q));
     }

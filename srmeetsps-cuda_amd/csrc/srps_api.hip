@@ -267,7 +267,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
         for (int t = 0; t < G.n_tiles[shape]; ++t)
             if (h_cls[shape][t] & TILE_OCCUPIED) h_list[shape].push_back(t);
         G.n_occ[shape] = (int)h_list[shape].size();
-        if (shape == 1) G.h_tile_list1 = h_list[shape];      // the resident strips cut this list into ranges of tile columns
+        G.h_tile_list[shape] = h_list[shape];                 // the resident strips cut these lists into ranges of tile columns
         if (G.n_occ[shape]) SRPS_HIP(hipMemcpyAsync(G.d_tile_list[shape], h_list[shape].data(), (size_t)G.n_occ[shape] * sizeof(int), hipMemcpyHostToDevice, ax));
     }
     SRPS_HIP(hipEventRecord(ctx->aux_event, ax));

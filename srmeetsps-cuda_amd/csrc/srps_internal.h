@@ -71,7 +71,7 @@ struct Grid {
     int tensor_channels = 0;      // channels of the last assembly
     bool M_valid = false;         // d_M holds the tensor of the last assembly
     float cx = 0.f, cy = 0.f;     // principal point used by the last assembly (xx = j - cx, yy = i - cy)
-    std::vector<int> h_tile_list1;   // host copy of d_tile_list[1] (the 256 x 64 tiling), made when the resident strips first ask for it
+    std::vector<int> h_tile_list[3]; // host copies of d_tile_list[.] (build_grid): the resident strips cut them into ranges of tile columns
     float* d_x = nullptr;         // [plane] z on the grid
     float* d_x2 = nullptr;        // [plane] the resident CG stores its result here and the two planes swap roles: the iterate a persistent
                                   // launch started from survives it (an aborted launch is repeated by the streaming kernels from exactly that iterate)
@@ -341,6 +341,23 @@ int launch_persistent(srps_ctx* ctx, const void* fn, int blocks, int threads, vo
 bool resident_supported(const srps_ctx* ctx);
 bool resident_rect_active(const srps_ctx* ctx);
 int resident_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);
+// one rank of a group of resident launches: what a tile-shape unit needs to build its kernel arguments (kernels_resident.hip)
+struct ResidentGroupSpec {
+    void* exch;                          // this rank's exchange buffer: ent | ent3 | halo
+    void* peer_exch[7];                  // the other ranks', in rank order without this one
+    int n_peers, left_peer, right_peer;  // indices into peer_exch of the ranks to the left / right (-1: none)
+    int tiles, nbr, nbc;                 // the whole grid's tiling in the unit's shape
+    int nb_total, list_base, blocks;     // granule slots of the group, this rank's first entry of the tile list, its blocks
+    int bc_first, bc_last;               // its first / last column of tiles
+    bool rect;
+    int max_steps;
+    bool fixed_steps;
+};
+size_t resident_group_bytes_n512(int tiles); size_t resident_group_bytes_n256(int tiles); size_t resident_group_bytes_n256c4(int tiles);
+size_t resident_group_bytes_n512c4(int tiles); size_t resident_group_bytes_n512c2(int tiles);
+int resident_group_launch_n512(srps_ctx* ctx, const ResidentGroupSpec& sp); int resident_group_launch_n256(srps_ctx* ctx, const ResidentGroupSpec& sp);
+int resident_group_launch_n256c4(srps_ctx* ctx, const ResidentGroupSpec& sp); int resident_group_launch_n512c4(srps_ctx* ctx, const ResidentGroupSpec& sp);
+int resident_group_launch_n512c2(srps_ctx* ctx, const ResidentGroupSpec& sp);
 int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_steps);
 int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps);      // one RANK of such a group: the other ranks are other processes / devices (cg_partition = 2); SRPS_ERR_UNSUPPORTED: use another path
 void resident_rank_release(srps_ctx* ctx);                                 // closes the peers' mappings, frees the exchange buffer      // the resident kernel on column strips of several contexts

@@ -236,9 +236,9 @@ def test_albedo_abort_with_strips_repeats_from_the_pass_start_plane(pkg, tmp_pat
 # ------------------------------------------------------------------------------------------------
 # round 4: the RESIDENT kernel on the strips (srps_strip_group_solve_resident)
 # ------------------------------------------------------------------------------------------------
-def _resident_single(pkg, dh):
+def _resident_single(pkg, dh, tile=512):
     c = pkg.Context(device_id=0)
-    c.set_option("cg_resident_tile", 512)                  # 256 x 64 tiles: the shape the strip group runs
+    c.set_option("cg_resident_tile", tile)                 # the tile shape the strip group is made to run too (512: 256 x 64 tiles)
     c.setup(dh)
     c.lighting(); c.albedo()
     e = c.depth()
@@ -248,11 +248,11 @@ def _resident_single(pkg, dh):
     return out
 
 
-def _resident_group(pkg, dh, world):
+def _resident_group(pkg, dh, world, tile=512):
     ctxs = []
     for _ in range(world):
         c = pkg.Context(device_id=0)                       # every context keeps its OWN stream: the launches must run side by side
-        c.set_option("cg_resident_tile", 512)
+        c.set_option("cg_resident_tile", tile)
         c.set_option("spin_budget_ms", 1000)               # the launches start one after the other: the first waits for the last
         c.setup(dh)
         ctxs.append(c)
@@ -271,9 +271,12 @@ def _resident_group(pkg, dh, world):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("h,w,sf,kind,world", [(1024, 2048, 4, "full", 1), (1024, 2048, 4, "full", 2), (1024, 2048, 4, "full", 4), (1024, 1536, 2, "ellipse", 3),
-                                               (2048, 2048, 4, "full", 2), (768, 1280, 1, "ragged", 2)])
-def test_resident_kernel_on_strips_equals_the_single_resident_launch_bit_for_bit(pkg, h, w, sf, kind, world):
+@pytest.mark.parametrize("h,w,sf,kind,world,tile", [(1024, 2048, 4, "full", 1, 512), (1024, 2048, 4, "full", 2, 512), (1024, 2048, 4, "full", 4, 512), (1024, 1536, 2, "ellipse", 3, 512),
+                                                    (2048, 2048, 4, "full", 2, 512), (768, 1280, 1, "ragged", 2, 512),
+                                                    # the other tile shapes: 256 x 32 with 512 and with 256 threads, 256 x 16 with 256 threads (sf 4) and with 512 (sf <= 2)
+                                                    (1024, 1024, 4, "full", 2, 32), (1024, 1024, 2, "ellipse", 3, 256), (512, 1024, 4, "full", 2, 16), (512, 768, 2, "ellipse", 3, 2),
+                                                    (768, 640, 1, "ragged", 2, 2)])
+def test_resident_kernel_on_strips_equals_the_single_resident_launch_bit_for_bit(pkg, h, w, sf, kind, world, tile):
     """The resident depth CG as `world` launches, one per context, each on its own range of 256 x 64 tile columns, side by side on this
     one device and exchanging the three sums of a step and the border tiles' edge columns through each other's memory while they run
     (the multi-GPU form of the kernel, with ordinary device memory in the place of peer memory): every block computes what it
@@ -281,13 +284,13 @@ def test_resident_kernel_on_strips_equals_the_single_resident_launch_bit_for_bit
     step count are those of srps_depth_solve on one context, bit for bit, on every rank."""
     sc = pkg.synth.make_scene(h, w, sf, 3, seed=h + 3 * w + sf, mask_kind=kind)
     dh = pkg.DataHandler.from_scene(sc)
-    e1, z1, it1, rect1 = _resident_single(pkg, dh)
-    group = _resident_group(pkg, dh, world)
+    e1, z1, it1, rect1 = _resident_single(pkg, dh, tile)
+    group = _resident_group(pkg, dh, world, tile)
     for e, z, it in group:
         assert it == it1 == 101
         np.testing.assert_array_equal(z, z1)
         assert e == e1
-    print(f"{h}x{w} sf {sf} {kind}: {world} resident strips == the single resident launch (rect body {rect1})")
+    print(f"{h}x{w} sf {sf} {kind}, tile option {tile}: {world} resident strips == the single resident launch (rect body {rect1})")
 
 
 def test_resident_strip_group_refuses_what_it_cannot_run(pkg):
@@ -304,7 +307,17 @@ def test_resident_strip_group_refuses_what_it_cannot_run(pkg):
     for c in ctxs:
         c.close()
     ctxs = []
-    for _ in range(5):                                      # 4 columns of tiles cannot be dealt to 5 ranks
+    for _ in range(5):                                      # five launches of one process: the runtime has four hardware queues for them
+        c = pkg.Context(device_id=0); c.setup(dh); c.lighting(); c.albedo(); c.depth_partial(); ctxs.append(c)
+    with pytest.raises(Exception) as ei:
+        pkg.Context.strip_group_solve_resident(ctxs)
+    assert "hardware queues" in str(ei.value)
+    for c in ctxs:
+        c.close()
+    sc = pkg.synth.make_scene(256, 32, 2, 2, seed=3, mask_kind="full")       # two columns of 256 x 16 tiles cannot be dealt to three ranks
+    dh = pkg.DataHandler.from_scene(sc)
+    ctxs = []
+    for _ in range(3):
         c = pkg.Context(device_id=0); c.setup(dh); c.lighting(); c.albedo(); c.depth_partial(); ctxs.append(c)
     with pytest.raises(Exception) as ei:
         pkg.Context.strip_group_solve_resident(ctxs)
