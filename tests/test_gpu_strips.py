@@ -326,7 +326,7 @@ def test_resident_strip_group_refuses_what_it_cannot_run(pkg):
         c.close()
 
 
-def _ipc_worker(rank, world, port, h, w, sf, kind, seed, out_dir):
+def _ipc_worker(rank, world, port, h, w, sf, kind, seed, tile, out_dir):
     import importlib
     import os
     import sys
@@ -341,7 +341,7 @@ def _ipc_worker(rank, world, port, h, w, sf, kind, seed, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _strip_protocol as strips
     sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
     ctx = pkg.Context(device_id=0)
-    ctx.set_option("cg_resident_tile", 512)
+    ctx.set_option("cg_resident_tile", tile)
     ctx.set_option("cg_partition", 2)                      # the resident kernel on this rank's strip of tile columns
     ctx.set_option("spin_budget_ms", 2000)                 # two processes start their launches a few milliseconds apart
     hc = strips.HostedCollectives(ctx, dist)               # all-reduce / broadcast over gloo: carries the hipIpc handles, the barrier, the strips of x
@@ -363,8 +363,8 @@ def _ipc_worker(rank, world, port, h, w, sf, kind, seed, out_dir):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("h,w,sf,kind,world", [(1024, 2048, 4, "full", 2), (1024, 1536, 2, "ellipse", 3)])
-def test_resident_strips_between_processes_through_ipc_mapped_buffers(pkg, tmp_path, h, w, sf, kind, world):
+@pytest.mark.parametrize("h,w,sf,kind,world,tile", [(1024, 2048, 4, "full", 2, 512), (1024, 1536, 2, "ellipse", 3, 512), (1024, 1024, 4, "full", 2, 32), (512, 768, 2, "ellipse", 2, 2)])
+def test_resident_strips_between_processes_through_ipc_mapped_buffers(pkg, tmp_path, h, w, sf, kind, world, tile):
     """cg_partition = 2 as a multi-GPU job would run it -- one PROCESS per rank, every rank's exchange buffer exported with
     hipIpcGetMemHandle and mapped by the others (the handles travel through the context's all-reduce), the ranks' resident kernels side
     by side for the whole solve, the strips of x broadcast afterwards -- with the ranks sharing this one device: two passes, the results
@@ -373,10 +373,10 @@ def test_resident_strips_between_processes_through_ipc_mapped_buffers(pkg, tmp_p
     import torch.multiprocessing as mp
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     seed = h + 3 * w + sf
-    mp.spawn(_ipc_worker, args=(world, port, h, w, sf, kind, seed, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_ipc_worker, args=(world, port, h, w, sf, kind, seed, tile, str(tmp_path)), nprocs=world, join=True)
     sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
     c = pkg.Context(device_id=0)
-    c.set_option("cg_resident_tile", 512)
+    c.set_option("cg_resident_tile", tile)
     c.setup(pkg.DataHandler.from_scene(sc))
     ref = {}
     for it in range(2):
