@@ -8,8 +8,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("srmeetsps-cuda_amd")
-sc = pkg.synth.make_scene(2048, 2048, 4, 2, seed=1237, mask_kind="full")
+opts = [a for a in sys.argv[1:] if "=" in a]            # NAME=INT options; a bare word: the mask kind
+kind = next((a for a in sys.argv[1:] if "=" not in a), "full")
+sc = pkg.synth.make_scene(2048, 2048, 4, 2, seed=1237, mask_kind=kind)
 ctx = pkg.Context(device_id=0)
+for kv in opts:
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 ctx.setup(pkg.DataHandler.from_scene(sc))
 pkg.alternating_loop(ctx, None, max_outer=1)
 b = ctx.bench_cg(solves=2, iters=101)
