@@ -483,10 +483,16 @@ class TorchCollectives:
             v.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
             return torch.as_tensor(v, device=device)
 
+        def to_host(g):
+            # into PINNED host memory (torch's caching host allocator): the device does not touch pageable pages (csrc/srps_xfer.hip says why)
+            t = torch.empty(g.shape, dtype=g.dtype, pin_memory=True)
+            t.copy_(g)
+            return t
+
         def allreduce(user, d_buf, n, f64):
             try:
                 g = view(d_buf, n, "<f8" if f64 else "<f4")
-                t = g.cpu()
+                t = to_host(g)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 g.copy_(t)
                 torch.cuda.synchronize()
@@ -498,7 +504,7 @@ class TorchCollectives:
         def broadcast(user, d_buf, n, root):
             try:
                 g = view(d_buf, n, "<f4")
-                t = g.cpu()
+                t = to_host(g)
                 dist.broadcast(t, src=root)
                 g.copy_(t)
                 torch.cuda.synchronize()

@@ -247,12 +247,12 @@ int srps_host_COO_to_device_CSR(srps_ctx* ctx, const int* row, const int* col, c
         const int d = cur[row[t]]++;
         ci[d] = col[t]; vv[d] = val[t];
     }
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    SRPS_HIP(hipMemcpy(d_row_ptr, rp.data(), (size_t)(n_row + 1) * sizeof(int), hipMemcpyHostToDevice));
+    SRPS_TRY(host_upload(ctx, d_row_ptr, rp.data(), (size_t)(n_row + 1) * sizeof(int), ctx->stream));
     if (nnz > 0) {
-        SRPS_HIP(hipMemcpy(d_col_ind, ci.data(), (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
-        SRPS_HIP(hipMemcpy(d_val, vv.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+        SRPS_TRY(host_upload(ctx, d_col_ind, ci.data(), (size_t)nnz * sizeof(int), ctx->stream));
+        SRPS_TRY(host_upload(ctx, d_val, vv.data(), (size_t)nnz * sizeof(float), ctx->stream));
     }
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
     return SRPS_OK;
 }
 

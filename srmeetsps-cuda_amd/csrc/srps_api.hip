@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <functional>
+#include <thread>
 #include <mutex>
 #include <dlfcn.h>
 #include "srps_internal.h"
@@ -182,10 +183,10 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
             }
         }
     }
-    if (after_release) SRPS_TRY((*after_release)());
     float* d_mask = (float*)ctx->ws_struct.p;
     const StructScratch sc = struct_scratch((char*)ctx->ws_struct.p + mask_bytes, h, w, sf);
-    SRPS_HIP(hipMemcpyAsync(d_mask, mask, hw * sizeof(float), hipMemcpyHostToDevice, ax));
+    SRPS_TRY(host_upload(ctx, d_mask, mask, hw * sizeof(float), ax));      // (before the images take the transfer buffer)
+    if (after_release) SRPS_TRY((*after_release)());
     SRPS_TRY(struct_phase1(ax, d_mask, h, w, sf, sc));
     int* hdr = (int*)(ctx->h_pinned + 128);                // behind everything a pass reads back
     SRPS_HIP(hipMemcpyAsync(hdr, sc.header, 8 * sizeof(int), hipMemcpyDeviceToHost, ax));
@@ -657,7 +658,7 @@ int srps_mean_across_channels(srps_ctx* ctx, const float* h_data, int h, int w, 
     SRPS_REQUIRE(h_data && d_mean && d_inpaint && h > 0 && w > 0 && nc > 0, SRPS_ERR_INVALID, "mean_across_channels: bad arguments");
     const size_t n = (size_t)h * w * nc;
     SRPS_TRY(ensure(ctx->ws_stage, n * sizeof(float)));
-    SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, h_data, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SRPS_TRY(host_upload(ctx, ctx->ws_stage.p, h_data, n * sizeof(float), ctx->stream));
     return launch_mean_channels(ctx->stream, (const float*)ctx->ws_stage.p, h, w, nc, d_mean, d_inpaint);
 }
 int srps_rho_init(srps_ctx* ctx, float* d_rho, int npix, int nc) {
@@ -903,31 +904,53 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
         const void* p = nullptr;
         srps_ctx* c = nullptr;
         ~Pin() {      // also on the error paths: no copy in flight when the caller's array is unpinned
-            if (p) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->gather_stream); (void)hipHostUnregister(const_cast<void*>(p)); }
+            if (!p) return;
+            (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->gather_stream);
+            const hipError_t e = hipHostUnregister(const_cast<void*>(p));
+            if (e != hipSuccess) {      // the array stays registered: say so (a later array at the same address would be taken for it)
+                fprintf(stderr, "srps_setup: hipHostUnregister(%p) failed: %s\n", p, hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
         }
     } pin;
     pin.c = ctx;
-    int slots = 0, queued = 0;
+    // The images reach the device in batches of `slots` images (all of them at once while they fit 2 GB of staging memory), each batch
+    // one transfer: through the library's pinned buffer (host_upload; on a thread of its own for the first batch, so that the copies
+    // run while this thread builds the grid structure), or -- "pin_uploads", off by default -- straight out of the caller's array,
+    // registered in place for the duration.
+    int slots = 0;
+    struct Uploader {
+        std::thread t;
+        int rc = SRPS_OK;
+        ~Uploader() { if (t.joinable()) t.join(); }      // also on the error paths: nothing reads the caller's array after srps_setup
+    } first_batch;
+    auto copy_batch = [&](int n0, int cnt) -> int {     // images n0 .. n0 + cnt - 1 into the staging slots 0 .. cnt - 1, on the context's stream
+        const char* src = host_I + (size_t)n0 * per * esz;
+        if (pin.p) { SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, src, (size_t)cnt * per * esz, hipMemcpyHostToDevice, ctx->stream)); return SRPS_OK; }
+        return host_upload(ctx, ctx->ws_stage.p, src, (size_t)cnt * per * esz, ctx->stream);
+    };
     std::function<int()> start_uploads = [&]() -> int {
         if (!host_I || NL_ <= 0) return SRPS_OK;
         const size_t bytes = (size_t)NL_ * per * esz;
         slots = (int)std::min<size_t>((size_t)NL_, std::max<size_t>(2, ((size_t)2 << 30) / (per * esz)));
         SRPS_TRY(ensure(ctx->ws_stage, (size_t)slots * per * esz));      // kept across set-ups (grow-only)
-        SRPS_TRY(setup_events(ctx, slots));
+        SRPS_TRY(setup_events(ctx, 1));
         if (ctx->pin_uploads && bytes >= ((size_t)8 << 20)) {
             if (hipHostRegister((void*)host_I, bytes, hipHostRegisterDefault) == hipSuccess) pin.p = host_I;
             else (void)hipGetLastError();
         }
-        // the copies that need no slot to come free are queued now, before the structure is built
-        for (int n = 0; n < slots; ++n) {
-            SRPS_HIP(hipMemcpyAsync((char*)ctx->ws_stage.p + (size_t)n * per * esz, host_I + (size_t)n * per * esz, per * esz, hipMemcpyHostToDevice, ctx->stream));
-            SRPS_HIP(hipEventRecord(ctx->ev_copied[n], ctx->stream));
-        }
-        queued = slots;
+        if (pin.p) return copy_batch(0, slots);                          // queued; the device reads the caller's pages
+        first_batch.t = std::thread([&, cnt = slots]() {
+            first_batch.rc = hipSetDevice(ctx->device) == hipSuccess ? copy_batch(0, cnt) : SRPS_ERR_HIP;
+        });
         return SRPS_OK;
     };
+    if (getenv("SRPS_SETUP_TRACE"))      // development aid: the caller's arrays (to place a fault address, should the device ever touch one)
+        fprintf(stderr, "srps_setup trace: mask %p + %zu, z_full %p + %zu, zs_lr %p + %zu, images %p + %zu\n", (const void*)pr->mask, (size_t)pr->h * pr->w * 4,
+                (const void*)pr->z_full, (size_t)pr->h * pr->w * 4, (const void*)pr->zs_lr, (size_t)pr->h * pr->w * 4 / ((size_t)pr->sf * pr->sf), (const void*)host_I,
+                (size_t)NL_ * per * esz);
     SRPS_TRY(build_grid(ctx, pr->h, pr->w, pr->sf, pr->mask, &start_uploads));
-    if (tm) { fprintf(stderr, "srps_setup: uploads queued (%s), grid structure on the device, grid arena: %.2f ms\n", pin.p ? "pinned in place" : "pageable", ms_since(t0)); t0 = now(); }
+    if (tm) { fprintf(stderr, "srps_setup: uploads started (%s), grid structure on the device, grid arena: %.2f ms\n", pin.p ? "caller's array registered in place" : "through the pinned transfer buffer", ms_since(t0)); t0 = now(); }
     Grid& G = ctx->grid;
     hipStream_t ax = ctx->aux_stream;
     const int P = G.P, C = pr->n_channels, NL = pr->n_images, NT = pr->n_images_total;
@@ -963,10 +986,10 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     {
         float* d_tmp = (float*)ctx->ws_struct.p;
         const size_t hw = (size_t)G.h * G.w, hws = hw / ((size_t)G.sf * G.sf);
-        SRPS_HIP(hipMemcpyAsync(d_tmp, pr->z_full, hw * sizeof(float), hipMemcpyHostToDevice, ax));
+        SRPS_TRY(host_upload(ctx, d_tmp, pr->z_full, hw * sizeof(float), ax));
         SRPS_TRY(launch_gather_index(ax, d_tmp, G.d_imask, P, ctx->z));
         // (stream order: the second copy into the scratch follows the gather that read the first)
-        SRPS_HIP(hipMemcpyAsync(d_tmp, pr->zs_lr, hws * sizeof(float), hipMemcpyHostToDevice, ax));
+        SRPS_TRY(host_upload(ctx, d_tmp, pr->zs_lr, hws * sizeof(float), ax));
         SRPS_TRY(launch_gather_index(ax, d_tmp, G.d_imasks, G.Ps, ctx->z0s));
     }
     SRPS_TRY(launch_meshgrid_compact(ax, G.d_imask, P, G.h, ctx->cx, ctx->cy, ctx->xx, ctx->yy));
@@ -983,23 +1006,27 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
         const size_t hwp = (size_t)G.h * G.w;
         hipStream_t gs = ctx->gather_stream;
         SRPS_HIP(hipStreamWaitEvent(gs, ctx->aux_event, 0));      // the index lists
-        for (int n = 0; n < NL; ++n) {
-            const int sl = n % slots;
-            char* stage = (char*)ctx->ws_stage.p + (size_t)sl * per * esz;
-            if (n >= queued) {                                     // a slot in its second use: the copy waits, on the device, for the gather that read it
-                SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[sl], 0));
-                SRPS_HIP(hipMemcpyAsync(stage, host_I + (size_t)n * per * esz, per * esz, hipMemcpyHostToDevice, ctx->stream));
-                SRPS_HIP(hipEventRecord(ctx->ev_copied[sl], ctx->stream));
+        for (int n0 = 0; n0 < NL; n0 += slots) {
+            const int cnt = std::min(slots, NL - n0);
+            if (n0 == 0) {
+                if (first_batch.t.joinable()) first_batch.t.join();
+                if (first_batch.rc != SRPS_OK) { set_error("srps_setup: the image upload failed"); return first_batch.rc; }
+            } else {                                               // the staging slots in their next use: the copies wait, on the device, for the gathers that read them
+                SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[0], 0));
+                SRPS_TRY(copy_batch(n0, cnt));
             }
-            SRPS_HIP(hipStreamWaitEvent(gs, ctx->ev_copied[sl], 0));
-            if (bytes_in)
-                SRPS_TRY(launch_gather_images_u8(gs, (const unsigned char*)stage, G.d_imask, P, C, hwp, 1, ctx->I + (size_t)n * C * P,
-                                                 want_bytes ? ctx->I8 + (size_t)n * C * P : nullptr));
-            else
-                SRPS_TRY(launch_gather_images(gs, (const float*)stage, G.d_imask, P, C, hwp, 1, ctx->I + (size_t)n * C * P));
-            SRPS_HIP(hipEventRecord(ctx->ev_gathered[sl], gs));
+            SRPS_HIP(hipEventRecord(ctx->ev_copied[0], ctx->stream));
+            SRPS_HIP(hipStreamWaitEvent(gs, ctx->ev_copied[0], 0));
+            for (int n = n0; n < n0 + cnt; ++n) {
+                const char* stage = (const char*)ctx->ws_stage.p + (size_t)(n - n0) * per * esz;
+                if (bytes_in)
+                    SRPS_TRY(launch_gather_images_u8(gs, (const unsigned char*)stage, G.d_imask, P, C, hwp, 1, ctx->I + (size_t)n * C * P,
+                                                     want_bytes ? ctx->I8 + (size_t)n * C * P : nullptr));
+                else
+                    SRPS_TRY(launch_gather_images(gs, (const float*)stage, G.d_imask, P, C, hwp, 1, ctx->I + (size_t)n * C * P));
+            }
+            SRPS_HIP(hipEventRecord(ctx->ev_gathered[0], gs));    // the batch is compacted
         }
-        SRPS_HIP(hipEventRecord(ctx->ev_gathered[0], gs));        // everything compacted
         SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[0], 0));
     }
     SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
@@ -1029,7 +1056,7 @@ static int upload_image_impl(srps_ctx* ctx, int li, const void* host_image, bool
     const size_t hw = (size_t)G.h * G.w, n = hw * ctx->C, esz = bytes_in ? 1 : sizeof(float);
     SRPS_HIP(hipStreamSynchronize(ctx->stream));     // staging buffer reuse
     SRPS_TRY(ensure(ctx->ws_stage, n * esz));
-    SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, host_image, n * esz, hipMemcpyHostToDevice, ctx->stream));
+    SRPS_TRY(host_upload(ctx, ctx->ws_stage.p, host_image, n * esz, ctx->stream));
     float* out = ctx->I + (size_t)li * ctx->C * G.P;
     if (!bytes_in) {
         ctx->i8_state = 0;                   // looked at again at the next sweep
@@ -1494,8 +1521,7 @@ int srps_get(srps_ctx* ctx, const char* name, float* host, size_t n) {
     float* p; size_t len;
     SRPS_TRY(lookup(ctx, name, &p, &len));
     SRPS_REQUIRE(n == len, SRPS_ERR_INVALID, "get('%s'): buffer holds %zu floats, array has %zu", name, n, len);
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    SRPS_HIP(hipMemcpy(host, p, len * sizeof(float), hipMemcpyDeviceToHost));
+    SRPS_TRY(host_download(ctx, host, p, len * sizeof(float), ctx->stream));
     return SRPS_OK;
 }
 int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
@@ -1510,8 +1536,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     ctx->depth_assembled = false;
     ctx->normals_pending = false;
     if (p == ctx->I) { ctx->i8_state = 0; if (ctx->it_state == 1) ctx->it_state = 0; }
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    SRPS_HIP(hipMemcpy(p, host, len * sizeof(float), hipMemcpyHostToDevice));
+    SRPS_TRY(host_upload(ctx, p, host, len * sizeof(float), ctx->stream));
     return SRPS_OK;
 }
 int srps_array_size(srps_ctx* ctx, const char* name, size_t* n_floats) {

@@ -138,7 +138,7 @@ struct srps_ctx {
     hipStream_t gather_stream = nullptr;   // non-blocking: the compaction of image n runs here while image n + 1 is copied
     hipEvent_t aux_event = nullptr;
     srps::DevBuf state_arena;        // the context's state arrays (srps_setup), kept across set-ups like the grid's arena
-    int pin_uploads = 1;             // srps_setup pins the caller's image array in place (hipHostRegister) while it uploads it
+    int pin_uploads = 0;             // 1: srps_setup registers the caller's image array in place (hipHostRegister) and lets the device read it (see srps_xfer.hip for why not by default)
     float* h_pinned = nullptr;       // 256 floats of pinned host memory for scalar read-back
     // The scalars the host reads back after a pass live in ONE device record with the layout of h_pinned -- [0..3] energy terms,
     // [8] lighting iterations, [16..47] albedo CG records, [64..71] depth CG scalars -- so that one copy fetches them all.
@@ -297,6 +297,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 int ensure(DevBuf& b, size_t bytes);
+// ---- copies between the caller's host arrays and the device, through the library's own pinned buffer (srps_xfer.hip) ----
+int host_upload(srps_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t st);        // returns when h_src has been read and the copies have run
+int host_download(srps_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, hipStream_t st);      // returns when h_dst holds the data (after the work queued on st)
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- kernel launchers (kernels_pixel.hip) ------------------------------------------------

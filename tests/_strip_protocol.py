@@ -142,9 +142,17 @@ class HostedTransport:
                     return 1
             return wrapper
 
+        def to_host(g):                       # pinned host memory: the device never touches pageable pages (csrc/srps_xfer.hip)
+            t = torch.empty(g.shape, dtype=g.dtype, pin_memory=True)
+            t.copy_(g)
+            return t
+
+        def host_buf(n):
+            return torch.empty(n, dtype=torch.float32, pin_memory=True)
+
         @guarded
         def allreduce(user, d_in, d_out):
-            t = view(d_in, 4, "<f8").cpu()
+            t = to_host(view(d_in, 4, "<f8"))
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             view(d_out, 4, "<f8").copy_(t)
             torch.cuda.synchronize()
@@ -154,11 +162,11 @@ class HostedTransport:
             ops, landing = [], []
             for b in range(nbuf):
                 if sl:
-                    out = view(sl[b], n).cpu(); inn = torch.empty(n, dtype=torch.float32)
+                    out = to_host(view(sl[b], n)); inn = host_buf(n)
                     ops += [dist.P2POp(dist.isend, out, self.rank - 1), dist.P2POp(dist.irecv, inn, self.rank - 1)]
                     landing.append((rl[b], inn))
                 if sr:
-                    out = view(sr[b], n).cpu(); inn = torch.empty(n, dtype=torch.float32)
+                    out = to_host(view(sr[b], n)); inn = host_buf(n)
                     ops += [dist.P2POp(dist.isend, out, self.rank + 1), dist.P2POp(dist.irecv, inn, self.rank + 1)]
                     landing.append((rr[b], inn))
             if ops:
@@ -174,7 +182,7 @@ class HostedTransport:
                 if count[q] == 0:
                     continue
                 piece = view(d_x + 4 * offset[q], count[q])
-                t = piece.cpu() if q == self.rank else torch.empty(count[q], dtype=torch.float32)
+                t = to_host(piece) if q == self.rank else host_buf(count[q])
                 dist.broadcast(t, src=q)
                 if q != self.rank:
                     piece.copy_(t)

@@ -532,3 +532,47 @@ def test_tiled_lighting_sweep_equals_the_sweep_of_four_blocks_per_range(pkg, h, 
     assert abs(float(b[0][-1]) - float(a[0][-1])) <= 2e-4 * abs(float(a[0][-1]))
     assert rmse(b[1], a[1]) < 2e-5
     assert rmse(b[2], a[2]) < 2e-4 and np.abs(b[3] - a[3]).max() < 5e-3
+
+
+def test_host_arrays_travel_through_the_transfer_buffer_unchanged(pkg):
+    """every copy between the caller's arrays and the device goes through the library's own pinned buffer (csrc/srps_xfer.hip): sizes that
+    are no multiple of a slot, a transfer large enough for the many-thread form (37.7 MB), the byte path, and `pin_uploads = 1` (the
+    caller's image array registered in place) against the default -- the state on the device is the caller's data, bit for bit"""
+    sc = pkg.synth.make_scene(1024, 1024, 2, 9, seed=77, n_ch=1, mask_kind="full")
+    dh = pkg.DataHandler.from_scene(sc)
+    ref = np.ascontiguousarray(np.asarray(dh.I, dtype=np.float32)).reshape(9, -1)        # full mask: the compact images are the images
+    states = {}
+    for pin in (0, 1):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("pin_uploads", pin)
+        ctx.setup(dh)
+        got = ctx.get("I")
+        states[pin] = got
+        np.testing.assert_array_equal(got.reshape(9, -1), ref)
+        if pin == 0:
+            rng = np.random.default_rng(5)
+            new = rng.random(got.size, dtype=np.float32)                                  # 37.7 MB: set (many threads) and get (ring of slots)
+            ctx.set("I", new)
+            np.testing.assert_array_equal(ctx.get("I"), new)
+            z = rng.random(1024 * 1024, dtype=np.float32)                                 # 4 MB: the single-thread form, two slots
+            ctx.set("z", z)
+            np.testing.assert_array_equal(ctx.get("z"), z)
+            img = rng.random(1024 * 1024, dtype=np.float32)
+            ctx.upload_image(3, img)
+            np.testing.assert_array_equal(ctx.get("I").reshape(9, -1)[3], img)
+        ctx.close()
+    np.testing.assert_array_equal(states[0], states[1])
+    sc2 = pkg.synth.make_scene(300, 200, 1, 3, seed=78, n_ch=3, mask_kind="ragged")       # odd sizes, a ragged mask, bytes
+    dh2 = pkg.DataHandler.from_scene(sc2)
+    k = np.rint(np.clip(np.asarray(dh2.I), 0, 1) * 255).astype(np.uint8)
+    dh8 = pkg.DataHandler.from_scene(sc2); dh8.I = None; dh8.I_u8 = k
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(dh8)
+    got = ctx.get("I").reshape(3, 3, -1)
+    ctx.close()
+    ctx = pkg.Context(device_id=0)
+    ctx.set_option("pin_uploads", 1)
+    ctx.setup(dh8)
+    np.testing.assert_array_equal(ctx.get("I").reshape(3, 3, -1), got)
+    ctx.close()
+    assert np.abs(got * 255.0 - np.rint(got * 255.0)).max() < 1e-4                       # k / 255.f of the caller's bytes

@@ -1,5 +1,6 @@
 """Where srps_setup's time goes at the metric's configuration (2048 x 2048, sf 4, 20 images): floats and bytes, first and repeated
-set-ups on one context (SRPS_SETUP_TIMING=1 prints the library's own breakdown to stderr).  python tools/setup_time.py [size] [images]"""
+set-ups on one context (SRPS_SETUP_TIMING=1 prints the library's own breakdown to stderr).
+python tools/setup_time.py [size] [images] [NAME=INT options, e.g. pin_uploads=0]"""
 import importlib
 import os
 import sys
@@ -13,6 +14,8 @@ os.environ.setdefault("SRPS_SETUP_TIMING", "1")
 
 def main():
     import torch
+    opts = [a for a in sys.argv[1:] if "=" in a]
+    sys.argv = [a for a in sys.argv if "=" not in a]
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     pkg = importlib.import_module("srmeetsps-cuda_amd")
@@ -23,6 +26,8 @@ def main():
     for name, d in (("floats", dh), ("bytes", dh8)):
         ctx = pkg.Context(device_id=0)
         ctx.set_option("exclusive_device", 1)
+        for kv in opts:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         for rep in range(4):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
