@@ -241,7 +241,10 @@ typedef struct srps_problem {
 } srps_problem;
 
 /* replaces: SRPS.cu:100-270 (mask indices, KT/Dx/Dy structure, compaction, s/rho init,
- * meshgrid, first normals). */
+ * meshgrid, first normals).  The host arrays of `prob` are ordinary (pageable) memory and are no longer needed when the call
+ * returns.  The device never maps them: they cross PCIe through a pinned buffer of the library's own, filled by a few host
+ * threads (option "pin_uploads" = 1 registers the image array in place instead; DESIGN.md §5 says why that is not the default).
+ * The same holds for srps_upload_image, srps_get, srps_set and every other entry point that takes a host pointer. */
 int srps_setup(srps_ctx* ctx, const srps_problem* prob);
 int srps_upload_image(srps_ctx* ctx, int local_index, const float* host_image /* [c][h*w] */);
 int srps_upload_image_u8(srps_ctx* ctx, int local_index, const unsigned char* host_image /* [c][h*w] bytes; I = byte / 255.f */);
