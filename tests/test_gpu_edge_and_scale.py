@@ -10,7 +10,7 @@ f32 = np.float32
 
 def _t(a):
     import torch
-    return torch.as_tensor(np.ascontiguousarray(a)).cuda().contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a)).pin_memory().cuda().contiguous()
 
 
 def rmse(a, b):

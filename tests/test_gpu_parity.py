@@ -21,7 +21,7 @@ def _t(a, dtype=None):
     t = torch.as_tensor(np.ascontiguousarray(a))
     if dtype is not None:
         t = t.to(dtype)
-    return t.cuda().contiguous()
+    return t.pin_memory().cuda().contiguous()      # through pinned memory: the device does not map pageable pages (csrc/srps_xfer.hip)
 
 
 def _scene(pkg, h=48, w=40, sf=2, n=5, kind="ragged", seed=3):

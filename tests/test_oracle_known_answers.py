@@ -147,7 +147,7 @@ def test_hip_library_on_the_hand_built_system(pkg):
     s, rho, dz, xx, yy, I, z0s, z0 = _tiny_inputs()
     _, _, _, A_, rhs = _literal_system()
     x_dense = np.linalg.solve(A_, rhs)
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda().contiguous()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).pin_memory().cuda().contiguous()
     for hint in (False, True):                                  # stored tensor / tensor rebuilt from (rho/dz)^2 in the kernel
         ctx = pkg.Context(device_id=0)
         ctx.bind_grid(H, W, SF, np.ones(H * W, f32))
