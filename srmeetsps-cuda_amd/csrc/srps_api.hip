@@ -940,9 +940,13 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
             else (void)hipGetLastError();
         }
         if (pin.p) return copy_batch(0, slots);                          // queued; the device reads the caller's pages
-        first_batch.t = std::thread([&, cnt = slots]() {
-            first_batch.rc = hipSetDevice(ctx->device) == hipSuccess ? copy_batch(0, cnt) : SRPS_ERR_HIP;
-        });
+        try {
+            first_batch.t = std::thread([&, cnt = slots]() {
+                first_batch.rc = hipSetDevice(ctx->device) == hipSuccess ? copy_batch(0, cnt) : SRPS_ERR_HIP;
+            });
+        } catch (...) {                                                 // no thread to be had: the copies run here, before the structure
+            return copy_batch(0, slots);
+        }
         return SRPS_OK;
     };
     if (getenv("SRPS_SETUP_TRACE"))      // development aid: the caller's arrays (to place a fault address, should the device ever touch one)

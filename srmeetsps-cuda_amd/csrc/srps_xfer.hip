@@ -104,12 +104,13 @@ int upload_small(char* base, void* d_dst, const void* h_src, size_t bytes, hipSt
 }
 
 // the many-thread form: every 16 MB slot is filled by all T threads (a slice each), then goes out as ONE copy, issued by thread 0
-int upload_big(srps_ctx* ctx, char* base, void* d_dst, const void* h_src, size_t bytes, hipStream_t st, SlotEvents& se, int T) {
+int upload_big(srps_ctx* ctx, char* base, void* d_dst, const void* h_src, size_t bytes, hipStream_t st, SlotEvents& se, int T_wanted) {
     const size_t nch = (bytes + kBig - 1) / kBig;
     SpinBarrier bar;
-    bar.n = T;
-    std::atomic<int> err{0};
+    std::atomic<int> err{0}, go{0};
+    int T = 1;                                 // threads that take part: set before `go` (a thread that could not be started is not waited for)
     auto worker = [&](int t) {
+        while (go.load(std::memory_order_acquire) == 0) std::this_thread::yield();
         if (t != 0 && hipSetDevice(ctx->device) != hipSuccess) err.store(1);
         for (size_t c = 0; c < nch; ++c) {
             const int s = (int)(c % kBigSlots);
@@ -129,7 +130,12 @@ int upload_big(srps_ctx* ctx, char* base, void* d_dst, const void* h_src, size_t
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(worker, t);
+    try {
+        for (int t = 1; t < T_wanted; ++t) { th.emplace_back(worker, t); T = t + 1; }
+    } catch (...) {                            // no more threads to be had: the ones that started do the work
+    }
+    bar.n = T;
+    go.store(1, std::memory_order_release);
     worker(0);
     for (auto& x : th) x.join();
     return err.load() ? SRPS_ERR_HIP : SRPS_OK;
