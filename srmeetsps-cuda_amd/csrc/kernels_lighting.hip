@@ -650,31 +650,43 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
     if (tid == 0) ea.part_e[blk] = t;
 }
 
-// one wave per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
-// The 64 lanes add the per-block partial sums (fixed order, double), lane 0 runs the 4x4 CG.
-__global__ __launch_bounds__(64) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
+// one block of four waves per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
+// The 256 lanes add the per-block partial sums (fixed order, double; one wave took 64 dependent rounds of loads for the 4 096
+// blocks of the tiled sweep: 12.8 us, four waves take 16), lane 0 runs the 4x4 CG.
+constexpr int LIGHT_SOLVE_THREADS = 256;
+__global__ __launch_bounds__(LIGHT_SOLVE_THREADS) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
                               int n_local, int C, int n_total, int img_offset, int zero_nonlocal,
                               float* __restrict__ s, int* __restrict__ iters_max, float tol, int max_iter) {
+    __shared__ double smw[LIGHT_SOLVE_THREADS / 64][14];
     const int t = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (t >= n_total * C) return;
     const int i = t / C, c = t - i * C;
     const int li = i - img_offset;
     float* sv = s + (size_t)t * 4;
     if (li < 0 || li >= n_local) {
-        if (zero_nonlocal && lane < 4) sv[lane] = 0.f;
+        if (zero_nonlocal && tid < 4) sv[tid] = 0.f;
         return;
     }
     double Gd[10], bd[4];
     for (int u = 0; u < 10; ++u) Gd[u] = 0.0;
     for (int k = 0; k < 4; ++k) bd[k] = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
+    for (int b = tid; b < nblk; b += LIGHT_SOLVE_THREADS) {
         for (int u = 0; u < 10; ++u) Gd[u] += (double)part_g[((size_t)b * C + c) * 10 + u];
         for (int k = 0; k < 4; ++k) bd[k] += (double)part_atb[(((size_t)b * n_local + li) * C + c) * 4 + k];
     }
     for (int u = 0; u < 10; ++u) Gd[u] = wave_sum(Gd[u]);
     for (int k = 0; k < 4; ++k) bd[k] = wave_sum(bd[k]);
-    if (lane != 0) return;
+    if (lane == 0) {
+        for (int u = 0; u < 10; ++u) smw[wave][u] = Gd[u];
+        for (int k = 0; k < 4; ++k) smw[wave][10 + k] = bd[k];
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < LIGHT_SOLVE_THREADS / 64; ++w) {      // the waves' totals in their order
+        for (int u = 0; u < 10; ++u) Gd[u] += smw[w][u];
+        for (int k = 0; k < 4; ++k) bd[k] += smw[w][10 + k];
+    }
     float A[4][4];
     {
         int u = 0;
@@ -861,7 +873,7 @@ int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, co
     SRPS_HIP(hipMemsetAsync(L.d_it, 0, sizeof(int), ctx->stream));
     if (n_local > 0 && !cached) SRPS_TRY(light_partial_launch<false>(ctx, L, d_rho, d_N, d_I, P, n_local, C, EnergyArgs{}));
     const int nt = n_total * C;
-    hipLaunchKernelGGL(k_light_solve, dim3(nt), dim3(64), 0, ctx->stream, L.part_atb, L.part_g, L.nblk, n_local, C,
+    hipLaunchKernelGGL(k_light_solve, dim3(nt), dim3(LIGHT_SOLVE_THREADS), 0, ctx->stream, L.part_atb, L.part_g, L.nblk, n_local, C,
                        n_total, img_offset, zero_nonlocal ? 1 : 0, d_s, L.d_it, ctx->cg_tol, ctx->cg_max_iter);
     SRPS_LAUNCH_CHECK();
     ctx->report_pending = true;          // d_it is part of the report record
