@@ -651,8 +651,8 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 }
 
 // one block of four waves per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
-// The 256 lanes add the per-block partial sums (fixed order, double; one wave took 64 dependent rounds of loads for the 4 096
-// blocks of the tiled sweep: 12.8 us, four waves take 16), lane 0 runs the 4x4 CG.
+// The 256 lanes add the per-block partial sums (fixed order, double; with one wave the kernel took 12.8 us behind the 512 blocks of
+// the tiled sweep, with four 10.0: most of it is the launch and lane 0's 4x4 CG, up to 13 steps of dependent arithmetic).
 constexpr int LIGHT_SOLVE_THREADS = 256;
 __global__ __launch_bounds__(LIGHT_SOLVE_THREADS) void k_light_solve(const float* __restrict__ part_atb, const float* __restrict__ part_g, int nblk,
                               int n_local, int C, int n_total, int img_offset, int zero_nonlocal,
