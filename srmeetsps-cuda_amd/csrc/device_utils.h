@@ -49,6 +49,29 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
 }
 
+// the same sum of partials that OTHER blocks of the running kernel have written (the caller has seen them arrive through an atomic
+// ticket and fenced): loads at device scope, the same order, the same bits
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// One value written THROUGH to device scope (sc1) / to the host (sc0 sc1), and waited for: what follows in program order -- the atomic
+// ticket, the sequence word -- is then behind it.  Instead of a release fence: at device scope that is a write-back of the whole L2
+// (buffer_wbl2), and in a sweep that has just stored 64 MB of normals, issued by each of its 512 blocks, it cost 90 us per pass.
+__device__ __forceinline__ void st_agent_done(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_system_done(void* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ double sum_partials_agent(const float* part, int n, double* sm_d /* [4] */) {
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    double acc = 0.0;
+    for (int i = tid; i < n; i += 256) acc += (double)ld_agent(part + i);
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) sm_d[tid >> 6] = acc;
+    __syncthreads();
+    return ((sm_d[0] + sm_d[1]) + sm_d[2]) + sm_d[3];
+}
+
 // four partial-sum arrays [4][stride] at once (one pair of barriers), the first n entries of each -- the ones the producing
 // launch wrote: entries behind them may be left over from a launch with more blocks (another strip width) --: the same pattern
 // and the same bits per array as sum_partials

@@ -683,12 +683,13 @@ __global__ __launch_bounds__(256) void k_energy_t1(const float* __restrict__ zg,
     const float t = block_sum(acc, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-int grid_energy_t1(srps_ctx* ctx, const float* d_z0s, float* d_out) {
+int grid_energy_t1(srps_ctx* ctx, const float* d_z0s, float* d_out, const float** part_out, int* n_part_out) {
     Grid& G = ctx->grid;
     const int nb = std::max(1, std::min(cdiv(G.Hl * G.Wl, 256), 1024));
     float* part = G.d_misc_part + 2048;
     hipLaunchKernelGGL(k_energy_t1, dim3(nb), dim3(256), 0, ctx->stream, G.d_x, G.d_lr_index, d_z0s, G.Hl, G.Wl, G.Hs, G.sf, part);
-    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, ctx->stream, part, nb, d_out);
+    if (part_out) { *part_out = part; *n_part_out = nb; }      // the energy sweep's last block adds them (ReportFinish)
+    else hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, ctx->stream, part, nb, d_out);
     SRPS_LAUNCH_CHECK();
     return SRPS_OK;
 }

@@ -28,6 +28,7 @@ struct EnergyArgs {
     // depth, the previous one -- and srps_normals swaps the sets instead of launching a kernel (null: nothing is stored)
     float* N_out;
     float* dz_out;
+    ReportFinish fin;          // ticket != null: the last block finishes the pass's report record (k_light_fused_tile only)
 };
 
 template <int V, int IB, bool ENERGY>
@@ -647,7 +648,30 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
         }
     }
     const float t = block_sum(e_acc, sme);
-    if (tid == 0) ea.part_e[blk] = t;
+    if (!ea.fin.ticket) { if (tid == 0) ea.part_e[blk] = t; return; }
+    // The last block to arrive finishes the report record (ReportFinish, srps_internal.h): both energy terms from their partial sums --
+    // k_final_sum's routine on the same values: the same bits --, then the record into the host's pinned copy and the sequence
+    // number behind it.  Every earlier kernel of the pass has written its part of the record before this kernel started.  No
+    // fences: the partial sum is written through and waited for before the ticket is taken, the last block reads at device scope.
+    __shared__ double smd[4];
+    __shared__ int s_last;
+    if (tid == 0) {
+        st_agent_done(ea.part_e + blk, t);
+        s_last = atomicAdd(ea.fin.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const double t2 = sum_partials_agent(ea.part_e, (int)gridDim.x, smd);
+    const double t1 = sum_partials_agent(ea.fin.t1_part, ea.fin.n_t1, smd);
+    if (tid == 0) { ea.fin.report[0] = (float)t1; ea.fin.report[1] = (float)t2; *ea.fin.ticket = 0u; }
+    if (ea.fin.host_report) {
+        if (tid < REPORT_FLOATS) {
+            const float v = tid == 0 ? (float)t1 : tid == 1 ? (float)t2 : ld_agent(ea.fin.report + tid);
+            st_system_done(ea.fin.host_report + tid, __float_as_uint(v));
+        }
+        __syncthreads();                                   // the record has left (every lane waited for its store)
+        if (tid == 0) st_system_done(ea.fin.host_report + REPORT_SEQ_AT, ea.fin.seq);
+    }
 }
 
 // one block of four waves per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
@@ -885,19 +909,23 @@ int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, co
 // stay in ws_light; lighting(..., use_cache) consumes them.
 int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                        const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
-                       float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out) {
+                       float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out, const ReportFinish* fin, bool* fin_armed) {
     Grid& G = ctx->grid;
+    if (fin_armed) *fin_armed = false;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_rho | (uintptr_t)d_I | (uintptr_t)d_xx | (uintptr_t)d_yy |
                                        (uintptr_t)d_dz | (uintptr_t)d_z | (uintptr_t)d_zx | (uintptr_t)d_zy) % 16 == 0);
     LightPlan L;
     SRPS_TRY(light_plan(ctx, vec, P, n_local, C, L, /*fused=*/true));
-    EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part, nullptr, nullptr};
+    EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part, nullptr, nullptr, ReportFinish{}};
+    const bool finish_in_sweep = fin && fin->ticket && L.tiled && n_local > 0;      // the tiled sweep's last block adds the energy terms itself
+    if (finish_in_sweep) ea.fin = *fin;
     // the channel-inner sweep (the one the pipeline runs for 1 and 3 channels) can leave the normals and dz of the new depth
     const bool ci = ctx->light_grouped && L.V == 4 && ctx->light_channel_inner && (C == 1 || C == 3);
     const bool write_normals = ci && ctx->fuse_normals && !ctx->nd_ptr_out && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && ctx->Nrm2 != nullptr && n_local > 0;
     if (write_normals) { ea.N_out = ctx->Nrm2; ea.dz_out = ctx->dz2; }
     SRPS_TRY(light_partial_launch<true>(ctx, L, d_rho, nullptr, d_I, P, n_local, C, ea));
-    SRPS_TRY(launch_final_sum(ctx->stream, G.d_misc_part, L.n_epart, d_out));
+    if (finish_in_sweep) { if (fin_armed) *fin_armed = true; }
+    else SRPS_TRY(launch_final_sum(ctx->stream, G.d_misc_part, L.n_epart, d_out));
     ctx->normals_pending = write_normals;      // srps_normals only has to make dz2 the current dz
     ctx->light_cache_valid = true;
     ctx->light_cache_normals = false;

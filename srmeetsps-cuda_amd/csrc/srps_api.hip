@@ -411,9 +411,10 @@ int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     if (e != hipSuccess) return fail(e, "hipStreamCreateWithFlags", __LINE__);
     e = hipEventCreateWithFlags(&c->aux_event, hipEventDisableTiming);
     if (e != hipSuccess) return fail(e, "hipEventCreateWithFlags", __LINE__);
-    e = hipHostMalloc((void**)&c->h_pinned, 256 * sizeof(float));
+    e = hipHostMalloc((void**)&c->h_pinned, 256 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent);      // a kernel writes the pass's report into it (ReportFinish)
     if (e != hipSuccess) return fail(e, "hipHostMalloc", __LINE__);
     memset(c->h_pinned, 0, 256 * sizeof(float));
+    if (hipHostGetDevicePointer((void**)&c->h_pinned_dev, c->h_pinned, 0) != hipSuccess) { (void)hipGetLastError(); c->h_pinned_dev = nullptr; }
     e = hipMalloc((void**)&c->d_report, 256 * sizeof(float));
     if (e == hipSuccess) e = hipMemset(c->d_report, 0, 256 * sizeof(float));
     if (e != hipSuccess) return fail(e, "hipMalloc", __LINE__);
@@ -498,6 +499,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->coop_launch = value ? 0 : 1;
     } else if (!strcmp(name, "host_wait_spin")) {
         ctx->host_wait_spin = value ? 1 : 0;
+    } else if (!strcmp(name, "report_zero_copy")) {
+        ctx->report_zero_copy = value ? 1 : 0;
     } else if (!strcmp(name, "spin_budget_ms")) {
         SRPS_REQUIRE(value >= 1 && value <= 600000, SRPS_ERR_INVALID, "spin_budget_ms: 1 .. 600000");
         ctx->spin_budget_ms = value;
@@ -645,6 +648,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "coop_launch")) *value = ctx->coop_launch;
     else if (!strcmp(name, "exclusive_device")) *value = ctx->coop_launch == 0 ? 1 : 0;
     else if (!strcmp(name, "host_wait_spin")) *value = ctx->host_wait_spin;
+    else if (!strcmp(name, "report_zero_copy")) *value = ctx->report_zero_copy;
     else if (!strcmp(name, "spin_budget_ms")) *value = ctx->spin_budget_ms;
     else if (!strcmp(name, "persistent_fallbacks")) *value = ctx->persistent_fallbacks;
     else if (!strcmp(name, "cg_resident_active")) *value = (ctx->grid.bound && resident_supported(ctx)) ? 1 : 0;
@@ -1205,6 +1209,26 @@ int srps_depth_solve(srps_ctx* ctx) {
 int srps_energy_partial(srps_ctx* ctx) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     PhaseSpan span(ctx, SRPS_PHASE_ENERGY);
+    ctx->report_seq_armed = 0;
+    // One GPU, fused sweep: the sweep's last block adds both energy terms and writes the pass's report into the host's pinned record
+    // itself (ReportFinish) -- no k_sum_to, no k_final_sum, no copy; srps_energy_finish waits for the record's sequence number.
+    // (A shard's energy term goes through an all-reduce first: the old way.)
+    const bool in_sweep = ctx->report_zero_copy && ctx->h_pinned_dev && ctx->fuse_energy_lighting && ctx->N_local > 0 && ctx->N_local == ctx->N_total &&
+                          !ctx->defer_shard_checks && ctx->energy_ex == ctx->d_report;
+    if (in_sweep) {
+        ReportFinish fin;
+        fin.ticket = reinterpret_cast<unsigned*>(ctx->d_report + REPORT_TICKET_AT);
+        SRPS_TRY(grid_energy_t1(ctx, ctx->z0s, ctx->energy_ex, &fin.t1_part, &fin.n_t1));
+        fin.report = ctx->d_report; fin.host_report = ctx->h_pinned_dev;
+        fin.seq = ++ctx->report_seq;
+        if (fin.seq == 0) fin.seq = ++ctx->report_seq;
+        bool armed = false;
+        SRPS_TRY(energy_light_fused(ctx, ctx->s, ctx->rho, ctx->I, ctx->xx, ctx->yy, ctx->dz, ctx->z, ctx->zx, ctx->zy, ctx->fx, ctx->fy,
+                                    ctx->grid.P, ctx->N_local, ctx->C, ctx->img_offset, ctx->energy_ex + 1, &fin, &armed));
+        if (armed) ctx->report_seq_armed = fin.seq;
+        else SRPS_TRY(launch_final_sum(ctx->stream, fin.t1_part, fin.n_t1, ctx->energy_ex));      // another sweep kernel ran: term 1 the old way (term 2 is done)
+        return SRPS_OK;
+    }
     SRPS_TRY(grid_energy_t1(ctx, ctx->z0s, ctx->energy_ex));
     // the sweep over I that evaluates the energy also leaves the lighting sums of the next outer iteration
     if (ctx->fuse_energy_lighting && ctx->N_local > 0)
@@ -1252,15 +1276,53 @@ static int redo_pass_tail(srps_ctx* ctx, int aborted) {
     return SRPS_OK;
 }
 
+// The end of a solve: the caller is waiting for this and nothing else, so the thread polls (option "host_wait_spin") -- a sleeping
+// hipStreamSynchronize wakes 20 - 40 us after the stream has drained, and with the report written by the sweep's last block the
+// stream is still finishing that sweep when the loop ends.
+static int wait_for_stream(srps_ctx* ctx) {
+    if (ctx->host_wait_spin) {
+        hipError_t q;
+        while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady) { }
+        if (q != hipSuccess) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+        return SRPS_OK;
+    }
+    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    return SRPS_OK;
+}
+
 int srps_energy_finish(srps_ctx* ctx, float* energy) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(energy != nullptr, SRPS_ERR_INVALID, "energy_finish: energy is NULL");
-    SRPS_TRY(report_fetch(ctx));
+    bool record_arrived = false;
+    if (ctx->report_seq_armed) {
+        // the sweep's last block writes the record into h_pinned and the sequence number behind it: the host looks at that word (and,
+        // every thousand looks, at the stream: an error ends the wait, and a stream that has drained without the word having arrived --
+        // it cannot, short of host memory the device's stores do not reach -- switches this way of reporting off for the context)
+        const unsigned want = ctx->report_seq_armed;
+        ctx->report_seq_armed = 0;
+        const unsigned* word = reinterpret_cast<const unsigned*>(ctx->h_pinned + REPORT_SEQ_AT);
+        for (unsigned looks = 1;; ++looks) {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) { record_arrived = true; break; }
+            if ((looks & 1023u) == 0u) {
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q == hipSuccess) {
+                    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) record_arrived = true;
+                    else { fprintf(stderr, "srps: the report record written by the energy sweep did not reach the host; fetching it by copy from now on\n"); ctx->report_zero_copy = 0; }
+                    break;
+                }
+                if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+            }
+        }
+        if (record_arrived) ctx->report_pending = false;
+    }
+    if (!record_arrived) SRPS_TRY(report_fetch(ctx));
     // The host's one wait per pass -- the stop rule needs the energy (SRPS.cu:318-331) -- and the only stretch of a pass in which
     // the device has nothing queued: hipStreamSynchronize puts the thread to sleep on the completion signal and wakes it ~20 us
     // late; polling the stream picks the result up within a few microseconds (option "host_wait_spin", on by default: the caller is
     // waiting for this result and nothing else).
-    if (ctx->host_wait_spin) {
+    if (record_arrived) {
+        // nothing to wait for: the record is complete (every kernel of the pass ran before the sweep's last block wrote it)
+    } else if (ctx->host_wait_spin) {
         hipError_t q;
         while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady) { }
         if (q != hipSuccess) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
@@ -1359,8 +1421,7 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
         if (max_outer > 0 && done >= max_outer) stop = true;
     } while (!stop);
     if (n_outer) *n_outer = done;
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    return SRPS_OK;
+    return wait_for_stream(ctx);
 }
 
 // Option "overlap_exchange": the sweep that feeds an all-reduce (the albedo sweep over the images -> num; the depth assembly from
@@ -1497,8 +1558,7 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
         if (max_outer > 0 && done >= max_outer) stop = true;
     } while (!stop);
     if (n_outer) *n_outer = done;
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    return SRPS_OK;
+    return wait_for_stream(ctx);
 }
 
 static int lookup(srps_ctx* ctx, const char* name, float** p, size_t* n) {

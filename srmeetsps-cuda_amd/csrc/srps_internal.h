@@ -144,6 +144,10 @@ struct srps_ctx {
     // [8] lighting iterations, [16..47] albedo CG records, [64..71] depth CG scalars -- so that one copy fetches them all.
     float* d_report = nullptr;       // 256 floats
     bool report_pending = false;     // the device record is newer than h_pinned
+    int report_zero_copy = 1;        // the energy + lighting sweep's last block finishes the pass's report record and writes it into h_pinned itself
+    unsigned report_seq = 0;         // sequence number of the last record armed that way; report_seq_armed != 0: srps_energy_finish waits for it
+    unsigned report_seq_armed = 0;
+    float* h_pinned_dev = nullptr;   // h_pinned as the device sees it
     // pipeline state (srps_setup); reference layouts
     bool have_state = false;
     int C = 0, N_local = 0, N_total = 0, img_offset = 0;
@@ -316,9 +320,22 @@ int launch_normals(hipStream_t st, const float* z, const float* zx, const float*
                    const float* yy, int P, float fx, float fy, float* N, float* dz);
 int lighting(srps_ctx* ctx, float* d_s, const float* d_rho, const float* d_N, const float* d_I, int P,
              int n_local, int C, int n_total, int img_offset, bool zero_nonlocal, bool use_cache = false);
+// What the last block of the fused energy + lighting sweep does when `ticket` is set (one GPU, tiled sweep): it adds the partial sums
+// of both energy terms -- the routine and the bits of k_final_sum --, stores them in the report record, copies the record's 80 floats
+// into the host's pinned copy and then stores `seq` behind it: two single-block kernels and a copy less per pass, and the host
+// sees the record the moment it is complete.
+struct ReportFinish {
+    unsigned* ticket = nullptr;      // arrivals of the sweep's blocks: zero before the launch, left zero by the last block
+    const float* t1_part = nullptr;  // k_energy_t1's partial sums
+    int n_t1 = 0;
+    float* report = nullptr;         // the device record: [0] = term 1, [1] = term 2
+    float* host_report = nullptr;    // the record in mapped host memory; host_report[REPORT_SEQ_AT] = seq when it is complete
+    unsigned seq = 0;
+};
+constexpr int REPORT_FLOATS = 80, REPORT_SEQ_AT = 100, REPORT_TICKET_AT = 250;
 int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                        const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
-                       float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out);
+                       float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out, const ReportFinish* fin = nullptr, bool* fin_armed = nullptr);
 int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float* d_I, int P, int n_local,
                   int C, int s_img_offset, float* d_numden, float fx = 0.f, float fy = 0.f, float* d_ssum = nullptr, int n_total = 0,
                   int q0 = 0, int q1 = 0 /* > 0: the pixels [q0, q1) only, q0 a multiple of 1024 */);
@@ -381,7 +398,7 @@ int grid_rhs(srps_ctx* ctx, const float* d_z0s);                 // r = KT' z0s 
 int grid_residual(srps_ctx* ctx);                                // r -= A_ x ; rr_part[0]
 int grid_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane);
 int grid_cg(srps_ctx* ctx, int max_steps, bool fixed_steps);     // the 101-step loop
-int grid_energy_t1(srps_ctx* ctx, const float* d_z0s, float* d_out /* one float, device */);
+int grid_energy_t1(srps_ctx* ctx, const float* d_z0s, float* d_out /* one float, device */, const float** part_out = nullptr, int* n_part_out = nullptr);      // part_out: the partial sums only, the caller adds them
 int cg_launch_apply(srps_ctx* ctx, int k);
 int cg_launch_update(srps_ctx* ctx, int k);
 bool use_march(const srps_ctx* ctx);

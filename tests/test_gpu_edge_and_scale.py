@@ -576,3 +576,28 @@ def test_host_arrays_travel_through_the_transfer_buffer_unchanged(pkg):
     np.testing.assert_array_equal(ctx.get("I").reshape(3, 3, -1), got)
     ctx.close()
     assert np.abs(got * 255.0 - np.rint(got * 255.0)).max() < 1e-4                       # k / 255.f of the caller's bytes
+
+
+@pytest.mark.parametrize("h,w,sf,n_img,n_ch,kind", [(96, 80, 2, 5, 3, "ragged"), (512, 384, 4, 7, 3, "ellipse"), (300, 200, 1, 3, 1, "ragged"), (1024, 1024, 4, 20, 3, "full")])
+def test_report_written_by_the_sweeps_last_block_equals_the_fetched_one(pkg, h, w, sf, n_img, n_ch, kind):
+    """`report_zero_copy` (default): the last block of the fused energy + lighting sweep adds both energy terms from their partial sums and
+    writes the pass's report record into the host's pinned copy itself; with the option off k_sum_to, k_final_sum and a copy do it.
+    Same sums in the same order: energies, iteration counts and the state after three passes agree bit for bit."""
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=31 + h, n_ch=n_ch, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for zc in (1, 0, 1):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("report_zero_copy", zc)
+        ctx.setup(dh)
+        en = pkg.alternating_loop(ctx, None, max_outer=3)
+        its = ctx.last_cg_iterations()
+        out.setdefault(zc, []).append((list(en), ctx.get("z"), ctx.get("rho"), ctx.get("s"), its["depth"], its["lighting_max"]))
+        assert ctx.get_option("report_zero_copy") == zc      # the record did arrive (the library switches the option off otherwise)
+        ctx.close()
+    (a, c), (b,) = out[1], out[0]
+    for x, y in ((a, b), (a, c)):
+        assert x[0] == y[0], (x[0], y[0])
+        for k in (1, 2, 3):
+            np.testing.assert_array_equal(x[k], y[k])
+        assert x[4:] == y[4:]
