@@ -64,7 +64,29 @@ __device__ __forceinline__ void st_system_done(void* p, unsigned v) {
 __device__ __forceinline__ double sum_partials_agent(const float* part, int n, double* sm_d /* [4] */) {
     const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
     double acc = 0.0;
-    for (int i = tid; i < n; i += 256) acc += (double)ld_agent(part + i);
+    // eight loads in flight per lane (a load at device scope comes from memory: ~1.5 us; one after the other, the 2 + 4 rounds of the
+    // energy sweep's two arrays took 9 us); entries past the end re-read the last one and are not added
+    for (int base = 0; base < n; base += 8 * 256) {
+        float v[8];
+        const float* q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = part + min(base + j * 256 + tid, n - 1);
+        asm volatile("global_load_dword %0, %8, off sc1\n\t"
+                     "global_load_dword %1, %9, off sc1\n\t"
+                     "global_load_dword %2, %10, off sc1\n\t"
+                     "global_load_dword %3, %11, off sc1\n\t"
+                     "global_load_dword %4, %12, off sc1\n\t"
+                     "global_load_dword %5, %13, off sc1\n\t"
+                     "global_load_dword %6, %14, off sc1\n\t"
+                     "global_load_dword %7, %15, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                     : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+                     : "memory");
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (base + j * 256 + tid < n) acc += (double)v[j];      // the order of sum_partials: i = tid, tid + 256, ...
+    }
     acc = wave_sum(acc);
     __syncthreads();
     if ((tid & 63) == 0) sm_d[tid >> 6] = acc;

@@ -1290,7 +1290,12 @@ static int wait_for_stream(srps_ctx* ctx) {
     return SRPS_OK;
 }
 
-int srps_energy_finish(srps_ctx* ctx, float* energy) {
+// `drain`: return with the context's stream idle -- what the entry points promise a caller who reads the results through other streams.
+// The library's own pass loops go on as soon as the record has arrived (the sweep that wrote it is in its last microseconds; everything
+// they queue follows it on the same stream) and drain once, at their end.
+static int energy_finish_impl(srps_ctx* ctx, float* energy, bool drain);
+int srps_energy_finish(srps_ctx* ctx, float* energy) { return energy_finish_impl(ctx, energy, true); }
+static int energy_finish_impl(srps_ctx* ctx, float* energy, bool drain) {
     CTX_CHECK(ctx); STATE_CHECK(ctx);
     SRPS_REQUIRE(energy != nullptr, SRPS_ERR_INVALID, "energy_finish: energy is NULL");
     bool record_arrived = false;
@@ -1320,7 +1325,7 @@ int srps_energy_finish(srps_ctx* ctx, float* energy) {
     // the device has nothing queued: hipStreamSynchronize puts the thread to sleep on the completion signal and wakes it ~20 us
     // late; polling the stream picks the result up within a few microseconds (option "host_wait_spin", on by default: the caller is
     // waiting for this result and nothing else).
-    if (record_arrived) {
+    if (record_arrived && !drain) {
         // nothing to wait for: the record is complete (every kernel of the pass ran before the sweep's last block wrote it)
     } else if (ctx->host_wait_spin) {
         hipError_t q;
@@ -1412,7 +1417,7 @@ int srps_execute(srps_ctx* ctx, int max_outer, float* energies, int* n_outer) {
         SRPS_TRY(srps_depth_solve(ctx));
         SRPS_TRY(srps_energy_partial(ctx));
         SRPS_TRY(srps_normals(ctx));       // SRPS.cu:310-315, enqueued before the host waits for the energy
-        SRPS_TRY(srps_energy_finish(ctx, &error));
+        SRPS_TRY(energy_finish_impl(ctx, &error, false));
         const float rel_err = fabsf(last_error - error) / fabsf(error);          // SRPS.cu:298
         if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop = true;   // SRPS.cu:299
         last_error = error;
@@ -1549,7 +1554,7 @@ int srps_execute_sharded(srps_ctx* ctx, int max_outer, float* energies, int* n_o
         SRPS_TRY(srps_energy_partial(ctx));
         SRPS_TRY(sharded_energy_exchange(ctx));
         SRPS_TRY(srps_normals(ctx));                                                            // SRPS.cu:310-315
-        SRPS_TRY(srps_energy_finish(ctx, &error));
+        SRPS_TRY(energy_finish_impl(ctx, &error, false));
         const float rel_err = fabsf(last_error - error) / fabsf(error);                         // SRPS.cu:298
         if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop = true;   // SRPS.cu:299
         last_error = error;
