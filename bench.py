@@ -36,11 +36,25 @@ def cpu_baseline(sc, pkg, budget_s=20.0):
     host cores on a bounded number of iterations of the SAME 2048^2 system.  Falls back to the numpy
     restatement when the C oracle is not built.  Checker code, imported here only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    try:
-        import c_oracle
-        return dict(c_oracle.bench_cpu_baseline(sc, budget_s), implementation="C/OpenMP (oracle/srps_oracle.c)")
-    except ImportError as exc:
-        print(f"bench.py: the C oracle is not built ({exc}); timing the numpy restatement on one thread instead", file=sys.stderr)
+    if os.path.exists(os.path.join(ROOT, "oracle", "libsrps_oracle.so")):
+        # as a CHILD process with the OpenMP threads bound (libgomp reads the binding when it is loaded; this process's libgomp came in
+        # with torch long ago, and a bound main thread here would hand its one-core mask to the GPU runtime's helper threads).  The child
+        # never touches the GPU.  Full mask, like `sc`.
+        import subprocess
+        assert int(np.count_nonzero(sc.mask)) == sc.h * sc.w, "the cpu_baseline child takes a full mask"
+        env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "GOMP_CPU_AFFINITY", "KMP_AFFINITY")}
+        env.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
+        try:
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline_main.py"), str(sc.h), str(sc.w), str(sc.sf), str(budget_s)],
+                                 env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            if res.returncode == 0 and line:
+                return dict(json.loads(line[-1]), implementation="C/OpenMP (oracle/srps_oracle.c), timed in a child process with bound threads")
+            print(f"bench.py: the cpu_baseline child failed (rc {res.returncode}): {res.stderr[-500:]}", file=sys.stderr)
+        except Exception as exc:
+            print(f"bench.py: the cpu_baseline child failed ({exc})", file=sys.stderr)
+    else:
+        print("bench.py: the C oracle is not built; timing the numpy restatement on one thread instead", file=sys.stderr)
     import srps_oracle as O
     geo = O.build_geometry(sc.h, sc.w, sc.sf, sc.mask)
     P = geo.npix
@@ -217,20 +231,68 @@ def launch_ranks(n_gpus):
     return rc
 
 
+def select_workload(args):
+    """Which of BASELINE.json's workloads a command line means (no GPU call, no torch: tests/test_bench_launcher.py runs it on CPU).
+    1 GPU and nothing said: the configuration the metric is quoted on (2048^2, sf 4, 20 images).  N > 1 and nothing said:
+    configs[3] -- 2048^2, sf 4, 40 images IN ALL, sharded over the N ranks (8 ranks hold 5 each): strong scaling of a workload
+    BASELINE names, not N x 20 images.  --images keeps the weak-scaling form (that many images per GPU)."""
+    world = args.gpus
+    if args.images is not None and args.images_total is not None:
+        sys.exit("bench.py: --images (per GPU) and --images-total exclude each other")
+    cfg = args.config
+    if cfg is None and world > 1 and args.images is None and args.images_total is None and args.size is None and args.sf is None:
+        cfg = 4
+    table = {3: (1024, 4, 20, "configs[2]"), 4: (2048, 4, 40, "configs[3]"), 5: (4096, 2, 64, "configs[4]")}
+    named = None
+    if cfg is not None:
+        size, sf, total, named = table[cfg]
+        args.size = args.size or size
+        args.sf = args.sf or sf
+        if args.images is None and args.images_total is None:
+            args.images_total = total
+        if cfg == 5 and args.partition is None and world > 1:
+            args.partition = "strips"
+    args.size = args.size or 2048
+    args.sf = args.sf or 4
+    args.partition = args.partition or "images"
+    if args.images is not None:
+        args.images_total = args.images * world
+        args.scaling = "weak"
+        how = f"{args.images} images/GPU x {world} GPU"
+    else:
+        if args.images_total is None:
+            args.images_total = 20
+        args.scaling = "strong" if world > 1 else "weak"          # one GPU: nothing is scaled; the field keeps the metric line's value
+        args.images = None if world > 1 else args.images_total
+        base, rem = divmod(args.images_total, world)                # api.shard_range: the first `rem` ranks hold one more
+        how = f"{args.images_total} images" + (f" sharded over {world} GPUs ({', '.join(str(base + (r < rem)) for r in range(world))} per rank)" if world > 1 else "/GPU x 1 GPU")
+    args.workload = f"synthetic full-mask HR grid {args.size}x{args.size}, sf {args.sf}, {how}, 3 channels"
+    if named and (args.size, args.sf, args.images_total) == table[cfg][:3]:
+        args.workload += f" [BASELINE.json {named}]"
+    elif world == 1 and (args.size, args.sf, args.images_total) == (2048, 4, 20):
+        args.workload += " [BASELINE.json metric configuration]"
+    return args
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=2048)
-    ap.add_argument("--sf", type=int, default=4)
-    ap.add_argument("--images", type=int, default=20, help="images per GPU (weak scaling)")
+    ap.add_argument("--size", type=int, default=None, help="HR grid is size x size (default 2048; --config 5: 4096)")
+    ap.add_argument("--sf", type=int, default=None, help="scale factor (default 4; --config 5: 2)")
+    ap.add_argument("--images", type=int, default=None, help="images per GPU: weak scaling in images (N GPUs hold N x this many)")
+    ap.add_argument("--images-total", type=int, default=None, help="images in all, sharded over the ranks: strong scaling")
+    ap.add_argument("--config", type=int, choices=[3, 4, 5], default=None,
+                    help="a workload of BASELINE.json by its number there (1-based): 3 = 1024^2 sf 4 x 20 images, 4 = 2048^2 sf 4 x 40 images sharded over "
+                         "the ranks, 5 = 4096^2 sf 2 x 64 images sharded over the ranks (with --partition strips unless said otherwise).  Default: "
+                         "1 GPU: the metric's configuration (2048^2 sf 4 x 20 images); N > 1: config 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-total-solve", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the streaming-CG legs (2048^2 streaming, 4096^2 sf 2)")
     ap.add_argument("--apply-mode", type=int, default=0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="srps_set_option before setup (A/B runs)")
-    ap.add_argument("--partition", choices=["images", "strips"], default="images",
+    ap.add_argument("--partition", choices=["images", "strips"], default=None,
                     help="N > 1: 'images' shards the images and replicates the depth CG (default); 'strips' also partitions the depth CG into "
                          "column strips over the ranks (option cg_partition; needs --comm library) -- meant for --size 4096 --sf 2")
     ap.add_argument("--comm", choices=["library", "torch"], default="library",
@@ -238,6 +300,7 @@ def main():
                          "torch.distributed.all_reduce on views of the library's exchange buffers")
     args = ap.parse_args()
     assert args.gpus >= 1, "--gpus must be at least 1"
+    select_workload(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
@@ -266,7 +329,7 @@ def main():
     pkg = importlib.import_module("srmeetsps-cuda_amd")
     pkg.load()                                       # no fallback: raises when the extension is missing
     H = W = args.size
-    n_total = args.images * world
+    n_total = args.images_total
     lo, hi = pkg.shard_range(n_total, world, rank)
     sc = pkg.synth.make_scene(H, W, args.sf, n_total, seed=1234 + 3, mask_kind="full", img_begin=lo, img_end=hi)
     dh = pkg.DataHandler.from_scene(sc)
@@ -352,8 +415,8 @@ def main():
     out = {
         "metric": "cg_iterations_per_sec", "value": cg_iters / dt, "unit": "cg_iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic full-mask HR grid {H}x{W}, sf {args.sf}, {args.images} images/GPU x {world} GPU, 3 channels",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload,
                    "hr_grid": [H, W], "sf": args.sf, "images_per_gpu": args.images, "images_total": n_total,
                    "unknowns": dims["npix"], "cg_steps_per_solve": depth_steps, "persistent_fallbacks": fallbacks,
                    "albedo_mode": {0: "SRPS_ALBEDO_CG", 1: "SRPS_ALBEDO_CLOSED_FORM", 2: "SRPS_ALBEDO_FUSED", 3: "SRPS_ALBEDO_AUTO (pipeline: the albedo CG's fixed point formed inside the sweep)"}[ctx.get_option("albedo_mode")],

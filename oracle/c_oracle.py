@@ -121,23 +121,46 @@ def depth_estimation(st: Structure, s, rho, I, xx, yy, dz, z0s, z, fx, fy, assem
     return energy(st, s, rho, dz, xx, yy, fx, fy, I, z0s, z), it
 
 
-def bench_cpu_baseline(sc, budget_s=20.0):
-    """bench.py cpu_baseline leg: the reference's formulation (assembled CSR + unfused BLAS-1 CG,
-    dc.cu:229-279) on the SAME HR grid, a bounded number of steps, all host cores (OpenMP).
-    The tensor is synthetic (values do not change the cost of an iteration)."""
-    st = Structure(sc.h, sc.w, sc.sf, sc.mask)
+def bench_cg_csr(rowptr, col, val, b0, iters, reps, threads):
+    """seconds of each of `reps` solves of `iters` CG steps on `threads` threads, after a warm-up (oc_bench_cg_csr)"""
+    _L.oc_bench_cg_csr.restype = C.c_int
+    sec = np.zeros(reps, np.float64)
+    b0 = np.ascontiguousarray(b0, f32)
+    rc = _L.oc_bench_cg_csr(rowptr.size - 1, _i(rowptr), _i(col), _f(val), _f(b0), int(iters), int(reps), int(threads), sec.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0, "oc_bench_cg_csr: out of memory"
+    return sec
+
+
+def bench_cpu_baseline(h, w, sf, mask, budget_s=20.0, reps=5):
+    """bench.py cpu_baseline leg: the reference's formulation (assembled CSR + unfused BLAS-1 CG, dc.cu:229-279) on the SAME HR grid.
+    Median of `reps` timed solves after a warm-up, at ONE thread and at all host threads, matrix and vectors first
+    touched by the threads that stream them (oc_bench_cg_csr); the caller binds the threads through the environment
+    (oracle/cpu_baseline_main.py is started with OMP_PROC_BIND=spread OMP_PLACES=cores).  The tensor is synthetic (values do not
+    change the cost of an iteration)."""
+    st = Structure(h, w, sf, mask)
     rng = np.random.default_rng(0)
     M = np.abs(rng.normal(size=(6, st.P))).astype(f32); M[[1, 2, 4]] *= 0.1
     M = M.reshape(-1)
     rp, ci, v = assemble(st, M)
-    x = np.zeros(st.P, f32); b = rng.normal(size=st.P).astype(f32)
-    cg_csr(rp, ci, v, x.copy(), b.copy(), fixed_iters=2)                 # warm-up
-    t0 = time.perf_counter(); cg_csr(rp, ci, v, x.copy(), b.copy(), fixed_iters=5); t5 = time.perf_counter() - t0
-    iters = int(max(5, min(101, budget_s / max(t5 / 5, 1e-6))))
-    t0 = time.perf_counter(); cg_csr(rp, ci, v, x, b, fixed_iters=iters); dt = time.perf_counter() - t0
-    x2 = np.zeros(st.P, f32); b2 = rng.normal(size=st.P).astype(f32)
-    t0 = time.perf_counter(); cg_mf(st, M, x2, b2, fixed_iters=max(5, iters // 2)); dt_mf = time.perf_counter() - t0
-    return {"value": iters / dt, "unit": "cg_iterations/s", "cores": num_threads(), "kind": "port",
-            "sample": f"{iters} CG steps of the assembled-CSR {sc.h}x{sc.w} system ({v.size / st.P:.1f} nnz/row), "
-                      f"C/OpenMP restatement of devicecalls.cu:229-279 on {num_threads()} threads",
-            "matrix_free_value": max(5, iters // 2) / dt_mf}
+    b = rng.normal(size=st.P).astype(f32)
+    nthr = num_threads()
+    out = {}
+    for label, thr in (("all", nthr), ("one", 1)):
+        t_probe = float(bench_cg_csr(rp, ci, v, b, 3, 1, thr)[0]) / 3                       # seconds per step, after the entry's own warm-up
+        share = budget_s * (0.5 if nthr > 1 else 1.0) / (reps + 1)                           # per solve, warm-up included
+        iters = int(max(3, min(101, share / max(t_probe, 1e-6))))
+        sec = bench_cg_csr(rp, ci, v, b, iters, reps, thr)
+        out[label] = {"it_per_s": iters / float(np.median(sec)), "iters_per_solve": iters, "solves": [iters / float(t) for t in sec],
+                      "spread": float((sec.max() - sec.min()) / np.median(sec)), "threads": thr}
+        if nthr == 1:
+            out["one"] = out["all"]
+            break
+    a, o = out["all"], out["one"]
+    return {"value": a["it_per_s"], "unit": "cg_iterations/s", "cores": nthr, "kind": "port",
+            "value_1_thread": o["it_per_s"],
+            "sample": f"median of {reps} solves of {a['iters_per_solve']} CG steps each (after a warm-up solve) of the assembled-CSR {h}x{w} system "
+                      f"({v.size / st.P:.1f} nnz/row), C/OpenMP restatement of devicecalls.cu:229-279 on {nthr} threads; "
+                      f"1 thread: {reps} solves of {o['iters_per_solve']} steps",
+            "solves_it_per_s": a["solves"], "solves_it_per_s_1_thread": o["solves"], "spread_over_solves": a["spread"],
+            "thread_binding": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")},
+            "first_touch": "matrix and vectors copied and first touched by the threads that stream them (static schedule)"}

@@ -311,16 +311,15 @@ static void op_apply(const oc_op* A, const float* x, float* y) {
     else oc_mf_apply(A->n, A->Ps, A->sf, A->nb, A->blk, A->blk_pix, A->M, A->lambda, x, y, A->work);
 }
 
-static int cg_run(const oc_op* A, float* x, float* b, float tol, int max_iter, int fixed_iters) {
+static int cg_run_ws(const oc_op* A, float* x, float* b, float tol, int max_iter, int fixed_iters, float* p, float* om) {
     const int n = A->n;
-    float* p = (float*)malloc((size_t)n * sizeof(float));
-    float* om = (float*)malloc((size_t)n * sizeof(float));
     float r0 = 0.f, r1 = sdot(n, b, b);                              /* dc.cu:251 */
     int k = 0;
     while (fixed_iters > 0 ? k < fixed_iters : (r1 > tol * tol && k <= max_iter)) {   /* dc.cu:252 */
         ++k;
         if (k == 1) {
-            memcpy(p, b, (size_t)n * sizeof(float));                 /* Scopy dc.cu:258 */
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < n; ++i) p[i] = b[i];                 /* Scopy dc.cu:258 */
         } else {
             const float beta = r1 / r0;                              /* dc.cu:262 */
 #pragma omp parallel for schedule(static)
@@ -338,8 +337,63 @@ static int cg_run(const oc_op* A, float* x, float* b, float tol, int max_iter, i
         r0 = r1;
         r1 = sdot(n, b, b);                                          /* dc.cu:274 */
     }
+    return k;
+}
+
+static int cg_run(const oc_op* A, float* x, float* b, float tol, int max_iter, int fixed_iters) {
+    const int n = A->n;
+    float* p = (float*)malloc((size_t)n * sizeof(float));
+    float* om = (float*)malloc((size_t)n * sizeof(float));
+    const int k = cg_run_ws(A, x, b, tol, max_iter, fixed_iters, p, om);
     free(p); free(om);
     return k;
+}
+
+/* bench.py's cpu_baseline leg (oracle/cpu_baseline_main.py): `reps` timed solves of `iters` steps each of the reference's CG
+ * (cg_run_ws above, dc.cu:229-279) on the assembled CSR system, after one untimed warm-up solve, on `threads` OpenMP threads.
+ * What makes the figure repeat from run to run on a two-socket host: the matrix and every vector are COPIES made here and first
+ * touched by the thread that will stream them (the static schedule of the loops above: a row's non-zeros, its x, b, p and omega
+ * element live on the memory node of the thread that owns the row), the workspaces are allocated once (no page faults inside the
+ * timed solves), and the caller binds the threads (OMP_PROC_BIND=spread, OMP_PLACES=cores in the environment of the process).
+ * seconds[reps] receives the wall time of each solve. */
+int oc_bench_cg_csr(int n, const int* rowptr, const int* col, const float* val, const float* b0, int iters, int reps, int threads, double* seconds) {
+#ifdef _OPENMP
+    const int before = omp_get_max_threads();
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    const long nnz = rowptr[n];
+    int* rp = (int*)malloc(((size_t)n + 1) * sizeof(int));
+    int* ci = (int*)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int));
+    float* va = (float*)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(float));
+    float *x = (float*)malloc((size_t)n * sizeof(float)), *b = (float*)malloc((size_t)n * sizeof(float));
+    float *p = (float*)malloc((size_t)n * sizeof(float)), *om = (float*)malloc((size_t)n * sizeof(float));
+    if (!rp || !ci || !va || !x || !b || !p || !om) { free(rp); free(ci); free(va); free(x); free(b); free(p); free(om); return -1; }
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < n; ++r) {
+        rp[r] = rowptr[r]; if (r == n - 1) rp[n] = rowptr[n];
+        for (int t = rowptr[r]; t < rowptr[r + 1]; ++t) { ci[t] = col[t]; va[t] = val[t]; }
+        x[r] = 0.f; b[r] = b0[r]; p[r] = 0.f; om[r] = 0.f;
+    }
+    oc_op A; memset(&A, 0, sizeof(A));
+    A.mode = 0; A.n = n; A.rowptr = rp; A.col = ci; A.val = va;
+    for (int k = -1; k < reps; ++k) {                                 /* k = -1: the warm-up */
+#pragma omp parallel for schedule(static)
+        for (int r = 0; r < n; ++r) { x[r] = 0.f; b[r] = b0[r]; }
+#ifdef _OPENMP
+        const double t0 = omp_get_wtime();
+#endif
+        cg_run_ws(&A, x, b, 0.f, 0, iters, p, om);
+#ifdef _OPENMP
+        if (k >= 0) seconds[k] = omp_get_wtime() - t0;
+#else
+        if (k >= 0) seconds[k] = 0.0;
+#endif
+    }
+    free(rp); free(ci); free(va); free(x); free(b); free(p); free(om);
+#ifdef _OPENMP
+    omp_set_num_threads(before);
+#endif
+    return 0;
 }
 
 int oc_cg_csr(int n, const int* rowptr, const int* col, const float* val, float* x, float* b, float tol, int max_iter, int fixed_iters) {

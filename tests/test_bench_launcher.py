@@ -37,3 +37,34 @@ def test_parent_starts_children_and_relays_their_failure(tmp_path):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
     assert "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
     assert '{"metric": "x"}' in out.stdout                         # the ranks' line is relayed
+
+
+def test_which_workload_a_command_line_means():
+    """one GPU, nothing said: the metric's configuration; N > 1, nothing said: BASELINE.json configs[3] (40 images IN ALL, sharded --
+    strong scaling); --config 5: configs[4] with the CG on strips; --images keeps the weak-scaling form"""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+
+    def pick(gpus, **kw):
+        a = types.SimpleNamespace(gpus=gpus, images=None, images_total=None, config=None, size=None, sf=None, partition=None)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return bench.select_workload(a)
+    a = pick(1)
+    assert (a.size, a.sf, a.images_total, a.scaling, a.partition) == (2048, 4, 20, "weak", "images") and "metric configuration" in a.workload
+    a = pick(8)
+    assert (a.size, a.sf, a.images_total, a.scaling) == (2048, 4, 40, "strong") and "(5, 5, 5, 5, 5, 5, 5, 5 per rank)" in a.workload and "configs[3]" in a.workload
+    a = pick(2)
+    assert a.images_total == 40 and "(20, 20 per rank)" in a.workload
+    a = pick(4, config=5)
+    assert (a.size, a.sf, a.images_total, a.partition) == (4096, 2, 64, "strips") and "configs[4]" in a.workload
+    a = pick(4, config=5, partition="images")
+    assert a.partition == "images"
+    a = pick(2, images=20)
+    assert (a.images_total, a.scaling) == (40, "weak") and "configs" not in a.workload
+    a = pick(3, images_total=20)
+    assert "(7, 7, 6 per rank)" in a.workload and a.scaling == "strong"
+    a = pick(1, config=3)
+    assert (a.size, a.sf, a.images_total) == (1024, 4, 20) and "configs[2]" in a.workload

@@ -148,6 +148,25 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.timeout(900)
+def test_bench_default_line_for_two_ranks_is_a_baseline_workload():
+    """`bench.py --gpus 2` with nothing else said (the driver's command line for N > 1) runs BASELINE.json's configs[3] -- 2048 x 2048,
+    sf 4, 40 images IN ALL, sharded 20 + 20 -- and says so; not 2 x 20 images of a workload BASELINE does not name.  Dry run on one GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-total-solve"],
+                         env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = two["config"]
+    assert cfg["workload"] == ("synthetic full-mask HR grid 2048x2048, sf 4, 40 images sharded over 2 GPUs (20, 20 per rank), 3 channels "
+                               "[BASELINE.json configs[3]]"), cfg["workload"]
+    assert cfg["images_per_rank"] == [20, 20] and cfg["images_total"] == 40 and two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert cfg["cg_steps_per_solve"] == 101 and cfg["ranks_seen_by_the_library"] == 2
+
+
+@pytest.mark.timeout(900)
 def test_bench_dry_run_with_the_resident_kernel_on_strips():
     """`bench.py --gpus 2 --partition strips` on one GPU: the images sharded 3 + 3, the library's sharded loop over gloo host collectives,
     and the depth CG as the resident kernel on two strips of tile columns -- two PROCESSES whose kernels run side by side and talk

@@ -1,0 +1,151 @@
+"""Whole solves -- SRPS::execute to the reference's stop rule (SRPS.cu:272-335) -- at the sizes bench.py times, against the oracle.
+
+The one-pass tests of tests/test_gpu_full_size.py compare the FIRST pass; what bench.py reports as `total_solve_s` is seven passes of
+a truncated CG (dc.cu:229-279) with a warm start, each pass built on the previous one's depth, albedo and lighting.  Here the oracle
+runs the same loop pass by pass -- numpy lighting (dc.cu:376-444), numpy albedo (the reference's CG on the diagonal system,
+dc.cu:395-406 + 513-548), the C oracle's depth step in the reference's assembled-CSR form (dc.cu:636-786), numpy normals
+(dc.cu:171-223), the stop rule of SRPS.cu:297-302 -- and the library's `srps_execute` is compared with it twice:
+
+  * with DEFAULT options (albedo step = the CG's fixed point formed inside the sweep, `SRPS_ALBEDO_AUTO`; beta from the predicted
+    r.r, `cg_one_sync` = 1): the two documented departures from the reference's arithmetic, compounding over the passes;
+  * with `albedo_mode = 0, cg_one_sync = 0`: the reference's arithmetic (albedo CG, direct r.r in every step).
+
+The difference between the two library runs is printed, so the departures' compound effect is a number in the test's output.
+
+Tolerances: depth RMSE < 1e-4 (north_star), every pass's energy 1e-3 (first pass: the per-size value of the one-pass tests), the
+pass count equal (one apart only inside assert_same_stop's window), albedo bounded through the depth's deviation (DESIGN.md section
+6: the normals multiply depth differences by the focal length), lighting through the shading it predicts.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_full_size import _oracle_start, rmse
+from test_gpu_parity import assert_same_stop
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def coracle():
+    import c_oracle
+    return c_oracle
+
+
+def _oracle_execute(sc, oracle, coracle, max_outer=None):
+    """SRPS.cu:272-335 with the oracle's phases; returns the state after every pass's depth step is NOT kept (1 GB of images is
+    enough) -- energies, pass count and the final z, rho, s, N"""
+    st, o = _oracle_start(sc, oracle, coracle)
+    n_img, n_ch, P = o["I"].shape
+    s = np.zeros((n_img, n_ch, 4), f32); s[:, :, 2] = -1                      # SRPS.cu:244-249
+    rho = np.full((n_ch, P), 0.5, f32)                                        # dc.cu:112-126
+    z, N, dz = o["z"].copy(), o["N"], o["dz"]
+    energies, alb_its = [], []
+    last_error = float("nan")
+    iteration = 1
+    while True:
+        oracle.lighting_estimation(s, rho, N, o["I"])
+        num, den = oracle.albedo_numden(s, N, o["I"])
+        it_a = []
+        oracle.albedo_solve_numden(rho, num, den, it_a)
+        alb_its.append(it_a)
+        e, it = coracle.depth_estimation(st, s, rho, o["I"], o["xx"], o["yy"], dz, o["z0s"], z, o["fx"], o["fy"], assembled=True)
+        assert it == 101
+        zx, zy = coracle.gradient(st, z)
+        N, dz = oracle.normal_init(z, zx, zy, o["xx"], o["yy"], o["fx"], o["fy"])
+        energies.append(float(e))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rel = abs(f32(last_error) - f32(e)) / abs(f32(e))
+        stop = (e > last_error) or (rel < oracle.OUTER_TOLERANCE) or (iteration > oracle.OUTER_MAX_ITERATIONS)   # SRPS.cu:298-301
+        last_error = e
+        iteration += 1
+        if stop or (max_outer is not None and len(energies) >= max_outer):
+            break
+    return dict(energies=energies, z=z, rho=rho, s=s, N=N, dz=dz, albedo_iterations=alb_its, fx=o["fx"], st=st)
+
+
+def _library_execute(pkg, sc, options, max_outer=0):
+    ctx = pkg.Context(device_id=0)
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    en = ctx.execute(max_outer)                                               # the loop inside the library: srps_execute
+    out = dict(energies=[float(e) for e in en], z=ctx.get("z"), rho=ctx.get("rho").reshape(sc.n_ch, -1), s=ctx.get("s").reshape(-1, sc.n_ch, 4),
+               depth_steps=ctx.last_cg_iterations()["depth"], resident=ctx.get_option("cg_resident_active"),
+               fallbacks=ctx.get_option("persistent_fallbacks"), albedo_mode=ctx.get_option("albedo_mode"), one_sync=ctx.get_option("cg_one_sync"))
+    ctx.close()
+    return out
+
+
+def _shading_rel(s, s_ref, rho_ref, N_ref):
+    worst = 0.0
+    for c in range(s.shape[1]):
+        A = (rho_ref[c][None, :] * N_ref).astype(np.float64)                  # [4][P], dc.cu:381
+        d = (s[:, c, :] - s_ref[:, c, :]).astype(np.float64) @ A
+        r = s_ref[:, c, :].astype(np.float64) @ A
+        worst = max(worst, float(np.linalg.norm(d) / np.linalg.norm(r)))
+    return worst
+
+
+def _compare(name, got, ref, first_pass_tol):
+    en, en_ref = got["energies"], ref["energies"]
+    n = min(len(en), len(en_ref))
+    rel = [abs(a - b) / abs(b) for a, b in zip(en[:n], en_ref[:n])]
+    d_z = rmse(got["z"], ref["z"])
+    z_max = float(np.abs(got["z"] - ref["z"]).max())
+    d_rho_max = float(np.abs(got["rho"] - ref["rho"]).max())
+    d_rho = rmse(got["rho"], ref["rho"])
+    sh = _shading_rel(got["s"], ref["s"], ref["rho"], ref["N"])
+    print(f"{name}: passes {len(en)} / oracle {len(en_ref)}; depth RMSE {d_z:.3e} (max {z_max:.3e}); albedo RMSE {d_rho:.3e} max {d_rho_max:.3e}; "
+          f"shading {sh:.3e}; energies rel {['%.2e' % r for r in rel]}; final energy {en[-1]:.6g} / {en_ref[-1]:.6g}")
+    assert got["depth_steps"] == 101 and got["fallbacks"] == 0
+    assert_same_stop(en, en_ref)
+    assert rel[0] < first_pass_tol, rel
+    assert max(rel) < 1e-3, rel
+    return dict(depth_rmse=d_z, depth_max=z_max, albedo_max=d_rho_max, albedo_rmse=d_rho, shading=sh, same_count=len(en) == len(en_ref))
+
+
+def _whole_solve(pkg, oracle, coracle, sc, first_pass_tol, expect_resident=True):
+    ref = _oracle_execute(sc, oracle, coracle)
+    default = _library_execute(pkg, sc, {})
+    assert default["albedo_mode"] == 3 and default["one_sync"] == 1, "this test is about the library's DEFAULT options"
+    assert default["resident"] == (1 if expect_resident else 0)
+    faithful = _library_execute(pkg, sc, {"albedo_mode": 0, "cg_one_sync": 0})
+    if len(default["energies"]) != len(ref["energies"]):                       # inside assert_same_stop's window: compare at the same pass count
+        ref_d = _oracle_execute(sc, oracle, coracle, max_outer=len(default["energies"]))
+    else:
+        ref_d = ref
+    if len(faithful["energies"]) != len(ref["energies"]):
+        ref_f = _oracle_execute(sc, oracle, coracle, max_outer=len(faithful["energies"]))
+    else:
+        ref_f = ref
+    tag = f"{sc.h}x{sc.w} x {sc.n_img} images, sf {sc.sf}"
+    r_d = _compare(f"{tag}, default options", default, ref_d, first_pass_tol)
+    r_f = _compare(f"{tag}, albedo_mode=0 cg_one_sync=0 (the reference's arithmetic)", faithful, ref_f, first_pass_tol)
+    both = len(default["energies"]) == len(faithful["energies"])
+    print(f"{tag}: default options against the reference's arithmetic, both in the library: passes {len(default['energies'])} / {len(faithful['energies'])}"
+          + (f", depth RMSE {rmse(default['z'], faithful['z']):.3e}, albedo max {float(np.abs(default['rho'] - faithful['rho']).max()):.3e}, "
+             f"final energy rel {abs(default['energies'][-1] - faithful['energies'][-1]) / abs(faithful['energies'][-1]):.3e}" if both else ""))
+    # the albedo inherits the depth's deviation through the normals: N = (fx zx, fy zy, .) / |.|, so depths d apart give normals up
+    # to 2 f d / dz apart (dz >= ~z: the unit-scale scenes have dz ~ 1) and albedos that far apart times rho <= 1
+    for r in (r_d, r_f):
+        assert r["depth_rmse"] < 1e-4, r
+        assert r["albedo_max"] < max(2e-3, 0.25 * 2 * ref["fx"] * r["depth_max"]), r
+        assert r["albedo_rmse"] < 2e-4, r
+        assert r["shading"] < 2e-3, r
+    if both:
+        assert rmse(default["z"], faithful["z"]) < 2e-5
+    return r_d, r_f
+
+
+@pytest.mark.timeout(1500)
+def test_config3_whole_solve_against_the_oracle(pkg, oracle, coracle):
+    """1024 x 1024, sf 4, 20 images (BASELINE.json configs[2]), full mask, to the stop rule"""
+    _whole_solve(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"), first_pass_tol=1e-4)
+
+
+@pytest.mark.timeout(3000)
+def test_metric_whole_solve_against_the_oracle(pkg, oracle, coracle):
+    """2048 x 2048, sf 4, 20 images -- the metric's configuration and bench.py's own scene (seed 1234 + 3): the solve whose
+    seconds the bench reports as total_solve_s, to the stop rule, against the oracle"""
+    _whole_solve(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 20, seed=1234 + 3, mask_kind="full"), first_pass_tol=6.5e-4)
