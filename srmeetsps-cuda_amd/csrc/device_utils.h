@@ -306,6 +306,23 @@ typedef unsigned srps_v4u __attribute__((ext_vector_type(4)));
                                  // time, and packed into 4 KB they queue on a few memory channels (16: 11.75, 64: 11.5, 256 and
                                  // 1024: 11.45 us per CG step at 2048 x 2048)
 #endif
+// Experiments of round 5 on the collect's round trip (every block's polling wave asks for all 256 granules at the same moment: 65 536
+// 16-byte requests for 256 lines per step).  SRPS_G3_GROUP = 4: four consecutive granules share a 64-byte segment (the four lanes
+// that read them in one instruction are then ONE request), the segments SRPS_G3_STRIDE * 4 bytes apart -- a quarter of the requests on
+// the same footprint.  SRPS_G3_REPLICAS = R: every block stores its granule R times, a block polls copy (slot mod R) -- the same
+// requests over R times the lines.
+#ifndef SRPS_G3_GROUP
+#define SRPS_G3_GROUP 1
+#endif
+#ifndef SRPS_G3_REPLICAS
+#define SRPS_G3_REPLICAS 1
+#endif
+// byte offset of granule g (of nbr = blocks rounded up to 256) in copy `rep` of generation parity `par`
+__device__ __forceinline__ size_t g3_offset(unsigned par, int rep, int nbr, int g) {
+    const size_t copy = ((size_t)par * SRPS_G3_REPLICAS + rep) * (size_t)nbr * SRPS_G3_STRIDE;
+    if (SRPS_G3_GROUP > 1) return copy + (size_t)(g / SRPS_G3_GROUP) * (SRPS_G3_STRIDE * SRPS_G3_GROUP) + (size_t)(g % SRPS_G3_GROUP) * 16;
+    return copy + (size_t)g * SRPS_G3_STRIDE;
+}
 // FLOAT32: the sums across the waves of a block and across the blocks in fp32 instead of fp64 -- for the depth CG, whose
 // critical path after the last block has published runs through this arithmetic (one thread's 24 dependent fp64 additions,
 // then the polling wave's fp64 DPP totals: ~0.25 us per CG step).  The per-thread and per-wave sums are fp32 either way; the
@@ -326,7 +343,9 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
     // the granule into this block's slot of the rank's own array and, in a group, of every other rank's
     auto store_granule = [&](const srps_v4u& g) {
         const int nbr = (nb + 255) & ~255;
-        const size_t at = ((size_t)(gen & 1u) * nbr + myslot) * SRPS_G3_STRIDE;
+#pragma unroll
+        for (int rep = 0; rep < SRPS_G3_REPLICAS; ++rep) {
+        const size_t at = g3_offset(gen & 1u, rep, nbr, myslot);
         const char* dst = reinterpret_cast<const char*>(ent3) + at;
         // s_nop 1: a store of more than 8 bytes must not be followed within two wait states by a write of its data registers
         // (gfx940 and later; the compiler inserts them for its own stores, it cannot see into the asm)
@@ -338,6 +357,7 @@ __device__ __forceinline__ void grid_sum3_publish(float v0, float v1, float v2, 
             }
         } else
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(g) : "memory");
+        }
     };
     if constexpr (NW > 0 && FLOAT32) {
         // Every wave leaves its three totals in LDS and counts itself in; the wave that arrives LAST adds the NW entries in
@@ -402,11 +422,13 @@ __device__ __forceinline__ void grid_sum3_collect(unsigned long long* ent3, unsi
         double acc[3] = {0.0, 0.0, 0.0};
         float facc[3] = {0.f, 0.f, 0.f};
         const int nbr = (nb + 255) & ~255;
-        const char* slot = reinterpret_cast<const char*>(ent3) + (size_t)(gen & 1u) * nbr * SRPS_G3_STRIDE;
+        const int myrep = SRPS_G3_REPLICAS > 1 ? (int)((gp ? gp->slot : (int)blockIdx.x) % SRPS_G3_REPLICAS) : 0;
+        const char* slot = reinterpret_cast<const char*>(ent3);
         for (int base = 0; base < nb; base += 256) {
             // lane l takes granules l, l + 64, l + 128, l + 192 of this group, all requested before the first is looked at
-            const char* src = slot + (size_t)(base + lane) * SRPS_G3_STRIDE;
-            const char *s1 = src + 64 * SRPS_G3_STRIDE, *s2 = src + 128 * SRPS_G3_STRIDE, *s3 = src + 192 * SRPS_G3_STRIDE;
+            const char* src = slot + g3_offset(gen & 1u, myrep, nbr, base + lane);
+            const char *s1 = slot + g3_offset(gen & 1u, myrep, nbr, base + lane + 64), *s2 = slot + g3_offset(gen & 1u, myrep, nbr, base + lane + 128),
+                       *s3 = slot + g3_offset(gen & 1u, myrep, nbr, base + lane + 192);
             srps_v4u w[4];
             // every round asks for all four again: a lane whose granules arrive in a different order than it looks at them
             // would otherwise pay one more round trip per granule

@@ -441,7 +441,11 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
 // TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
 // U8: the images from the context's 8-bit store (bytes, k / 255.f formed in registers: device_utils.h unit_from_byte -- the same floats);
 // the sweep's vector pipes are a third busy, the bytes are a quarter of the floats.
-template <int IBW, int NCH, bool TAIL, bool TM = false, bool U8 = false>
+// RUN (round 5): a wave takes the tile's four 1 KiB pieces of ONE (image, channel) plane back to back -- a 4 KiB run, the albedo sweep's
+// access shape -- instead of one piece of each of its IBW images.  What kept round 4 from it were the products rho N_k of four pieces
+// held in registers per channel (hipcc spilled); here nothing per piece is held: every (plane, piece) step re-reads the piece's seven
+// LDS planes (28 KiB of LDS reads per 4 KiB of image: the LDS has the bandwidth) and re-forms the 16 products.
+template <int IBW, int NCH, bool TAIL, bool TM = false, bool U8 = false, bool RUN = false>
 __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img,
                                                             int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
                                                             EnergyArgs ea) {
@@ -541,6 +545,79 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
             // 0.245 ms: the loads alone run at 5.0 TB/s, the arithmetic hides under them.  A wave reads 1 KiB runs of five image planes;
             // the albedo sweep, whose block reads 4 KiB runs, draws 6.1 TB/s.)
             const int npieces = __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8));      // wave-uniform: the range's last tile may be short
+            if constexpr (RUN) {
+                constexpr int NSR = NCH * IBW;                           // the wave's planes, one step each: k = ii * NCH + c
+                Vec<4> ivr[2][4];
+                auto issue_run = [&](int k, Vec<4> (&buf)[4]) {
+                    const int ii = k / NCH, c = k - ii * NCH;
+                    const size_t row = (size_t)min(ib + ii, n_img - 1) * C + c;      // images past the end re-read the last one
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const int q = t0 + (sub * 64 + lane) * 4;
+                        buf[sub] = ld_img<4, U8, TM>(I, I8, row, P, q < p1 ? q : p1 - 4, n_img * C);
+                    }
+                };
+                issue_run(0, ivr[0]);
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) {
+                    const int ii = k / NCH, c = k % NCH;
+                    if (k + 1 < NSR) issue_run(k + 1, ivr[(k + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);                   // the next plane's loads go out before this plane's arithmetic
+                    Vec<4> (&iv)[4] = ivr[k & 1];
+                    const float4 sv = svs[grp][c * IBW + ii];             // one LDS broadcast per plane
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        if (sub < npieces) {                              // wave-uniform
+                            const int li = sub * 64 + lane;
+                            const int q = t0 + li * 4;
+                            const bool ragged = __builtin_amdgcn_readfirstlane(t0 + sub * 256 + 256) > p1;
+                            if (ragged) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) iv[sub].v[e] = (q < p1) ? iv[sub].v[e] : 0.f;
+                            }
+                            float4 nkq[3];
+#pragma unroll
+                            for (int kk = 0; kk < 3; ++kk) nkq[kk] = geo[kk][li];
+                            const float (*nk)[4] = reinterpret_cast<const float (*)[4]>(nkq);
+                            const float4 rq = geo[3 + c][li];
+                            const float r[4] = {rq.x, rq.y, rq.z, rq.w};
+                            float a[4][4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                a[0][e] = r[e] * nk[0][e]; a[1][e] = r[e] * nk[1][e]; a[2][e] = r[e] * nk[2][e];       // dc.cu:381
+                                a[3][e] = r[e] * 1.f;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk) acc[c][ii][kk] = fmaf(a[kk][e], iv[sub].v[e], acc[c][ii][kk]);
+                            if (!TAIL || ib + ii < n_img) {               // wave-uniform
+                                float4 Eq[3];
+#pragma unroll
+                                for (int kk = 0; kk < 3; ++kk) Eq[kk] = geo[3 + NCH + 3 * c + kk][li];
+                                const float (*E)[4] = reinterpret_cast<const float (*)[4]>(Eq);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float res = fmaf(E[0][e], sv.x, fmaf(E[1][e], sv.y, fmaf(E[2][e], sv.z, fmaf(r[e], sv.w, -iv[sub].v[e]))));
+                                    e_acc = fmaf(res, res, e_acc);
+                                }
+                            }
+                            if (ii == 0 && c == gram_c) {                 // wave-uniform: the Gram matrix once per pixel, beside the wave's first image
+                                int t = 0;
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                                    for (int l = kk; l < 4; ++l) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) g[t] = fmaf(a[kk][e], a[l][e], g[t]);
+                                        ++t;
+                                    }
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
             constexpr int NS = 4 * NCH;
             constexpr int PF = SRPS_LIGHT_PREFETCH;                  // steps of look-ahead (PF + 1 sets of IBW float4 rotate)
             Vec<4> ivb[PF + 1][IBW];
@@ -665,12 +742,27 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
     const double t1 = sum_partials_agent(ea.fin.t1_part, ea.fin.n_t1, smd);
     if (tid == 0) { ea.fin.report[0] = (float)t1; ea.fin.report[1] = (float)t2; *ea.fin.ticket = 0u; }
     if (ea.fin.host_report) {
+        // The record crosses PCIe as write-through stores (sc0 sc1), each waited for by its lane; the sequence word follows behind a
+        // barrier.  What orders them on the way is the fabric's handling of acknowledged stores -- not a release fence (at system scope
+        // that is a write-back of the whole L2 behind 64 MB of freshly stored normals) -- so the host does not take the sequence word's
+        // word for it (round-4 advisor finding): a CHECK word goes out with it, seq ^ (xor of the record's 80 words), and the host accepts
+        // the record only when the words it reads give that check (energy_finish_impl re-reads until they do).
+        __shared__ unsigned s_xor[4];
+        unsigned bits = 0u;
         if (tid < REPORT_FLOATS) {
             const float v = tid == 0 ? (float)t1 : tid == 1 ? (float)t2 : ld_agent(ea.fin.report + tid);
-            st_system_done(ea.fin.host_report + tid, __float_as_uint(v));
+            bits = __float_as_uint(v);
+            st_system_done(ea.fin.host_report + tid, bits);
         }
+        unsigned x = bits;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x ^= (unsigned)__shfl_xor((int)x, o, 64);
+        if ((tid & 63) == 0) s_xor[tid >> 6] = x;
         __syncthreads();                                   // the record has left (every lane waited for its store)
-        if (tid == 0) st_system_done(ea.fin.host_report + REPORT_SEQ_AT, ea.fin.seq);
+        if (tid == 0) {
+            st_system_done(ea.fin.host_report + REPORT_CHECK_AT, ea.fin.seq ^ s_xor[0] ^ s_xor[1] ^ s_xor[2] ^ s_xor[3]);
+            st_system_done(ea.fin.host_report + REPORT_SEQ_AT, ea.fin.seq);
+        }
     }
 }
 
@@ -843,12 +935,16 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
         // to its top and spills 330 bytes; the guards are wave-uniform branches on a scalar compare)
         const float* d_It = image_store_tiles(ctx, d_I);       // the tile-major copy of the context's images, when it keeps one
         const unsigned char* d_I8 = ctx->light_bytes ? image_store_bytes(ctx, d_I) : nullptr;      // byte images: the sweep reads the bytes (option "light_bytes")
-#define SRPS_LT(BB, CC) do { if (d_I8) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
+#define SRPS_LT_ARGS dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea
+#define SRPS_LT(BB, CC) do { if (d_I8 && ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true, true>), SRPS_LT_ARGS); \
+                             else if (d_I8) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true>), SRPS_LT_ARGS); \
                              else if (d_It) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
-                             else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); } while (0)
+                             else if (ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false, true>), SRPS_LT_ARGS); \
+                             else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false>), SRPS_LT_ARGS); } while (0)
         if (C == 3) { switch (ibw) { case 1: SRPS_LT(1, 3); break; case 2: SRPS_LT(2, 3); break; case 3: SRPS_LT(3, 3); break; case 4: SRPS_LT(4, 3); break; default: SRPS_LT(5, 3); } }
         else { switch (ibw) { case 1: SRPS_LT(1, 1); break; case 2: SRPS_LT(2, 1); break; case 3: SRPS_LT(3, 1); break; case 4: SRPS_LT(4, 1); break; default: SRPS_LT(5, 1); } }
 #undef SRPS_LT
+#undef SRPS_LT_ARGS
         SRPS_LAUNCH_CHECK();
         return SRPS_OK;
     }

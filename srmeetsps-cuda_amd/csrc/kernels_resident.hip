@@ -23,6 +23,8 @@
 //   * the column body has no branches and its results are pinned by empty asm statements: otherwise the
 //     arithmetic is sunk to the first use of omega, after the loop, together with everything it reads;
 //   * structure masks are formed by v_bfe_i32 in assembly (the portable forms become and + compare + select).
+#include <unistd.h>
+
 #include "srps_internal.h"
 #include "device_utils.h"
 
@@ -124,6 +126,9 @@ __device__ __forceinline__ v2f andm2(v2f v, v2i m) { return __builtin_bit_cast(v
 // 8.58 us per step (general body 10.35 against 9.90) -- they do not; the packed body stays.
 #ifndef SRPS_RES_UNPACKED
 #define SRPS_RES_UNPACKED 0
+#endif
+#ifndef SRPS_RES_LAZY_RR
+#define SRPS_RES_LAZY_RR 0
 #endif
 struct r2f { float x, y; };
 struct r2i { int x, y; };
@@ -846,7 +851,9 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                     for (int e = 0; e < 4; ++e) {
                         x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
                         r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
+#if !SRPS_RES_LAZY_RR
                         red = fmaf(r[c].e[e], r[c].e[e], red);
+#endif
                     }
                 SRPS_STAMP(12);
                 await_ring(wr);
@@ -866,7 +873,17 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 // (A step counter kept in a register instead of k & 15 cost 1.4 us per step in code generation.)
                 if ((SRPS_RES_DEBUG_ON(a)) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
                     r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : (float)pred);
-                else { r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm, gp)); r1_anchor = r1; }
+                else {
+#if SRPS_RES_LAZY_RR
+                    // the direct sum of r.r is needed in about one step of 16: its 32 multiply-adds are formed here, not in every step
+                    // (same operands, same order: the same bits)
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) red = fmaf(r[c].e[e], r[c].e[e], red);
+#endif
+                    r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm, gp)); r1_anchor = r1;
+                }
             }
             // ---- the next step's p = beta p + r, own pixels and ring (dc.cu:256-264), here, where r.r has just become known: at the
             // top of the next pass it cost a phase of its own behind the loop's turn.  After pass 0: beta = 0, p = 0 p + r = r.
@@ -1036,7 +1053,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const int nc = march_recompute_channels(ctx);
     const int nbr = cdiv(G.Hg, TR), nbc = cdiv(G.Wg, TC), tiles = nbr * nbc;
     // ent [2][tiles] | ent3 [2][tiles rounded up to 256] 16-byte granules | edge granules [tiles][2][HALO_N]
-    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
+    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * SRPS_G3_REPLICAS * (SRPS_G3_STRIDE / 8);
     const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
     SRPS_TRY(ensure(ctx->ws_resident, need));
     SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));
@@ -1083,14 +1100,14 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
 
 // ---- one rank of a GROUP of resident launches in this unit's tile shape (drivers: resident_cg_group / resident_cg_rank below) --------
 size_t SRPS_RES_NAME(resident_group_bytes)(int tiles) {
-    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
+    const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * SRPS_G3_REPLICAS * (SRPS_G3_STRIDE / 8);
     return (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
 }
 int SRPS_RES_NAME(resident_group_launch)(srps_ctx* ctx, const ResidentGroupSpec& sp) {
     Grid& G = ctx->grid;
     const int nc = march_recompute_channels(ctx);
     const int shape = TC == 64 ? 1 : (TC == 32 ? 0 : 2);
-    const size_t ent_n = ((size_t)sp.tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((sp.tiles + 255) & ~255) * 2 * (SRPS_G3_STRIDE / 8);
+    const size_t ent_n = ((size_t)sp.tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((sp.tiles + 255) & ~255) * 2 * SRPS_G3_REPLICAS * (SRPS_G3_STRIDE / 8);
     auto carve = [&](void* base, unsigned long long*& ent, unsigned long long*& ent3, unsigned long long*& halo) {
         ent = (unsigned long long*)base; ent3 = ent + ent_n; halo = ent3 + ent3_n;
     };
@@ -1214,6 +1231,8 @@ bool group_plan(const srps_ctx* ctx, int n, bool one_device, GroupPlan& pl) {
 }
 }  // namespace
 
+int resident_exchange_buffer(srps_ctx* ctx, size_t need, bool coarse_ok);      // below
+
 int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_steps) {
     SRPS_REQUIRE(n >= 1 && n <= 8, SRPS_ERR_INVALID, "resident strip group: 1 .. 8 ranks");
     srps_ctx* c0 = ctxs[0];
@@ -1244,16 +1263,37 @@ int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_st
     const GroupUnit& U = *pl.unit;
     const size_t need = U.bytes(pl.tiles);
     std::vector<hipEvent_t> ready((size_t)n, nullptr);
+    std::vector<void*> exch((size_t)n, nullptr);           // every rank's granule arrays
     auto cleanup = [&]() { for (auto e : ready) if (e) (void)hipEventDestroy(e); };
     int rc = SRPS_OK;
     for (int r = 0; r < n && rc == SRPS_OK; ++r) {
         srps_ctx* c = ctxs[r];
         if (hipSetDevice(c->device) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
-        if (!one_device)
-            for (int q = 0; q < n; ++q)
-                if (ctxs[q]->device != c->device) { (void)hipDeviceEnablePeerAccess(ctxs[q]->device, 0); (void)hipGetLastError(); }
-        if ((rc = ensure(c->ws_resident, need)) != SRPS_OK) break;
-        if (hipMemsetAsync(c->ws_resident.p, 0, need, c->stream) != hipSuccess || hipEventCreateWithFlags(&ready[(size_t)r], hipEventDisableTiming) != hipSuccess ||
+        if (!one_device) {
+            // Peers on other DEVICES store into this rank's arrays and this rank polls them while the kernels run: that needs memory that is
+            // coherent across agents at instruction granularity -- fine-grained -- and a device that can reach the peer's memory at all.
+            // (hipMalloc memory is coherent across agents at kernel boundaries only: the owner's polls may be served from its own L2 for
+            // ever.  Round-4 review: on one device both kinds work, which is why the one-GPU tests could not tell.)
+            for (int q = 0; q < n && rc == SRPS_OK; ++q) {
+                if (ctxs[q]->device == c->device) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, c->device, ctxs[q]->device) != hipSuccess || !can) {
+                    (void)hipGetLastError();
+                    set_error("resident strip group: device %d cannot access device %d's memory", c->device, ctxs[q]->device);
+                    rc = SRPS_ERR_UNSUPPORTED; break;
+                }
+                const hipError_t e = hipDeviceEnablePeerAccess(ctxs[q]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("resident strip group: hipDeviceEnablePeerAccess(%d): %s", ctxs[q]->device, hipGetErrorString(e)); rc = SRPS_ERR_UNSUPPORTED; }
+                (void)hipGetLastError();
+            }
+            if (rc != SRPS_OK) break;
+            if ((rc = resident_exchange_buffer(c, need, /*coarse_ok=*/false)) != SRPS_OK) break;
+            exch[(size_t)r] = c->xg_buf;
+        } else {
+            if ((rc = ensure(c->ws_resident, need)) != SRPS_OK) break;
+            exch[(size_t)r] = c->ws_resident.p;
+        }
+        if (hipMemsetAsync(exch[(size_t)r], 0, need, c->stream) != hipSuccess || hipEventCreateWithFlags(&ready[(size_t)r], hipEventDisableTiming) != hipSuccess ||
             hipEventRecord(ready[(size_t)r], c->stream) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
     }
     // launches: every rank waits until ALL granule arrays are zeroed, then runs on its own stream
@@ -1265,12 +1305,12 @@ int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_st
         if (rc != SRPS_OK) break;
         ResidentGroupSpec sp;
         memset(&sp, 0, sizeof(sp));
-        sp.exch = c->ws_resident.p; sp.left_peer = -1; sp.right_peer = -1;
+        sp.exch = exch[(size_t)r]; sp.left_peer = -1; sp.right_peer = -1;
         for (int q = 0; q < n; ++q) {
             if (q == r) continue;
             if (q == r - 1) sp.left_peer = sp.n_peers;
             if (q == r + 1) sp.right_peer = sp.n_peers;
-            sp.peer_exch[sp.n_peers++] = ctxs[q]->ws_resident.p;
+            sp.peer_exch[sp.n_peers++] = exch[(size_t)q];
         }
         sp.tiles = pl.tiles; sp.nbr = pl.nbr; sp.nbc = pl.nbc; sp.nb_total = pl.NB; sp.list_base = pl.lbase[r]; sp.blocks = pl.lbase[r + 1] - pl.lbase[r];
         sp.bc_first = pl.tc0[r]; sp.bc_last = pl.tc0[r + 1] - 1; sp.rect = pl.rect; sp.max_steps = max_steps; sp.fixed_steps = fixed_steps;
@@ -1321,56 +1361,156 @@ int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_st
 // buffers; nothing else happens between the 101 steps.
 void resident_rank_release(srps_ctx* ctx) {
     for (int q = 0; q < 8; ++q) {
-        if (ctx->xg_peer[q] && ctx->xg_peer[q] != ctx->xg_buf) (void)hipIpcCloseMemHandle(ctx->xg_peer[q]);
-        ctx->xg_peer[q] = nullptr;
+        if (ctx->xg_peer[q] && ctx->xg_peer_ipc[q]) (void)hipIpcCloseMemHandle(ctx->xg_peer[q]);      // (a same-process peer's pointer is that rank's own buffer: not ours to close)
+        ctx->xg_peer[q] = nullptr; ctx->xg_peer_ipc[q] = 0;
     }
     ctx->xg_world = 0;
     if (ctx->xg_buf) (void)hipFree(ctx->xg_buf);
-    ctx->xg_buf = nullptr; ctx->xg_bytes = 0;
+    ctx->xg_buf = nullptr; ctx->xg_bytes = 0; ctx->xg_fine = 0;
     (void)hipGetLastError();
 }
+// A rank's exchange buffer: FINE-grained device memory (coherent across agents while kernels run: another device stores into it and this
+// device's waves poll it) -- coarse-grained memory (hipMalloc) is coherent across agents at kernel boundaries only, and is accepted only
+// when `coarse_ok`: every rank of the group sits on this very device (the one-GPU test beds), where the L2 in front of the memory is one.
+int resident_exchange_buffer(srps_ctx* ctx, size_t need, bool coarse_ok) {
+    if (ctx->xg_buf && ctx->xg_bytes >= need && (ctx->xg_fine || coarse_ok)) return SRPS_OK;
+    if (ctx->xg_buf) { (void)hipFree(ctx->xg_buf); ctx->xg_buf = nullptr; ctx->xg_bytes = 0; ctx->xg_fine = 0; }
+    if (hipExtMallocWithFlags(&ctx->xg_buf, need, hipDeviceMallocFinegrained) == hipSuccess) { ctx->xg_bytes = need; ctx->xg_fine = 1; return SRPS_OK; }
+    (void)hipGetLastError();
+    ctx->xg_buf = nullptr;
+    if (!coarse_ok) { set_error("resident strips: no fine-grained device memory for the exchange buffer (%zu bytes), and the ranks are not all on one device", need); return SRPS_ERR_UNSUPPORTED; }
+    if (hipMalloc(&ctx->xg_buf, need) != hipSuccess) { (void)hipGetLastError(); ctx->xg_buf = nullptr; set_error("resident strips: no memory for the exchange buffer"); return SRPS_ERR_UNSUPPORTED; }
+    ctx->xg_bytes = need;
+    return SRPS_OK;
+}
+
+// What a rank tells the others in the handshake, one float per byte (any float all-reduce carries it: RCCL or the caller's collectives):
+//   [0, 64)   the hipIpc handle of its exchange buffer (zeros: none)
+//   [64, 72)  the buffer's address -- what a rank of the SAME PROCESS uses instead of the handle: HIP does not open a handle in the process
+//             that exported it (srps_comm_init_all and the C++ host keep all ranks in one process, a thread per device)
+//   [72, 76)  the process id
+//   [76, 80)  the device: PCI domain (2 bytes), bus, device
+//   [80]      the device's ordinal in that process (for hipDeviceEnablePeerAccess between ranks of one process)
+//   [81]      1: the buffer is fine-grained memory
+//   [82]      1: this rank got as far as having a buffer at all
+constexpr int XG_REC = 96;
+struct XgRecord {
+    unsigned char handle[64];
+    unsigned long long addr;
+    unsigned pid;
+    unsigned char pci[4];
+    int ordinal, fine, ok;
+};
+static void xg_pack(const XgRecord& r, float* f) {
+    for (int b = 0; b < 64; ++b) f[b] = (float)r.handle[b];
+    for (int b = 0; b < 8; ++b) f[64 + b] = (float)((r.addr >> (8 * b)) & 0xffull);
+    for (int b = 0; b < 4; ++b) f[72 + b] = (float)((r.pid >> (8 * b)) & 0xffu);
+    for (int b = 0; b < 4; ++b) f[76 + b] = (float)r.pci[b];
+    f[80] = (float)r.ordinal; f[81] = (float)r.fine; f[82] = (float)r.ok;
+}
+static void xg_unpack(const float* f, XgRecord& r) {
+    memset(&r, 0, sizeof(r));
+    for (int b = 0; b < 64; ++b) r.handle[b] = (unsigned char)f[b];
+    for (int b = 0; b < 8; ++b) r.addr |= (unsigned long long)(unsigned char)f[64 + b] << (8 * b);
+    for (int b = 0; b < 4; ++b) r.pid |= (unsigned)(unsigned char)f[72 + b] << (8 * b);
+    for (int b = 0; b < 4; ++b) r.pci[b] = (unsigned char)f[76 + b];
+    r.ordinal = (int)f[80]; r.fine = (int)f[81]; r.ok = (int)f[82];
+}
 // Collective: every rank of the communicator calls it in the same solve (the grid, and with it `need`, is the same on all).  Whatever
-// goes wrong locally, the rank still takes part in the exchange of the handles (with zeros) -- the others must not be left waiting --
-// and reports failure; resident_cg_rank then lets all ranks decide together.
+// goes wrong locally is RECORDED and the rank still takes part in the one exchange (with a record that says so): no return path lies
+// in front of the collective (round-4 advisor finding), and every rank reads the same records, so all ranks reach the same verdict.
+// `debug_ipc_same_process` (tests): a same-process peer is mapped through its handle as if it were another process's -- HIP refuses
+// that, which is what the direct-pointer route exists for; the failure must be recognised, not hang or crash.
 static int resident_rank_open(srps_ctx* ctx, size_t need) {
     const int world = ctx->comm_world, rank = ctx->comm_rank;
     if (ctx->xg_world == world && ctx->xg_bytes >= need) return SRPS_OK;
     bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
-    resident_rank_release(ctx);
-    if (ok && hipExtMallocWithFlags(&ctx->xg_buf, need, hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
-        ctx->xg_buf = nullptr;
-        ok = hipMalloc(&ctx->xg_buf, need) == hipSuccess;      // same-device groups work with ordinary memory too
+    for (int q = 0; q < 8; ++q) {
+        if (ctx->xg_peer[q] && ctx->xg_peer_ipc[q]) (void)hipIpcCloseMemHandle(ctx->xg_peer[q]);
+        ctx->xg_peer[q] = nullptr; ctx->xg_peer_ipc[q] = 0;
     }
-    if (ok) ctx->xg_bytes = need; else { ctx->xg_buf = nullptr; (void)hipGetLastError(); }
-    hipIpcMemHandle_t mine;
+    ctx->xg_world = 0;
+    // fine-grained if it can be had; whether coarse memory will do is known only after the exchange (are all ranks on this device?)
+    ok = ok && resident_exchange_buffer(ctx, need, /*coarse_ok=*/true) == SRPS_OK;
+    XgRecord mine;
     memset(&mine, 0, sizeof(mine));
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
-    if (ok && hipIpcGetMemHandle(&mine, ctx->xg_buf) != hipSuccess) { (void)hipGetLastError(); ok = false; memset(&mine, 0, sizeof(mine)); }
-    const size_t nf = (size_t)world * 64;
+    if (ok) {
+        hipIpcMemHandle_t hm;
+        if (hipIpcGetMemHandle(&hm, ctx->xg_buf) == hipSuccess) memcpy(mine.handle, &hm, 64);
+        else (void)hipGetLastError();                      // ranks of this process do not need it; another process's will say so
+        mine.addr = (unsigned long long)(uintptr_t)ctx->xg_buf;
+        mine.fine = ctx->xg_fine;
+    }
+    mine.pid = (unsigned)getpid();
+    {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) {
+            mine.pci[0] = (unsigned char)(pr.pciDomainID & 0xff); mine.pci[1] = (unsigned char)((pr.pciDomainID >> 8) & 0xff);
+            mine.pci[2] = (unsigned char)(pr.pciBusID & 0xff); mine.pci[3] = (unsigned char)(pr.pciDeviceID & 0xff);
+        } else { (void)hipGetLastError(); ok = false; }
+    }
+    mine.ordinal = ctx->device;
+    mine.ok = ok ? 1 : 0;
+    const size_t nf = (size_t)world * XG_REC;
     std::vector<float> h(nf, 0.f);
-    for (int b = 0; b < 64; ++b) h[(size_t)rank * 64 + b] = (float)((const unsigned char*)&mine)[b];
-    SRPS_TRY(ensure(ctx->ws_misc, nf * sizeof(float)));
+    xg_pack(mine, h.data() + (size_t)rank * XG_REC);
+    // the exchange itself: its failure is every rank's failure (a collective that one rank cannot enter cannot be entered by the others either)
+    int xrc = ensure(ctx->ws_misc, nf * sizeof(float));
     float* d = (float*)ctx->ws_misc.p;
-    SRPS_HIP(hipMemcpyAsync(d, h.data(), nf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    SRPS_TRY(comm_all_reduce_sum(ctx, d, nf));             // every rank's 64 bytes, one float each
-    SRPS_HIP(hipMemcpyAsync(h.data(), d, nf * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
-    if (!ok) { set_error("resident strips: this rank could not allocate or export its exchange buffer"); return SRPS_ERR_UNSUPPORTED; }
+    if (xrc == SRPS_OK) xrc = host_upload(ctx, d, h.data(), nf * sizeof(float), ctx->stream);
+    if (xrc != SRPS_OK) return xrc;                        // no device buffer to enter the collective with: fatal for the job, not a fall-back
+    SRPS_TRY(comm_all_reduce_sum(ctx, d, nf));             // every rank's record, one float per byte
+    SRPS_TRY(host_download(ctx, h.data(), d, nf * sizeof(float), ctx->stream));
+    std::vector<XgRecord> rec((size_t)world);
+    bool all_ok = true, one_device = true, all_fine = true;
     for (int q = 0; q < world; ++q) {
+        xg_unpack(h.data() + (size_t)q * XG_REC, rec[(size_t)q]);
+        all_ok = all_ok && rec[(size_t)q].ok == 1;
+        all_fine = all_fine && rec[(size_t)q].fine == 1;
+        one_device = one_device && memcmp(rec[(size_t)q].pci, rec[0].pci, 4) == 0;
+    }
+    if (!all_ok) { set_error("resident strips: a rank could not allocate or export its exchange buffer"); return SRPS_ERR_UNSUPPORTED; }
+    if (!all_fine && !one_device) {                        // the same verdict on every rank: they all read the same records
+        set_error("resident strips: the ranks sit on different devices and not every exchange buffer is fine-grained memory");
+        return SRPS_ERR_UNSUPPORTED;
+    }
+    bool mapped = true;
+    for (int q = 0; q < world && mapped; ++q) {
         if (q == rank) { ctx->xg_peer[q] = ctx->xg_buf; continue; }
+        const XgRecord& r = rec[(size_t)q];
+        const bool same_process = r.pid == mine.pid && !ctx->debug_ipc_same_process;
+        if (same_process) {
+            // a rank of this process (another host thread, its own context): its pointer is valid here as it stands; a peer DEVICE must be
+            // made accessible from this one
+            if (r.ordinal != ctx->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, ctx->device, r.ordinal) != hipSuccess || !can) {
+                    (void)hipGetLastError();
+                    set_error("resident strips: device %d cannot access device %d's memory", ctx->device, r.ordinal);
+                    mapped = false; break;
+                }
+                const hipError_t e = hipDeviceEnablePeerAccess(r.ordinal, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("resident strips: hipDeviceEnablePeerAccess(%d): %s", r.ordinal, hipGetErrorString(e)); mapped = false; }
+                (void)hipGetLastError();
+            }
+            ctx->xg_peer[q] = (void*)(uintptr_t)r.addr;
+            continue;
+        }
         hipIpcMemHandle_t hq;
+        memcpy(&hq, r.handle, 64);
         bool any = false;
-        for (int b = 0; b < 64; ++b) { ((unsigned char*)&hq)[b] = (unsigned char)h[(size_t)q * 64 + b]; any = any || h[(size_t)q * 64 + b] != 0.f; }
-        void* p = nullptr;
-        const hipError_t e = any ? hipIpcOpenMemHandle(&p, hq, hipIpcMemLazyEnablePeerAccess) : hipErrorInvalidValue;
+        for (int b = 0; b < 64; ++b) any = any || r.handle[b] != 0;
+        void* pq = nullptr;
+        const hipError_t e = any ? hipIpcOpenMemHandle(&pq, hq, hipIpcMemLazyEnablePeerAccess) : hipErrorInvalidValue;
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            set_error("resident strips: rank %d's exchange buffer could not be mapped (%s)", q, any ? hipGetErrorString(e) : "that rank exported none");
-            return SRPS_ERR_UNSUPPORTED;
+            set_error("resident strips: rank %d's exchange buffer could not be mapped (%s)", q, any ? hipGetErrorString(e) : "that rank exported no handle");
+            mapped = false; break;
         }
-        ctx->xg_peer[q] = p;
+        ctx->xg_peer[q] = pq; ctx->xg_peer_ipc[q] = 1;
     }
+    if (!mapped) return SRPS_ERR_UNSUPPORTED;              // (the caller's one-float all-reduce tells the other ranks)
     ctx->xg_world = world;
     return SRPS_OK;
 }
@@ -1383,18 +1523,19 @@ int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     if (!group_plan(ctx, n, /*one_device=*/false, pl)) return SRPS_ERR_UNSUPPORTED;
     const GroupUnit& U = *pl.unit;
     const size_t need = U.bytes(pl.tiles);
-    const bool opened = resident_rank_open(ctx, need) == SRPS_OK;
-    if (opened) SRPS_HIP(hipMemsetAsync(ctx->xg_buf, 0, need, ctx->stream));
+    const int orc = resident_rank_open(ctx, need);
+    if (orc != SRPS_OK && orc != SRPS_ERR_UNSUPPORTED) return orc;      // the exchange itself failed: no rank can go on
+    bool opened = orc == SRPS_OK;
+    if (opened && hipMemsetAsync(ctx->xg_buf, 0, need, ctx->stream) != hipSuccess) { (void)hipGetLastError(); opened = false; }
     // One float through the all-reduce: the barrier (every rank's buffer is zeroed before any rank's kernel publishes into it) AND the
     // decision -- a rank whose mapping failed says so, and ALL ranks leave this path together (a rank that went its own way would meet
-    // the others in different collectives)
-    SRPS_TRY(ensure(ctx->ws_misc, 64));
+    // the others in different collectives).  Local failures up to here are in `opened`: nothing returns in front of the collective.
     const float mine_failed = opened ? 0.f : 1.f;
     float failed = 0.f;
-    SRPS_HIP(hipMemcpyAsync(ctx->ws_misc.p, &mine_failed, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SRPS_TRY(ensure(ctx->ws_misc, 64));                    // (holds the handshake's records already: cannot fail here)
+    SRPS_TRY(host_upload(ctx, ctx->ws_misc.p, &mine_failed, sizeof(float), ctx->stream));
     SRPS_TRY(comm_all_reduce_sum(ctx, (float*)ctx->ws_misc.p, 1));
-    SRPS_HIP(hipMemcpyAsync(&failed, ctx->ws_misc.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    SRPS_TRY(host_download(ctx, &failed, ctx->ws_misc.p, sizeof(float), ctx->stream));
     if (failed != 0.f) { ctx->xg_failed = 1; return SRPS_ERR_UNSUPPORTED; }
     ResidentGroupSpec sp;
     memset(&sp, 0, sizeof(sp));

@@ -185,8 +185,9 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     }
     float* d_mask = (float*)ctx->ws_struct.p;
     const StructScratch sc = struct_scratch((char*)ctx->ws_struct.p + mask_bytes, h, w, sf);
-    SRPS_TRY(host_upload(ctx, d_mask, mask, hw * sizeof(float), ax));      // (before the images take the transfer buffer)
+    // the images first (a thread of their own, a transfer buffer of their own): the mask crosses beside them instead of ahead of them
     if (after_release) SRPS_TRY((*after_release)());
+    SRPS_TRY(host_upload(ctx, d_mask, mask, hw * sizeof(float), ax));
     SRPS_TRY(struct_phase1(ax, d_mask, h, w, sf, sc));
     int* hdr = (int*)(ctx->h_pinned + 128);                // behind everything a pass reads back
     SRPS_HIP(hipMemcpyAsync(hdr, sc.header, 8 * sizeof(int), hipMemcpyDeviceToHost, ax));
@@ -531,6 +532,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->cg_resident_debug = value;
     } else if (!strcmp(name, "shard_range_check")) {
         ctx->shard_range_check = value ? 1 : 0;
+    } else if (!strcmp(name, "debug_ipc_same_process")) {
+        ctx->debug_ipc_same_process = value ? 1 : 0;       // tests: see resident_rank_open
     } else if (!strcmp(name, "debug_inject_abort")) {
         // test hook: the next look at the abort flags finds these bits (1 depth, 2 albedo) as if ANOTHER rank had reported them
         SRPS_REQUIRE(value >= 0 && value <= 3, SRPS_ERR_INVALID, "debug_inject_abort: 0..3, got %d", value);
@@ -548,6 +551,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "light_bytes")) {
         ctx->light_bytes = value ? 1 : 0;
         ctx->light_cache_valid = false;
+    } else if (!strcmp(name, "light_run")) {
+        ctx->light_run = value ? 1 : 0;
     } else if (!strcmp(name, "light_tiled")) {
         ctx->light_tiled = value ? 1 : 0;
         ctx->light_cache_valid = false;
@@ -613,6 +618,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "fuse_normals")) *value = ctx->fuse_normals;
     else if (!strcmp(name, "march_nt")) *value = ctx->march_nt;
     else if (!strcmp(name, "light_tiled")) *value = ctx->light_tiled;
+    else if (!strcmp(name, "light_run")) *value = ctx->light_run;
     else if (!strcmp(name, "light_bytes")) *value = ctx->light_bytes;
     else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;
@@ -926,7 +932,7 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     struct Uploader {
         std::thread t;
         int rc = SRPS_OK;
-        ~Uploader() { if (t.joinable()) t.join(); }      // also on the error paths: nothing reads the caller's array after srps_setup
+        std::string msg;                                 // the thread's own error text (srps_last_error is per thread), handed to the caller's
     } first_batch;
     auto copy_batch = [&](int n0, int cnt) -> int {     // images n0 .. n0 + cnt - 1 into the staging slots 0 .. cnt - 1, on the context's stream
         const char* src = host_I + (size_t)n0 * per * esz;
@@ -947,12 +953,19 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
         try {
             first_batch.t = std::thread([&, cnt = slots]() {
                 first_batch.rc = hipSetDevice(ctx->device) == hipSuccess ? copy_batch(0, cnt) : SRPS_ERR_HIP;
+                if (first_batch.rc != SRPS_OK) first_batch.msg = srps_last_error();
             });
         } catch (...) {                                                 // no thread to be had: the copies run here, before the structure
             return copy_batch(0, slots);
         }
         return SRPS_OK;
     };
+    // declared AFTER the two functions the thread calls, so that on every return path the thread has ended before they are destroyed
+    // (round-4 advisor finding); also on the error paths: nothing reads the caller's array after srps_setup
+    struct Joiner {
+        Uploader& u;
+        ~Joiner() { if (u.t.joinable()) u.t.join(); }
+    } join_first_batch{first_batch};
     if (getenv("SRPS_SETUP_TRACE"))      // development aid: the caller's arrays (to place a fault address, should the device ever touch one)
         fprintf(stderr, "srps_setup trace: mask %p + %zu, z_full %p + %zu, zs_lr %p + %zu, images %p + %zu\n", (const void*)pr->mask, (size_t)pr->h * pr->w * 4,
                 (const void*)pr->z_full, (size_t)pr->h * pr->w * 4, (const void*)pr->zs_lr, (size_t)pr->h * pr->w * 4 / ((size_t)pr->sf * pr->sf), (const void*)host_I,
@@ -1018,7 +1031,7 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
             const int cnt = std::min(slots, NL - n0);
             if (n0 == 0) {
                 if (first_batch.t.joinable()) first_batch.t.join();
-                if (first_batch.rc != SRPS_OK) { set_error("srps_setup: the image upload failed"); return first_batch.rc; }
+                if (first_batch.rc != SRPS_OK) { set_error("srps_setup: the image upload failed: %s", first_batch.msg.c_str()); return first_batch.rc; }
             } else {                                               // the staging slots in their next use: the copies wait, on the device, for the gathers that read them
                 SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[0], 0));
                 SRPS_TRY(copy_batch(n0, cnt));
@@ -1306,13 +1319,22 @@ static int energy_finish_impl(srps_ctx* ctx, float* energy, bool drain) {
         const unsigned want = ctx->report_seq_armed;
         ctx->report_seq_armed = 0;
         const unsigned* word = reinterpret_cast<const unsigned*>(ctx->h_pinned + REPORT_SEQ_AT);
+        // the sequence word says "complete", the check word proves it: seq ^ (xor of the record's words) as the device formed it; a
+        // record whose words are not all in yet does not give it, and is looked at again
+        auto complete = [&]() -> bool {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) return false;
+            const unsigned* rec = reinterpret_cast<const unsigned*>(ctx->h_pinned);
+            unsigned x = want;
+            for (int i = 0; i < REPORT_FLOATS; ++i) x ^= __atomic_load_n(rec + i, __ATOMIC_RELAXED);
+            return x == __atomic_load_n(rec + REPORT_CHECK_AT, __ATOMIC_RELAXED);
+        };
         for (unsigned looks = 1;; ++looks) {
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) { record_arrived = true; break; }
+            if (complete()) { record_arrived = true; break; }
             if ((looks & 1023u) == 0u) {
                 const hipError_t q = hipStreamQuery(ctx->stream);
                 if (q == hipSuccess) {
-                    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) record_arrived = true;
-                    else { fprintf(stderr, "srps: the report record written by the energy sweep did not reach the host; fetching it by copy from now on\n"); ctx->report_zero_copy = 0; }
+                    if (complete()) record_arrived = true;
+                    else { fprintf(stderr, "srps: the report record written by the energy sweep did not reach the host whole; fetching it by copy from now on\n"); ctx->report_zero_copy = 0; }
                     break;
                 }
                 if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);

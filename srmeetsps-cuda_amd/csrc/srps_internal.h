@@ -177,6 +177,7 @@ struct srps_ctx {
     int light_channel_inner = 1;     // fused energy + lighting sweep with the channels in the inner loop (C in {1, 3})
     int march_nt = 0;                // streaming CG step with non-temporal loads / stores: 0 never (default: measured 15 - 35 % SLOWER at 2304^2 ... 4096^2, tools/march_nt_sweep.sh -- the strips re-read their halo columns, which then miss the L2; stores only, 3: 59.5 -> 65.0 us at 2560^2, 153 -> 165 - 176 at 4096^2 sf 4), 1 always, 2 when its vectors exceed the Infinity Cache, 3 stores only
     int light_bytes = 1;             // the tiled lighting sweep reads the 8-bit image store when the context holds one (round 4)
+    int light_run = 1;               // ... and every wave reading ONE image plane's four pieces back to back: 4 KiB runs (round 5; 0: one piece of each of the wave's images)
     int light_tiled = 1;             // ... with the four image groups as the waves of one block and the geometry shared through LDS (k_light_fused_tile)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue
@@ -201,6 +202,9 @@ struct srps_ctx {
     void* xg_buf = nullptr;
     size_t xg_bytes = 0;
     void* xg_peer[8] = {};
+    int xg_peer_ipc[8] = {};         // 1: mapped with hipIpcOpenMemHandle (closed on release); 0: the pointer of a rank of this process
+    int xg_fine = 0;                 // 1: xg_buf is fine-grained memory (coherent across devices while kernels run)
+    int debug_ipc_same_process = 0;  // tests: map a same-process peer through its handle (HIP refuses: the failure must be recognised)
     int xg_world = 0;                // ranks the peers were opened for (0: not open)
     int xg_failed = 0;               // the handshake or a launch failed once: not tried again on this context
     double* d_strip_tot = nullptr;   // [12]: [0..3] this rank's sums of a launch, [4..7] / [8..11] the sums over all ranks of the launches of even / odd
@@ -304,6 +308,7 @@ int ensure(DevBuf& b, size_t bytes);
 // ---- copies between the caller's host arrays and the device, through the library's own pinned buffer (srps_xfer.hip) ----
 int host_upload(srps_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t st);        // returns when h_src has been read and the copies have run
 int host_download(srps_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, hipStream_t st);      // returns when h_dst holds the data (after the work queued on st)
+int xfer_buffers_made();                                                                              // pinned transfer buffers the process has made (every transfer in flight holds its own)
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- kernel launchers (kernels_pixel.hip) ------------------------------------------------
@@ -329,10 +334,10 @@ struct ReportFinish {
     const float* t1_part = nullptr;  // k_energy_t1's partial sums
     int n_t1 = 0;
     float* report = nullptr;         // the device record: [0] = term 1, [1] = term 2
-    float* host_report = nullptr;    // the record in mapped host memory; host_report[REPORT_SEQ_AT] = seq when it is complete
+    float* host_report = nullptr;    // the record in mapped host memory; host_report[REPORT_SEQ_AT] = seq when it is complete, [REPORT_CHECK_AT] = seq ^ xor of its words
     unsigned seq = 0;
 };
-constexpr int REPORT_FLOATS = 80, REPORT_SEQ_AT = 100, REPORT_TICKET_AT = 250;
+constexpr int REPORT_FLOATS = 80, REPORT_SEQ_AT = 100, REPORT_CHECK_AT = 101, REPORT_TICKET_AT = 250;
 int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, const float* d_I, const float* d_xx,
                        const float* d_yy, const float* d_dz, const float* d_z, const float* d_zx, const float* d_zy,
                        float fx, float fy, int P, int n_local, int C, int img_offset, float* d_out, const ReportFinish* fin = nullptr, bool* fin_armed = nullptr);

@@ -8,8 +8,21 @@
 // more; khugepaged then collapses recycled heap pages seconds later), the copy engine faulted on the pool's kernel: "Memory access
 // fault by GPU" at the first 2 MB boundary inside the image array, or inside the mask / depth array of a set-up -- three times in
 // round 4's test runs (tools/stress_upload_thp.py).  A copy through a buffer that cannot move has no such window.
+//
+// Round 5.  (i) Every transfer takes a buffer of its OWN from a pool (round-4 advisor finding: one buffer behind one mutex, held across
+// waits on work the caller had queued, serialised the set-ups of `srps --gpus N`, made one context's srps_get block every other context,
+// and could deadlock a phase-by-phase sharded driver).  No lock is held while anything is copied or waited for; two transfers never
+// share a buffer; a buffer goes back to the pool when its transfer has ended.  It also lets srps_setup upload the mask and the depth
+// maps WHILE the images stream (they used to wait for the image transfer's lock: 2 - 3 ms of a 23 ms set-up).  (ii) A large upload is
+// a pipeline: T filling threads claim 1 MB pieces from one counter and copy them into the 16 MB slot their chunk maps to with
+// non-temporal stores (no read-for-ownership of the destination, nothing of the 1 GB left dirty in the caches for the DMA to snoop);
+// the calling thread only issues each slot's DMA when its pieces are in and frees the slot when the DMA's event has fired.  No
+// barrier couples the threads: fillers run up to three chunks ahead of the copy engine.
+#include <immintrin.h>
+
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -21,18 +34,48 @@ namespace srps {
 namespace {
 
 constexpr size_t kSlot = (size_t)2 << 20;      // small transfers: bytes per slot (37 us of PCIe, 0.2 ms of one thread's memcpy)
-constexpr int kSlots = 32;                     // 64 MB pinned in all
-constexpr size_t kBig = (size_t)16 << 20;      // large transfers: the same buffer as four slots of 16 MB, each filled by all copying threads together
-constexpr int kBigSlots = 4;                   // (one DMA per 16 MB: per 2 MB slot the runtime's calls, serialised among 16 threads, cost a third of the rate)
+constexpr int kSlots = 32;                     // 64 MB pinned per buffer
+constexpr size_t kBig = (size_t)16 << 20;      // large transfers: the same buffer as four slots of 16 MB, one DMA each
+constexpr int kBigSlots = 4;                   // (one DMA per 16 MB: per 2 MB slot the runtime's calls cost a third of the rate)
 static_assert(kBig * kBigSlots == kSlot * kSlots, "one buffer, two ways to cut it");
-constexpr int kMaxThreads = 16;
+constexpr size_t kPiece = (size_t)1 << 20;     // what a filling thread claims at a time
+constexpr int kMaxThreads = 32;
 
-struct Bounce {
-    std::mutex m;                              // one transfer at a time owns the slots
-    char* base = nullptr;                      // allocated by the first transfer, kept for the life of the process (64 MB of pinned host memory:
-                                               // pinning takes milliseconds, contexts come and go)
+// ---- the pool: pinned buffers are expensive to make (milliseconds) and contexts come and go, so they live as long as the process ----
+struct PoolBuf { char* p; size_t bytes; };
+struct BouncePool {
+    std::mutex m;                              // guards the list only: never held while a transfer runs
+    std::vector<PoolBuf> free_;
+    int made = 0;
+} g_pool;
+
+// a buffer of at least `bytes` (two sizes occur: 64 MB, and four slots of the large-transfer chunk)
+int pool_acquire(size_t bytes, PoolBuf* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        for (size_t i = 0; i < g_pool.free_.size(); ++i)
+            if (g_pool.free_[i].bytes >= bytes) { *out = g_pool.free_[i]; g_pool.free_.erase(g_pool.free_.begin() + (long)i); return SRPS_OK; }
+    }
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (transfer buffer)", __FILE__, __LINE__);
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        ++g_pool.made;
+    }
+    *out = PoolBuf{(char*)p, bytes};
+    return SRPS_OK;
+}
+void pool_release(const PoolBuf& b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    g_pool.free_.push_back(b);
+}
+struct Lease {                                 // a transfer's buffer, back in the pool when the transfer ends (its copies have been waited for by then)
+    PoolBuf buf{nullptr, 0};
+    char* base = nullptr;
+    ~Lease() { pool_release(buf); }
 };
-Bounce g_bounce;
 
 // the slots' events of one transfer, on the device of its stream; destroyed (after a wait) when the transfer ends
 struct SlotEvents {
@@ -53,39 +96,51 @@ struct SlotEvents {
     }
 };
 
-int bounce_base(char** out) {
-    if (!g_bounce.base) {
-        void* p = nullptr;
-        const hipError_t e = hipHostMalloc(&p, kSlot * kSlots, hipHostMallocPortable);
-        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (transfer buffer)", __FILE__, __LINE__);
-        g_bounce.base = (char*)p;
-    }
-    *out = g_bounce.base;
-    return SRPS_OK;
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+// bytes per DMA of a large transfer (SRPS_XFER_CHUNK_MB: development, tools/setup_time.py): a multiple of the piece
+size_t big_chunk() {
+    static const size_t c = (size_t)std::max(1, std::min(env_int("SRPS_XFER_CHUNK_MB", (int)(kBig >> 20)), 256)) << 20;
+    return c;
+}
+// streams a large transfer's DMAs alternate between (SRPS_XFER_STREAMS; 1: all on the caller's stream): consecutive copies of ONE stream
+// run one after the other with a gap between them, copies of two streams overlap
+int big_streams() {
+    static const int n = std::max(1, std::min(env_int("SRPS_XFER_STREAMS", 1), 2));
+    return n;
 }
 
+// filling threads of a large upload.  SRPS_XFER_THREADS overrides (development: tools/setup_time.py sweeps it)
 int copy_threads(size_t bytes) {
-    if (bytes < 2 * kBig) return 1;
-    const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::max(2u, std::min<unsigned>(hc / 4, (unsigned)kMaxThreads));
+    if (bytes < kBig / 2) return 0;            // below 8 MB the calling thread copies by itself (upload_small)
+    const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+    int t = (int)std::max(2u, std::min<unsigned>(hc / 4, 16u));
+    if (bytes < 4 * kBig) t = std::min(t, 4);  // the mask, a depth map: a few threads for 1 ms of copying
+    t = env_int("SRPS_XFER_THREADS", t);
+    return std::max(1, std::min(t, kMaxThreads));
 }
 
-// all threads of a large transfer meet here twice per 16 MB; they wait for a fraction of a millisecond at most (one DMA)
-struct SpinBarrier {
-    std::atomic<int> count{0}, gen{0};
-    int n = 1;
-    void wait() {
-        const int g = gen.load(std::memory_order_acquire);
-        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
-            count.store(0, std::memory_order_relaxed);
-            gen.fetch_add(1, std::memory_order_release);
-            return;
-        }
-        for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) {
-            if (spins < 2048) __builtin_ia32_pause(); else std::this_thread::yield();
-        }
+// dst is 64-byte aligned (slot base + a multiple of 1 MB); src is the caller's, any alignment; n any length
+__attribute__((target("avx2"))) void copy_nt(char* dst, const char* src, size_t n) {
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i*)(src + i)), b = _mm256_loadu_si256((const __m256i*)(src + i + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i*)(src + i + 64)), d = _mm256_loadu_si256((const __m256i*)(src + i + 96));
+        _mm256_stream_si256((__m256i*)(dst + i), a); _mm256_stream_si256((__m256i*)(dst + i + 32), b);
+        _mm256_stream_si256((__m256i*)(dst + i + 64), c); _mm256_stream_si256((__m256i*)(dst + i + 96), d);
     }
-};
+    if (i < n) memcpy(dst + i, src + i, n - i);
+    _mm_sfence();                              // the streamed lines are globally visible before the piece is reported filled
+}
+inline void fill(char* dst, const char* src, size_t n) {
+#if !defined(__HIP_DEVICE_COMPILE__)           // host code only: the device pass of hipcc parses this file too and has no x86 builtins
+    static const bool nt = (__builtin_cpu_init(), __builtin_cpu_supports("avx2")) && env_int("SRPS_XFER_NT", 1) != 0;
+    if (nt) { copy_nt(dst, src, n); return; }
+#endif
+    memcpy(dst, src, n);
+}
 
 // the single-thread form: chunks of 2 MB through a ring of slots, the memcpy of one chunk while the previous ones cross PCIe
 int upload_small(char* base, void* d_dst, const void* h_src, size_t bytes, hipStream_t st, SlotEvents& se) {
@@ -95,7 +150,7 @@ int upload_small(char* base, void* d_dst, const void* h_src, size_t bytes, hipSt
         const int s = (int)(i % kRing);
         const size_t off = i * kSlot, len = std::min(kSlot, bytes - off);
         if (se.make(s) != SRPS_OK || se.wait(s) != SRPS_OK) return SRPS_ERR_HIP;
-        memcpy(base + (size_t)s * kSlot, (const char*)h_src + off, len);
+        fill(base + (size_t)s * kSlot, (const char*)h_src + off, len);
         if (hipMemcpyAsync((char*)d_dst + off, base + (size_t)s * kSlot, len, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipEventRecord(se.ev[s], st) != hipSuccess) return SRPS_ERR_HIP;
         se.pending[s] = true;
@@ -103,58 +158,112 @@ int upload_small(char* base, void* d_dst, const void* h_src, size_t bytes, hipSt
     return SRPS_OK;
 }
 
-// the many-thread form: every 16 MB slot is filled by all T threads (a slice each), then goes out as ONE copy, issued by thread 0
-int upload_big(srps_ctx* ctx, char* base, void* d_dst, const void* h_src, size_t bytes, hipStream_t st, SlotEvents& se, int T_wanted) {
-    const size_t nch = (bytes + kBig - 1) / kBig;
-    SpinBarrier bar;
-    std::atomic<int> err{0}, go{0};
-    int T = 1;                                 // threads that take part: set before `go` (a thread that could not be started is not waited for)
-    auto worker = [&](int t) {
-        while (go.load(std::memory_order_acquire) == 0) std::this_thread::yield();
-        if (t != 0 && hipSetDevice(ctx->device) != hipSuccess) err.store(1);
-        for (size_t c = 0; c < nch; ++c) {
+// The many-thread form.  Pieces are claimed in order from `next`; piece q lies in chunk q / ppc, which uses slot chunk % kBigSlots once
+// the slot's previous chunk has crossed (`crossed` = number of chunks whose DMA has completed, published by the calling thread).
+// `filled[chunk % kBigSlots]` counts the pieces in; the calling thread issues chunk c's DMA when its count is complete.
+int upload_big(char* base, void* d_dst, const void* h_src, size_t bytes, hipStream_t st, SlotEvents& se, int T_wanted) {
+    const size_t CH = big_chunk();
+    const int ppc = (int)(CH / kPiece);
+    const size_t nch = (bytes + CH - 1) / CH;
+    const size_t npieces = (bytes + kPiece - 1) / kPiece;
+    std::atomic<size_t> next{0};
+    std::atomic<long> crossed{0};
+    std::atomic<int> filled[kBigSlots];
+    for (auto& f : filled) f.store(0, std::memory_order_relaxed);
+    std::atomic<int> stop{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t q = next.fetch_add(1, std::memory_order_relaxed);
+            if (q >= npieces) return;
+            const size_t c = q / (size_t)ppc;
             const int s = (int)(c % kBigSlots);
-            const size_t off = c * kBig, len = std::min(kBig, bytes - off);
-            if (t == 0 && !err.load() && (se.make(s) != SRPS_OK || se.wait(s) != SRPS_OK)) err.store(1);      // the slot's previous copy has run
-            bar.wait();
-            if (!err.load()) {
-                const size_t per = ((len + (size_t)T - 1) / (size_t)T + 63) & ~(size_t)63, b = std::min(len, per * (size_t)t), e = std::min(len, b + per);
-                if (e > b) memcpy(base + (size_t)s * kBig + b, (const char*)h_src + off + b, e - b);
+            for (int spins = 0; (long)c - kBigSlots >= crossed.load(std::memory_order_acquire); ++spins) {      // the slot still holds chunk c - kBigSlots
+                if (stop.load(std::memory_order_relaxed)) return;
+                if (spins < 4096) __builtin_ia32_pause(); else std::this_thread::yield();
             }
-            bar.wait();
-            if (t == 0 && !err.load()) {
-                if (hipMemcpyAsync((char*)d_dst + off, base + (size_t)s * kBig, len, hipMemcpyHostToDevice, st) != hipSuccess ||
-                    hipEventRecord(se.ev[s], st) != hipSuccess) err.store(1);
-                else se.pending[s] = true;
-            }
+            const size_t off = q * kPiece, len = std::min(kPiece, bytes - off);
+            fill(base + (size_t)s * CH + (off - c * CH), (const char*)h_src + off, len);
+            filled[s].fetch_add(1, std::memory_order_release);
         }
     };
     std::vector<std::thread> th;
     try {
-        for (int t = 1; t < T_wanted; ++t) { th.emplace_back(worker, t); T = t + 1; }
+        for (int t = 0; t < T_wanted; ++t) th.emplace_back(worker);
     } catch (...) {                            // no more threads to be had: the ones that started do the work
     }
-    bar.n = T;
-    go.store(1, std::memory_order_release);
-    worker(0);
+    if (th.empty()) return upload_small(base, d_dst, h_src, bytes, st, se);      // none at all: this thread, chunk by chunk
+    int rc = SRPS_OK;
+    // a second stream for every other chunk: both start behind the work already queued on st (the destination may be in use there)
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev0 = nullptr;
+    if (big_streams() > 1 && nch > 1) {
+        if (hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev0, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(ev0, st) != hipSuccess || hipStreamWaitEvent(st2, ev0, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (st2) (void)hipStreamDestroy(st2);
+            st2 = nullptr;
+        }
+    }
+    size_t issued = 0, done = 0;
+    auto pieces_of = [&](size_t c) { return (int)std::min<size_t>((size_t)ppc, npieces - c * (size_t)ppc); };
+    for (int s = 0; s < kBigSlots && rc == SRPS_OK; ++s) rc = se.make(s);
+    while (rc == SRPS_OK && done < nch) {
+        bool progressed = false;
+        if (issued < nch) {
+            const int s = (int)(issued % kBigSlots);
+            if (filled[s].load(std::memory_order_acquire) >= pieces_of(issued)) {
+                const size_t off = issued * CH, len = std::min(CH, bytes - off);
+                filled[s].store(0, std::memory_order_relaxed);          // nobody adds to it again before `crossed` lets the slot's next chunk in
+                hipStream_t cs = (st2 && (issued & 1)) ? st2 : st;
+                if (hipMemcpyAsync((char*)d_dst + off, base + (size_t)s * CH, len, hipMemcpyHostToDevice, cs) != hipSuccess ||
+                    hipEventRecord(se.ev[s], cs) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+                se.pending[s] = true;
+                ++issued;
+                progressed = true;
+            }
+        }
+        if (done < issued) {
+            const int s = (int)(done % kBigSlots);
+            const hipError_t q = hipEventQuery(se.ev[s]);
+            if (q == hipSuccess) {
+                se.pending[s] = false;
+                ++done;
+                crossed.store((long)done, std::memory_order_release);
+                progressed = true;
+            } else if (q != hipErrorNotReady) { rc = SRPS_ERR_HIP; break; }
+            else (void)hipGetLastError();
+        }
+        if (!progressed) __builtin_ia32_pause();
+    }
+    stop.store(1);
+    if (rc != SRPS_OK) next.store(npieces);    // nothing more to claim
     for (auto& x : th) x.join();
-    return err.load() ? SRPS_ERR_HIP : SRPS_OK;
+    if (st2) {                                 // everything on the second stream has been waited for (done == nch), or is waited for now
+        (void)hipStreamSynchronize(st2);
+        (void)hipStreamDestroy(st2);
+    }
+    if (ev0) (void)hipEventDestroy(ev0);
+    return rc;
 }
 
 }  // namespace
 
-// h_src -> d_dst on stream st.  Returns when the caller's array has been read AND the last slot's copy has run (the slots go back to
+// h_src -> d_dst on stream st.  Returns when the caller's array has been read AND the last slot's copy has run (the buffer goes back to
 // the pool): work queued on st afterwards finds the data, and so does the host after a wait for st.
 int host_upload(srps_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t st) {
     if (bytes == 0) return SRPS_OK;
     SRPS_REQUIRE(d_dst && h_src, SRPS_ERR_INVALID, "host_upload: null pointer");
-    std::lock_guard<std::mutex> lk(g_bounce.m);
-    char* base = nullptr;
-    SRPS_TRY(bounce_base(&base));
-    SlotEvents se;
     const int T = copy_threads(bytes);
-    int rc = T == 1 ? upload_small(base, d_dst, h_src, bytes, st, se) : upload_big(ctx, base, d_dst, h_src, bytes, st, se, T);
-    for (int s = 0; s < kSlots && rc == SRPS_OK; ++s) rc = se.wait(s);
+    Lease buf;
+    SRPS_TRY(pool_acquire(T == 0 ? kSlot * kSlots : std::max(kSlot * kSlots, big_chunk() * kBigSlots), &buf.buf));
+    buf.base = buf.buf.p;
+    (void)ctx;
+    int rc;
+    {
+        SlotEvents se;
+        rc = T == 0 ? upload_small(buf.base, d_dst, h_src, bytes, st, se) : upload_big(buf.base, d_dst, h_src, bytes, st, se, T);
+        for (int s = 0; s < kSlots && rc == SRPS_OK; ++s) rc = se.wait(s);
+    }                                          // (~SlotEvents waits for whatever an error path left pending: the buffer is idle when it goes back)
     if (rc != SRPS_OK) { set_error("host_upload: a HIP call failed (%s)", hipGetErrorString(hipGetLastError())); return rc; }
     return SRPS_OK;
 }
@@ -163,31 +272,39 @@ int host_upload(srps_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hip
 int host_download(srps_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, hipStream_t st) {
     if (bytes == 0) return SRPS_OK;
     SRPS_REQUIRE(h_dst && d_src, SRPS_ERR_INVALID, "host_download: null pointer");
-    std::lock_guard<std::mutex> lk(g_bounce.m);
-    char* base = nullptr;
-    SRPS_TRY(bounce_base(&base));
-    SlotEvents se;
-    const size_t nch = (bytes + kSlot - 1) / kSlot;
-    constexpr int kRing = 4;                   // copies in flight ahead of the host's memcpy
+    Lease buf;
+    SRPS_TRY(pool_acquire(kSlot * kSlots, &buf.buf));
+    char* base = buf.buf.p;
     int rc = SRPS_OK;
-    for (size_t i = 0; i < nch + kRing && rc == SRPS_OK; ++i) {
-        if (i >= (size_t)kRing) {              // chunk i - kRing has arrived: hand it to the caller
-            const size_t j = i - kRing, off = j * kSlot, len = std::min(kSlot, bytes - off);
-            const int s = (int)(j % kRing);
-            if ((rc = se.wait(s)) != SRPS_OK) break;
-            memcpy((char*)h_dst + off, base + (size_t)s * kSlot, len);
-        }
-        if (i < nch) {
-            const size_t off = i * kSlot, len = std::min(kSlot, bytes - off);
-            const int s = (int)(i % kRing);
-            if (se.make(s) != SRPS_OK || hipMemcpyAsync(base + (size_t)s * kSlot, (const char*)d_src + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipEventRecord(se.ev[s], st) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
-            se.pending[s] = true;
+    {
+        SlotEvents se;
+        const size_t nch = (bytes + kSlot - 1) / kSlot;
+        constexpr int kRing = 8;               // copies in flight ahead of the host's memcpy
+        for (size_t i = 0; i < nch + kRing && rc == SRPS_OK; ++i) {
+            if (i >= (size_t)kRing) {          // chunk i - kRing has arrived: hand it to the caller
+                const size_t j = i - kRing, off = j * kSlot, len = std::min(kSlot, bytes - off);
+                const int s = (int)(j % kRing);
+                if ((rc = se.wait(s)) != SRPS_OK) break;
+                memcpy((char*)h_dst + off, base + (size_t)s * kSlot, len);
+            }
+            if (i < nch) {
+                const size_t off = i * kSlot, len = std::min(kSlot, bytes - off);
+                const int s = (int)(i % kRing);
+                if (se.make(s) != SRPS_OK || hipMemcpyAsync(base + (size_t)s * kSlot, (const char*)d_src + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipEventRecord(se.ev[s], st) != hipSuccess) { rc = SRPS_ERR_HIP; break; }
+                se.pending[s] = true;
+            }
         }
     }
     (void)ctx;
     if (rc != SRPS_OK) { set_error("host_download: a HIP call failed (%s)", hipGetErrorString(hipGetLastError())); return rc; }
     return SRPS_OK;
+}
+
+// how many pinned buffers the process has made so far (tests: concurrent transfers each take their own)
+int xfer_buffers_made() {
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    return g_pool.made;
 }
 
 }  // namespace srps

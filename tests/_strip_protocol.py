@@ -201,3 +201,66 @@ def HostedCollectives(ctx, dist, device: str = "cuda:0"):
     """moved into the package in round 4 (api.TorchCollectives: bench.py's one-GPU dry run of the sharded loop uses it too)"""
     api = importlib.import_module("srmeetsps-cuda_amd.api")
     return api.TorchCollectives(ctx, dist, device)
+
+
+class ThreadCollectives:
+    """srps_set_host_collectives for ranks that are THREADS of one process (what `srps --gpus N` and srps_comm_init_all are, with RCCL
+    in the place of this): every rank's all-reduce / broadcast meets the others' at a threading.Barrier; the sum is formed in rank
+    order, so all ranks hold the same bits.  Test infrastructure for one-GPU boxes, where RCCL refuses two ranks on one device."""
+
+    def __init__(self, world: int):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slot = [None] * world
+        self.errors = []
+        self._keep = []
+
+    def bind(self, pkg, ctx, rank: int, device: str = "cuda:0"):
+        import torch
+        lib = pkg._lib
+
+        def view(ptr, n, typestr):
+            class V:
+                pass
+            v = V()
+            v.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(v, device=device)
+
+        def allreduce(user, d_buf, n, f64):
+            try:
+                g = view(d_buf, n, "<f8" if f64 else "<f4")
+                self.slot[rank] = g.cpu()
+                self.bar.wait(timeout=120)
+                tot = self.slot[0].clone()
+                for q in range(1, self.world):
+                    tot += self.slot[q]
+                self.bar.wait(timeout=120)
+                g.copy_(tot)
+                torch.cuda.synchronize()
+                return 0
+            except Exception as exc:                    # a broken barrier ends the other ranks' waits too
+                self.errors.append(repr(exc)); self.bar.abort()
+                return 1
+
+        def broadcast(user, d_buf, n, root):
+            try:
+                g = view(d_buf, n, "<f4")
+                if rank == root:
+                    self.slot[root] = g.cpu()
+                self.bar.wait(timeout=120)
+                if rank != root:
+                    g.copy_(self.slot[root])
+                    torch.cuda.synchronize()
+                self.bar.wait(timeout=120)
+                return 0
+            except Exception as exc:
+                self.errors.append(repr(exc)); self.bar.abort()
+                return 1
+
+        fns = (lib.HOST_ALLREDUCE_FN(allreduce), lib.HOST_BROADCAST_FN(broadcast))
+        self._keep.append(fns)
+        pkg._lib.check(ctx.lib.srps_set_host_collectives(ctx.h, rank, self.world, *fns, None))
+
+    def unbind(self, pkg, ctx):
+        pkg._lib.check(ctx.lib.srps_set_host_collectives(ctx.h, 0, 1, pkg._lib.HOST_ALLREDUCE_FN(), pkg._lib.HOST_BROADCAST_FN(), None))

@@ -389,3 +389,108 @@ def test_resident_strips_between_processes_through_ipc_mapped_buffers(pkg, tmp_p
             np.testing.assert_array_equal(r[f"z{it}"], ref[f"z{it}"])
             assert float(r[f"e{it}"]) == ref[f"e{it}"]
     print(f"{h}x{w} sf {sf} {kind}: {world} processes, resident strips through hipIpc-mapped buffers == the single resident launch")
+
+
+def _thread_ranks(pkg, sc, world, tile, options=None, passes=2):
+    """cg_partition = 2 with the ranks as THREADS of this process, each with a context of its own on device 0 and the library's
+    collectives served by tests/_strip_protocol.ThreadCollectives -- the shape of `srps --gpus N` and srps_comm_init_all (one process, a
+    host thread and a context per device), on a one-GPU box"""
+    import threading
+    import _strip_protocol as strips
+    tc = strips.ThreadCollectives(world)
+    out = [dict() for _ in range(world)]
+    errs = []
+
+    def rank_main(rank):
+        ctx = None
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            ctx = pkg.Context(device_id=0)
+            ctx.set_option("cg_resident_tile", tile)
+            ctx.set_option("cg_partition", 2)
+            ctx.set_option("spin_budget_ms", 2000)
+            for k, v in (options or {}).items():
+                ctx.set_option(k, v)
+            tc.bind(pkg, ctx, rank)
+            ctx.setup(pkg.DataHandler.from_scene(sc))
+            o = out[rank]
+            for it in range(passes):
+                ctx.lighting(); ctx.albedo()
+                o[f"e{it}"] = ctx.depth()
+                ctx.normals()
+                o[f"z{it}"] = ctx.get("z")
+            o["resident"] = ctx.get_option("cg_partition_resident_active"); o["strips"] = ctx.get_option("cg_partition_active")
+            o["fb"] = ctx.get_option("persistent_fallbacks"); o["it"] = ctx.last_cg_iterations()["depth"]
+            o["err"] = pkg.last_error() if hasattr(pkg, "last_error") else ""
+        except Exception as exc:
+            errs.append((rank, repr(exc)))
+            tc.bar.abort()
+        finally:
+            if ctx is not None:
+                try:
+                    tc.unbind(pkg, ctx)
+                    ctx.close()
+                except Exception as exc:
+                    errs.append((rank, "close: " + repr(exc)))
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not any(t.is_alive() for t in th), "a rank thread hangs"
+    return out, errs, tc.errors
+
+
+def _single_reference(pkg, sc, tile, passes=2):
+    c = pkg.Context(device_id=0)
+    c.set_option("cg_resident_tile", tile)
+    c.setup(pkg.DataHandler.from_scene(sc))
+    ref = {}
+    for it in range(passes):
+        c.lighting(); c.albedo(); ref[f"e{it}"] = c.depth(); c.normals(); ref[f"z{it}"] = c.get("z")
+    c.close()
+    return ref
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("h,w,sf,kind,world,tile", [(1024, 2048, 4, "full", 2, 512), (1024, 1536, 2, "ellipse", 3, 512)])
+def test_resident_strips_between_ranks_of_one_process(pkg, h, w, sf, kind, world, tile):
+    """Ranks that share a PROCESS (srps_comm_init_all, the C++ host's thread per device) must not go through hipIpcOpenMemHandle -- HIP
+    does not open a handle in the process that exported it: the handshake carries the process id and the buffer's address, and a
+    same-process peer is reached through its pointer.  Two / three host threads with a context each, bound by host collectives: the
+    solve must END on the resident path (cg_partition_resident_active == 1) with the single launch's bits."""
+    seed = h + 3 * w + sf
+    sc = pkg.synth.make_scene(h, w, sf, 3, seed=seed, mask_kind=kind)
+    out, errs, cerrs = _thread_ranks(pkg, sc, world, tile)
+    assert not errs and not cerrs, (errs, cerrs)
+    ref = _single_reference(pkg, sc, tile)
+    for q in range(world):
+        r = out[q]
+        assert r["resident"] == 1 and r["fb"] == 0 and r["it"] == 101, {k: r[k] for k in ("resident", "strips", "fb", "it")}
+        for it in range(2):
+            np.testing.assert_array_equal(r[f"z{it}"], ref[f"z{it}"])
+            assert r[f"e{it}"] == ref[f"e{it}"]
+    print(f"{h}x{w} sf {sf} {kind}: {world} ranks as threads of one process, resident strips through each other's pointers == the single resident launch")
+
+
+@pytest.mark.timeout(900)
+def test_in_process_ipc_mapping_failure_is_recognised(pkg):
+    """With `debug_ipc_same_process` the ranks of one process map each other's buffers through the hipIpc handles, as round 4 did: HIP
+    refuses (a handle is opened by OTHER processes only).  The failure must be recognised by all ranks together -- no hang, no crash --
+    and the solve goes on without the resident strips (the streaming strips where the ranks have a neighbour transport, else the
+    replicated CG) with the same result to rounding; the context reports that the resident path is not in use."""
+    sc = pkg.synth.make_scene(1024, 2048, 4, 3, seed=99, mask_kind="full")
+    out, errs, cerrs = _thread_ranks(pkg, sc, 2, 512, options={"debug_ipc_same_process": 1}, passes=1)
+    assert not errs and not cerrs, (errs, cerrs)
+    ref = _single_reference(pkg, sc, 512, passes=1)
+    for r in out:
+        assert r["it"] == 101
+        if r["resident"] == 1:                              # a runtime that does open its own handles: then it must simply be right
+            np.testing.assert_array_equal(r["z0"], ref["z0"])
+        else:
+            assert rmse(r["z0"], ref["z0"]) < 2e-5             # another CG path took over, on every rank alike
+    assert out[0]["resident"] == out[1]["resident"] and out[0]["strips"] == out[1]["strips"]
+    np.testing.assert_array_equal(out[0]["z0"], out[1]["z0"])
+    print("in-process hipIpcOpenMemHandle:", "opened (runtime allows it)" if out[0]["resident"] == 1 else
+          "refused, recognised by both ranks; " + ("streaming strips" if out[0]["strips"] else "replicated CG") + " took over")

@@ -43,16 +43,24 @@ def _oracle_execute(sc, oracle, coracle, max_outer=None):
     energies, alb_its = [], []
     last_error = float("nan")
     iteration = 1
+    import time
+    tm = {"lighting": 0.0, "albedo": 0.0, "depth": 0.0, "normals": 0.0}
     while True:
+        t0 = time.perf_counter()
         oracle.lighting_estimation(s, rho, N, o["I"])
+        t1 = time.perf_counter()
         num, den = oracle.albedo_numden(s, N, o["I"])
         it_a = []
         oracle.albedo_solve_numden(rho, num, den, it_a)
         alb_its.append(it_a)
+        t2 = time.perf_counter()
         e, it = coracle.depth_estimation(st, s, rho, o["I"], o["xx"], o["yy"], dz, o["z0s"], z, o["fx"], o["fy"], assembled=True)
         assert it == 101
+        t3 = time.perf_counter()
         zx, zy = coracle.gradient(st, z)
         N, dz = oracle.normal_init(z, zx, zy, o["xx"], o["yy"], o["fx"], o["fy"])
+        t4 = time.perf_counter()
+        tm["lighting"] += t1 - t0; tm["albedo"] += t2 - t1; tm["depth"] += t3 - t2; tm["normals"] += t4 - t3
         energies.append(float(e))
         with np.errstate(invalid="ignore", divide="ignore"):
             rel = abs(f32(last_error) - f32(e)) / abs(f32(e))
@@ -61,6 +69,7 @@ def _oracle_execute(sc, oracle, coracle, max_outer=None):
         iteration += 1
         if stop or (max_outer is not None and len(energies) >= max_outer):
             break
+    print(f"oracle solve {sc.h}x{sc.w} x {n_img}: {len(energies)} passes, seconds per phase", {k: round(v, 1) for k, v in tm.items()})
     return dict(energies=energies, z=z, rho=rho, s=s, N=N, dz=dz, albedo_iterations=alb_its, fx=o["fx"], st=st)
 
 
@@ -106,7 +115,10 @@ def _compare(name, got, ref, first_pass_tol):
 
 
 def _whole_solve(pkg, oracle, coracle, sc, first_pass_tol, expect_resident=True):
+    import time
+    t0 = time.perf_counter()
     ref = _oracle_execute(sc, oracle, coracle)
+    print(f"oracle solve: {time.perf_counter() - t0:.1f} s in all")
     default = _library_execute(pkg, sc, {})
     assert default["albedo_mode"] == 3 and default["one_sync"] == 1, "this test is about the library's DEFAULT options"
     assert default["resident"] == (1 if expect_resident else 0)
