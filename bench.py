@@ -42,8 +42,9 @@ def cpu_baseline(sc, pkg, budget_s=20.0):
         # never touches the GPU.  Full mask, like `sc`.
         import subprocess
         assert int(np.count_nonzero(sc.mask)) == sc.h * sc.w, "the cpu_baseline child takes a full mask"
-        env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "GOMP_CPU_AFFINITY", "KMP_AFFINITY")}
-        env.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
+        import cpu_budget                                   # checker-side helper: the CPUs the job may really use (affinity, cgroup quota)
+        env = {k: v for k, v in os.environ.items() if k not in ("GOMP_CPU_AFFINITY", "KMP_AFFINITY")}
+        env.update(OMP_PROC_BIND="spread", OMP_PLACES="cores", OMP_NUM_THREADS=str(cpu_budget.effective_cpus()))
         try:
             res = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline_main.py"), str(sc.h), str(sc.w), str(sc.sf), str(budget_s)],
                                  env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)

@@ -78,6 +78,10 @@ int srps_destroy(srps_ctx* ctx);
  * --device straight to cudaSetDevice (Main.cpp:29, SRPS.cu:88) and lets the runtime fail; a host that spreads a job over
  * --gpus N devices asks first. */
 int srps_device_count(int* n);
+/* Diagnostic: the pinned transfer buffers this process has made so far (csrc/srps_xfer.hip).  Every transfer between a caller's host
+ * array and the device holds one of its own for its duration and returns it to a process-wide pool: two transfers that overlap in
+ * time -- two contexts on two host threads, or srps_setup's image stream beside its mask and depth uploads -- show up as two buffers. */
+int srps_transfer_buffers(int* n);
 int srps_set_stream(srps_ctx* ctx, void* hip_stream);      /* NULL = the context's own stream */
 int srps_synchronize(srps_ctx* ctx);
 /* options: "albedo_mode" (SRPS_ALBEDO_*), "apply_mode" (SRPS_APPLY_*), "cg_max_iter", "march_strip" (0 = automatic,
@@ -122,9 +126,17 @@ int srps_synchronize(srps_ctx* ctx);
  * "cg_partition" (0|1|2: the depth CG over the ranks of the context's communicator -- 1: column strips with the streaming step and a
  *  4-double all-reduce + edge-column exchange per step, see srps_strip_group_solve; 2 (round 4): the RESIDENT kernel on strips of
  *  256 x 64 tile columns, the ranks' kernels side by side for the whole solve, exchanging their sums and border edges through
- *  exchange buffers mapped into each other with hipIpc (handles travel through the context's all-reduce) -- no collective between the
- *  101 steps; falls back to 1 / to the replicated CG where the grid does not fit or the mapping fails; "cg_partition_resident_active"
- *  tells.  Exercised on one device with two PROCESSES (tests/test_gpu_strips.py); across devices not yet),
+ *  each other's exchange buffers -- no collective between the 101 steps.  The handshake (one all-reduce of a 96-float record per rank:
+ *  hipIpc handle, buffer address, process id, PCI id, memory kind) maps a rank of ANOTHER process with hipIpcOpenMemHandle and reaches
+ *  a rank of the SAME process (srps_comm_init_all, a thread per device) through its pointer + hipDeviceEnablePeerAccess -- HIP opens a
+ *  handle in other processes only.  Buffers are fine-grained memory (coherent across devices while kernels run); ordinary memory is
+ *  accepted only when every rank sits on one device.  Falls back to 1 / to the replicated CG where the grid does not fit or the mapping
+ *  fails, on all ranks together; "cg_partition_resident_active" tells.  Exercised on one device with two and three PROCESSES and with
+ *  two and three THREADS of one process (tests/test_gpu_strips.py); across devices not yet),
+ * "debug_ipc_same_process" (test hook: same-process ranks map each other through the hipIpc handles -- HIP refuses; the ranks must
+ *  recognise it together),
+ * "light_run" (0|1, default 0: the energy + lighting sweep's waves read one image plane's four 1 KiB pieces back to back instead of one
+ *  piece of each of their images -- measured slower in round 5, kept for the record),
  * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader
  *  produces, Utilities.cpp:343 -- the context also keeps the images as bytes and the two image sweeps of a pass read those:
  *  the same floats, the same results bit for bit, a quarter of the traffic; other images are read as floats) */
@@ -244,7 +256,10 @@ typedef struct srps_problem {
  * meshgrid, first normals).  The host arrays of `prob` are ordinary (pageable) memory and are no longer needed when the call
  * returns.  The device never maps them: they cross PCIe through a pinned buffer of the library's own, filled by a few host
  * threads (option "pin_uploads" = 1 registers the image array in place instead; DESIGN.md §5 says why that is not the default).
- * The same holds for srps_upload_image, srps_get, srps_set and every other entry point that takes a host pointer. */
+ * The same holds for srps_upload_image, srps_get, srps_set and every other entry point that takes a host pointer.  Every transfer
+ * takes a buffer of its own from a process-wide pool (round 5): no lock is held while bytes move, contexts on other threads are
+ * never blocked by one context's transfer or wait.  With a full-frame mask and float images the images as they arrive ARE
+ * I[n][c][P]: no compaction pass, no second copy on the device. */
 int srps_setup(srps_ctx* ctx, const srps_problem* prob);
 int srps_upload_image(srps_ctx* ctx, int local_index, const float* host_image /* [c][h*w] */);
 int srps_upload_image_u8(srps_ctx* ctx, int local_index, const unsigned char* host_image /* [c][h*w] bytes; I = byte / 255.f */);

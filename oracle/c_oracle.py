@@ -36,10 +36,23 @@ def set_threads(n: int):
     _L.oc_set_threads(C.c_int(n))
 
 
+# The OpenMP team is bounded by what the process may really use (cpu_budget.py: affinity and cgroup quota) -- again before every call,
+# because another library of the process (torch) sets the runtime's thread count to the machine's core count when it is imported.
+import cpu_budget as _budget
+_EFF = int(os.environ.get("SRPS_ORACLE_THREADS", "0")) or _budget.effective_cpus()
+
+
+def _bound():
+    if _L.oc_num_threads() > _EFF:
+        _L.oc_set_threads(C.c_int(_EFF))
+
+
+
 class Structure:
     """neighbour lists and KT blocks of a mask (make_gradient SRPS.cu:23-71, KT SRPS.cu:170-193)"""
 
     def __init__(self, h, w, sf, mask):
+        _bound()
         mask = np.ascontiguousarray(mask, dtype=f32)
         P = C.c_int(0); Ps = C.c_int(0)
         _L.oc_count(h, w, sf, _f(mask), C.byref(P), C.byref(Ps))
@@ -51,6 +64,7 @@ class Structure:
 
 
 def tensor(st: Structure, s, rho, dz, xx, yy, fx, fy, I):
+    _bound()
     n_img, n_ch, P = I.shape
     M = np.empty(6 * P, f32); q = np.empty(3 * P, f32)
     a = [np.ascontiguousarray(v, dtype=f32) for v in (s, rho, dz, xx, yy, I)]
@@ -59,6 +73,7 @@ def tensor(st: Structure, s, rho, dz, xx, yy, fx, fy, I):
 
 
 def mf_apply(st: Structure, M, x, lam=1.0):
+    _bound()
     x = np.ascontiguousarray(x, f32); y = np.empty(st.P, f32); work = np.empty(3 * st.P + st.Ps + 8, f32)
     _L.oc_mf_apply(st.P, st.Ps, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), _f(M), C.c_float(lam), _f(x), _f(y), _f(work))
     return y
@@ -66,18 +81,21 @@ def mf_apply(st: Structure, M, x, lam=1.0):
 
 def gradient(st: Structure, x):
     """zx = Dx x, zy = Dy x (rows of make_gradient, SRPS.cu:29-47)"""
+    _bound()
     x = np.ascontiguousarray(x, f32); gx = np.empty(st.P, f32); gy = np.empty(st.P, f32)
     _L.oc_gradient(st.P, _i(st.nb), _f(x), _f(gx), _f(gy))
     return gx, gy
 
 
 def rhs(st: Structure, q, z0s, lam=1.0):
+    _bound()
     out = np.empty(st.P, f32); z0s = np.ascontiguousarray(z0s, f32)
     _L.oc_rhs(st.P, st.sf, _i(st.nb), _i(st.blk), _f(q), _f(z0s), C.c_float(lam), _f(out))
     return out
 
 
 def assemble(st: Structure, M, lam=1.0):
+    _bound()
     cap = st.P * (13 + st.sf * st.sf)
     rowptr = np.empty(st.P + 1, np.int32); col = np.empty(cap, np.int32); val = np.empty(cap, f32)
     nnz = _L.oc_assemble(st.P, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), _f(M), C.c_float(lam), _i(rowptr), _i(col), _f(val), C.c_long(cap))
@@ -86,21 +104,25 @@ def assemble(st: Structure, M, lam=1.0):
 
 
 def csr_spmv(rowptr, col, val, x):
+    _bound()
     x = np.ascontiguousarray(x, f32); y = np.empty(rowptr.size - 1, f32)
     _L.oc_csr_spmv(rowptr.size - 1, _i(rowptr), _i(col), _f(val), _f(x), _f(y))
     return y
 
 
 def cg_csr(rowptr, col, val, x, b, tol=1e-9, max_iter=100, fixed_iters=0):
+    _bound()
     return _L.oc_cg_csr(rowptr.size - 1, _i(rowptr), _i(col), _f(val), _f(x), _f(b), C.c_float(tol), max_iter, fixed_iters)
 
 
 def cg_mf(st: Structure, M, x, b, lam=1.0, tol=1e-9, max_iter=100, fixed_iters=0):
+    _bound()
     return _L.oc_cg_mf(st.P, st.Ps, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), _f(M), C.c_float(lam), _f(x), _f(b),
                        C.c_float(tol), max_iter, fixed_iters)
 
 
 def energy(st: Structure, s, rho, dz, xx, yy, fx, fy, I, z0s, z, lam=1.0):
+    _bound()
     n_img, n_ch, P = I.shape
     a = [np.ascontiguousarray(v, dtype=f32) for v in (s, rho, dz, xx, yy, I, z0s, z)]
     return float(_L.oc_energy(P, st.Ps, n_img, n_ch, st.sf, _i(st.nb), _i(st.blk_pix), _f(a[0]), _f(a[1]), _f(a[2]), _f(a[3]),

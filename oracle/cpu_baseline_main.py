@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None     # before libgomp binds this thread
+    import cpu_budget
+    eff = cpu_budget.effective_cpus()
+    os.environ["SRPS_ORACLE_THREADS"] = str(eff)           # c_oracle would otherwise count the CPUs of the already bound main thread: one
     import numpy as np
     import c_oracle
     h, w, sf = (int(a) for a in sys.argv[1:4])
@@ -19,6 +22,9 @@ def main():
     out = c_oracle.bench_cpu_baseline(h, w, sf, np.ones(h * w, np.float32), budget_s=budget)
     out["nproc"] = os.cpu_count()
     out["affinity_cpus"] = cpus
+    out["cgroup_cpu_max"] = cpu_budget.quota_text()
+    out["cores_note"] = ("`cores` = OpenMP threads used = min(affinity, cgroup CPU quota): the box shows %d logical CPUs, the job may use %d"
+                         % (os.cpu_count(), eff))
     print(json.dumps(out))
 
 

@@ -143,6 +143,7 @@ def load():
         "srps_strip_range": (i, [i, i, i, i, ip, ip]),
         "srps_shard_range": (i, [i, i, i, ip, ip]),
         "srps_device_count": (i, [ip]),
+        "srps_transfer_buffers": (i, [ip]),
         "srps_set_strip_transport": (i, [vp, i, i, STRIP_ALLREDUCE_FN, STRIP_EXCHANGE_FN, STRIP_ALLGATHER_FN, vp]),
         "srps_get": (i, [vp, C.c_char_p, fp, C.c_size_t]),
         "srps_set": (i, [vp, C.c_char_p, fp, C.c_size_t]),

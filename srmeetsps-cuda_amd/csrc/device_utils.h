@@ -306,16 +306,17 @@ typedef unsigned srps_v4u __attribute__((ext_vector_type(4)));
                                  // time, and packed into 4 KB they queue on a few memory channels (16: 11.75, 64: 11.5, 256 and
                                  // 1024: 11.45 us per CG step at 2048 x 2048)
 #endif
-// Experiments of round 5 on the collect's round trip (every block's polling wave asks for all 256 granules at the same moment: 65 536
-// 16-byte requests for 256 lines per step).  SRPS_G3_GROUP = 4: four consecutive granules share a 64-byte segment (the four lanes
-// that read them in one instruction are then ONE request), the segments SRPS_G3_STRIDE * 4 bytes apart -- a quarter of the requests on
-// the same footprint.  SRPS_G3_REPLICAS = R: every block stores its granule R times, a block polls copy (slot mod R) -- the same
-// requests over R times the lines.
+// Round 5, the collect's round trip (every block's polling wave asks for all 256 granules at the same moment: 65 536 16-byte requests
+// for 256 lines per step).  SRPS_G3_REPLICAS = R: every block stores its granule R times, a block polls copy (slot mod R) -- the same
+// requests over R times the lines.  Same-box A/B at 2048 x 2048 (tools/ab_variants.sh, three rounds): R = 1 7.95 - 7.99 us per CG step,
+// R = 2 7.81 - 7.84, R = 8 7.79 - 7.84: two copies are the default (one more 16-byte store per block and step).  SRPS_G3_GROUP = 4 (four
+// consecutive granules in one 64-byte segment, so that the four lanes that read them in one instruction are ONE request, a quarter of
+// the requests on the same footprint) measured 8.03 - 8.09: off.
 #ifndef SRPS_G3_GROUP
 #define SRPS_G3_GROUP 1
 #endif
 #ifndef SRPS_G3_REPLICAS
-#define SRPS_G3_REPLICAS 1
+#define SRPS_G3_REPLICAS 2
 #endif
 // byte offset of granule g (of nbr = blocks rounded up to 256) in copy `rep` of generation parity `par`
 __device__ __forceinline__ size_t g3_offset(unsigned par, int rep, int nbr, int g) {

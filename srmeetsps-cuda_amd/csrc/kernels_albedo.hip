@@ -618,6 +618,7 @@ int albedo_finish(srps_ctx* ctx, float* d_rho, const float* d_numden, int P, int
     ctx->albedo_iters_pending = 0;
     const int nb = std::max(1, std::min(cdiv(P, 256 * 4), 512));
     const size_t nv = (size_t)C * P;
+    static_assert(SRPS_G3_REPLICAS <= 3, "the granule area below holds three triples (grid_sum9) or SRPS_G3_REPLICAS copies of one (grid_sum3)");
     const size_t bytes = (2 * nv + (size_t)C * 3 * nb) * sizeof(float) + 8 * sizeof(DcgScal) + 2 * 1024 * sizeof(unsigned long long) + 3 * 2 * 1024 * SRPS_G3_STRIDE + 256;
     SRPS_TRY(ensure(ctx->ws_albedo, bytes));
     float* r = (float*)ctx->ws_albedo.p;

@@ -438,6 +438,9 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
 #ifndef SRPS_LIGHT_PREFETCH
 #define SRPS_LIGHT_PREFETCH 1
 #endif
+#ifndef SRPS_LIGHT_XTILE
+#define SRPS_LIGHT_XTILE 1
+#endif
 // TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
 // U8: the images from the context's 8-bit store (bytes, k / 255.f formed in registers: device_utils.h unit_from_byte -- the same floats);
 // the sweep's vector pipes are a third busy, the bytes are a quarter of the floats.
@@ -484,6 +487,28 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
         float4 svr[NCH][IBW];                              // ... and kept in registers for the round: an LDS read per use cost a wait each
         bool sv_loaded = false;
 #endif
+        // The image loads run as ONE software pipeline over all tiles of the block's range (SRPS_LIGHT_XTILE, round 5): the loads of a
+        // tile's first step(s) go out BEFORE the previous tile's last arithmetic and before the geometry phase between the barriers --
+        // until round 4 every wave's memory pipe ran dry there (nothing depends on the geometry in a load of image samples).
+        constexpr int NS = 4 * NCH;
+        constexpr int PF = SRPS_LIGHT_PREFETCH;                  // steps of look-ahead (PF + 1 sets of IBW float4 rotate)
+        static_assert(NS % (PF + 1) == 0, "the buffer rotation continues across tiles");
+        Vec<4> ivb[PF + 1][IBW];
+        auto pieces_of = [&](int t0) { return __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8)); };      // wave-uniform: the range's last tile may be short
+        auto issue = [&](int k, Vec<4> (&buf)[IBW], int t0) {
+            const int sub = k / NCH, c = k - sub * NCH;
+            const int q = t0 + (sub * 64 + lane) * 4;
+            const int ql = q < p1 ? q : p1 - 4;
+#pragma unroll
+            for (int ii = 0; ii < IBW; ++ii) {
+                buf[ii] = ld_img<4, U8, TM>(I, I8, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);      // images past the end re-read the last one
+            }
+        };
+        if (!RUN && SRPS_LIGHT_XTILE && active && p0 < p1) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+                if (k < NS && k / NCH < pieces_of(p0)) issue(k, ivb[k % (PF + 1)], p0);
+        }
         for (int t0 = p0; t0 < p1; t0 += TP) {
             __syncthreads();                               // the previous tile has been read by every wave
             {
@@ -618,26 +643,20 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                 }
                 continue;
             }
-            constexpr int NS = 4 * NCH;
-            constexpr int PF = SRPS_LIGHT_PREFETCH;                  // steps of look-ahead (PF + 1 sets of IBW float4 rotate)
-            Vec<4> ivb[PF + 1][IBW];
-            auto issue = [&](int k, Vec<4> (&buf)[IBW]) {
-                const int sub = k / NCH, c = k - sub * NCH;
-                const int q = t0 + (sub * 64 + lane) * 4;
-                const int ql = q < p1 ? q : p1 - 4;
+            const bool more = t0 + TP < p1;                             // block-uniform: another tile follows
+            const int npieces_next = more ? pieces_of(t0 + TP) : 0;
+            if (!SRPS_LIGHT_XTILE) {
 #pragma unroll
-                for (int ii = 0; ii < IBW; ++ii) {
-                    buf[ii] = ld_img<4, U8, TM>(I, I8, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);      // images past the end re-read the last one
-                }
-            };
-#pragma unroll
-            for (int k = 0; k < PF; ++k)
-                if (k < NS && k / NCH < npieces) issue(k, ivb[k % (PF + 1)]);
+                for (int k = 0; k < PF; ++k)
+                    if (k < NS && k / NCH < npieces) issue(k, ivb[k % (PF + 1)], t0);
+            }
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int sub = k / NCH, c = k % NCH;
+                // the look-ahead step: of this tile, or -- behind its last steps -- of the next one
+                if (k + PF < NS) { if ((k + PF) / NCH < npieces) issue(k + PF, ivb[(k + PF) % (PF + 1)], t0); }
+                else if (SRPS_LIGHT_XTILE && (k + PF - NS) / NCH < npieces_next) issue(k + PF - NS, ivb[(k + PF) % (PF + 1)], t0 + TP);
                 if (sub < npieces) {                                   // wave-uniform (no break: the loop must unroll completely, k is an array index)
-                if (k + PF < NS && (k + PF) / NCH < npieces) issue(k + PF, ivb[(k + PF) % (PF + 1)]);
                 // pinned: the compiler otherwise clusters the loads of two steps, consumes both sets and only then issues the next two --
                 // the memory pipe ran dry every second step (s_waitcnt vmcnt(0) in the middle of the sequence)
                 __builtin_amdgcn_sched_barrier(0);

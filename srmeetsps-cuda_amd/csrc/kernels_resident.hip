@@ -127,9 +127,6 @@ __device__ __forceinline__ v2f andm2(v2f v, v2i m) { return __builtin_bit_cast(v
 #ifndef SRPS_RES_UNPACKED
 #define SRPS_RES_UNPACKED 0
 #endif
-#ifndef SRPS_RES_LAZY_RR
-#define SRPS_RES_LAZY_RR 0
-#endif
 struct r2f { float x, y; };
 struct r2i { int x, y; };
 __device__ __forceinline__ r2f operator+(r2f a, r2f b) { return {a.x + b.x, a.y + b.y}; }
@@ -851,9 +848,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                     for (int e = 0; e < 4; ++e) {
                         x[c].e[e] = fmaf(alpha, p[c].e[e], x[c].e[e]);      // dc.cu:270
                         r[c].e[e] = fmaf(-alpha, w[c].e[e], r[c].e[e]);     // dc.cu:272
-#if !SRPS_RES_LAZY_RR
-                        red = fmaf(r[c].e[e], r[c].e[e], red);
-#endif
+                        red = fmaf(r[c].e[e], r[c].e[e], red);      // (forming this only in the 1-in-16 steps that use it measured the same: 7.93 - 7.99 us)
                     }
                 SRPS_STAMP(12);
                 await_ring(wr);
@@ -873,17 +868,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 // (A step counter kept in a register instead of k & 15 cost 1.4 us per step in code generation.)
                 if ((SRPS_RES_DEBUG_ON(a)) || (pred > 1e-2 * ((double)r1 + fabs(t1) + t2) && pred > 0.25 * (double)r1_anchor && (k & 15) != 0))
                     r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : (float)pred);
-                else {
-#if SRPS_RES_LAZY_RR
-                    // the direct sum of r.r is needed in about one step of 16: its 32 multiply-adds are formed here, not in every step
-                    // (same operands, same order: the same bits)
-#pragma unroll
-                    for (int c = 0; c < CPT; ++c)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) red = fmaf(r[c].e[e], r[c].e[e], red);
-#endif
-                    r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm, gp)); r1_anchor = r1;
-                }
+                else { r1 = uniform_f(grid_sum(red, a.ent, ++gen, sm, gp)); r1_anchor = r1; }
             }
             // ---- the next step's p = beta p + r, own pixels and ring (dc.cu:256-264), here, where r.r has just become known: at the
             // top of the next pass it cost a phase of its own behind the loop's turn.  After pass 0: beta = 0, p = 0 p + r = r.

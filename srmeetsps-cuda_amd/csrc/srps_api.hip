@@ -373,6 +373,12 @@ int srps_device_count(int* n) {
     return SRPS_OK;
 }
 
+int srps_transfer_buffers(int* n) {
+    SRPS_REQUIRE(n != nullptr, SRPS_ERR_INVALID, "transfer_buffers: n is NULL");
+    *n = xfer_buffers_made();
+    return SRPS_OK;
+}
+
 int srps_create(int device_id, int block_x, int block_y, srps_ctx** out) {
     SRPS_REQUIRE(out != nullptr, SRPS_ERR_INVALID, "srps_create: out is NULL");
     *out = nullptr;
@@ -451,6 +457,7 @@ int srps_destroy(srps_ctx* ctx) {
     if (ctx->ws_ssum.p) (void)hipFree(ctx->ws_ssum.p);
     if (ctx->ws_albedo.p) (void)hipFree(ctx->ws_albedo.p);
     if (ctx->ws_stage.p) (void)hipFree(ctx->ws_stage.p);
+    if (ctx->ws_images.p) (void)hipFree(ctx->ws_images.p);
     if (ctx->ws_misc.p) (void)hipFree(ctx->ws_misc.p);
     if (ctx->ev_created)
         for (int i = 0; i < SRPS_N_PHASES; ++i) { (void)hipEventDestroy(ctx->ev_begin[i]); (void)hipEventDestroy(ctx->ev_end[i]); }
@@ -936,14 +943,14 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     } first_batch;
     auto copy_batch = [&](int n0, int cnt) -> int {     // images n0 .. n0 + cnt - 1 into the staging slots 0 .. cnt - 1, on the context's stream
         const char* src = host_I + (size_t)n0 * per * esz;
-        if (pin.p) { SRPS_HIP(hipMemcpyAsync(ctx->ws_stage.p, src, (size_t)cnt * per * esz, hipMemcpyHostToDevice, ctx->stream)); return SRPS_OK; }
-        return host_upload(ctx, ctx->ws_stage.p, src, (size_t)cnt * per * esz, ctx->stream);
+        if (pin.p) { SRPS_HIP(hipMemcpyAsync(ctx->ws_images.p, src, (size_t)cnt * per * esz, hipMemcpyHostToDevice, ctx->stream)); return SRPS_OK; }
+        return host_upload(ctx, ctx->ws_images.p, src, (size_t)cnt * per * esz, ctx->stream);
     };
     std::function<int()> start_uploads = [&]() -> int {
         if (!host_I || NL_ <= 0) return SRPS_OK;
         const size_t bytes = (size_t)NL_ * per * esz;
         slots = (int)std::min<size_t>((size_t)NL_, std::max<size_t>(2, ((size_t)2 << 30) / (per * esz)));
-        SRPS_TRY(ensure(ctx->ws_stage, (size_t)slots * per * esz));      // kept across set-ups (grow-only)
+        SRPS_TRY(ensure(ctx->ws_images, (size_t)slots * per * esz));      // kept across set-ups (grow-only)
         SRPS_TRY(setup_events(ctx, 1));
         if (ctx->pin_uploads && bytes >= ((size_t)8 << 20)) {
             if (hipHostRegister((void*)host_I, bytes, hipHostRegisterDefault) == hipSuccess) pin.p = host_I;
@@ -977,11 +984,16 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     const int P = G.P, C = pr->n_channels, NL = pr->n_images, NT = pr->n_images_total;
     ctx->C = C; ctx->N_local = NL; ctx->N_total = NT; ctx->img_offset = pr->image_offset;
     ctx->fx = pr->K[0]; ctx->fy = pr->K[4]; ctx->cx = pr->K[6]; ctx->cy = pr->K[7];       // SRPS.cu:256, 269
+    // A full-frame mask makes the compaction (copy_if, SRPS.cu:223-234) the identity: the float images as they arrive, [n][c][h w], ARE
+    // I[n][c][P] -- when they all fit the transfer area at once the context's I is that area, no compaction pass runs (1 GB read and
+    // written: 0.5 ms at the metric's configuration, and a second gigabyte of device memory)
+    const bool alias_I = !bytes_in && host_I && NL > 0 && slots == NL && (size_t)P == (size_t)G.h * G.w;
+    ctx->I_in_ws_images = alias_I;
     // ---- state arena ----
     {
         const size_t fP = al256((size_t)P * sizeof(float));
         size_t need = al256((size_t)NT * C * 4 * sizeof(float)) + al256((size_t)C * P * sizeof(float)) + 2 * al256(4 * (size_t)P * sizeof(float)) + 8 * fP +
-                      al256((size_t)std::max(G.Ps, 1) * sizeof(float)) + al256((size_t)std::max(NL, 1) * C * P * sizeof(float)) + al256(2 * (size_t)C * P * sizeof(float)) +
+                      al256((size_t)std::max(G.Ps, 1) * sizeof(float)) + (alias_I ? 0 : al256((size_t)std::max(NL, 1) * C * P * sizeof(float))) + al256(2 * (size_t)C * P * sizeof(float)) +
                       (NL != NT ? al256(3 * (size_t)P * sizeof(float)) : 0) + 256;
         SRPS_TRY(ensure(ctx->state_arena, need));                    // grows only when this problem is larger than every earlier one
         size_t used = 0;
@@ -992,7 +1004,7 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
         ctx->zx = carve((size_t)P * sizeof(float));
         ctx->zy = carve((size_t)P * sizeof(float)); ctx->xx = carve((size_t)P * sizeof(float)); ctx->yy = carve((size_t)P * sizeof(float));
         ctx->z0s = carve((size_t)std::max(G.Ps, 1) * sizeof(float));
-        ctx->I = carve((size_t)std::max(NL, 1) * C * P * sizeof(float));
+        ctx->I = alias_I ? (float*)ctx->ws_images.p : carve((size_t)std::max(NL, 1) * C * P * sizeof(float));
         ctx->albedo_ex = carve(2 * (size_t)C * P * sizeof(float)); ctx->energy_ex = ctx->d_report;
         if (NL != NT) ctx->q_ex = carve(3 * (size_t)P * sizeof(float));      // a shard exchanges q compactly (3 P floats, not 3 padded planes)
     }
@@ -1038,8 +1050,8 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
             }
             SRPS_HIP(hipEventRecord(ctx->ev_copied[0], ctx->stream));
             SRPS_HIP(hipStreamWaitEvent(gs, ctx->ev_copied[0], 0));
-            for (int n = n0; n < n0 + cnt; ++n) {
-                const char* stage = (const char*)ctx->ws_stage.p + (size_t)(n - n0) * per * esz;
+            for (int n = n0; n < n0 + cnt && !alias_I; ++n) {
+                const char* stage = (const char*)ctx->ws_images.p + (size_t)(n - n0) * per * esz;
                 if (bytes_in)
                     SRPS_TRY(launch_gather_images_u8(gs, (const unsigned char*)stage, G.d_imask, P, C, hwp, 1, ctx->I + (size_t)n * C * P,
                                                      want_bytes ? ctx->I8 + (size_t)n * C * P : nullptr));

@@ -134,6 +134,8 @@ struct srps_ctx {
     srps::Grid grid;
     // grow-only workspaces for the per-pixel phases
     srps::DevBuf ws_light, ws_albedo, ws_stage, ws_misc, ws_struct;
+    srps::DevBuf ws_images;          // where srps_setup's image transfers land: [n][c][h w] floats or bytes.  With a full-frame mask and float images that IS
+                                     // I[n][c][P]: the context's I then points here (I_in_ws_images) and no compaction pass runs
     hipStream_t aux_stream = nullptr;   // non-blocking: the structure build of srps_setup / srps_bind_grid runs here while the images cross PCIe on `stream`
     hipStream_t gather_stream = nullptr;   // non-blocking: the compaction of image n runs here while image n + 1 is copied
     hipEvent_t aux_event = nullptr;
@@ -177,7 +179,8 @@ struct srps_ctx {
     int light_channel_inner = 1;     // fused energy + lighting sweep with the channels in the inner loop (C in {1, 3})
     int march_nt = 0;                // streaming CG step with non-temporal loads / stores: 0 never (default: measured 15 - 35 % SLOWER at 2304^2 ... 4096^2, tools/march_nt_sweep.sh -- the strips re-read their halo columns, which then miss the L2; stores only, 3: 59.5 -> 65.0 us at 2560^2, 153 -> 165 - 176 at 4096^2 sf 4), 1 always, 2 when its vectors exceed the Infinity Cache, 3 stores only
     int light_bytes = 1;             // the tiled lighting sweep reads the 8-bit image store when the context holds one (round 4)
-    int light_run = 1;               // ... and every wave reading ONE image plane's four pieces back to back: 4 KiB runs (round 5; 0: one piece of each of the wave's images)
+    bool I_in_ws_images = false;
+    int light_run = 0;               // 1: every wave reads ONE image plane's four pieces back to back (4 KiB runs) -- measured in round 5: 268 - 273 us against 256 - 259 (same box), off
     int light_tiled = 1;             // ... with the four image groups as the waves of one block and the geometry shared through LDS (k_light_fused_tile)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue

@@ -19,6 +19,7 @@
 // the calling thread only issues each slot's DMA when its pieces are in and frees the slot when the DMA's event has fired.  No
 // barrier couples the threads: fillers run up to three chunks ahead of the copy engine.
 #include <immintrin.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -42,7 +43,7 @@ constexpr size_t kPiece = (size_t)1 << 20;     // what a filling thread claims a
 constexpr int kMaxThreads = 32;
 
 // ---- the pool: pinned buffers are expensive to make (milliseconds) and contexts come and go, so they live as long as the process ----
-struct PoolBuf { char* p; size_t bytes; };
+struct PoolBuf { char* p; size_t bytes; bool wc; };      // wc: write-combined host memory (uploads only: the host never reads it)
 struct BouncePool {
     std::mutex m;                              // guards the list only: never held while a transfer runs
     std::vector<PoolBuf> free_;
@@ -50,20 +51,20 @@ struct BouncePool {
 } g_pool;
 
 // a buffer of at least `bytes` (two sizes occur: 64 MB, and four slots of the large-transfer chunk)
-int pool_acquire(size_t bytes, PoolBuf* out) {
+int pool_acquire(size_t bytes, PoolBuf* out, bool wc = false) {
     {
         std::lock_guard<std::mutex> lk(g_pool.m);
         for (size_t i = 0; i < g_pool.free_.size(); ++i)
-            if (g_pool.free_[i].bytes >= bytes) { *out = g_pool.free_[i]; g_pool.free_.erase(g_pool.free_.begin() + (long)i); return SRPS_OK; }
+            if (g_pool.free_[i].bytes >= bytes && g_pool.free_[i].wc == wc) { *out = g_pool.free_[i]; g_pool.free_.erase(g_pool.free_.begin() + (long)i); return SRPS_OK; }
     }
     void* p = nullptr;
-    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | (wc ? hipHostMallocWriteCombined : 0));
     if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (transfer buffer)", __FILE__, __LINE__);
     {
         std::lock_guard<std::mutex> lk(g_pool.m);
         ++g_pool.made;
     }
-    *out = PoolBuf{(char*)p, bytes};
+    *out = PoolBuf{(char*)p, bytes, wc};
     return SRPS_OK;
 }
 void pool_release(const PoolBuf& b) {
@@ -72,7 +73,7 @@ void pool_release(const PoolBuf& b) {
     g_pool.free_.push_back(b);
 }
 struct Lease {                                 // a transfer's buffer, back in the pool when the transfer ends (its copies have been waited for by then)
-    PoolBuf buf{nullptr, 0};
+    PoolBuf buf{nullptr, 0, false};
     char* base = nullptr;
     ~Lease() { pool_release(buf); }
 };
@@ -112,11 +113,34 @@ int big_streams() {
     return n;
 }
 
-// filling threads of a large upload.  SRPS_XFER_THREADS overrides (development: tools/setup_time.py sweeps it)
+// CPUs the process may really use: its affinity mask and its cgroup's quota (cpu.max: "quota period" in microseconds, or "max").  The GPU
+// boxes of this pool show 256 logical CPUs and grant 16: a set-up whose 16 filling threads, issuing thread and structure thread ran
+// together was throttled by the scheduler at random -- 21 / 26 / 32 ms for the same 1 GB (gpurun_out/r5c).
+int cpu_budget() {
+    static const int n = [] {
+        int cpus = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::max(1, CPU_COUNT(&set));
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long quota = atol(q);
+                if (quota > 0) cpus = (int)std::min<long>(cpus, std::max<long>(1, (quota + period - 1) / period));
+            }
+            fclose(f);
+        }
+        return cpus;
+    }();
+    return n;
+}
+
+// filling threads of a large upload: half of what the process may use (the other half is the caller's: its own threads, the runtime's),
+// eight at most -- same-box sweep on 1 GB: 8 threads 20.6 ms, 16 threads 21.0, 32 threads 23 - 38.  SRPS_XFER_THREADS overrides
+// (development: tools/setup_time.py sweeps it)
 int copy_threads(size_t bytes) {
     if (bytes < kBig / 2) return 0;            // below 8 MB the calling thread copies by itself (upload_small)
-    const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
-    int t = (int)std::max(2u, std::min<unsigned>(hc / 4, 16u));
+    int t = std::max(2, std::min(cpu_budget() / 2, 8));
     if (bytes < 4 * kBig) t = std::min(t, 4);  // the mask, a depth map: a few threads for 1 ms of copying
     t = env_int("SRPS_XFER_THREADS", t);
     return std::max(1, std::min(t, kMaxThreads));
@@ -255,7 +279,8 @@ int host_upload(srps_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hip
     SRPS_REQUIRE(d_dst && h_src, SRPS_ERR_INVALID, "host_upload: null pointer");
     const int T = copy_threads(bytes);
     Lease buf;
-    SRPS_TRY(pool_acquire(T == 0 ? kSlot * kSlots : std::max(kSlot * kSlots, big_chunk() * kBigSlots), &buf.buf));
+    static const bool wc = env_int("SRPS_XFER_WC", 0) != 0;      // (development: write-combined staging for the large uploads)
+    SRPS_TRY(pool_acquire(T == 0 ? kSlot * kSlots : std::max(kSlot * kSlots, big_chunk() * kBigSlots), &buf.buf, wc && T > 0));
     buf.base = buf.buf.p;
     (void)ctx;
     int rc;

@@ -135,8 +135,10 @@ void SRPS::execute_sharded(const std::vector<float>& zs, const std::vector<float
     for (int r = 0; r < n_gpus; ++r) {
         srps_check(srps_create(Preferences::deviceId + r, Preferences::blockX, Preferences::blockY, &shard_ctx[r]));
         srps_check(srps_set_option(shard_ctx[r], "exclusive_device", Preferences::exclusiveDevice ? 1 : 0));
-        // --partition strips: 2 = the resident kernel on strips of tile columns where they fit (exchange buffers mapped with hipIpc),
-        // else the library falls back to the streaming strips (1) by itself
+        // --partition strips: 2 = the resident kernel on strips of tile columns where they fit.  The ranks are threads of THIS process: the
+        // library's handshake finds that out (process ids travel with the buffer handles) and reaches the other ranks' exchange buffers
+        // through their pointers + hipDeviceEnablePeerAccess -- hipIpc handles open in other processes only.  Where the strips do not
+        // fit (or no fine-grained memory is to be had across devices) the library falls back to the streaming strips (1) by itself.
         if (Preferences::partitionStrips) srps_check(srps_set_option(shard_ctx[r], "cg_partition", 2));
     }
     ctx = shard_ctx[0];
@@ -185,6 +187,13 @@ void SRPS::execute_sharded(const std::vector<float>& zs, const std::vector<float
             if (error > last_error || rel_err < TOLERANCE || iteration > MAX_ITERATIONS) stop_loop = true;   // SRPS.cu:299
             last_error = error;
             if (r == 0) {
+                if (iteration == 1 && Preferences::partitionStrips && n_gpus > 1) {      // which form of the depth CG the pass really ran
+                    int resident = 0, strips = 0;
+                    srps_check(srps_get_option(c, "cg_partition_resident_active", &resident));
+                    srps_check(srps_get_option(c, "cg_partition_active", &strips));
+                    printf("Depth CG: %s\n", resident ? "the resident kernel on strips of tile columns (ranks of one process: peer pointers)"
+                                                      : strips ? "streaming column strips (an all-reduce and a neighbour exchange per step)" : "replicated on every rank");
+                }
                 float ms[SRPS_N_PHASES];
                 srps_check(srps_get_timings(c, ms));
                 auto sec = [&](int a, int b = -1) { return 1e-3 * ((ms[a] > 0 ? ms[a] : 0.f) + (b >= 0 && ms[b] > 0 ? ms[b] : 0.f)); };

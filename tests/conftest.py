@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 if os.path.join(ROOT, "oracle") not in sys.path:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
+# Thread pools of the test process (OpenMP in the C oracle and torch, OpenBLAS under numpy) are sized to the CPUs the process may really
+# use -- its cgroup quota, not the 256 logical CPUs a GPU box shows (oracle/cpu_budget.py) -- before any of those libraries is loaded.
+import cpu_budget  # noqa: E402
+for _var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, str(cpu_budget.effective_cpus()))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

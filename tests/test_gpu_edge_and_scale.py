@@ -601,3 +601,40 @@ def test_report_written_by_the_sweeps_last_block_equals_the_fetched_one(pkg, h, 
         for k in (1, 2, 3):
             np.testing.assert_array_equal(x[k], y[k])
         assert x[4:] == y[4:]
+
+
+def test_transfers_of_two_contexts_do_not_wait_for_each_other(pkg):
+    """Round-4 advisor finding: every srps_get / srps_set of the process went through ONE pinned buffer behind ONE mutex, held across the
+    whole transfer -- a context's 100 MB upload made every other context's 4-byte read wait for it.  Every transfer now holds a buffer
+    of its own: while one thread uploads large arrays through one context, the small reads of another context on another thread
+    are served at their own pace, and the process has made (at least) two transfer buffers."""
+    import ctypes as C
+    import threading
+    import time
+    sc = pkg.synth.make_scene(1024, 1024, 4, 2, seed=5, mask_kind="full")
+    a = pkg.Context(device_id=0); b = pkg.Context(device_id=0)
+    a.setup(pkg.DataHandler.from_scene(sc)); b.setup(pkg.DataHandler.from_scene(sc))
+    big = a.get("N")                                       # 16 MB
+    stop = threading.Event()
+    uploads = [0]
+
+    def uploader():
+        while not stop.is_set():
+            a.set("N", big); uploads[0] += 1
+    th = threading.Thread(target=uploader)
+    lat = []
+    th.start()
+    try:
+        time.sleep(0.05)
+        for _ in range(200):
+            t0 = time.perf_counter(); b.get("s"); lat.append(time.perf_counter() - t0)
+    finally:
+        stop.set(); th.join()
+    t0 = time.perf_counter(); a.set("N", big); one_upload = time.perf_counter() - t0
+    n = C.c_int(0)
+    pkg._lib.check(a.lib.srps_transfer_buffers(C.byref(n)))
+    med = sorted(lat)[len(lat) // 2]
+    print(f"{uploads[0]} uploads of 16 MB ({1e3 * one_upload:.2f} ms each) beside 200 small reads: median {1e6 * med:.0f} us, max {1e6 * max(lat):.0f} us; transfer buffers made: {n.value}")
+    assert uploads[0] >= 3 and n.value >= 2
+    assert med < 0.5 * one_upload                          # behind one lock the median read waited for most of an upload
+    a.close(); b.close()

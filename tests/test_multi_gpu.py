@@ -133,6 +133,10 @@ def test_command_line_program_on_two_gpus(pkg, tmp_path, partition):
     two = subprocess.run([pkg.host.CLI, f"--dsloc={path}", "-o", str(tmp_path / "b"), "--gpus", "2", "--partition", partition], capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stderr
     assert "Images sharded over 2 GPUs" in two.stdout and two.stdout.count("Iteration") == one.stdout.count("Iteration") and "Done!" in two.stdout
+    if partition == "strips":
+        # the ranks are threads of one process: the handshake must take the peer-pointer route (hipIpc handles open in OTHER processes only)
+        # and the solve must end on the resident kernel, not on a fall-back (256 x 192, sf 2: 12 tiles of 256 x 16 over two ranks)
+        assert "Depth CG: the resident kernel on strips" in two.stdout, two.stdout[-1500:]
     za = scipy.io.loadmat(str(tmp_path / "a" / "z.mat"))["x"][:, 0]; zb = scipy.io.loadmat(str(tmp_path / "b" / "z.mat"))["x"][:, 0]
     assert rmse(za, zb) < 3e-5
     ra = scipy.io.loadmat(str(tmp_path / "a" / "rho.mat"))["x"][:, 0]; rb = scipy.io.loadmat(str(tmp_path / "b" / "rho.mat"))["x"][:, 0]
