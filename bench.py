@@ -129,6 +129,16 @@ def _profile(name):
         return None
 
 
+def _newest_profile(suffix):
+    """(name, contents) of the newest round's profiles/rNN_<suffix> that parses"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True):
+        d = _profile(os.path.basename(path))
+        if d:
+            return os.path.basename(path), d
+    return None, None
+
+
 def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
     """isolated inner loop (srps_bench_cg: HIP events on the launch stream) and the roofline of its dominant kernel"""
     out = {}
@@ -140,11 +150,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
     P = ctx.dims()["npix"]
     resident = bool(ctx.get_option("cg_resident_active"))
     assert resident == resident_expected or not resident_expected, "the resident CG kernel was expected to run"
-    tj, tj_name = {}, None
-    for tj_name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
-        tj = _profile(tj_name)
-        if tj:
-            break
+    tj_name, tj = _newest_profile("traffic.json")
     tj = tj or {}
     # `traffic` is NOT measured by this process: PMC counters need a profiler pass of their own (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # tools/profile_round.sh + tools/pmc_traffic.py); the line replays the committed summary of that pass and says so
@@ -160,7 +166,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         launch_us = 1e6 * b["seconds"] / (b["iterations"] / 101)
         flops = float(P) * (101 * FLOPS_PER_UNKNOWN_STEP + FLOPS_PER_UNKNOWN_RESIDUAL_PASS)
         ach = flops / (launch_us * 1e6)                     # TFLOP/s
-        isa = _profile("r03_resident_isa.json") or _profile("r02_resident_isa.json")
+        isa_name, isa = _newest_profile("resident_isa.json")
         issue = None
         rect = bool(ctx.get_option("cg_resident_rect_active"))
         ikey = key if rect else key + "_general_kernel"
@@ -169,7 +175,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
             floor_us = clk / (isa[ikey]["GHz"] * 1e3)
             issue = {"kind": "static_estimate: the emitted instruction stream priced with measured issue costs per class, both branches of the direct-sum path counted; not a counter",
                      "valu_issue_clocks_per_simd_step": clk, "issue_floor_us_per_step": floor_us, "kernel": isa[ikey]["kernel"],
-                     "measured_us_per_step": launch_us / 101.0, "issue_frac": floor_us / (launch_us / 101.0), "source": isa[ikey]["source"]}
+                     "measured_us_per_step": launch_us / 101.0, "issue_frac": floor_us / (launch_us / 101.0), "source": isa[ikey]["source"], "report": "profiles/" + isa_name}
         out["roofline"] = {"bound": "valu", "kernel": "k_cg_resident (" + ("mask-free body: every tile lies inside the mask" if rect else "general body") +
                                                       "): residual pass + the whole truncated CG (101 steps) in one persistent launch",
                            "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
@@ -437,6 +443,27 @@ def main():
                                    + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},
         "energies": energies,
     }
+    if not args.no_total_solve:
+        # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up; reported with and without srps_setup.  Timed HERE, right
+        # behind the timed passes and before the side legs: behind them (a dozen contexts made and closed, gigabytes allocated and freed, the
+        # host's CPU quota spent) the same set-up measured 1.0 - 1.6 ms longer (gpurun_out/r5g: 20.1 ms against 21.1 - 21.7)
+        # (= SRPS.cu:100-270: the upload of the images from host memory, compaction, first normals)
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+        t_setup0 = time.perf_counter()
+        ctx.setup(dh)
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        t0 = time.perf_counter()
+        en = solve()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if rank == 0:
+            out["total_solve_s"] = t1 - t0
+            out["total_solve_with_setup_s"] = t1 - t_setup0
+            out["setup_s"] = t0 - t_setup0
+            out["setup_host_bytes"] = int(dh.I.nbytes)
+            out["total_solve_outer_iterations"] = len(en)
     # the isolated CG loop: with the depth CG partitioned over the ranks (strips) a solve is a collective -- every rank takes part, rank 0 reports
     cg_collective = world > 1 and (ctx.get_option("cg_partition_active") == 1 or ctx.get_option("cg_partition_resident_active") == 1)
     if rank == 0 or cg_collective:
@@ -657,25 +684,6 @@ def main():
         except Exception as exc:                      # never fail the bench line because of the side measurement
             out["device_copy_GBs"] = None
             out["device_copy_error"] = str(exc)
-    if not args.no_total_solve:
-        # full solve to the reference's stop rule (SRPS.cu:297-302), from a fresh set-up; reported with and without srps_setup
-        # (= SRPS.cu:100-270: the upload of the images from host memory, compaction, first normals)
-        if dist: dist.barrier()
-        torch.cuda.synchronize()
-        t_setup0 = time.perf_counter()
-        ctx.setup(dh)
-        torch.cuda.synchronize()
-        if dist: dist.barrier()
-        t0 = time.perf_counter()
-        en = solve()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        if rank == 0:
-            out["total_solve_s"] = t1 - t0
-            out["total_solve_with_setup_s"] = t1 - t_setup0
-            out["setup_s"] = t0 - t_setup0
-            out["setup_host_bytes"] = int(dh.I.nbytes)
-            out["total_solve_outer_iterations"] = len(en)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc, pkg)

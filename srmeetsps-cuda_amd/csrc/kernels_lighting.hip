@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
 #define SRPS_LIGHT_PREFETCH 1
 #endif
 #ifndef SRPS_LIGHT_XTILE
-#define SRPS_LIGHT_XTILE 1
+#define SRPS_LIGHT_XTILE 0
 #endif
 // TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
 // U8: the images from the context's 8-bit store (bytes, k / 255.f formed in registers: device_utils.h unit_from_byte -- the same floats);
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
         // until round 4 every wave's memory pipe ran dry there (nothing depends on the geometry in a load of image samples).
         constexpr int NS = 4 * NCH;
         constexpr int PF = SRPS_LIGHT_PREFETCH;                  // steps of look-ahead (PF + 1 sets of IBW float4 rotate)
-        static_assert(NS % (PF + 1) == 0, "the buffer rotation continues across tiles");
+        static_assert(!SRPS_LIGHT_XTILE || NS % (PF + 1) == 0, "the buffer rotation continues across tiles");
         Vec<4> ivb[PF + 1][IBW];
         auto pieces_of = [&](int t0) { return __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8)); };      // wave-uniform: the range's last tile may be short
         auto issue = [&](int k, Vec<4> (&buf)[IBW], int t0) {
@@ -571,10 +571,14 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
             // the albedo sweep, whose block reads 4 KiB runs, draws 6.1 TB/s.)
             const int npieces = __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8));      // wave-uniform: the range's last tile may be short
             if constexpr (RUN) {
-                constexpr int NSR = NCH * IBW;                           // the wave's planes, one step each: k = ii * NCH + c
+                // Channel by channel: the products rho_c N_k of the tile's four pieces are formed once per channel and kept in registers
+                // (64; the lighting vectors stay in LDS, which is what makes room for them), then the wave's IBW planes of that channel
+                // follow, each as one 4 KiB run (four loads back to back), the next plane's run requested before this one's arithmetic.
+                // Per (plane, piece) only the residual's three factors are re-read from LDS.
+                constexpr int NSR = NCH * IBW;                           // steps: k = c * IBW + ii
                 Vec<4> ivr[2][4];
                 auto issue_run = [&](int k, Vec<4> (&buf)[4]) {
-                    const int ii = k / NCH, c = k - ii * NCH;
+                    const int c = k / IBW, ii = k - c * IBW;
                     const size_t row = (size_t)min(ib + ii, n_img - 1) * C + c;      // images past the end re-read the last one
 #pragma unroll
                     for (int sub = 0; sub < 4; ++sub) {
@@ -583,11 +587,44 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                     }
                 };
                 issue_run(0, ivr[0]);
+                float a[4][4][4];                                        // [piece][k][pixel of the lane's four]
+                float rr[4][4];                                          // rho_c of the four pieces
 #pragma unroll
                 for (int k = 0; k < NSR; ++k) {
-                    const int ii = k / NCH, c = k % NCH;
+                    const int c = k / IBW, ii = k % IBW;
                     if (k + 1 < NSR) issue_run(k + 1, ivr[(k + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);                   // the next plane's loads go out before this plane's arithmetic
+                    if (ii == 0) {                                       // a new channel: its products
+#pragma unroll
+                        for (int sub = 0; sub < 4; ++sub) {
+                            const int li = sub * 64 + lane;
+                            const float4 n0 = geo[0][li], n1 = geo[1][li], n2 = geo[2][li], rq = geo[3 + c][li];
+                            const float nk0[4] = {n0.x, n0.y, n0.z, n0.w}, nk1[4] = {n1.x, n1.y, n1.z, n1.w}, nk2[4] = {n2.x, n2.y, n2.z, n2.w};
+                            const float r4[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                rr[sub][e] = r4[e];
+                                a[sub][0][e] = r4[e] * nk0[e]; a[sub][1][e] = r4[e] * nk1[e]; a[sub][2][e] = r4[e] * nk2[e];       // dc.cu:381
+                                a[sub][3][e] = r4[e] * 1.f;
+                            }
+                        }
+                        if (c == gram_c) {                               // wave-uniform: the Gram matrix of this channel, once per pixel
+#pragma unroll
+                            for (int sub = 0; sub < 4; ++sub) {
+                                if (sub < npieces) {
+                                    int t = 0;
+#pragma unroll
+                                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                                        for (int l = kk; l < 4; ++l) {
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) g[t] = fmaf(a[sub][kk][e], a[sub][l][e], g[t]);
+                                            ++t;
+                                        }
+                                }
+                            }
+                        }
+                    }
                     Vec<4> (&iv)[4] = ivr[k & 1];
                     const float4 sv = svs[grp][c * IBW + ii];             // one LDS broadcast per plane
 #pragma unroll
@@ -600,22 +637,10 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) iv[sub].v[e] = (q < p1) ? iv[sub].v[e] : 0.f;
                             }
-                            float4 nkq[3];
-#pragma unroll
-                            for (int kk = 0; kk < 3; ++kk) nkq[kk] = geo[kk][li];
-                            const float (*nk)[4] = reinterpret_cast<const float (*)[4]>(nkq);
-                            const float4 rq = geo[3 + c][li];
-                            const float r[4] = {rq.x, rq.y, rq.z, rq.w};
-                            float a[4][4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                a[0][e] = r[e] * nk[0][e]; a[1][e] = r[e] * nk[1][e]; a[2][e] = r[e] * nk[2][e];       // dc.cu:381
-                                a[3][e] = r[e] * 1.f;
-                            }
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                                for (int kk = 0; kk < 4; ++kk) acc[c][ii][kk] = fmaf(a[kk][e], iv[sub].v[e], acc[c][ii][kk]);
+                                for (int kk = 0; kk < 4; ++kk) acc[c][ii][kk] = fmaf(a[sub][kk][e], iv[sub].v[e], acc[c][ii][kk]);
                             if (!TAIL || ib + ii < n_img) {               // wave-uniform
                                 float4 Eq[3];
 #pragma unroll
@@ -623,20 +648,9 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                                 const float (*E)[4] = reinterpret_cast<const float (*)[4]>(Eq);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    const float res = fmaf(E[0][e], sv.x, fmaf(E[1][e], sv.y, fmaf(E[2][e], sv.z, fmaf(r[e], sv.w, -iv[sub].v[e]))));
+                                    const float res = fmaf(E[0][e], sv.x, fmaf(E[1][e], sv.y, fmaf(E[2][e], sv.z, fmaf(rr[sub][e], sv.w, -iv[sub].v[e]))));
                                     e_acc = fmaf(res, res, e_acc);
                                 }
-                            }
-                            if (ii == 0 && c == gram_c) {                 // wave-uniform: the Gram matrix once per pixel, beside the wave's first image
-                                int t = 0;
-#pragma unroll
-                                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                                    for (int l = kk; l < 4; ++l) {
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) g[t] = fmaf(a[kk][e], a[l][e], g[t]);
-                                        ++t;
-                                    }
                             }
                         }
                     }

@@ -127,6 +127,9 @@ __device__ __forceinline__ v2f andm2(v2f v, v2i m) { return __builtin_bit_cast(v
 #ifndef SRPS_RES_UNPACKED
 #define SRPS_RES_UNPACKED 0
 #endif
+#ifndef SRPS_RES_ROWEDGE_LDS
+#define SRPS_RES_ROWEDGE_LDS 0       // measured in round 5 (same box, three rounds): 8.08 - 8.14 us per step against 7.81 - 7.83 -- the one store behind the sums' barrier delays the polling wave's loads
+#endif
 struct r2f { float x, y; };
 struct r2i { int x, y; };
 __device__ __forceinline__ r2f operator+(r2f a, r2f b) { return {a.x + b.x, a.y + b.y}; }
@@ -240,6 +243,11 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
     float* sm = reinterpret_cast<float*>(hfl + RING);     // [40]
     int* sflag = reinterpret_cast<int*>(sm + 40);         // [4] block-wide structure summary
     float* ucol = reinterpret_cast<float*>(sflag + 4);    // [2][TR] what the ring columns add to the tile's first / last column
+    // [2][TC] the tile's first / last row of the vector whose edges travel (ROWEDGE_LDS, RECT body): in the half of ucol that only a tile with
+    // backward differences in x writes and reads -- a RECT tile has none (the LDS is full: 512 bytes more than this do not fit beside the
+    // static arrays of the grid-wide sums)
+    float* erow = ucol + TR;
+    constexpr bool ROWEDGE_LDS = SRPS_RES_ROWEDGE_LDS && RECT && 2 * TC <= TR;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -771,11 +779,36 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 store2(d + 2, rc.e[2], rc.e[3]);
                 }
             }
-            if (lane == 0 || lane == 63) {
-                unsigned long long* d = hb + 2 * TR + (lane == 0 ? 0 : TC) + CPT * wave;
+            if constexpr (ROWEDGE_LDS) {
+                // The row edges -- lanes 0 and 63 of every wave, CPT values each -- used to leave as CPT / 2 store instructions per wave with
+                // one or two active lanes each: 32 sparse write-through stores per block in front of the block's sums.  They go to LDS here
+                // (two ds_write_b128 per wave) and out as ONE store instruction of one wave behind the sums' barrier (publish_row_edges).
+                if (lane == 0 || lane == 63) {
+                    float* d = erow + (lane == 0 ? 0 : TC) + CPT * wave;
 #pragma unroll
-                for (int c = 0; c < CPT; c += 2)
-                    store2(d + c, lane == 0 ? src[c].e[0] : src[c].e[3], lane == 0 ? src[c + 1].e[0] : src[c + 1].e[3]);
+                    for (int c = 0; c < CPT; ++c) d[c] = lane == 0 ? src[c].e[0] : src[c].e[3];
+                }
+            } else {
+                if (lane == 0 || lane == 63) {
+                    unsigned long long* d = hb + 2 * TR + (lane == 0 ? 0 : TC) + CPT * wave;
+#pragma unroll
+                    for (int c = 0; c < CPT; c += 2)
+                        store2(d + c, lane == 0 ? src[c].e[0] : src[c].e[3], lane == 0 ? src[c + 1].e[0] : src[c + 1].e[3]);
+                }
+            }
+        };
+        // behind a barrier that follows publish_edges (the one inside the sums' publish): wave 1 -- not the polling wave -- stores the 2 TC
+        // row-edge granules, two per lane, TC lanes: the first-row region and the last-row region of the tile's edge array are adjacent
+        auto publish_row_edges = [&]() {
+            if constexpr (ROWEDGE_LDS) {
+            if (wave == 1 && lane < TC) {
+                unsigned long long* hb = a.halo + ((size_t)tile * 2 + (hgen & 1u)) * HALO_N;
+                const float2 v = reinterpret_cast<const float2*>(erow)[lane];       // values 2 lane, 2 lane + 1 of [first row | last row]
+                const srps_v4u g = {__float_as_uint(v.x), hgen, __float_as_uint(v.y), hgen};
+                unsigned long long* d = hb + 2 * TR + 2 * lane;
+                if constexpr (GROUP) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(d), "v"(g) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(d), "v"(g) : "memory");
+            }
             }
         };
         // the ring values of this generation: requested early (request), waited for late (await)
@@ -824,6 +857,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                     }
                 ++gen;
                 grid_sum_publish(red, a.ent, gen, sm, gp);
+                publish_row_edges();
                 request_ring();
                 r1 = uniform_f((SRPS_RES_DEBUG_ON(a)) ? 1.f : grid_sum_collect(a.ent, gen, sm, gp));
                 r1_anchor = r1;
@@ -833,6 +867,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             } else {
                 ++gen;
                 grid_sum3_publish<NWV, true>(red, red_rw, red_ww, a.ent3, gen, SRPS_STAMP_PTR, gp);
+                publish_row_edges();
                 request_ring();
                 SRPS_STAMP(5);
                 double pw, rw, ww;
@@ -920,6 +955,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             else {
                 ++gen;
                 grid_sum_publish(red, a.ent, gen, sm, gp);
+                publish_row_edges();
                 request_ring();
                 r1 = uniform_f(grid_sum_collect(a.ent, gen, sm, gp));
                 float rv[RPT];

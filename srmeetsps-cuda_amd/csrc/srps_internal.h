@@ -180,7 +180,8 @@ struct srps_ctx {
     int march_nt = 0;                // streaming CG step with non-temporal loads / stores: 0 never (default: measured 15 - 35 % SLOWER at 2304^2 ... 4096^2, tools/march_nt_sweep.sh -- the strips re-read their halo columns, which then miss the L2; stores only, 3: 59.5 -> 65.0 us at 2560^2, 153 -> 165 - 176 at 4096^2 sf 4), 1 always, 2 when its vectors exceed the Infinity Cache, 3 stores only
     int light_bytes = 1;             // the tiled lighting sweep reads the 8-bit image store when the context holds one (round 4)
     bool I_in_ws_images = false;
-    int light_run = 0;               // 1: every wave reads ONE image plane's four pieces back to back (4 KiB runs) -- measured in round 5: 268 - 273 us against 256 - 259 (same box), off
+    int light_run = 1;               // the energy + lighting sweep's waves read ONE image plane's four 1 KiB pieces back to back (4 KiB runs), channel by channel, the
+                                     // channel's products rho N_k of the four pieces in registers (round 5: 0.29 -> 0.257 ms same box); 0: one piece of each of the wave's images
     int light_tiled = 1;             // ... with the four image groups as the waves of one block and the geometry shared through LDS (k_light_fused_tile)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue

@@ -227,17 +227,27 @@ class ThreadCollectives:
             v.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
             return torch.as_tensor(v, device=device)
 
+        # Every rank's copies run on a NON-BLOCKING stream of its own and only that stream is waited for: a device-wide wait (or the
+        # default stream, which waits for the others) inside one rank's collective would wait for the OTHER rank's resident kernel --
+        # launched the moment that rank left the barrier, and itself waiting for this rank's kernel: neither would ever be launched
+        # (seen as a fall-back in one run of three before this was a stream per rank).
+        st = torch.cuda.Stream()
+
         def allreduce(user, d_buf, n, f64):
             try:
-                g = view(d_buf, n, "<f8" if f64 else "<f4")
-                self.slot[rank] = g.cpu()
-                self.bar.wait(timeout=120)
-                tot = self.slot[0].clone()
-                for q in range(1, self.world):
-                    tot += self.slot[q]
-                self.bar.wait(timeout=120)
-                g.copy_(tot)
-                torch.cuda.synchronize()
+                with torch.cuda.stream(st):
+                    g = view(d_buf, n, "<f8" if f64 else "<f4")
+                    h = torch.empty(g.shape, dtype=g.dtype, pin_memory=True)
+                    h.copy_(g, non_blocking=True)
+                    st.synchronize()
+                    self.slot[rank] = h
+                    self.bar.wait(timeout=120)
+                    tot = self.slot[0].clone()
+                    for q in range(1, self.world):
+                        tot += self.slot[q]
+                    self.bar.wait(timeout=120)
+                    g.copy_(tot.pin_memory(), non_blocking=True)
+                    st.synchronize()
                 return 0
             except Exception as exc:                    # a broken barrier ends the other ranks' waits too
                 self.errors.append(repr(exc)); self.bar.abort()
@@ -245,14 +255,18 @@ class ThreadCollectives:
 
         def broadcast(user, d_buf, n, root):
             try:
-                g = view(d_buf, n, "<f4")
-                if rank == root:
-                    self.slot[root] = g.cpu()
-                self.bar.wait(timeout=120)
-                if rank != root:
-                    g.copy_(self.slot[root])
-                    torch.cuda.synchronize()
-                self.bar.wait(timeout=120)
+                with torch.cuda.stream(st):
+                    g = view(d_buf, n, "<f4")
+                    if rank == root:
+                        h = torch.empty(g.shape, dtype=g.dtype, pin_memory=True)
+                        h.copy_(g, non_blocking=True)
+                        st.synchronize()
+                        self.slot[root] = h
+                    self.bar.wait(timeout=120)
+                    if rank != root:
+                        g.copy_(self.slot[root], non_blocking=True)
+                        st.synchronize()
+                    self.bar.wait(timeout=120)
                 return 0
             except Exception as exc:
                 self.errors.append(repr(exc)); self.bar.abort()

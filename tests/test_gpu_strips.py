@@ -403,18 +403,38 @@ def _thread_ranks(pkg, sc, world, tile, options=None, passes=2):
     out = [dict() for _ in range(world)]
     errs = []
 
+    # The contexts are made here, one after the other: a context creates three streams, the runtime deals streams to its (four) hardware
+    # queues in the order of their creation, and two resident launches that share a hardware queue run one AFTER the other -- never
+    # side by side (seen once with three contexts created concurrently by the rank threads: a fall-back, correct results, but not the
+    # path under test).  On a multi-GPU node every rank has a device, and with it the queues, to itself.
+    import torch
+    torch.cuda.set_device(0)
+    # Each rank's context runs on a stream of a different PRIORITY: the runtime keeps a pool of hardware queues per priority level, so the
+    # ranks' resident launches cannot land in one queue whatever streams the process has made before (streams of one level share four
+    # queues, dealt by use count: in a long test session two contexts' streams did end up in one queue, one run in three).
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    assert world <= 3, "three priority levels"
+    streams = []
+    for prio in (0, -1, 1)[:world]:
+        sh = C.c_void_p()
+        rc = hip.hipStreamCreateWithPriority(C.byref(sh), C.c_uint(1), C.c_int(prio))      # 1 = hipStreamNonBlocking
+        assert rc == 0 and sh.value, rc
+        streams.append(sh)
+    ctxs = [pkg.Context(device_id=0) for _ in range(world)]
+    for rank, ctx in enumerate(ctxs):
+        ctx.set_stream(streams[rank].value)
+        ctx.set_option("cg_resident_tile", tile)
+        ctx.set_option("cg_partition", 2)
+        ctx.set_option("spin_budget_ms", 2000)
+        for k, v in (options or {}).items():
+            ctx.set_option(k, v)
+        tc.bind(pkg, ctx, rank)
+
     def rank_main(rank):
-        ctx = None
+        ctx = ctxs[rank]
         try:
-            import torch
             torch.cuda.set_device(0)
-            ctx = pkg.Context(device_id=0)
-            ctx.set_option("cg_resident_tile", tile)
-            ctx.set_option("cg_partition", 2)
-            ctx.set_option("spin_budget_ms", 2000)
-            for k, v in (options or {}).items():
-                ctx.set_option(k, v)
-            tc.bind(pkg, ctx, rank)
             ctx.setup(pkg.DataHandler.from_scene(sc))
             o = out[rank]
             for it in range(passes):
@@ -429,18 +449,19 @@ def _thread_ranks(pkg, sc, world, tile, options=None, passes=2):
             errs.append((rank, repr(exc)))
             tc.bar.abort()
         finally:
-            if ctx is not None:
-                try:
-                    tc.unbind(pkg, ctx)
-                    ctx.close()
-                except Exception as exc:
-                    errs.append((rank, "close: " + repr(exc)))
+            try:
+                tc.unbind(pkg, ctx)
+                ctx.close()
+            except Exception as exc:
+                errs.append((rank, "close: " + repr(exc)))
     th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
         t.join(600)
     assert not any(t.is_alive() for t in th), "a rank thread hangs"
+    for sh in streams:
+        hip.hipStreamDestroy(sh)
     return out, errs, tc.errors
 
 

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}" || exit 1
 cp srmeetsps-cuda_amd/libsrps_hip.so /tmp/keep.so
 for rep in 1 2 3; do
-  for f in srmeetsps-cuda_amd/variants/*.so; do
+  for f in ${VARIANTS:-srmeetsps-cuda_amd/variants}/*.so; do
     cp "$f" srmeetsps-cuda_amd/libsrps_hip.so
     echo -n "$(basename "$f" .so): "
     timeout 300 python3 tools/pass_time.py 2048 4 20 10 "$@" 2>&1 | grep -v amdgpu.ids | tail -1
