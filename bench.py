@@ -448,22 +448,29 @@ def main():
         # behind the timed passes and before the side legs: behind them (a dozen contexts made and closed, gigabytes allocated and freed, the
         # host's CPU quota spent) the same set-up measured 1.0 - 1.6 ms longer (gpurun_out/r5g: 20.1 ms against 21.1 - 21.7)
         # (= SRPS.cu:100-270: the upload of the images from host memory, compaction, first normals)
-        if dist: dist.barrier()
-        torch.cuda.synchronize()
-        t_setup0 = time.perf_counter()
-        ctx.setup(dh)
-        torch.cuda.synchronize()
-        if dist: dist.barrier()
-        t0 = time.perf_counter()
-        en = solve()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        # Three runs, the MEDIAN reported (all three listed): the set-up is a 1 GB host-to-device transfer fed by host threads under a
+        # CPU quota, and one run in five on these boxes is 6 - 10 ms off (28.0 against 20.4 ms in two back-to-back bench runs, gpurun_out/r5h)
+        runs = []
+        for _ in range(3):
+            if dist: dist.barrier()
+            torch.cuda.synchronize()
+            t_setup0 = time.perf_counter()
+            ctx.setup(dh)
+            torch.cuda.synchronize()
+            if dist: dist.barrier()
+            t0 = time.perf_counter()
+            en = solve()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            runs.append({"total_solve_s": t1 - t0, "total_solve_with_setup_s": t1 - t_setup0, "setup_s": t0 - t_setup0, "outer_iterations": len(en)})
         if rank == 0:
-            out["total_solve_s"] = t1 - t0
-            out["total_solve_with_setup_s"] = t1 - t_setup0
-            out["setup_s"] = t0 - t_setup0
+            mid = sorted(runs, key=lambda r: r["total_solve_with_setup_s"])[1]
+            out["total_solve_s"] = mid["total_solve_s"]
+            out["total_solve_with_setup_s"] = mid["total_solve_with_setup_s"]
+            out["setup_s"] = mid["setup_s"]
             out["setup_host_bytes"] = int(dh.I.nbytes)
-            out["total_solve_outer_iterations"] = len(en)
+            out["total_solve_outer_iterations"] = mid["outer_iterations"]
+            out["total_solve_runs"] = {"reported": "the median of three by total_solve_with_setup_s", "runs": runs}
     # the isolated CG loop: with the depth CG partitioned over the ranks (strips) a solve is a collective -- every rank takes part, rank 0 reports
     cg_collective = world > 1 and (ctx.get_option("cg_partition_active") == 1 or ctx.get_option("cg_partition_resident_active") == 1)
     if rank == 0 or cg_collective:

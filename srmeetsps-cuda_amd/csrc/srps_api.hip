@@ -163,7 +163,9 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     // it means hipFree, which waits for the device, i.e. for the whole DMA (round-3 advisor finding).  So an arena that exists and is
     // smaller than what a FULL-frame mask of this h x w would need is replaced now, before the copies are queued; the exact size
     // below can then only be smaller (a plan with more partial sums than the full frame's is the one exception and still grows it).
-    if (G.arena) {
+    // (also for the context's FIRST grid: an arena made to the exact size was replaced by the bound in the second set-up -- a hipFree and
+    // a hipMalloc of 300 MB, 5 ms, in exactly the set-up bench.py times)
+    {
         Grid ub;
         ub.h = h; ub.w = w; ub.sf = sf; ub.Hg = h; ub.Wg = w; ub.P = (int)hw; ub.Ps = (int)(hw / ((size_t)sf * sf));
         ub.Hs = ((ub.Hg + 2 * PAD + 31) / 32) * 32; ub.Ws = ub.Wg + 512 + 2 * PAD; ub.plane = (size_t)ub.Hs * ub.Ws;
@@ -176,7 +178,7 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
             for (int shape = 0; shape < 3; ++shape) ub.n_tiles[shape] = cdiv(ub.Hg, 256) * cdiv(ub.Wg, shape == 0 ? 32 : shape == 1 ? 64 : 16);
             const size_t need_ub = grid_arena_bytes(ub);
             if (G.arena_bytes < need_ub) {
-                SRPS_HIP(hipFree(G.arena));
+                if (G.arena) SRPS_HIP(hipFree(G.arena));
                 G.arena = nullptr; G.arena_bytes = 0;
                 SRPS_HIP(hipMalloc(&G.arena, need_ub));
                 G.arena_bytes = need_ub;

@@ -135,12 +135,12 @@ int cpu_budget() {
     return n;
 }
 
-// filling threads of a large upload: half of what the process may use (the other half is the caller's: its own threads, the runtime's),
-// eight at most -- same-box sweep on 1 GB: 8 threads 20.6 ms, 16 threads 21.0, 32 threads 23 - 38.  SRPS_XFER_THREADS overrides
-// (development: tools/setup_time.py sweeps it)
+// filling threads of a large upload: a quarter of what the process may use (the rest is the caller's: its own threads, the runtime's),
+// two to eight -- same-box sweeps on 1 GB: 4 threads 19.8 - 20.2 ms and 99 ms of CPU time per set-up, 8 threads 19.8 - 20.2 ms and 171 ms,
+// 16 threads 21.0, 32 threads 23 - 38 (throttled by the CPU quota).  SRPS_XFER_THREADS overrides (development: tools/setup_time.py)
 int copy_threads(size_t bytes) {
     if (bytes < kBig / 2) return 0;            // below 8 MB the calling thread copies by itself (upload_small)
-    int t = std::max(2, std::min(cpu_budget() / 2, 8));
+    int t = std::max(2, std::min(cpu_budget() / 4, 8));
     if (bytes < 4 * kBig) t = std::min(t, 4);  // the mask, a depth map: a few threads for 1 ms of copying
     t = env_int("SRPS_XFER_THREADS", t);
     return std::max(1, std::min(t, kMaxThreads));

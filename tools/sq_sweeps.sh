@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/r04f; mkdir -p $OUT
+OUT=$R/gpurun_out/${1:-r04f}; mkdir -p $OUT      # bash tools/r04_sq.sh <output directory under gpurun_out>
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sq1 -- python3 $R/tools/pass_prof.py 2048 4 20 3 > $OUT/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq2 -- python3 $R/tools/pass_prof.py 2048 4 20 3 > $OUT/sq2.log 2>&1
