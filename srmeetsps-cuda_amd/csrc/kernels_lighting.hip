@@ -438,16 +438,22 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
 #ifndef SRPS_LIGHT_PREFETCH
 #define SRPS_LIGHT_PREFETCH 1
 #endif
+#ifndef SRPS_LIGHT_RUN_DEPTH
+#define SRPS_LIGHT_RUN_DEPTH 2
+#endif
 #ifndef SRPS_LIGHT_XTILE
 #define SRPS_LIGHT_XTILE 0
 #endif
 // TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
 // U8: the images from the context's 8-bit store (bytes, k / 255.f formed in registers: device_utils.h unit_from_byte -- the same floats);
 // the sweep's vector pipes are a third busy, the bytes are a quarter of the floats.
-// RUN (round 5): a wave takes the tile's four 1 KiB pieces of ONE (image, channel) plane back to back -- a 4 KiB run, the albedo sweep's
-// access shape -- instead of one piece of each of its IBW images.  What kept round 4 from it were the products rho N_k of four pieces
-// held in registers per channel (hipcc spilled); here nothing per piece is held: every (plane, piece) step re-reads the piece's seven
-// LDS planes (28 KiB of LDS reads per 4 KiB of image: the LDS has the bandwidth) and re-forms the 16 products.
+// RUN (round 5, option "light_run", the default): a wave takes the tile's four 1 KiB pieces of ONE (image, channel) plane back to back -- a
+// 4 KiB run, the albedo sweep's access shape -- instead of one piece of each of its IBW images.  It goes channel by channel: the
+// channel's products rho_c N_k of the four pieces are formed once and kept in registers (64; the lighting vectors are read from LDS,
+// which is what makes the room), then its IBW planes of that channel follow, the next plane's run requested before this one's
+// arithmetic; per (plane, piece) only the residual's three factors are re-read from LDS.  Same-box A/B at 2048^2 x 20 float images:
+// 0.287 - 0.298 -> 0.244 - 0.265 ms.  (A first form that held nothing per piece -- seven LDS planes re-read and the products re-formed for
+// every (plane, piece) -- was 4 % SLOWER than the non-RUN form: profiles/r05_ab_lighting_sweep.jsonl.)
 template <int IBW, int NCH, bool TAIL, bool TM = false, bool U8 = false, bool RUN = false>
 __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img,
                                                             int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
@@ -576,7 +582,8 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                 // follow, each as one 4 KiB run (four loads back to back), the next plane's run requested before this one's arithmetic.
                 // Per (plane, piece) only the residual's three factors are re-read from LDS.
                 constexpr int NSR = NCH * IBW;                           // steps: k = c * IBW + ii
-                Vec<4> ivr[2][4];
+                constexpr int RD = SRPS_LIGHT_RUN_DEPTH;                 // planes in flight ahead of the one being consumed, + 1
+                Vec<4> ivr[RD][4];
                 auto issue_run = [&](int k, Vec<4> (&buf)[4]) {
                     const int c = k / IBW, ii = k - c * IBW;
                     const size_t row = (size_t)min(ib + ii, n_img - 1) * C + c;      // images past the end re-read the last one
@@ -586,14 +593,15 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                         buf[sub] = ld_img<4, U8, TM>(I, I8, row, P, q < p1 ? q : p1 - 4, n_img * C);
                     }
                 };
-                issue_run(0, ivr[0]);
-                float a[4][4][4];                                        // [piece][k][pixel of the lane's four]
-                float rr[4][4];                                          // rho_c of the four pieces
+#pragma unroll
+                for (int k = 0; k < RD - 1; ++k)
+                    if (k < NSR) issue_run(k, ivr[k % RD]);
+                float a[4][4][4];                                        // [piece][k][pixel of the lane's four]; a[.][3] = rho_c itself (N3 == 1, dc.cu:175)
 #pragma unroll
                 for (int k = 0; k < NSR; ++k) {
                     const int c = k / IBW, ii = k % IBW;
-                    if (k + 1 < NSR) issue_run(k + 1, ivr[(k + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);                   // the next plane's loads go out before this plane's arithmetic
+                    if (k + RD - 1 < NSR) issue_run(k + RD - 1, ivr[(k + RD - 1) % RD]);
+                    __builtin_amdgcn_sched_barrier(0);                   // the look-ahead plane's loads go out before this plane's arithmetic
                     if (ii == 0) {                                       // a new channel: its products
 #pragma unroll
                         for (int sub = 0; sub < 4; ++sub) {
@@ -603,7 +611,6 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                             const float r4[4] = {rq.x, rq.y, rq.z, rq.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                rr[sub][e] = r4[e];
                                 a[sub][0][e] = r4[e] * nk0[e]; a[sub][1][e] = r4[e] * nk1[e]; a[sub][2][e] = r4[e] * nk2[e];       // dc.cu:381
                                 a[sub][3][e] = r4[e] * 1.f;
                             }
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                             }
                         }
                     }
-                    Vec<4> (&iv)[4] = ivr[k & 1];
+                    Vec<4> (&iv)[4] = ivr[k % RD];
                     const float4 sv = svs[grp][c * IBW + ii];             // one LDS broadcast per plane
 #pragma unroll
                     for (int sub = 0; sub < 4; ++sub) {
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                                 const float (*E)[4] = reinterpret_cast<const float (*)[4]>(Eq);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    const float res = fmaf(E[0][e], sv.x, fmaf(E[1][e], sv.y, fmaf(E[2][e], sv.z, fmaf(rr[sub][e], sv.w, -iv[sub].v[e]))));
+                                    const float res = fmaf(E[0][e], sv.x, fmaf(E[1][e], sv.y, fmaf(E[2][e], sv.z, fmaf(a[sub][3][e], sv.w, -iv[sub].v[e]))));
                                     e_acc = fmaf(res, res, e_acc);
                                 }
                             }
