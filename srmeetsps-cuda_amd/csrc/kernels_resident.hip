@@ -127,6 +127,9 @@ __device__ __forceinline__ v2f andm2(v2f v, v2i m) { return __builtin_bit_cast(v
 #ifndef SRPS_RES_UNPACKED
 #define SRPS_RES_UNPACKED 0
 #endif
+#ifndef SRPS_RES_EARLY_EDGES
+#define SRPS_RES_EARLY_EDGES 0        // measured in round 5 (same box, three rounds): 7.94 - 7.96 us per step against 7.77 - 7.80 with the burst behind the loop (general body 9.87 - 9.93 / 9.73 - 9.78)
+#endif
 #ifndef SRPS_RES_ROWEDGE_LDS
 #define SRPS_RES_ROWEDGE_LDS 0       // measured in round 5 (same box, three rounds): 8.08 - 8.14 us per step against 7.81 - 7.83 -- the one store behind the sums' barrier delays the polling wave's loads
 #endif
@@ -736,8 +739,18 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         unsigned flk[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) { flk[c] = fl[c]; if (!RECT) asm volatile("" : "+v"(flk[c])); }
+        const unsigned hgen = (unsigned)k + 1u;           // edge generation: k + 1 (0 means "never written"), slot (k + 1) & 1
+        // EARLY_EDGES (one-wait form, single launch): the edge granules of omega leave column by column, as soon as a column's final values
+        // exist, between the multiply-adds of the columns that follow -- not as a burst of six store instructions per wave behind the
+        // loop (0.45 us of the chain between "finalize done" and the block's sums, profiles/r05_resident_stamps.txt)
+        constexpr bool EARLY_EDGES = SRPS_RES_EARLY_EDGES && ONE_SYNC && !GROUP;
+        unsigned long long* const hb_e = a.halo + ((size_t)tile * 2 + (hgen & 1u)) * HALO_N;
+        auto store2_e = [&](unsigned long long* d, float v0, float v1) {
+            const srps_v4u g = {__float_as_uint(v0), hgen, __float_as_uint(v1), hgen};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(d), "v"(g) : "memory");
+        };
 #pragma unroll
-        for (int c = 0; c < CPT; ++c)
+        for (int c = 0; c < CPT; ++c) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float s = ((SF == 4) ? ksum[c / 4] : S[c].e[e]) * inv_sf4_v;
@@ -746,7 +759,21 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
                 red = fmaf(p[c].e[e], w[c].e[e], red);
                 if (ONE_SYNC) { red_rw = fmaf(r[c].e[e], w[c].e[e], red_rw); red_ww = fmaf(w[c].e[e], w[c].e[e], red_ww); }
             }
-        const unsigned hgen = (unsigned)k + 1u;           // edge generation: k + 1 (0 means "never written"), slot (k + 1) & 1
+            if constexpr (EARLY_EDGES) {
+                if (c == 0 && wave == 0) {                           // the tile's first column
+                    unsigned long long* d = hb_e + 4 * lane;
+                    store2_e(d, w[0].e[0], w[0].e[1]); store2_e(d + 2, w[0].e[2], w[0].e[3]);
+                }
+                if (c == CPT - 1 && wave == NWV - 1) {               // its last column
+                    unsigned long long* d = hb_e + TR + 4 * lane;
+                    store2_e(d, w[CPT - 1].e[0], w[CPT - 1].e[1]); store2_e(d + 2, w[CPT - 1].e[2], w[CPT - 1].e[3]);
+                }
+                if ((c & 1) && (lane == 0 || lane == 63)) {          // first / last row, two columns per store
+                    unsigned long long* d = hb_e + 2 * TR + (lane == 0 ? 0 : TC) + CPT * wave + (c - 1);
+                    store2_e(d, lane == 0 ? w[c - 1 >= 0 ? c - 1 : 0].e[0] : w[c - 1 >= 0 ? c - 1 : 0].e[3], lane == 0 ? w[c].e[0] : w[c].e[3]);
+                }
+            }
+        }
         // the tile's edges of `src` as generation-tagged granules
         auto publish_edges = [&](const F4 (&src)[CPT]) {
             // two granules {value, generation} per 16-byte store (each granule is read on its own, as 8 bytes): half the store
@@ -843,7 +870,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
             // the right are reduced together with p.omega (float per thread and wave, double from there on).  Guard: when
             // that difference cancels more than two digits the direct sum is taken (one more wait, rare).
             SRPS_STAMP(4);
-            publish_edges(w);
+            if constexpr (!EARLY_EDGES) publish_edges(w);
             SRPS_STAMP(11);
             float wr[RPT];
             if (pass0) {
