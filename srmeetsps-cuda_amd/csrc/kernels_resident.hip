@@ -1183,7 +1183,7 @@ int SRPS_RES_NAME(resident_group_launch)(srps_ctx* ctx, const ResidentGroupSpec&
     if (sp.blocks == 0) {      // a strip without a masked pixel launches nothing: its report record says what the others' kernels say of a full solve
         SRPS_HIP(hipMemsetAsync(G.d_scal, 0, 5 * sizeof(int), ctx->stream));
         const int steps = sp.max_steps;
-        SRPS_HIP(hipMemcpyAsync(&G.d_scal->iters, &steps, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        SRPS_TRY(host_upload(ctx, &G.d_scal->iters, &steps, sizeof(int), ctx->stream));
         return SRPS_OK;
     }
     const void* fn = nullptr;

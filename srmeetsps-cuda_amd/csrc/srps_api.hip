@@ -263,20 +263,20 @@ static int build_grid(srps_ctx* ctx, int h, int w, int sf, const float* mask, co
     std::vector<int> h_list[3];
     for (int shape = 0; shape < 3; ++shape) {
         h_cls[shape].resize((size_t)G.n_tiles[shape]);
-        SRPS_HIP(hipMemcpyAsync(h_cls[shape].data(), G.d_tile_cls[shape], (size_t)G.n_tiles[shape], hipMemcpyDeviceToHost, ax));
+        // (library-side vectors are host arrays like a caller's: through the pinned path, which returns when they hold the data)
+        SRPS_TRY(host_download(ctx, h_cls[shape].data(), G.d_tile_cls[shape], (size_t)G.n_tiles[shape], ax));
     }
-    SRPS_HIP(hipStreamSynchronize(ax));
     for (int shape = 0; shape < 3; ++shape) {
         G.n_rect_tiles[shape] = hrect[shape];
         for (int t = 0; t < G.n_tiles[shape]; ++t)
             if (h_cls[shape][t] & TILE_OCCUPIED) h_list[shape].push_back(t);
         G.n_occ[shape] = (int)h_list[shape].size();
         G.h_tile_list[shape] = h_list[shape];                 // the resident strips cut these lists into ranges of tile columns
-        if (G.n_occ[shape]) SRPS_HIP(hipMemcpyAsync(G.d_tile_list[shape], h_list[shape].data(), (size_t)G.n_occ[shape] * sizeof(int), hipMemcpyHostToDevice, ax));
+        if (G.n_occ[shape]) SRPS_TRY(host_upload(ctx, G.d_tile_list[shape], h_list[shape].data(), (size_t)G.n_occ[shape] * sizeof(int), ax));
     }
     SRPS_HIP(hipEventRecord(ctx->aux_event, ax));
     SRPS_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
-    SRPS_HIP(hipStreamSynchronize(ax));                    // the host vectors go out of scope
+    SRPS_HIP(hipStreamSynchronize(ax));
     ctx->x_swapped = false;
     G.bound = true;
     ctx->tensor_valid = false;
@@ -824,8 +824,7 @@ static int image_store_prepare(srps_ctx* ctx) {
     int inexact = 0;
     SRPS_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
     SRPS_TRY(launch_pack_bytes(ctx->stream, ctx->I, n, nullptr, flag));
-    SRPS_HIP(hipMemcpyAsync(&inexact, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    SRPS_TRY(host_download(ctx, &inexact, flag, sizeof(int), ctx->stream));
     if (inexact) return SRPS_OK;
     if (!ctx->I8_cap_ok(n)) {
         if (ctx->I8) { SRPS_HIP(hipFree(ctx->I8)); ctx->I8 = nullptr; }
@@ -1540,8 +1539,7 @@ static int sharded_ranges_tile(srps_ctx* ctx) {
     SRPS_LAUNCH_CHECK();
     SRPS_TRY(comm_all_reduce_sum(ctx, cover, (size_t)n));
     std::vector<float> h((size_t)n);
-    SRPS_HIP(hipMemcpyAsync(h.data(), cover, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    SRPS_HIP(hipStreamSynchronize(ctx->stream));
+    SRPS_TRY(host_download(ctx, h.data(), cover, (size_t)n * sizeof(float), ctx->stream));
     for (int i = 0; i < n; ++i)
         SRPS_REQUIRE(h[i] == 1.f, SRPS_ERR_INVALID,
                      "execute_sharded: image %d of %d is held by %d ranks (this rank %d of %d holds [%d, %d)): the ranks' image ranges must tile the image set",

@@ -184,3 +184,26 @@ def test_numpy_and_c_oracle_agree_on_the_mitten_crop(oracle, CO):
         assert it == 101
         assert np.sqrt(np.mean((z_c.astype(np.float64) - z_np) ** 2)) / scale < 1e-4
         assert abs(e_c - e_np) <= 1e-3 * abs(e_np)
+
+
+def test_cpu_budget_and_the_baseline_entry_point():
+    """oracle/cpu_budget.py (the CPUs the process may really use: affinity and cgroup quota) and the C oracle's timing entry point behind
+    bench.py's cpu_baseline leg (oc_bench_cg_csr: own first-touched copies, a warm-up, `reps` timed solves on `threads` threads)"""
+    import os
+    import cpu_budget
+    import c_oracle as CO
+    n = cpu_budget.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert CO._EFF >= 1
+    st = CO.Structure(32, 24, 2, np.ones(32 * 24, np.float32))
+    rng = np.random.default_rng(1)
+    M = np.abs(rng.normal(size=(6, st.P))).astype(np.float32); M[[1, 2, 4]] *= 0.1
+    rp, ci, v = CO.assemble(st, M.reshape(-1))
+    b = rng.normal(size=st.P).astype(np.float32)
+    sec = CO.bench_cg_csr(rp, ci, v, b, iters=5, reps=3, threads=1)
+    assert sec.shape == (3,) and (sec > 0).all()
+    assert CO.num_threads() <= max(CO._EFF, 1)                      # the team is bounded again after the call
+    # the timed recurrence is the oracle's CG: the same five steps through the ordinary entry point give the same iterate as a second call
+    x1 = np.zeros(st.P, np.float32); x2 = np.zeros(st.P, np.float32)
+    CO.cg_csr(rp, ci, v, x1, b.copy(), fixed_iters=5); CO.cg_csr(rp, ci, v, x2, b.copy(), fixed_iters=5)
+    np.testing.assert_array_equal(x1, x2)
