@@ -978,6 +978,7 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
 #define SRPS_LT_ARGS dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea
 #define SRPS_LT(BB, CC) do { if (d_I8 && ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true, true>), SRPS_LT_ARGS); \
                              else if (d_I8) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true>), SRPS_LT_ARGS); \
+                             else if (d_It && ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true, false, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
                              else if (d_It) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
                              else if (ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false, true>), SRPS_LT_ARGS); \
                              else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false>), SRPS_LT_ARGS); } while (0)
