@@ -188,6 +188,9 @@ struct ResidentArgs {
     float cx, cy;
     int i_lo, j_lo;
     int debug;                 // timing experiments only: 1 = no grid-wide sums, no ring polls (wrong results)
+    unsigned gen_base;         // every generation tag of this launch lies above it (a multiple of 1024: slot parities are unchanged).  The single launch
+                               // numbers its launches, so that granules left by EARLIER launches never carry a tag this one waits for and the arrays need
+                               // no zeroing per solve (5.4 us + a launch per pass); 0 with freshly zeroed arrays (the group / rank launches)
     unsigned long long spin_ticks;   // budget of the whole launch in s_memrealtime ticks (10 ns): waits give up after it
     const uint8_t* tile_cls;   // [tiles] TILE_* bits per tile (kernels_structure.hip), nullptr: every tile takes the general body
     const uint8_t* tile_occ;   // [tiles] the same array, always: TILE_OCCUPIED says whether a neighbouring tile has a block at all
@@ -421,7 +424,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
 
     // num_records in bytes as an int: the host refuses planes of 2 GiB and more before the launch (resident_cg)
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G + (size_t)(NC - 1) * pl), 0, (int)(pl * sizeof(float)), 0x00020000);
-    unsigned gen = 0;                                      // reduction generation (entries zeroed: first is 1)
+    unsigned gen = a.gen_base;                             // reduction generation (first is base + 1; no granule of the arrays carries a tag above the base)
     float r1 = 0.f, r0 = 0.f, alpha = 0.f, r1_anchor = 0.f;
     int k = 0;
     // Pass 0 forms the residual r = b - A_ x0 (devicecalls.cu:758) with the same operator code: p := x, then r -= omega.
@@ -739,7 +742,7 @@ __device__ __forceinline__ void resident_body(const ResidentArgs& a, const int t
         unsigned flk[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) { flk[c] = fl[c]; if (!RECT) asm volatile("" : "+v"(flk[c])); }
-        const unsigned hgen = (unsigned)k + 1u;           // edge generation: k + 1 (0 means "never written"), slot (k + 1) & 1
+        const unsigned hgen = a.gen_base + (unsigned)k + 1u;      // edge generation: base + k + 1 (never a tag an earlier launch left), slot (k + 1) & 1
         // EARLY_EDGES (one-wait form, single launch): the edge granules of omega leave column by column, as soon as a column's final values
         // exist, between the multiply-adds of the columns that follow -- not as a burst of six store instructions per wave behind the
         // loop (0.45 us of the chain between "finalize done" and the block's sums, profiles/r05_resident_stamps.txt)
@@ -1104,7 +1107,16 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const size_t ent_n = ((size_t)tiles * 2 + 1) & ~(size_t)1, ent3_n = (size_t)((tiles + 255) & ~255) * 2 * SRPS_G3_REPLICAS * (SRPS_G3_STRIDE / 8);
     const size_t need = (ent_n + ent3_n + (size_t)tiles * 2 * HALO_N) * sizeof(unsigned long long);
     SRPS_TRY(ensure(ctx->ws_resident, need));
-    SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, need, ctx->stream));
+    // The granule arrays are zeroed when they are new, when another driver has used them (the strip groups number from zero) and when the
+    // launch numbers run out; otherwise this launch's tags lie above every tag in them (gen_base) and nothing is zeroed: a tag is
+    // compared for EQUALITY with the generation a block waits for, and a launch uses fewer than 1024 generations (pass 0 + 101 steps +
+    // the direct sums of the one-wait form; two waits per step: 2 x 102).
+    if (ctx->res_tags_ptr != ctx->ws_resident.p || ctx->res_tags_bytes < need || ctx->res_launch_seq + (unsigned)((2 * ((long long)max_steps + 2) + 16 + 1023) >> 10) >= (1u << 21)) {
+        SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, ctx->ws_resident.bytes, ctx->stream));
+        ctx->res_tags_ptr = ctx->ws_resident.p; ctx->res_tags_bytes = ctx->ws_resident.bytes; ctx->res_launch_seq = 0;
+    }
+    const unsigned gen_base = ctx->res_launch_seq << 10;
+    ctx->res_launch_seq += (unsigned)((2 * ((long long)max_steps + 2) + 16 + 1023) >> 10);      // the tags this launch may use, in units of 1024 (option "cg_max_iter" can ask for many steps)
     // the kernel addresses the streamed g plane through a buffer descriptor whose num_records is an int of BYTES
     SRPS_REQUIRE((unsigned long long)G.plane * sizeof(float) < (1ull << 31), SRPS_ERR_UNSUPPORTED,
                  "resident CG: a plane of %zu floats does not fit the kernel's buffer descriptor (2 GiB)", (size_t)G.plane);
@@ -1122,6 +1134,7 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     a.max_steps = max_steps;
     a.cx = G.cx; a.cy = G.cy; a.i_lo = G.i_lo; a.j_lo = G.j_lo;
     a.debug = ctx->cg_resident_debug;
+    a.gen_base = gen_base;
     a.spin_ticks = (unsigned long long)ctx->spin_budget_ms * 100000ull;      // s_memrealtime: 100 MHz
     const int shape = TC == 64 ? 1 : (TC == 32 ? 0 : 2);      // index of the tiling in Grid::d_tile_cls
     const int blocks = G.n_occ[shape];
@@ -1340,6 +1353,7 @@ int resident_cg_group(srps_ctx* const* ctxs, int n, int max_steps, bool fixed_st
         } else {
             if ((rc = ensure(c->ws_resident, need)) != SRPS_OK) break;
             exch[(size_t)r] = c->ws_resident.p;
+            c->res_tags_ptr = nullptr;                       // the group numbers its generations from zero: the next single launch zeroes the arrays
         }
         if (hipMemsetAsync(exch[(size_t)r], 0, need, c->stream) != hipSuccess || hipEventCreateWithFlags(&ready[(size_t)r], hipEventDisableTiming) != hipSuccess ||
             hipEventRecord(ready[(size_t)r], c->stream) != hipSuccess) { rc = SRPS_ERR_HIP; break; }

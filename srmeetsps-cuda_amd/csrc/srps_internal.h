@@ -233,6 +233,9 @@ struct srps_ctx {
     int cg_fused_step = 1;           // streaming depth CG: the whole step in one launch (kernels_march.hip MODE 3) instead of operator + update
     int cg_resident = 1;             // depth CG as one persistent launch with its state in registers + LDS, when the grid fits
     srps::DevBuf ws_resident;
+    const void* res_tags_ptr = nullptr;      // the granule arrays the single resident launch last used (see resident_cg: launch-numbered generation tags)
+    size_t res_tags_bytes = 0;
+    unsigned res_launch_seq = 0;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
     int shard_range_check = 1;       // srps_execute_sharded verifies (one small all-reduce per call) that the ranks' image ranges tile the image set
     int debug_inject_abort = 0;      // test hook: ABORT_* bits the next persistent_aborts finds, as reported by another rank
