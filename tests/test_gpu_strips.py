@@ -409,18 +409,27 @@ def _thread_ranks(pkg, sc, world, tile, options=None, passes=2):
     # path under test).  On a multi-GPU node every rank has a device, and with it the queues, to itself.
     import torch
     torch.cuda.set_device(0)
-    # Each rank's context runs on a stream of a different PRIORITY: the runtime keeps a pool of hardware queues per priority level, so the
-    # ranks' resident launches cannot land in one queue whatever streams the process has made before (streams of one level share four
-    # queues, dealt by use count: in a long test session two contexts' streams did end up in one queue, one run in three).
+    # Each rank's context runs on a stream that has been SEEN to run side by side with the other ranks' streams: the runtime deals the
+    # streams of a process to a few hardware queues (four per priority level, by use count), and two resident launches in one queue
+    # run one after the other, never side by side -- late in a long session two of three fresh streams did land in one queue, one run
+    # in three.  tools/libcu_holder.so: cu_streams_concurrent spins a one-block kernel on one stream and looks whether a kernel on
+    # the other gets through meanwhile.  Candidates of both priority levels are made until `world` mutually concurrent ones are found.
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
-    assert world <= 3, "three priority levels"
-    streams = []
-    for prio in (0, -1, 1)[:world]:
+    aid = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "libcu_holder.so"))
+    aid.cu_streams_concurrent.argtypes = [C.c_void_p, C.c_void_p]
+    streams, spare = [], []
+    for cand in range(12):
         sh = C.c_void_p()
-        rc = hip.hipStreamCreateWithPriority(C.byref(sh), C.c_uint(1), C.c_int(prio))      # 1 = hipStreamNonBlocking
+        rc = hip.hipStreamCreateWithPriority(C.byref(sh), C.c_uint(1), C.c_int(0 if cand % 2 == 0 else -1))      # 1 = hipStreamNonBlocking
         assert rc == 0 and sh.value, rc
-        streams.append(sh)
+        if all(aid.cu_streams_concurrent(t, sh) == 1 and aid.cu_streams_concurrent(sh, t) == 1 for t in streams):
+            streams.append(sh)
+            if len(streams) == world:
+                break
+        else:
+            spare.append(sh)                                 # kept alive: it holds its queue's use count where it is
+    assert len(streams) == world, f"no {world} streams of this process run side by side ({len(spare)} candidates shared a queue)"
     ctxs = [pkg.Context(device_id=0) for _ in range(world)]
     for rank, ctx in enumerate(ctxs):
         ctx.set_stream(streams[rank].value)
@@ -460,7 +469,7 @@ def _thread_ranks(pkg, sc, world, tile, options=None, passes=2):
     for t in th:
         t.join(600)
     assert not any(t.is_alive() for t in th), "a rank thread hangs"
-    for sh in streams:
+    for sh in streams + spare:
         hip.hipStreamDestroy(sh)
     return out, errs, tc.errors
 

@@ -30,6 +30,36 @@ extern "C" int cu_holder_launch(int blocks, int ms, int lds_kb) {
 }
 extern "C" int cu_holder_wait(void) { return g_stream ? (int)hipStreamSynchronize(g_stream) : 0; }
 
+// Do two streams of this process run side by side?  The runtime deals streams to a few hardware queues (four per priority level, by use
+// count), and kernels of two streams that share a queue run one after the other.  A one-block kernel spins on stream a for 30 ms; a
+// one-block kernel that returns at once follows on stream b: 1 if b's finished while a's was still spinning, 0 if it had to wait, -1 on
+// an error.  (Test aid: ranks of one process on ONE device need streams that pass this, tests/test_gpu_strips.py.)
+__global__ void k_nop(int* out) { if (out == nullptr) __builtin_trap(); }
+extern "C" int cu_streams_concurrent(void* stream_a, void* stream_b) {
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    if (!g_out && hipMalloc(&g_out, 64) != hipSuccess) return -1;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) return -1;
+    (void)hipFuncSetAttribute((const void*)k_hold, hipFuncAttributeMaxDynamicSharedMemorySize, 1024);
+    hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 1024, a, 30ull * 100000ull, g_out);
+    (void)hipEventRecord(ea, a);
+    hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, b, g_out);
+    (void)hipEventRecord(eb, b);
+    int side_by_side = 0;
+    for (;;) {
+        const hipError_t qb = hipEventQuery(eb), qa = hipEventQuery(ea);
+        if (qb == hipSuccess) { side_by_side = (qa == hipErrorNotReady) ? 1 : 0; break; }
+        if (qa == hipSuccess && qb != hipSuccess) {              // a is done, b not yet: b waited behind it (or is just finishing)
+            side_by_side = 0; break;
+        }
+        if ((qa != hipErrorNotReady && qa != hipSuccess) || (qb != hipErrorNotReady && qb != hipSuccess)) { side_by_side = -1; break; }
+    }
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    return side_by_side;
+}
+
 int main(int argc, char** argv) {
     const int blocks = argc > 1 ? atoi(argv[1]) : 64;
     const int ms = argc > 2 ? atoi(argv[2]) : 2000;
