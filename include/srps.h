@@ -256,7 +256,7 @@ typedef struct srps_problem {
 /* replaces: SRPS.cu:100-270 (mask indices, KT/Dx/Dy structure, compaction, s/rho init,
  * meshgrid, first normals).  The host arrays of `prob` are ordinary (pageable) memory and are no longer needed when the call
  * returns.  The device never maps them: they cross PCIe through a pinned buffer of the library's own, filled by a few host
- * threads (option "pin_uploads" = 1 registers the image array in place instead; DESIGN.md §5 says why that is not the default).
+ * threads (option "pin_uploads" = 1 registers the image array in place instead; DESIGN.md §4.5 and docs/HISTORY.md say why that is not the default).
  * The same holds for srps_upload_image, srps_get, srps_set and every other entry point that takes a host pointer.  Every transfer
  * takes a buffer of its own from a process-wide pool (round 5): no lock is held while bytes move, contexts on other threads are
  * never blocked by one context's transfer or wait.  With a full-frame mask and float images the images as they arrive ARE

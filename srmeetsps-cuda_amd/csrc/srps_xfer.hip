@@ -7,7 +7,7 @@
 // while the copy runs.  When the kernel moves those pages meanwhile (numpy asks for transparent huge pages on every array of 4 MB and
 // more; khugepaged then collapses recycled heap pages seconds later), the copy engine faulted on the pool's kernel: "Memory access
 // fault by GPU" at the first 2 MB boundary inside the image array, or inside the mask / depth array of a set-up -- three times in
-// round 4's test runs (tools/stress_upload_thp.py).  A copy through a buffer that cannot move has no such window.
+// round 4's test runs (tools/stress_upload_thp.py, DESIGN.md §4.5, docs/HISTORY.md).  A copy through a buffer that cannot move has no such window.
 //
 // Round 5.  (i) Every transfer takes a buffer of its OWN from a pool (round-4 advisor finding: one buffer behind one mutex, held across
 // waits on work the caller had queued, serialised the set-ups of `srps --gpus N`, made one context's srps_get block every other context,
