@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
 // sweep has num, den and the three image sums in registers anyway; rho = num / den (k_albedo_closed), g = (rho / dz)^2 and the
 // right-hand side q (k_depth_from_sums, the same expressions in the same order: the same bits as the unfused closed form) follow
 // without num, den and the nine sum planes ever being stored -- 250 MB less written, 250 MB less read, two kernels fewer per pass.
+#ifndef SRPS_ALBEDO_UNROLL
+#define SRPS_ALBEDO_UNROLL 4      // image loads in flight per thread (round 5 swept 4 / 5 / 8 / 10: profiles/r05_ab_albedo_sweep.jsonl)
+#endif
 template <int V, bool U8, bool TM = false>
 __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ s, const float* __restrict__ N, const float* __restrict__ I,
                                                       const unsigned char* __restrict__ I8, int P, int n_img, int C, float* __restrict__ rho,
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ 
         Vec<V> nu, de, sa, sap, sb;
 #pragma unroll
         for (int e = 0; e < V; ++e) { nu.v[e] = 0.f; de.v[e] = 0.f; sa.v[e] = 0.f; sap.v[e] = 0.f; sb.v[e] = 0.f; }
-#pragma unroll 4
+#pragma unroll SRPS_ALBEDO_UNROLL
         for (int i = 0; i < n_img; ++i) {                                        // k_albedo_numden<V, true>: the same loop
             const float* sv = s + ((size_t)i * C + c) * 4;
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
