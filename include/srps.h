@@ -146,6 +146,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value);
  * therefore runs as the persistent on-chip kernel), "num_cus", "persistent_fallbacks" (persistent launches that gave up a wait
  * so far), "cg_resident_rect_tiles_16" / "_256" / "_512" (tiles of the bound grid that qualify for the body without structure bits),
  * "cg_resident_rect_active" (1 when all of them do and the next depth CG therefore runs the kernel without structure bits),
+ * "exchange_buffer_fine" (1 when the context's exchange buffer of the resident strips, "cg_partition" = 2, is fine-grained device memory),
  * "image_store_bytes_active" (1 when the context's images are held as bytes and the sweeps read them) */
 int srps_get_option(srps_ctx* ctx, const char* name, int* value);
 

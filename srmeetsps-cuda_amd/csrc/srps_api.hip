@@ -628,6 +628,7 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "march_nt")) *value = ctx->march_nt;
     else if (!strcmp(name, "light_tiled")) *value = ctx->light_tiled;
     else if (!strcmp(name, "light_run")) *value = ctx->light_run;
+    else if (!strcmp(name, "exchange_buffer_fine")) *value = (ctx->xg_buf && ctx->xg_fine) ? 1 : 0;      // the resident strips' exchange buffer is fine-grained memory
     else if (!strcmp(name, "light_bytes")) *value = ctx->light_bytes;
     else if (!strcmp(name, "albedo_persistent")) *value = ctx->albedo_persistent;
     else if (!strcmp(name, "cg_resident")) *value = ctx->cg_resident;

@@ -356,6 +356,7 @@ def _ipc_worker(rank, world, port, h, w, sf, kind, seed, tile, out_dir):
         out[f"z{it}"] = ctx.get("z")
     out["resident"] = ctx.get_option("cg_partition_resident_active"); out["fb"] = ctx.get_option("persistent_fallbacks")
     out["it"] = ctx.last_cg_iterations()["depth"]
+    out["fine"] = ctx.get_option("exchange_buffer_fine")
     assert not hc.errors, hc.errors
     np.savez(os.path.join(out_dir, f"ipc_rank{rank}.npz"), **out)
     dist.barrier()
@@ -387,10 +388,12 @@ def test_resident_strips_between_processes_through_ipc_mapped_buffers(pkg, tmp_p
     for q in range(world):
         r = np.load(tmp_path / f"ipc_rank{q}.npz")
         assert int(r["resident"]) == 1 and int(r["fb"]) == 0 and int(r["it"]) == 101, (int(r["resident"]), int(r["fb"]), int(r["it"]))
+        # the memory kind a multi-GPU job needs (coherent across devices while kernels run) is what is exported and mapped here too
+        assert int(r["fine"]) == 1, "the exchange buffer is not fine-grained memory on this box"
         for it in range(2):
             np.testing.assert_array_equal(r[f"z{it}"], ref[f"z{it}"])
             assert float(r[f"e{it}"]) == ref[f"e{it}"]
-    print(f"{h}x{w} sf {sf} {kind}: {world} processes, resident strips through hipIpc-mapped buffers == the single resident launch")
+    print(f"{h}x{w} sf {sf} {kind}: {world} processes, resident strips through hipIpc-mapped fine-grained buffers == the single resident launch")
 
 
 def _thread_ranks(pkg, sc, world, tile, options=None, passes=2):
