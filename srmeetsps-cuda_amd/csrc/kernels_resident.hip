@@ -1037,7 +1037,11 @@ __global__ __launch_bounds__(NT) void k_cg_resident(ResidentArgs a) {
     int tile = blockIdx.x;
     {
         const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = tile & 7, kk = tile >> 3;
+#ifdef SRPS_RES_REVERSE_KK      // experiment: is a slow block slow because of its CU or because of its tile?
+        tile = xcd * q + min(xcd, rem) + ((q + (xcd < rem ? 1 : 0)) - 1 - kk);
+#else
         tile = xcd * q + min(xcd, rem) + kk;
+#endif
     }
     tile = a.tile_list[tile];                              // one block per occupied tile
     const unsigned cls = RECT ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.tile_cls[tile]) : 0u;

@@ -57,3 +57,16 @@ if t[:, :, 8].any():
     print("last store issue -> median retries-done", (np.median(t10, axis=1) - t8.max(axis=1)).mean(), " -> first", (t10.min(axis=1) - t8.max(axis=1)).mean(), " -> last", (t10.max(axis=1) - t8.max(axis=1)).mean())
     print("spread of store issue (max-min)", (t8.max(axis=1) - t8.min(axis=1)).mean(), "(max-median)", (t8.max(axis=1) - np.median(t8, axis=1)).mean())
 ctx.close()
+# round 5: which blocks are systematically slow?  per-block mean of the compute span (stamps 0 -> 4), the ten slowest and fastest with their
+# XCD (block & 7), tile and the tile's position (row br of 8, column bc of 32 at 2048 x 2048)
+import numpy as _np
+ownm = (t[:, :, 4] - t[:, :, 0]).mean(axis=0)
+order = _np.argsort(ownm)
+def _where(b):
+    nwg = 256; q = nwg >> 3; xcd = b & 7; kk = b >> 3; tile = xcd * q + kk
+    return f"block {b:3d} xcd {xcd} tile {tile:3d} (br {tile % 8}, bc {tile // 8}) {ownm[b]:6.0f} ns"
+print("slowest:", "; ".join(_where(int(b)) for b in order[::-1][:10]))
+print("fastest:", "; ".join(_where(int(b)) for b in order[:10]))
+print("per-XCD mean of the compute span:", [round(float(ownm[_np.arange(256) % 8 == x].mean())) for x in range(8)])
+print("by tile row br:", [round(float(_np.mean([ownm[b] for b in range(256) if (((b & 7) * 32 + (b >> 3)) % 8) == r]))) for r in range(8)])
+print("by tile column bc (groups of 4):", [round(float(_np.mean([ownm[b] for b in range(256) if (((b & 7) * 32 + (b >> 3)) // 8) // 4 == g]))) for g in range(8)])
