@@ -161,3 +161,11 @@ def test_metric_whole_solve_against_the_oracle(pkg, oracle, coracle):
     """2048 x 2048, sf 4, 20 images -- the metric's configuration and bench.py's own scene (seed 1234 + 3): the solve whose
     seconds the bench reports as total_solve_s, to the stop rule, against the oracle"""
     _whole_solve(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 20, seed=1234 + 3, mask_kind="full"), first_pass_tol=6.5e-4)
+
+
+@pytest.mark.timeout(3000)
+def test_ellipse_whole_solve_against_the_oracle(pkg, oracle, coracle):
+    """2048 x 2048, sf 4, 8 images, the elliptical mask of SURVEY 8(d) (semi-axes 0.45 h x 0.45 w, snapped to sf blocks; 2.67 M unknowns):
+    the resident kernel's GENERAL body -- the one every real mask runs (SRPS.cu:29-47: backward differences on the right / lower
+    boundary) -- over a whole solve to the stop rule, against the oracle"""
+    _whole_solve(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 8, seed=1241, mask_kind="ellipse"), first_pass_tol=6.5e-4)
