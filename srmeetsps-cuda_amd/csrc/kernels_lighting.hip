@@ -424,6 +424,52 @@ __global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict_
     if (tid == 0) ea.part_e[blockIdx.x] = t;
 }
 
+// The end of the tiled sweeps (k_light_fused_tile, k_light_fused_mfma): the block's energy partial sum and -- in the last block to arrive --
+// the pass's report record.
+__device__ __forceinline__ void light_tile_finish(float e_acc, const EnergyArgs& ea, float* sme, int blk) {
+    const int tid = threadIdx.x;
+    const float t = block_sum(e_acc, sme);
+    if (!ea.fin.ticket) { if (tid == 0) ea.part_e[blk] = t; return; }
+    // The last block to arrive finishes the report record (ReportFinish, srps_internal.h): both energy terms from their partial sums --
+    // k_final_sum's routine on the same values: the same bits --, then the record into the host's pinned copy and the sequence
+    // number behind it.  Every earlier kernel of the pass has written its part of the record before this kernel started.  No
+    // fences: the partial sum is written through and waited for before the ticket is taken, the last block reads at device scope.
+    __shared__ double smd[4];
+    __shared__ int s_last;
+    if (tid == 0) {
+        st_agent_done(ea.part_e + blk, t);
+        s_last = atomicAdd(ea.fin.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const double t2 = sum_partials_agent(ea.part_e, (int)gridDim.x, smd);
+    const double t1 = sum_partials_agent(ea.fin.t1_part, ea.fin.n_t1, smd);
+    if (tid == 0) { ea.fin.report[0] = (float)t1; ea.fin.report[1] = (float)t2; *ea.fin.ticket = 0u; }
+    if (ea.fin.host_report) {
+        // The record crosses PCIe as write-through stores (sc0 sc1), each waited for by its lane; the sequence word follows behind a
+        // barrier.  What orders them on the way is the fabric's handling of acknowledged stores -- not a release fence (at system scope
+        // that is a write-back of the whole L2 behind 64 MB of freshly stored normals) -- so the host does not take the sequence word's
+        // word for it (round-4 advisor finding): a CHECK word goes out with it, seq ^ (xor of the record's 80 words), and the host accepts
+        // the record only when the words it reads give that check (energy_finish_impl re-reads until they do).
+        __shared__ unsigned s_xor[4];
+        unsigned bits = 0u;
+        if (tid < REPORT_FLOATS) {
+            const float v = tid == 0 ? (float)t1 : tid == 1 ? (float)t2 : ld_agent(ea.fin.report + tid);
+            bits = __float_as_uint(v);
+            st_system_done(ea.fin.host_report + tid, bits);
+        }
+        unsigned x = bits;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x ^= (unsigned)__shfl_xor((int)x, o, 64);
+        if ((tid & 63) == 0) s_xor[tid >> 6] = x;
+        __syncthreads();                                   // the record has left (every lane waited for its store)
+        if (tid == 0) {
+            st_system_done(ea.fin.host_report + REPORT_CHECK_AT, ea.fin.seq ^ s_xor[0] ^ s_xor[1] ^ s_xor[2] ^ s_xor[3]);
+            st_system_done(ea.fin.host_report + REPORT_SEQ_AT, ea.fin.seq);
+        }
+    }
+}
+
 // Round 4: the same sweep with the geometry read ONCE per pixel.  The four image groups of a pixel range are the four WAVES of one
 // block instead of four blocks: per tile of 1024 pixels the block's 256 threads load the six geometry planes and the albedo (16 B per
 // lane), form the normal of the new depth once per pixel (perspective_normal: k_normals' instruction sequence), the channel-
@@ -764,46 +810,403 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
             }
         }
     }
-    const float t = block_sum(e_acc, sme);
-    if (!ea.fin.ticket) { if (tid == 0) ea.part_e[blk] = t; return; }
-    // The last block to arrive finishes the report record (ReportFinish, srps_internal.h): both energy terms from their partial sums --
-    // k_final_sum's routine on the same values: the same bits --, then the record into the host's pinned copy and the sequence
-    // number behind it.  Every earlier kernel of the pass has written its part of the record before this kernel started.  No
-    // fences: the partial sum is written through and waited for before the ticket is taken, the last block reads at device scope.
-    __shared__ double smd[4];
-    __shared__ int s_last;
-    if (tid == 0) {
-        st_agent_done(ea.part_e + blk, t);
-        s_last = atomicAdd(ea.fin.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const double t2 = sum_partials_agent(ea.part_e, (int)gridDim.x, smd);
-    const double t1 = sum_partials_agent(ea.fin.t1_part, ea.fin.n_t1, smd);
-    if (tid == 0) { ea.fin.report[0] = (float)t1; ea.fin.report[1] = (float)t2; *ea.fin.ticket = 0u; }
-    if (ea.fin.host_report) {
-        // The record crosses PCIe as write-through stores (sc0 sc1), each waited for by its lane; the sequence word follows behind a
-        // barrier.  What orders them on the way is the fabric's handling of acknowledged stores -- not a release fence (at system scope
-        // that is a write-back of the whole L2 behind 64 MB of freshly stored normals) -- so the host does not take the sequence word's
-        // word for it (round-4 advisor finding): a CHECK word goes out with it, seq ^ (xor of the record's 80 words), and the host accepts
-        // the record only when the words it reads give that check (energy_finish_impl re-reads until they do).
-        __shared__ unsigned s_xor[4];
-        unsigned bits = 0u;
-        if (tid < REPORT_FLOATS) {
-            const float v = tid == 0 ? (float)t1 : tid == 1 ? (float)t2 : ld_agent(ea.fin.report + tid);
-            bits = __float_as_uint(v);
-            st_system_done(ea.fin.host_report + tid, bits);
-        }
-        unsigned x = bits;
+    light_tile_finish(e_acc, ea, sme, blk);
+}
+
+// Round 5, option "light_run" = 2 (not the default -- see the measurement below): the sweep's contraction A'I (dc.cu:408-444: for every
+// image i and channel c the four sums over the pixels of rho_c N_k I_ic) on the MATRIX pipe, the one use north_star reserves it for.
+// v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 outer products D_b += A_b B_b' (tools/mfma4x4_probe.hip: lane 4 b + q supplies A_b[q]
+// and B_b[q]; lane 4 b + j receives D_b[.][j] in its four accumulator registers), exact f32, one rounding per product like the fmaf chain it
+// replaces.  Block b = a slot of pixels, A = the four products rho_c N_k of a pixel, B = that pixel in FOUR images: lane 4 b + q loads pixels
+// 4 (16 t + b) .. + 3 of image 4 G + q, so one load instruction reads 256 consecutive bytes of each of four planes and sixteen of them the
+// tile's 4 KiB of those planes; the lane's product rho_c N_q comes from LDS (N_0..2 and a plane of ones, 64 bytes apart more than a plane so
+// that the sixteen lanes of a read hit sixteen different bank groups) and costs one multiplication, the four multiply-adds per sample of the
+// vector form become one matrix instruction per sample, and -- what the change is about -- a wave keeps FOUR accumulator registers per
+// (channel, four images) instead of the vector form's 64 registers of products and 60 of sums, which leaves room for SRPS_LIGHT_MF_DEPTH loads
+// in flight.  The work of a tile is its 3 x ceil(n / 4) units (channel, group of four images) of sixteen loads; wave g takes units g, g + 4, ...
+// (15 units at 20 images: 4 + 4 + 4 + 3).  The Gram matrices are one more matrix instruction (A = B = the products) in the units of the first
+// group.  The energy's residual stays on the vector pipe, per lane for ITS image: the expression of the other sweeps, other summation order.
+#ifndef SRPS_LIGHT_MF_DEPTH
+#define SRPS_LIGHT_MF_DEPTH 3
+#endif
+#ifndef SRPS_LIGHT_MF_TP
+#define SRPS_LIGHT_MF_TP 1024     // pixels per tile: 1024 (66 KB of LDS, two blocks per CU) or 512 (33 KB, four)
+#endif
+#ifndef SRPS_LIGHT_MF_BPC
+#define SRPS_LIGHT_MF_BPC 2
+#endif
+#ifndef SRPS_LIGHT_MF_GEOPF
+#define SRPS_LIGHT_MF_GEOPF 0
+#endif
+#ifndef SRPS_LIGHT_MFW_GEOPF
+#define SRPS_LIGHT_MFW_GEOPF 0
+#endif
+typedef float srps_f32x4 __attribute__((ext_vector_type(4)));
+// (No branch inside the pipeline of loads: with wave-uniform branches around its steps hipcc 7.2 loses count of the loads in flight -- s_waitcnt
+// vmcnt(0) in front of every load -- and copies the accumulators at every join: 0.40 ms against the vector form's 0.255.  A wave whose last
+// unit does not exist -- 15 units on 4 waves -- runs it all the same on the planes of its first unit (L2 hits, no HBM traffic) and drops the
+// sums; lanes whose image does not exist only feed their own accumulator column, which is never stored.)
+template <bool U8>      // U8: the images from the context's 8-bit store (k / 255.f formed in registers: the same floats)
+__global__ __launch_bounds__(256, SRPS_LIGHT_MF_BPC) void k_light_fused_mfma(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img, int chunk,
+                                                            float* __restrict__ part_atb, float* __restrict__ part_g, EnergyArgs ea) {
+    constexpr int C = 3, TP = SRPS_LIGHT_MF_TP, NE = 4 * C;              // LDS planes: rho_c | E0_c E1_c E2_c
+    constexpr int NKS = TP / 4 + 4;                          // float4 between the planes N_0, N_1, N_2, ones: a plane + 64 bytes
+    constexpr int RI = 20, UPW = 4;                          // images per round; units per wave and round (3 * 5 units on 4 waves)
+    constexpr int SPU = TP / 64;                             // loads of a unit and tile: four planes x 256 bytes each
+    constexpr int D = SRPS_LIGHT_MF_DEPTH, NSTEP = UPW * SPU;
+    __shared__ float4 nkp[4][NKS];
+    __shared__ float4 geo[NE][TP / 4];
+    __shared__ float sme[16];
+    const int tid = threadIdx.x, lane = tid & 63, b = lane >> 2, j = lane & 3;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x;
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    float e_acc = 0.f;
+    if (tid < TP / 4) nkp[3][tid] = make_float4(1.f, 1.f, 1.f, 1.f);           // N_3 == 1 (dc.cu:175); visible behind the tile loop's first barrier
+    for (int b0 = 0; b0 < n_img; b0 += RI) {
+        const int nunits = C * ((min(RI, n_img - b0) + 3) >> 2);
+        size_t ip[UPW];                                      // the lane's image plane of every unit of its wave (its first sample's index)
+        float4 sv[UPW];                                      // its lighting vector
+        bool img_ok[UPW];
+        int cofs[UPW];                                       // the unit's channel as a byte offset between LDS planes (wave-uniform)
+        float e_u[UPW];                                      // the energy of the unit's samples: added at the end where the lane's image exists
+        srps_f32x4 acc[UPW], gram = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x ^= (unsigned)__shfl_xor((int)x, o, 64);
-        if ((tid & 63) == 0) s_xor[tid >> 6] = x;
-        __syncthreads();                                   // the record has left (every lane waited for its store)
-        if (tid == 0) {
-            st_system_done(ea.fin.host_report + REPORT_CHECK_AT, ea.fin.seq ^ s_xor[0] ^ s_xor[1] ^ s_xor[2] ^ s_xor[3]);
-            st_system_done(ea.fin.host_report + REPORT_SEQ_AT, ea.fin.seq);
+        for (int us = 0; us < UPW; ++us) {
+            const int u0 = grp + 4 * us;
+            const int u = u0 < nunits ? u0 : grp;            // a unit that does not exist: the wave's first one again
+            const int G = u / C, c = u - G * C;
+            const int img = b0 + 4 * G + j;
+            img_ok[us] = u0 < nunits && img < n_img;
+            const int imgc = min(img, n_img - 1);            // images past the end re-read the last one; nothing of them is kept
+            ip[us] = ((size_t)imgc * C + c) * (size_t)P;
+            sv[us] = *reinterpret_cast<const float4*>(ea.s + ((size_t)(ea.img_offset + imgc) * C + c) * 4);
+            cofs[us] = __builtin_amdgcn_readfirstlane(c * (TP * 4));
+            acc[us] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
+            e_u[us] = 0.f;
+        }
+        const bool do_gram = b0 == 0 && grp < C;             // wave-uniform: unit 0 of waves 0..2 is (group 0, channel g)
+        // the geometry of a tile is requested while the tile before it is being swept (SRPS_LIGHT_MF_GEOPF): nine loads per lane that
+        // otherwise stand, with their whole latency, between the two barriers of every tile
+        Vec<4> gq[6], gr[C];
+        auto load_geo = [&](int t0n) {
+            const int qn = t0n + tid * 4, qc = qn < p1 ? qn : p1 - 4;      // lanes past the end re-read the last pixels; nothing of them is used
+            gq[0] = ldv<4>(ea.dz + qc); gq[1] = ldv<4>(ea.xx + qc); gq[2] = ldv<4>(ea.yy + qc);
+            gq[3] = ldv<4>(ea.z + qc); gq[4] = ldv<4>(ea.zx + qc); gq[5] = ldv<4>(ea.zy + qc);
+#pragma unroll
+            for (int c = 0; c < C; ++c) gr[c] = ldv<4>(rho + (size_t)c * P + qc);
+        };
+        if (SRPS_LIGHT_MF_GEOPF && p0 < p1) load_geo(p0);
+        for (int t0 = p0; t0 < p1; t0 += TP) {
+            __syncthreads();                                 // the previous tile has been read by every wave
+            if (!SRPS_LIGHT_MF_GEOPF) load_geo(t0);
+            if (tid < TP / 4) {
+                const int q = t0 + tid * 4;
+                if (q < p1) {
+                    const Vec<4> vdz = gq[0], vxx = gq[1], vyy = gq[2];
+                    const Vec<4> vz = gq[3], vzx = gq[4], vzy = gq[5];
+                    Vec<4> vnrm, n0, n1, n2;
+                    float T[3][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float nrm;
+                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], n0.v[e], n1.v[e], n2.v[e], nrm);
+                        vnrm.v[e] = nrm;
+                        T[0][e] = ea.fx * vzx.v[e];
+                        T[1][e] = ea.fy * vzy.v[e];
+                        T[2][e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                    }
+                    nkp[0][tid] = make_float4(n0.v[0], n0.v[1], n0.v[2], n0.v[3]);
+                    nkp[1][tid] = make_float4(n1.v[0], n1.v[1], n1.v[2], n1.v[3]);
+                    nkp[2][tid] = make_float4(n2.v[0], n2.v[1], n2.v[2], n2.v[3]);
+                    if (ea.N_out && b0 == 0) {               // block-uniform: the first round of images
+                        stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + q, n0); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, n1); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, n2);
+                        stv_stream<4, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const Vec<4> r = gr[c];
+                        float4 E0, E1, E2;
+                        float* e0 = &E0.x; float* e1 = &E1.x; float* e2 = &E2.x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float vg = r.v[e] / vdz.v[e];
+                            e0[e] = vg * T[0][e];
+                            e1[e] = vg * T[1][e];
+                            e2[e] = -vg * T[2][e];
+                        }
+                        geo[c][tid] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                        geo[C + c][tid] = E0; geo[2 * C + c][tid] = E1; geo[3 * C + c][tid] = E2;      // plane = kind * C + channel: a channel is one offset
+                    }
+                } else {
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    nkp[0][tid] = z4; nkp[1][tid] = z4; nkp[2][tid] = z4;
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) geo[k][tid] = z4;
+                }
+            }
+            __syncthreads();
+            if (SRPS_LIGHT_MF_GEOPF && t0 + TP < p1) load_geo(t0 + TP);      // block-uniform
+            // one software pipeline over the wave's UPW x 16 loads of the tile: D - 1 of them in flight ahead of the one being consumed; written
+            // once, instantiated for whole tiles and for the range's last, short one (whose lanes past the end hold zeros instead of samples)
+            auto run_tile = [&](auto ragged_c) __attribute__((always_inline)) {
+                constexpr bool RAGGED = decltype(ragged_c)::value;
+                Vec<4> buf[D];
+                auto issue = [&](int k, Vec<4>& dst) {
+                    const int us = k / SPU, t = k % SPU;
+                    const int q = t0 + 4 * (16 * t + b);
+                    const size_t at = ip[us] + (size_t)(RAGGED ? (q < p1 ? q : p1 - 4) : q);
+                    if constexpr (U8) dst = ld_img<4, true>(nullptr, I8 + at, 0, P, 0);
+                    else dst = ldv_stream<4>(I + at);
+                };
+#pragma unroll
+                for (int k = 0; k < D - 1; ++k) issue(k, buf[k % D]);
+#pragma unroll
+                for (int k = 0; k < NSTEP; ++k) {
+                    if (k + D - 1 < NSTEP) issue(k + D - 1, buf[(k + D - 1) % D]);
+                    __builtin_amdgcn_sched_barrier(0);       // the look-ahead load goes out before this step's arithmetic
+                    const int us = k / SPU, t = k % SPU;
+                    const int li = 16 * t + b;
+                    Vec<4>& iv = buf[k % D];
+                    if (RAGGED) {
+                        const bool valid = t0 + 4 * li < p1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) iv.v[e] = valid ? iv.v[e] : 0.f;
+                    }
+                    const char* gb = reinterpret_cast<const char*>(&geo[0][li]) + cofs[us];
+                    const float4 nq4 = nkp[j][li], rq4 = *reinterpret_cast<const float4*>(gb);
+                    const float4 E04 = *reinterpret_cast<const float4*>(gb + C * TP * 4), E14 = *reinterpret_cast<const float4*>(gb + 2 * C * TP * 4),
+                                 E24 = *reinterpret_cast<const float4*>(gb + 3 * C * TP * 4);
+                    const float nq[4] = {nq4.x, nq4.y, nq4.z, nq4.w}, rq[4] = {rq4.x, rq4.y, rq4.z, rq4.w};
+                    const float E0[4] = {E04.x, E04.y, E04.z, E04.w}, E1[4] = {E14.x, E14.y, E14.z, E14.w}, E2[4] = {E24.x, E24.y, E24.z, E24.w};
+                    const float4 s4 = sv[us];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = rq[e] * nq[e];                                          // dc.cu:381 (lane q: rho_c N_q)
+                        acc[us] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, iv.v[e], acc[us], 0, 0, 0);
+                        if (us == 0) gram = __builtin_amdgcn_mfma_f32_4x4x1f32(a, a, gram, 0, 0, 0);      // every wave, every round (no branch: see above); kept where do_gram
+                        const float res = fmaf(E0[e], s4.x, fmaf(E1[e], s4.y, fmaf(E2[e], s4.z, fmaf(rq[e] * 1.f, s4.w, -iv.v[e]))));
+                        e_u[us] = fmaf(res, res, e_u[us]);
+                    }
+                    asm volatile("" : "+v"(e_u[us]));      // pinned: the compiler otherwise sinks the residuals (and the LDS values they read) below the loop
+                }
+            };
+            if (__builtin_amdgcn_readfirstlane(t0 + TP) > p1) run_tile(std::true_type{});      // block-uniform: the range's last tile may be short
+            else run_tile(std::false_type{});
+        }
+        // the sixteen pixel slots of every sum: lanes 4 b + j, b = 0..15, added in one fixed order; lanes 0..3 hold image j's four sums
+#pragma unroll
+        for (int us = 0; us < UPW; ++us) {
+            const int u = grp + 4 * us, G = u / C, c = u - G * C;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[us][r];
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) v[r] += __shfl_xor(v[r], o, 64);
+            }
+            const int img = b0 + 4 * G + j;
+            if (u < nunits && lane < 4 && img < n_img)
+                *reinterpret_cast<float4*>(part_atb + (((size_t)blk * n_img + img) * C + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            e_acc += img_ok[us] ? e_u[us] : 0.f;
+        }
+        if (do_gram) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = gram[r];
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                // register r of lane j = entry (r, j); the upper triangle in the order of the other sweeps: (0,0) (0,1) .. (0,3) (1,1) ..
+                if (lane < 4 && r <= j) part_g[((size_t)blk * C + grp) * 10 + (r * 4 - (r * (r - 1)) / 2 + (j - r))] = v;
+            }
         }
     }
+    light_tile_finish(e_acc, ea, sme, blk);
+}
+
+// The same contraction with the four waves of a block DECOUPLED (option "light_run" = 3, at most twenty images): a wave owns 256 of the
+// block's 1024 pixels per round and ALL 3 x NG units of them -- 4 NU accumulator registers, which only the matrix form can afford -- in a
+// tile of LDS of its own, so no wave ever waits for another: no block barrier inside the sweep (k_light_fused_mfma spends a tenth of its
+// time around the two of every tile: timing experiments in profiles/r05_ab_lighting_mfma.txt).  The sums of the four waves meet once, at
+// the end.  NG = groups of four images (1..5).
+template <int NG, bool U8>
+__global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img, int chunk,
+                                                           float* __restrict__ part_atb, float* __restrict__ part_g, EnergyArgs ea) {
+    constexpr int C = 3, WP = 256, NE = 4 * C;               // pixels of a wave's tile; LDS planes rho_c | E0_c | E1_c | E2_c
+    constexpr int NKS = WP / 4 + 4;                          // float4 between the planes N_0, N_1, N_2, ones: a plane + 64 bytes
+    constexpr int NU = C * NG, SPU = WP / 64;                // units (channel, four images); loads of a unit and tile
+    constexpr int D = SRPS_LIGHT_MF_DEPTH, NSTEP = NU * SPU;
+    __shared__ float4 nkp_all[4][4][NKS];
+    __shared__ float4 geo_all[4][NE][WP / 4];
+    __shared__ float4 svs[NU * 4];                           // the lighting vector of (unit, image of the group)
+    __shared__ float red[4][NU * 16 + C * 16];               // the waves' sums at the end
+    __shared__ float sme[16];
+    const int tid = threadIdx.x, lane = tid & 63, b = lane >> 2, j = lane & 3;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float4 (*nkp)[NKS] = nkp_all[grp];
+    float4 (*geo)[WP / 4] = geo_all[grp];
+    const int blk = blockIdx.x;
+    const int p0 = blk * chunk;
+    const int p1 = min(P, p0 + chunk);
+    if (tid < NU * 4) {
+        const int u = tid >> 2, G = u / C, c = u - G * C, img = min(4 * G + (tid & 3), n_img - 1);
+        svs[tid] = *reinterpret_cast<const float4*>(ea.s + ((size_t)(ea.img_offset + img) * C + c) * 4);
+    }
+    nkp[3][lane] = make_float4(1.f, 1.f, 1.f, 1.f);          // N_3 == 1 (dc.cu:175)
+    __syncthreads();                                         // the only barrier before the end: svs
+    // the lane's image within a group: j, and in the last group -- where image j does not exist -- the last one again (nothing of it is kept)
+    // (as 32-bit offsets from a plane address that is uniform: 36 P bytes at most; per-unit pointers per lane would be thirty registers)
+    const bool last_ok = 4 * (NG - 1) + j < n_img;
+    const unsigned vo = (unsigned)j * C * (unsigned)P, vo_t = (unsigned)min(j, n_img - 1 - 4 * (NG - 1)) * C * (unsigned)P;
+    srps_f32x4 acc[NU], gram[C];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) gram[c] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
+    float e_main = 0.f, e_last = 0.f;
+    // The geometry of the wave's NEXT tile is requested in the middle of the sweep of this one (SRPS_LIGHT_MFW_GEOPF): nine loads per lane
+    // whose latency otherwise opens every tile.  Without a branch inside the pipeline (see k_light_fused_mfma): behind the range's last tile
+    // they re-read its last pixels and nothing is done with them.  Their 36 registers are live where the sweep needs fewest.
+    Vec<4> gq[6], gr[C];
+    auto load_geo = [&](int t0n) {
+        const int qn = t0n + lane * 4, qc = qn < p1 ? qn : p1 - 4;
+        gq[0] = ldv<4>(ea.dz + qc); gq[1] = ldv<4>(ea.xx + qc); gq[2] = ldv<4>(ea.yy + qc);
+        gq[3] = ldv<4>(ea.z + qc); gq[4] = ldv<4>(ea.zx + qc); gq[5] = ldv<4>(ea.zy + qc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) gr[c] = ldv<4>(rho + (size_t)c * P + qc);
+    };
+    if (SRPS_LIGHT_MFW_GEOPF) load_geo(p0 + WP * grp);
+    for (int t0 = p0 + WP * grp; t0 < p1; t0 += 4 * WP) {
+        {
+            const int q = t0 + lane * 4;
+            if (!SRPS_LIGHT_MFW_GEOPF) load_geo(t0);
+            if (q < p1) {
+                const Vec<4> vdz = gq[0], vxx = gq[1], vyy = gq[2];
+                const Vec<4> vz = gq[3], vzx = gq[4], vzy = gq[5];
+                Vec<4> vnrm, n0, n1, n2;
+                float T[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float nrm;
+                    perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], n0.v[e], n1.v[e], n2.v[e], nrm);
+                    vnrm.v[e] = nrm;
+                    T[0][e] = ea.fx * vzx.v[e];
+                    T[1][e] = ea.fy * vzy.v[e];
+                    T[2][e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
+                }
+                nkp[0][lane] = make_float4(n0.v[0], n0.v[1], n0.v[2], n0.v[3]);
+                nkp[1][lane] = make_float4(n1.v[0], n1.v[1], n1.v[2], n1.v[3]);
+                nkp[2][lane] = make_float4(n2.v[0], n2.v[1], n2.v[2], n2.v[3]);
+                if (ea.N_out) {
+                    stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + q, n0); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, n1); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, n2);
+                    stv_stream<4, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const Vec<4> r = gr[c];
+                    float4 E0, E1, E2;
+                    float* e0 = &E0.x; float* e1 = &E1.x; float* e2 = &E2.x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float vg = r.v[e] / vdz.v[e];
+                        e0[e] = vg * T[0][e];
+                        e1[e] = vg * T[1][e];
+                        e2[e] = -vg * T[2][e];
+                    }
+                    geo[c][lane] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                    geo[C + c][lane] = E0; geo[2 * C + c][lane] = E1; geo[3 * C + c][lane] = E2;
+                }
+            } else {
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                nkp[0][lane] = z4; nkp[1][lane] = z4; nkp[2][lane] = z4;
+#pragma unroll
+                for (int k = 0; k < NE; ++k) geo[k][lane] = z4;
+            }
+        }
+        // no barrier: the tile is this wave's own, and a wave's LDS instructions execute in their order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto run_tile = [&](auto ragged_c) __attribute__((always_inline)) {
+            constexpr bool RAGGED = decltype(ragged_c)::value;
+            Vec<4> buf[D];
+            auto issue = [&](int k, Vec<4>& dst) {
+                const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
+                const int q = t0 + 4 * (16 * t + b);
+                const size_t plane = (size_t)(4 * G * C + c) * (size_t)P;         // uniform
+                const unsigned at = (G == NG - 1 ? vo_t : vo) + (unsigned)(RAGGED ? (q < p1 ? q : p1 - 4) : q);
+                if constexpr (U8) dst = ld_img<4, true>(nullptr, I8 + plane + at, 0, P, 0);
+                else dst = ldv_stream<4>(I + plane + at);
+            };
+#pragma unroll
+            for (int k = 0; k < D - 1; ++k) issue(k, buf[k % D]);
+#pragma unroll
+            for (int k = 0; k < NSTEP; ++k) {
+                if (k + D - 1 < NSTEP) issue(k + D - 1, buf[(k + D - 1) % D]);
+                if (SRPS_LIGHT_MFW_GEOPF && k == NSTEP / 2) load_geo(t0 + 4 * WP);
+                __builtin_amdgcn_sched_barrier(0);           // the look-ahead load goes out before this step's arithmetic
+                const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
+                const int li = 16 * t + b;
+                Vec<4>& iv = buf[k % D];
+                if (RAGGED) {
+                    const bool valid = t0 + 4 * li < p1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) iv.v[e] = valid ? iv.v[e] : 0.f;
+                }
+                const float4 nq4 = nkp[j][li], rq4 = geo[c][li];
+                const float4 E04 = geo[C + c][li], E14 = geo[2 * C + c][li], E24 = geo[3 * C + c][li];
+                const float4 s4 = svs[u * 4 + j];
+                const float nq[4] = {nq4.x, nq4.y, nq4.z, nq4.w}, rq[4] = {rq4.x, rq4.y, rq4.z, rq4.w};
+                const float E0[4] = {E04.x, E04.y, E04.z, E04.w}, E1[4] = {E14.x, E14.y, E14.z, E14.w}, E2[4] = {E24.x, E24.y, E24.z, E24.w};
+                float& e_dst = (G == NG - 1) ? e_last : e_main;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = rq[e] * nq[e];                                              // dc.cu:381 (lane q: rho_c N_q)
+                    acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, iv.v[e], acc[u], 0, 0, 0);
+                    if (G == 0) gram[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, a, gram[c], 0, 0, 0);
+                    const float res = fmaf(E0[e], s4.x, fmaf(E1[e], s4.y, fmaf(E2[e], s4.z, fmaf(rq[e] * 1.f, s4.w, -iv.v[e]))));
+                    e_dst = fmaf(res, res, e_dst);
+                }
+                asm volatile("" : "+v"(e_dst));              // pinned: see k_light_fused_mfma
+            }
+        };
+        if (__builtin_amdgcn_readfirstlane(t0 + WP) > p1) run_tile(std::true_type{});      // wave-uniform: the range's last tile may be short
+        else run_tile(std::false_type{});
+        __builtin_amdgcn_wave_barrier();                     // the tile has been read before the next one is written (same wave: program order)
+    }
+    // the sixteen pixel slots of every sum (lanes 4 b + j, b = 0..15, one fixed order), then the four waves in their order
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[u][r];
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < 4) red[grp][(u * 4 + lane) * 4 + r] = v;
+        }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = gram[c][r];
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < 4) red[grp][NU * 16 + (c * 4 + r) * 4 + lane] = v;      // entry (r, lane) of channel c
+        }
+    __syncthreads();
+    for (int it = tid; it < NU * 16 + C * 16; it += 256) {   // 288 sums at five groups
+        const float v = ((red[0][it] + red[1][it]) + red[2][it]) + red[3][it];
+        if (it < NU * 16) {                                  // (unit, image of the group, component)
+            const int u = it >> 4, jj = (it >> 2) & 3, G = u / C, c = u - G * C, img = 4 * G + jj;
+            if (img < n_img) part_atb[(((size_t)blk * n_img + img) * C + c) * 4 + (it & 3)] = v;
+        } else {
+            const int t = it - NU * 16, c = t >> 4, r = (t >> 2) & 3, jj = t & 3;
+            // the upper triangle in the order of the other sweeps: (0,0) (0,1) .. (0,3) (1,1) ..
+            if (r <= jj) part_g[((size_t)blk * C + c) * 10 + (r * 4 - (r * (r - 1)) / 2 + (jj - r))] = v;
+        }
+    }
+    light_tile_finish(e_main + (last_ok ? e_last : 0.f), ea, sme, blk);
 }
 
 // one block of four waves per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
@@ -937,7 +1340,7 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     L.tiled = fused && vec && ctx->light_grouped && ctx->light_channel_inner && ctx->light_tiled && (C == 1 || C == 3);
     if (L.tiled) {
         // one round of blocks, each a range of whole 1024-pixel tiles (k_light_fused_tile); one energy partial per block
-        const int per_cu = fused_tile_blocks_per_cu(tile_images_per_wave(n_local), C);
+        const int per_cu = (ctx->light_run >= 2 && C == 3) ? SRPS_LIGHT_MF_BPC : fused_tile_blocks_per_cu(tile_images_per_wave(n_local), C);      // k_light_fused_mfma: its launch bound
         const int target = std::max(1, std::min(ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * per_cu, 2048));
         L.chunk = std::max(1024, cdiv(cdiv(P, target), 1024) * 1024);
     } else if (ctx->light_grouped && L.V == 4) {
@@ -975,6 +1378,20 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
         // to its top and spills 330 bytes; the guards are wave-uniform branches on a scalar compare)
         const float* d_It = image_store_tiles(ctx, d_I);       // the tile-major copy of the context's images, when it keeps one
         const unsigned char* d_I8 = ctx->light_bytes ? image_store_bytes(ctx, d_I) : nullptr;      // byte images: the sweep reads the bytes (option "light_bytes")
+        if (ctx->light_run == 3 && C == 3 && !d_It && n_local <= 20) {      // ... with the block's four waves decoupled
+#define SRPS_LMW(NGV) do { if (d_I8) hipLaunchKernelGGL((k_light_fused_mfw<NGV, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
+                           else hipLaunchKernelGGL((k_light_fused_mfw<NGV, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); } while (0)
+            switch (cdiv(n_local, 4)) { case 1: SRPS_LMW(1); break; case 2: SRPS_LMW(2); break; case 3: SRPS_LMW(3); break; case 4: SRPS_LMW(4); break; default: SRPS_LMW(5); }
+#undef SRPS_LMW
+            SRPS_LAUNCH_CHECK();
+            return SRPS_OK;
+        }
+        if (ctx->light_run >= 2 && C == 3 && !d_It) {      // the contraction on the matrix pipe (images in their plane layout, floats or bytes)
+            if (d_I8) hipLaunchKernelGGL(k_light_fused_mfma<true>, dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea);
+            else hipLaunchKernelGGL(k_light_fused_mfma<false>, dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea);
+            SRPS_LAUNCH_CHECK();
+            return SRPS_OK;
+        }
 #define SRPS_LT_ARGS dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea
 #define SRPS_LT(BB, CC) do { if (d_I8 && ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true, true>), SRPS_LT_ARGS); \
                              else if (d_I8) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true>), SRPS_LT_ARGS); \

@@ -561,7 +561,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->light_bytes = value ? 1 : 0;
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "light_run")) {
-        ctx->light_run = value ? 1 : 0;
+        ctx->light_run = (value == 2 || value == 3) ? value : (value ? 1 : 0);
     } else if (!strcmp(name, "light_tiled")) {
         ctx->light_tiled = value ? 1 : 0;
         ctx->light_cache_valid = false;

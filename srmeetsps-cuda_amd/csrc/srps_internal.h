@@ -180,8 +180,11 @@ struct srps_ctx {
     int march_nt = 0;                // streaming CG step with non-temporal loads / stores: 0 never (default: measured 15 - 35 % SLOWER at 2304^2 ... 4096^2, tools/march_nt_sweep.sh -- the strips re-read their halo columns, which then miss the L2; stores only, 3: 59.5 -> 65.0 us at 2560^2, 153 -> 165 - 176 at 4096^2 sf 4), 1 always, 2 when its vectors exceed the Infinity Cache, 3 stores only
     int light_bytes = 1;             // the tiled lighting sweep reads the 8-bit image store when the context holds one (round 4)
     bool I_in_ws_images = false;
-    int light_run = 1;               // the energy + lighting sweep's waves read ONE image plane's four 1 KiB pieces back to back (4 KiB runs), channel by channel, the
-                                     // channel's products rho N_k of the four pieces in registers (round 5: 0.29 -> 0.257 ms same box); 0: one piece of each of the wave's images
+    int light_run = 3;               // the energy + lighting sweep (float images, three channels): 3 = the contraction A'I on the matrix pipe (v_mfma_f32_4x4x1), a block's
+                                     // waves decoupled, each with a quarter of the pixels and all the images (k_light_fused_mfw; up to 20 images, more: 2); 2 = matrix pipe,
+                                     // waves share a tile (k_light_fused_mfma); 1 = vector form, a wave reads ONE image plane's four 1 KiB pieces back to back, channel by
+                                     // channel (k_light_fused_tile; byte images, tile-major copies and one channel always); 0 = round 4's form.  Same box, 2048^2 x 20:
+                                     // 0: 0.29, 1: 0.247 - 0.264, 2: 0.240 - 0.253, 3: 0.216 - 0.247 ms (profiles/r05_ab_lighting_mfma.txt)
     int light_tiled = 1;             // ... with the four image groups as the waves of one block and the geometry shared through LDS (k_light_fused_tile)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue

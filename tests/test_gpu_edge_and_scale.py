@@ -505,7 +505,8 @@ def test_normals_stored_by_the_energy_sweep_equal_the_normals_kernel(pkg, h, w, 
 # round 4: the tiled energy + lighting sweep (k_light_fused_tile) against round 3's four blocks per pixel range (k_light_fused_ci)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("h,w,sf,n_img,n_ch,kind,bytes_in", [(96, 80, 2, 5, 3, "ragged", False), (512, 384, 4, 23, 3, "ellipse", False), (300, 200, 1, 2, 1, "ragged", False),
-                                                             (1024, 1024, 4, 20, 3, "full", False), (256, 128, 4, 20, 3, "full", True), (320, 240, 2, 45, 3, "ellipse", False)])
+                                                             (1024, 1024, 4, 20, 3, "full", False), (256, 128, 4, 20, 3, "full", True), (320, 240, 2, 45, 3, "ellipse", False),
+                                                             (192, 128, 4, 24, 3, "full", True)])
 def test_tiled_lighting_sweep_equals_the_sweep_of_four_blocks_per_range(pkg, h, w, sf, n_img, n_ch, kind, bytes_in):
     """option light_tiled: the four image groups of a pixel range as the four waves of one block, geometry and normals once per pixel
     through LDS, image loads prefetched (and, with byte images, from the 8-bit store: light_bytes) -- the same expressions per pixel as
@@ -532,6 +533,35 @@ def test_tiled_lighting_sweep_equals_the_sweep_of_four_blocks_per_range(pkg, h, 
     assert abs(float(b[0][-1]) - float(a[0][-1])) <= 2e-4 * abs(float(a[0][-1]))
     assert rmse(b[1], a[1]) < 2e-5
     assert rmse(b[2], a[2]) < 2e-4 and np.abs(b[3] - a[3]).max() < 5e-3
+
+
+@pytest.mark.parametrize("h,w,sf,n_img,kind", [(96, 80, 2, 5, "ragged"), (512, 384, 4, 23, "ellipse"), (1024, 1024, 4, 20, "full"), (320, 240, 2, 45, "ellipse"),
+                                                (256, 256, 4, 4, "full"), (300, 260, 2, 13, "ragged")])
+def test_lighting_sweep_on_the_matrix_pipe_equals_the_vector_form(pkg, h, w, sf, n_img, kind):
+    """option light_run = 2 (k_light_fused_mfma): the contraction A'I of dc.cu:408-444 and the Gram matrices as v_mfma_f32_4x4x1 outer
+    products -- exact f32, one rounding per product like the fmaf chains of the vector form (light_run = 1), summed over other pixel
+    subsets per lane: energies, lighting, albedo and depth agree to rounding over three passes; image counts that are no multiple of
+    four (5, 23, 45: lanes whose image does not exist), more than one round of twenty, ragged tiles"""
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img + 2, n_ch=3, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    out = {}
+    for run in (1, 2, 3):                                                  # 3: the same with the block's waves decoupled (k_light_fused_mfw; at most 20 images, else = 2)
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("light_run", run)
+        assert ctx.get_option("light_run") == run
+        srps = pkg.SRPS(dh, ctx=ctx)
+        en = srps.execute(max_outer=3)
+        out[run] = (np.array(en, f32), srps.z(), srps.rho(), ctx.get("s"), ctx.get("N"))
+        ctx.close()
+    a = out[1]
+    for run in (2, 3):
+        b = out[run]
+        print(f"{h}x{w} sf {sf} x {n_img}, light_run {run}: energies {a[0]} / {b[0]}; depth rmse {rmse(b[1], a[1]):.2e}, albedo rmse {rmse(b[2], a[2]):.2e}, lighting max {np.abs(b[3] - a[3]).max():.2e}")
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-3)
+        assert abs(float(b[0][-1]) - float(a[0][-1])) <= 2e-4 * abs(float(a[0][-1]))
+        assert rmse(b[1], a[1]) < 2e-5
+        assert rmse(b[2], a[2]) < 2e-4 and np.abs(b[3] - a[3]).max() < 5e-3
+        assert np.abs(b[4] - a[4]).max() < 2e-2                          # the normals multiply depth differences by the focal length (DESIGN.md section 6)
 
 
 def test_host_arrays_travel_through_the_transfer_buffer_unchanged(pkg):

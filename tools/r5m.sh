@@ -1,5 +1,10 @@
-mkdir -p gpurun_out/r5m; O=gpurun_out/r5m
-bash tools/ab_pass.sh > $O/ab_pass.log 2>&1
-python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; echo rc=$? >> $O/pytest.log
-timeout 200 python tools/stress_resident.py 60 > $O/stress.log 2>&1; echo rc=$? >> $O/stress.log
-cut -c1-200 $O/ab_pass.log; grep -v "Gloo\|amdgpu\|socket.cpp" $O/pytest.log | tail -6; tail -4 $O/stress.log
+#!/bin/bash
+# light_run = 2 (the lighting contraction on the matrix pipe) against light_run = 1: parity test, then alternating passes on one box
+O=gpurun_out/r5m; mkdir -p $O
+python -m pytest tests/test_gpu_edge_and_scale.py -x -q -m gpu -k "matrix_pipe" -s > $O/test.log 2>&1
+tail -15 $O/test.log
+for i in 1 2 3; do
+python tools/pass_time.py 2048 4 20 10 light_run=1 >> $O/pass.jsonl 2>>$O/pass.err
+python tools/pass_time.py 2048 4 20 10 light_run=2 >> $O/pass.jsonl 2>>$O/pass.err
+done
+cut -c1-260 $O/pass.jsonl

@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/r5n; O=gpurun_out/r5n
-python -m pytest tests -x -q -m gpu > $O/pytest1.log 2>&1; echo rc=$? >> $O/pytest1.log
-python -m pytest tests -x -q -m gpu -s -k "strips or comm or distributed or one_process" > $O/pytest2.log 2>&1; echo rc=$? >> $O/pytest2.log
-python bench.py > $O/bench.json 2> $O/bench.err
-grep -v "Gloo\|amdgpu\|socket.cpp" $O/pytest1.log | tail -4; grep -E "passed|failed|rc=|attempts" $O/pytest2.log | tail -6
+#!/bin/bash
+O=gpurun_out/r5n; mkdir -p $O
+python -m pytest tests/test_gpu_edge_and_scale.py -q -m gpu -k "matrix_pipe" -s > $O/test.log 2>&1
+grep -E "passed|failed|energies" $O/test.log | cut -c1-250
+VARIANTS=srmeetsps-cuda_amd/variants_m bash tools/ab_pass.sh light_run=2 > $O/ab.log 2>&1
+cut -c1-200 $O/ab.log

@@ -1,12 +1,13 @@
-mkdir -p gpurun_out/r5o; O=gpurun_out/r5o
-VARIANTS=srmeetsps-cuda_amd/variants_l bash tools/ab_pass.sh > $O/ab_albedo.log 2>&1
-python - <<'PY'
-import json
-for l in open('gpurun_out/r5o/ab_albedo.log'):
-    n, j = l.split(': ', 1)
-    try:
-        d = json.loads(j)
-        print(n, d['ms_per_pass'], d['phase_ms']['albedo_sweep'], d['phase_ms']['energy'])
-    except Exception as e:
-        print(l[:150])
-PY
+#!/bin/bash
+O=gpurun_out/r5o; mkdir -p $O
+cp srmeetsps-cuda_amd/libsrps_hip.so /tmp/keep.so
+for rep in 1 2 3; do
+  for f in srmeetsps-cuda_amd/variants_m/*.so; do
+    cp "$f" srmeetsps-cuda_amd/libsrps_hip.so
+    n=$(basename "$f" .so); opt=light_run=2; [ "$n" = a_vector ] && opt=light_run=1
+    echo -n "$n: " >> $O/ab.log
+    timeout 300 python3 tools/pass_time.py 2048 4 20 10 $opt 2>&1 | grep -v amdgpu.ids | tail -1 >> $O/ab.log
+  done
+done
+cp /tmp/keep.so srmeetsps-cuda_amd/libsrps_hip.so
+cut -c1-215 $O/ab.log
