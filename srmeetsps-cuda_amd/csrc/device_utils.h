@@ -742,6 +742,18 @@ __device__ __forceinline__ Vec<V> ld_img(const float* __restrict__ I, const unsi
         return ldv_stream<V>(I + row * (size_t)P + q);
     }
 }
+// the same bytes in two steps -- the raw load, and the conversion where the samples are used: a software pipeline keeps the dword in
+// flight, not the four floats (whose conversion would wait for the load where it is issued)
+__device__ __forceinline__ unsigned ld_bytes4_stream(const unsigned char* __restrict__ p) {
+    if constexpr (SRPS_NT_IMAGES) return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
+    else return *reinterpret_cast<const unsigned*>(p);
+}
+__device__ __forceinline__ Vec<4> bytes4_to_unit(unsigned w) {
+    Vec<4> r;
+    r.v[0] = unit_from_byte((float)(w & 0xffu)); r.v[1] = unit_from_byte((float)((w >> 8) & 0xffu));
+    r.v[2] = unit_from_byte((float)((w >> 16) & 0xffu)); r.v[3] = unit_from_byte((float)(w >> 24));
+    return r;
+}
 template <int V>
 __device__ __forceinline__ void stv(float* __restrict__ p, const Vec<V>& a);
 template <>

@@ -842,6 +842,12 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 #define SRPS_LIGHT_MFW_GEOPF 0
 #endif
 typedef float srps_f32x4 __attribute__((ext_vector_type(4)));
+// what a load of the pipeline leaves in flight: four floats, or the dword of four bytes (converted where it is used)
+template <bool U8> struct ImgBuf { Vec<4> f; __device__ __forceinline__ Vec<4> get() const { return f; } };
+template <> struct ImgBuf<true> { unsigned w; __device__ __forceinline__ Vec<4> get() const { return bytes4_to_unit(w); } };
+#ifndef SRPS_LIGHT_MF_DEPTH_U8
+#define SRPS_LIGHT_MF_DEPTH_U8 8      // bytes: a load carries a quarter of the bytes, and a register instead of four
+#endif
 // (No branch inside the pipeline of loads: with wave-uniform branches around its steps hipcc 7.2 loses count of the loads in flight -- s_waitcnt
 // vmcnt(0) in front of every load -- and copies the accumulators at every join: 0.40 ms against the vector form's 0.255.  A wave whose last
 // unit does not exist -- 15 units on 4 waves -- runs it all the same on the planes of its first unit (L2 hits, no HBM traffic) and drops the
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(256, SRPS_LIGHT_MF_BPC) void k_light_fused_mfma(con
     constexpr int NKS = TP / 4 + 4;                          // float4 between the planes N_0, N_1, N_2, ones: a plane + 64 bytes
     constexpr int RI = 20, UPW = 4;                          // images per round; units per wave and round (3 * 5 units on 4 waves)
     constexpr int SPU = TP / 64;                             // loads of a unit and tile: four planes x 256 bytes each
-    constexpr int D = SRPS_LIGHT_MF_DEPTH, NSTEP = UPW * SPU;
+    constexpr int D = U8 ? SRPS_LIGHT_MF_DEPTH_U8 : SRPS_LIGHT_MF_DEPTH, NSTEP = UPW * SPU;
     __shared__ float4 nkp[4][NKS];
     __shared__ float4 geo[NE][TP / 4];
     __shared__ float sme[16];
@@ -952,13 +958,13 @@ __global__ __launch_bounds__(256, SRPS_LIGHT_MF_BPC) void k_light_fused_mfma(con
             // once, instantiated for whole tiles and for the range's last, short one (whose lanes past the end hold zeros instead of samples)
             auto run_tile = [&](auto ragged_c) __attribute__((always_inline)) {
                 constexpr bool RAGGED = decltype(ragged_c)::value;
-                Vec<4> buf[D];
-                auto issue = [&](int k, Vec<4>& dst) {
+                ImgBuf<U8> buf[D];
+                auto issue = [&](int k, ImgBuf<U8>& dst) {
                     const int us = k / SPU, t = k % SPU;
                     const int q = t0 + 4 * (16 * t + b);
                     const size_t at = ip[us] + (size_t)(RAGGED ? (q < p1 ? q : p1 - 4) : q);
-                    if constexpr (U8) dst = ld_img<4, true>(nullptr, I8 + at, 0, P, 0);
-                    else dst = ldv_stream<4>(I + at);
+                    if constexpr (U8) dst.w = ld_bytes4_stream(I8 + at);
+                    else dst.f = ldv_stream<4>(I + at);
                 };
 #pragma unroll
                 for (int k = 0; k < D - 1; ++k) issue(k, buf[k % D]);
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(256, SRPS_LIGHT_MF_BPC) void k_light_fused_mfma(con
                     __builtin_amdgcn_sched_barrier(0);       // the look-ahead load goes out before this step's arithmetic
                     const int us = k / SPU, t = k % SPU;
                     const int li = 16 * t + b;
-                    Vec<4>& iv = buf[k % D];
+                    Vec<4> iv = buf[k % D].get();
                     if (RAGGED) {
                         const bool valid = t0 + 4 * li < p1;
 #pragma unroll
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restr
     constexpr int C = 3, WP = 256, NE = 4 * C;               // pixels of a wave's tile; LDS planes rho_c | E0_c | E1_c | E2_c
     constexpr int NKS = WP / 4 + 4;                          // float4 between the planes N_0, N_1, N_2, ones: a plane + 64 bytes
     constexpr int NU = C * NG, SPU = WP / 64;                // units (channel, four images); loads of a unit and tile
-    constexpr int D = SRPS_LIGHT_MF_DEPTH, NSTEP = NU * SPU;
+    constexpr int D = U8 ? SRPS_LIGHT_MF_DEPTH_U8 : SRPS_LIGHT_MF_DEPTH, NSTEP = NU * SPU;
     __shared__ float4 nkp_all[4][4][NKS];
     __shared__ float4 geo_all[4][NE][WP / 4];
     __shared__ float4 svs[NU * 4];                           // the lighting vector of (unit, image of the group)
@@ -1130,14 +1136,14 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restr
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         auto run_tile = [&](auto ragged_c) __attribute__((always_inline)) {
             constexpr bool RAGGED = decltype(ragged_c)::value;
-            Vec<4> buf[D];
-            auto issue = [&](int k, Vec<4>& dst) {
+            ImgBuf<U8> buf[D];
+            auto issue = [&](int k, ImgBuf<U8>& dst) {
                 const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
                 const int q = t0 + 4 * (16 * t + b);
                 const size_t plane = (size_t)(4 * G * C + c) * (size_t)P;         // uniform
                 const unsigned at = (G == NG - 1 ? vo_t : vo) + (unsigned)(RAGGED ? (q < p1 ? q : p1 - 4) : q);
-                if constexpr (U8) dst = ld_img<4, true>(nullptr, I8 + plane + at, 0, P, 0);
-                else dst = ldv_stream<4>(I + plane + at);
+                if constexpr (U8) dst.w = ld_bytes4_stream(I8 + plane + at);
+                else dst.f = ldv_stream<4>(I + plane + at);
             };
 #pragma unroll
             for (int k = 0; k < D - 1; ++k) issue(k, buf[k % D]);
@@ -1148,7 +1154,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restr
                 __builtin_amdgcn_sched_barrier(0);           // the look-ahead load goes out before this step's arithmetic
                 const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
                 const int li = 16 * t + b;
-                Vec<4>& iv = buf[k % D];
+                Vec<4> iv = buf[k % D].get();
                 if (RAGGED) {
                     const bool valid = t0 + 4 * li < p1;
 #pragma unroll

@@ -15,7 +15,7 @@ for sub in ('sq1','sq2','sq3'):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         n=r['Kernel_Name']
-        if 'k_light_fused_tile' in n or 'k_albedo_fused' in n:
+        if 'k_light_fused_tile' in n or 'k_light_fused_mf' in n or 'k_albedo_fused' in n:
             agg[(n.split('(')[0][-40:], r['Counter_Name'])].append(float(r['Counter_Value']))
     for k,v in sorted(agg.items()): print(sub, k, sorted(v)[len(v)//2])
 PY
