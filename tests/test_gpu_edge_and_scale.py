@@ -536,7 +536,7 @@ def test_tiled_lighting_sweep_equals_the_sweep_of_four_blocks_per_range(pkg, h, 
 
 
 @pytest.mark.parametrize("h,w,sf,n_img,kind", [(96, 80, 2, 5, "ragged"), (512, 384, 4, 23, "ellipse"), (1024, 1024, 4, 20, "full"), (320, 240, 2, 45, "ellipse"),
-                                                (256, 256, 4, 4, "full"), (300, 260, 2, 13, "ragged")])
+                                                (256, 256, 4, 4, "full"), (300, 260, 2, 13, "ellipse"), (128, 96, 2, 10, "ellipse"), (72, 56, 2, 2, "full"), (64, 48, 2, 3, "ellipse")])
 def test_lighting_sweep_on_the_matrix_pipe_equals_the_vector_form(pkg, h, w, sf, n_img, kind):
     """option light_run = 2 (k_light_fused_mfma): the contraction A'I of dc.cu:408-444 and the Gram matrices as v_mfma_f32_4x4x1 outer
     products -- exact f32, one rounding per product like the fmaf chains of the vector form (light_run = 1), summed over other pixel
