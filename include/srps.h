@@ -139,7 +139,7 @@ int srps_synchronize(srps_ctx* ctx);
  *  tile back to back -- a 4 KiB run --, channel by channel, the channel's products rho N_k of the four pieces in registers; 0: one piece
  *  of each of the wave's images per step, round 4's form.  2 and 3 (float images in their plane layout, three channels; otherwise 1 is
  *  taken): the contraction A'I of dc.cu:408-444 and the Gram matrices as v_mfma_f32_4x4x1 outer products on the matrix pipe -- exact f32 --,
- *  with 3 (at most twenty images per device, else 2) the four waves of a block decoupled, a quarter of the pixels and all the images each.
+ *  with 3 the four waves of a block decoupled, a quarter of the pixels and all the images (of a round of at most twenty) each.
  *  0.29 / 0.255 / 0.245 / 0.23 ms same box; results agree to rounding),
  * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader
  *  produces, Utilities.cpp:343 -- the context also keeps the images as bytes and the two image sweeps of a pass read those:

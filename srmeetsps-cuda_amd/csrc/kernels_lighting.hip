@@ -838,9 +838,6 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 #ifndef SRPS_LIGHT_MF_GEOPF
 #define SRPS_LIGHT_MF_GEOPF 0
 #endif
-#ifndef SRPS_LIGHT_MFW_GEOPF
-#define SRPS_LIGHT_MFW_GEOPF 0
-#endif
 typedef float srps_f32x4 __attribute__((ext_vector_type(4)));
 // what a load of the pipeline leaves in flight: four floats, or the dword of four bytes (converted where it is used)
 template <bool U8> struct ImgBuf { Vec<4> f; __device__ __forceinline__ Vec<4> get() const { return f; } };
@@ -1031,22 +1028,24 @@ __global__ __launch_bounds__(256, SRPS_LIGHT_MF_BPC) void k_light_fused_mfma(con
     light_tile_finish(e_acc, ea, sme, blk);
 }
 
-// The same contraction with the four waves of a block DECOUPLED (option "light_run" = 3, at most twenty images): a wave owns 256 of the
+// The same contraction with the four waves of a block DECOUPLED (option "light_run" = 3): a wave owns 256 of the
 // block's 1024 pixels per round and ALL 3 x NG units of them -- 4 NU accumulator registers, which only the matrix form can afford -- in a
 // tile of LDS of its own, so no wave ever waits for another: no block barrier inside the sweep (k_light_fused_mfma spends a tenth of its
 // time around the two of every tile: timing experiments in profiles/r05_ab_lighting_mfma.txt).  The sums of the four waves meet once, at
-// the end.  NG = groups of four images (1..5).
+// the end of a round of 4 NG images.  NG = groups of four images per round (1..5); more than twenty images: rounds (the host picks NG = 5, 4
+// or 3 so that the rounds are full when it can).
 template <int NG, bool U8>
 __global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img, int chunk,
                                                            float* __restrict__ part_atb, float* __restrict__ part_g, EnergyArgs ea) {
     constexpr int C = 3, WP = 256, NE = 4 * C;               // pixels of a wave's tile; LDS planes rho_c | E0_c | E1_c | E2_c
     constexpr int NKS = WP / 4 + 4;                          // float4 between the planes N_0, N_1, N_2, ones: a plane + 64 bytes
     constexpr int NU = C * NG, SPU = WP / 64;                // units (channel, four images); loads of a unit and tile
+    constexpr int RS = 4 * NG;                               // images per round (more than RS images: rounds, the geometry formed again in each)
     constexpr int D = U8 ? SRPS_LIGHT_MF_DEPTH_U8 : SRPS_LIGHT_MF_DEPTH, NSTEP = NU * SPU;
     __shared__ float4 nkp_all[4][4][NKS];
     __shared__ float4 geo_all[4][NE][WP / 4];
     __shared__ float4 svs[NU * 4];                           // the lighting vector of (unit, image of the group)
-    __shared__ float red[4][NU * 16 + C * 16];               // the waves' sums at the end
+    __shared__ float red[4][NU * 16 + C * 16];               // the waves' sums at the end of a round
     __shared__ float sme[16];
     const int tid = threadIdx.x, lane = tid & 63, b = lane >> 2, j = lane & 3;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1055,164 +1054,163 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restr
     const int blk = blockIdx.x;
     const int p0 = blk * chunk;
     const int p1 = min(P, p0 + chunk);
-    if (tid < NU * 4) {
-        const int u = tid >> 2, G = u / C, c = u - G * C, img = min(4 * G + (tid & 3), n_img - 1);
-        svs[tid] = *reinterpret_cast<const float4*>(ea.s + ((size_t)(ea.img_offset + img) * C + c) * 4);
-    }
     nkp[3][lane] = make_float4(1.f, 1.f, 1.f, 1.f);          // N_3 == 1 (dc.cu:175)
-    __syncthreads();                                         // the only barrier before the end: svs
-    // the lane's image within a group: j, and in the last group -- where image j does not exist -- the last one again (nothing of it is kept)
-    // (as 32-bit offsets from a plane address that is uniform: 36 P bytes at most; per-unit pointers per lane would be thirty registers)
-    const bool last_ok = 4 * (NG - 1) + j < n_img;
-    const unsigned vo = (unsigned)j * C * (unsigned)P, vo_t = (unsigned)min(j, n_img - 1 - 4 * (NG - 1)) * C * (unsigned)P;
-    srps_f32x4 acc[NU], gram[C];
+    float e_acc = 0.f;
+    for (int b0 = 0; b0 < n_img; b0 += RS) {
+        const int nr = min(RS, n_img - b0);                  // images of this round; image 4 G + j of it exists when 4 G + j < nr
+        if (b0 > 0) __syncthreads();                         // the previous round's svs and red have been read
+        if (tid < NU * 4) {
+            const int u = tid >> 2, G = u / C, c = u - G * C, img = b0 + min(4 * G + (tid & 3), nr - 1);
+            svs[tid] = *reinterpret_cast<const float4*>(ea.s + ((size_t)(ea.img_offset + img) * C + c) * 4);
+        }
+        __syncthreads();                                     // the only barriers of a round: svs here, the waves' sums at its end
+        // the lane's image of every group as a 32-bit offset (in samples) from the images' start: image b0 + 4 G + j, or -- where that does not
+        // exist -- the round's last one again (nothing of it is kept); per-unit pointers per lane would be thirty registers
+        unsigned vo[NG];
+        bool ok[NG];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) acc[u] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int G = 0; G < NG; ++G) {
+            ok[G] = 4 * G + j < nr;
+            vo[G] = (unsigned)(b0 + min(4 * G + j, nr - 1)) * C * (unsigned)P;
+        }
+        srps_f32x4 acc[NU], gram[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) gram[c] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
-    float e_main = 0.f, e_last = 0.f;
-    // The geometry of the wave's NEXT tile is requested in the middle of the sweep of this one (SRPS_LIGHT_MFW_GEOPF): nine loads per lane
-    // whose latency otherwise opens every tile.  Without a branch inside the pipeline (see k_light_fused_mfma): behind the range's last tile
-    // they re-read its last pixels and nothing is done with them.  Their 36 registers are live where the sweep needs fewest.
-    Vec<4> gq[6], gr[C];
-    auto load_geo = [&](int t0n) {
-        const int qn = t0n + lane * 4, qc = qn < p1 ? qn : p1 - 4;
-        gq[0] = ldv<4>(ea.dz + qc); gq[1] = ldv<4>(ea.xx + qc); gq[2] = ldv<4>(ea.yy + qc);
-        gq[3] = ldv<4>(ea.z + qc); gq[4] = ldv<4>(ea.zx + qc); gq[5] = ldv<4>(ea.zy + qc);
+        for (int u = 0; u < NU; ++u) acc[u] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < C; ++c) gr[c] = ldv<4>(rho + (size_t)c * P + qc);
-    };
-    if (SRPS_LIGHT_MFW_GEOPF) load_geo(p0 + WP * grp);
-    for (int t0 = p0 + WP * grp; t0 < p1; t0 += 4 * WP) {
-        {
-            const int q = t0 + lane * 4;
-            if (!SRPS_LIGHT_MFW_GEOPF) load_geo(t0);
-            if (q < p1) {
-                const Vec<4> vdz = gq[0], vxx = gq[1], vyy = gq[2];
-                const Vec<4> vz = gq[3], vzx = gq[4], vzy = gq[5];
-                Vec<4> vnrm, n0, n1, n2;
-                float T[3][4];
+        for (int c = 0; c < C; ++c) gram[c] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
+        float e_g[NG];                                       // the energy of a group's samples: kept where the lane's image exists
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float nrm;
-                    perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], n0.v[e], n1.v[e], n2.v[e], nrm);
-                    vnrm.v[e] = nrm;
-                    T[0][e] = ea.fx * vzx.v[e];
-                    T[1][e] = ea.fy * vzy.v[e];
-                    T[2][e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
-                }
-                nkp[0][lane] = make_float4(n0.v[0], n0.v[1], n0.v[2], n0.v[3]);
-                nkp[1][lane] = make_float4(n1.v[0], n1.v[1], n1.v[2], n1.v[3]);
-                nkp[2][lane] = make_float4(n2.v[0], n2.v[1], n2.v[2], n2.v[3]);
-                if (ea.N_out) {
-                    stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + q, n0); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, n1); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, n2);
-                    stv_stream<4, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
-                }
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const Vec<4> r = gr[c];
-                    float4 E0, E1, E2;
-                    float* e0 = &E0.x; float* e1 = &E1.x; float* e2 = &E2.x;
+        for (int G = 0; G < NG; ++G) e_g[G] = 0.f;
+        for (int t0 = p0 + WP * grp; t0 < p1; t0 += 4 * WP) {
+            {
+                const int q = t0 + lane * 4;
+                if (q < p1) {
+                    const Vec<4> vdz = ldv<4>(ea.dz + q), vxx = ldv<4>(ea.xx + q), vyy = ldv<4>(ea.yy + q);
+                    const Vec<4> vz = ldv<4>(ea.z + q), vzx = ldv<4>(ea.zx + q), vzy = ldv<4>(ea.zy + q);
+                    Vec<4> vnrm, n0, n1, n2;
+                    float T[3][4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float vg = r.v[e] / vdz.v[e];
-                        e0[e] = vg * T[0][e];
-                        e1[e] = vg * T[1][e];
-                        e2[e] = -vg * T[2][e];
+                        float nrm;
+                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], n0.v[e], n1.v[e], n2.v[e], nrm);
+                        vnrm.v[e] = nrm;
+                        T[0][e] = ea.fx * vzx.v[e];
+                        T[1][e] = ea.fy * vzy.v[e];
+                        T[2][e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
                     }
-                    geo[c][lane] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
-                    geo[C + c][lane] = E0; geo[2 * C + c][lane] = E1; geo[3 * C + c][lane] = E2;
-                }
-            } else {
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                nkp[0][lane] = z4; nkp[1][lane] = z4; nkp[2][lane] = z4;
+                    nkp[0][lane] = make_float4(n0.v[0], n0.v[1], n0.v[2], n0.v[3]);
+                    nkp[1][lane] = make_float4(n1.v[0], n1.v[1], n1.v[2], n1.v[3]);
+                    nkp[2][lane] = make_float4(n2.v[0], n2.v[1], n2.v[2], n2.v[3]);
+                    if (ea.N_out && b0 == 0) {               // block-uniform: the first round of images
+                        stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + q, n0); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, n1); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, n2);
+                        stv_stream<4, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
+                    }
 #pragma unroll
-                for (int k = 0; k < NE; ++k) geo[k][lane] = z4;
+                    for (int c = 0; c < C; ++c) {
+                        const Vec<4> r = ldv<4>(rho + (size_t)c * P + q);
+                        float4 E0, E1, E2;
+                        float* e0 = &E0.x; float* e1 = &E1.x; float* e2 = &E2.x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float vg = r.v[e] / vdz.v[e];
+                            e0[e] = vg * T[0][e];
+                            e1[e] = vg * T[1][e];
+                            e2[e] = -vg * T[2][e];
+                        }
+                        geo[c][lane] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                        geo[C + c][lane] = E0; geo[2 * C + c][lane] = E1; geo[3 * C + c][lane] = E2;
+                    }
+                } else {
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    nkp[0][lane] = z4; nkp[1][lane] = z4; nkp[2][lane] = z4;
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) geo[k][lane] = z4;
+                }
             }
-        }
-        // no barrier: the tile is this wave's own, and a wave's LDS instructions execute in their order
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        auto run_tile = [&](auto ragged_c) __attribute__((always_inline)) {
-            constexpr bool RAGGED = decltype(ragged_c)::value;
-            ImgBuf<U8> buf[D];
-            auto issue = [&](int k, ImgBuf<U8>& dst) {
-                const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
-                const int q = t0 + 4 * (16 * t + b);
-                const size_t plane = (size_t)(4 * G * C + c) * (size_t)P;         // uniform
-                const unsigned at = (G == NG - 1 ? vo_t : vo) + (unsigned)(RAGGED ? (q < p1 ? q : p1 - 4) : q);
-                if constexpr (U8) dst.w = ld_bytes4_stream(I8 + plane + at);
-                else dst.f = ldv_stream<4>(I + plane + at);
+            // no barrier: the tile is this wave's own, and a wave's LDS instructions execute in their order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            auto run_tile = [&](auto ragged_c) __attribute__((always_inline)) {
+                constexpr bool RAGGED = decltype(ragged_c)::value;
+                ImgBuf<U8> buf[D];
+                auto issue = [&](int k, ImgBuf<U8>& dst) {
+                    const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
+                    const int q = t0 + 4 * (16 * t + b);
+                    const size_t plane = (size_t)c * (size_t)P;                       // uniform
+                    const unsigned at = vo[G] + (unsigned)(RAGGED ? (q < p1 ? q : p1 - 4) : q);
+                    if constexpr (U8) dst.w = ld_bytes4_stream(I8 + plane + at);
+                    else dst.f = ldv_stream<4>(I + plane + at);
+                };
+#pragma unroll
+                for (int k = 0; k < D - 1; ++k) issue(k, buf[k % D]);
+#pragma unroll
+                for (int k = 0; k < NSTEP; ++k) {
+                    if (k + D - 1 < NSTEP) issue(k + D - 1, buf[(k + D - 1) % D]);
+                    __builtin_amdgcn_sched_barrier(0);       // the look-ahead load goes out before this step's arithmetic
+                    const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
+                    const int li = 16 * t + b;
+                    Vec<4> iv = buf[k % D].get();
+                    if (RAGGED) {
+                        const bool valid = t0 + 4 * li < p1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) iv.v[e] = valid ? iv.v[e] : 0.f;
+                    }
+                    const float4 nq4 = nkp[j][li], rq4 = geo[c][li];
+                    const float4 E04 = geo[C + c][li], E14 = geo[2 * C + c][li], E24 = geo[3 * C + c][li];
+                    const float4 s4 = svs[u * 4 + j];
+                    const float nq[4] = {nq4.x, nq4.y, nq4.z, nq4.w}, rq[4] = {rq4.x, rq4.y, rq4.z, rq4.w};
+                    const float E0[4] = {E04.x, E04.y, E04.z, E04.w}, E1[4] = {E14.x, E14.y, E14.z, E14.w}, E2[4] = {E24.x, E24.y, E24.z, E24.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = rq[e] * nq[e];                                          // dc.cu:381 (lane q: rho_c N_q)
+                        acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, iv.v[e], acc[u], 0, 0, 0);
+                        if (G == 0) gram[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, a, gram[c], 0, 0, 0);      // every round (no branch); kept in the first
+                        const float res = fmaf(E0[e], s4.x, fmaf(E1[e], s4.y, fmaf(E2[e], s4.z, fmaf(rq[e] * 1.f, s4.w, -iv.v[e]))));
+                        e_g[G] = fmaf(res, res, e_g[G]);
+                    }
+                    asm volatile("" : "+v"(e_g[G]));         // pinned: see k_light_fused_mfma
+                }
             };
+            if (__builtin_amdgcn_readfirstlane(t0 + WP) > p1) run_tile(std::true_type{});      // wave-uniform: the range's last tile may be short
+            else run_tile(std::false_type{});
+            __builtin_amdgcn_wave_barrier();                 // the tile has been read before the next one is written (same wave: program order)
+        }
+        // the sixteen pixel slots of every sum (lanes 4 b + j, b = 0..15, one fixed order), then the four waves in their order
 #pragma unroll
-            for (int k = 0; k < D - 1; ++k) issue(k, buf[k % D]);
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int k = 0; k < NSTEP; ++k) {
-                if (k + D - 1 < NSTEP) issue(k + D - 1, buf[(k + D - 1) % D]);
-                if (SRPS_LIGHT_MFW_GEOPF && k == NSTEP / 2) load_geo(t0 + 4 * WP);
-                __builtin_amdgcn_sched_barrier(0);           // the look-ahead load goes out before this step's arithmetic
-                const int u = k / SPU, t = k % SPU, G = u / C, c = u % C;
-                const int li = 16 * t + b;
-                Vec<4> iv = buf[k % D].get();
-                if (RAGGED) {
-                    const bool valid = t0 + 4 * li < p1;
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[u][r];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) iv.v[e] = valid ? iv.v[e] : 0.f;
-                }
-                const float4 nq4 = nkp[j][li], rq4 = geo[c][li];
-                const float4 E04 = geo[C + c][li], E14 = geo[2 * C + c][li], E24 = geo[3 * C + c][li];
-                const float4 s4 = svs[u * 4 + j];
-                const float nq[4] = {nq4.x, nq4.y, nq4.z, nq4.w}, rq[4] = {rq4.x, rq4.y, rq4.z, rq4.w};
-                const float E0[4] = {E04.x, E04.y, E04.z, E04.w}, E1[4] = {E14.x, E14.y, E14.z, E14.w}, E2[4] = {E24.x, E24.y, E24.z, E24.w};
-                float& e_dst = (G == NG - 1) ? e_last : e_main;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = rq[e] * nq[e];                                              // dc.cu:381 (lane q: rho_c N_q)
-                    acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, iv.v[e], acc[u], 0, 0, 0);
-                    if (G == 0) gram[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, a, gram[c], 0, 0, 0);
-                    const float res = fmaf(E0[e], s4.x, fmaf(E1[e], s4.y, fmaf(E2[e], s4.z, fmaf(rq[e] * 1.f, s4.w, -iv.v[e]))));
-                    e_dst = fmaf(res, res, e_dst);
-                }
-                asm volatile("" : "+v"(e_dst));              // pinned: see k_light_fused_mfma
+                for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < 4) red[grp][(u * 4 + lane) * 4 + r] = v;
             }
-        };
-        if (__builtin_amdgcn_readfirstlane(t0 + WP) > p1) run_tile(std::true_type{});      // wave-uniform: the range's last tile may be short
-        else run_tile(std::false_type{});
-        __builtin_amdgcn_wave_barrier();                     // the tile has been read before the next one is written (same wave: program order)
-    }
-    // the sixteen pixel slots of every sum (lanes 4 b + j, b = 0..15, one fixed order), then the four waves in their order
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
+        for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[u][r];
+            for (int r = 0; r < 4; ++r) {
+                float v = gram[c][r];
 #pragma unroll
-            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-            if (lane < 4) red[grp][(u * 4 + lane) * 4 + r] = v;
-        }
+                for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < 4) red[grp][NU * 16 + (c * 4 + r) * 4 + lane] = v;      // entry (r, lane) of channel c
+            }
 #pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = gram[c][r];
-#pragma unroll
-            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-            if (lane < 4) red[grp][NU * 16 + (c * 4 + r) * 4 + lane] = v;      // entry (r, lane) of channel c
-        }
-    __syncthreads();
-    for (int it = tid; it < NU * 16 + C * 16; it += 256) {   // 288 sums at five groups
-        const float v = ((red[0][it] + red[1][it]) + red[2][it]) + red[3][it];
-        if (it < NU * 16) {                                  // (unit, image of the group, component)
-            const int u = it >> 4, jj = (it >> 2) & 3, G = u / C, c = u - G * C, img = 4 * G + jj;
-            if (img < n_img) part_atb[(((size_t)blk * n_img + img) * C + c) * 4 + (it & 3)] = v;
-        } else {
-            const int t = it - NU * 16, c = t >> 4, r = (t >> 2) & 3, jj = t & 3;
-            // the upper triangle in the order of the other sweeps: (0,0) (0,1) .. (0,3) (1,1) ..
-            if (r <= jj) part_g[((size_t)blk * C + c) * 10 + (r * 4 - (r * (r - 1)) / 2 + (jj - r))] = v;
+        for (int G = 0; G < NG; ++G) e_acc += ok[G] ? e_g[G] : 0.f;
+        __syncthreads();
+        for (int it = tid; it < NU * 16 + (b0 == 0 ? C * 16 : 0); it += 256) {   // 288 sums at five groups
+            const float v = ((red[0][it] + red[1][it]) + red[2][it]) + red[3][it];
+            if (it < NU * 16) {                              // (unit, image of the group, component)
+                const int u = it >> 4, jj = (it >> 2) & 3, G = u / C, c = u - G * C;
+                if (4 * G + jj < nr) part_atb[(((size_t)blk * n_img + b0 + 4 * G + jj) * C + c) * 4 + (it & 3)] = v;
+            } else {
+                const int t = it - NU * 16, c = t >> 4, r = (t >> 2) & 3, jj = t & 3;
+                // the upper triangle in the order of the other sweeps: (0,0) (0,1) .. (0,3) (1,1) ..
+                if (r <= jj) part_g[((size_t)blk * C + c) * 10 + (r * 4 - (r * (r - 1)) / 2 + (jj - r))] = v;
+            }
         }
     }
-    light_tile_finish(e_main + (last_ok ? e_last : 0.f), ea, sme, blk);
+    light_tile_finish(e_acc, ea, sme, blk);
 }
 
 // one block of four waves per (image, channel) of the WHOLE image set; non-local rows are zeroed when sharded.
@@ -1384,10 +1382,13 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
         // to its top and spills 330 bytes; the guards are wave-uniform branches on a scalar compare)
         const float* d_It = image_store_tiles(ctx, d_I);       // the tile-major copy of the context's images, when it keeps one
         const unsigned char* d_I8 = ctx->light_bytes ? image_store_bytes(ctx, d_I) : nullptr;      // byte images: the sweep reads the bytes (option "light_bytes")
-        if (ctx->light_run == 3 && C == 3 && !d_It && n_local <= 20) {      // ... with the block's four waves decoupled
+        if (ctx->light_run == 3 && C == 3 && !d_It && (size_t)n_local * C * (size_t)P < ((size_t)1 << 32)) {      // ... with the block's four waves decoupled (32-bit sample offsets)
 #define SRPS_LMW(NGV) do { if (d_I8) hipLaunchKernelGGL((k_light_fused_mfw<NGV, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
                            else hipLaunchKernelGGL((k_light_fused_mfw<NGV, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); } while (0)
-            switch (cdiv(n_local, 4)) { case 1: SRPS_LMW(1); break; case 2: SRPS_LMW(2); break; case 3: SRPS_LMW(3); break; case 4: SRPS_LMW(4); break; default: SRPS_LMW(5); }
+            // groups of four images per round: all of them in one round up to twenty images; beyond, rounds of 20, 16 or 12 -- full ones if the count allows
+            int ng = cdiv(n_local, 4);
+            if (ng > 5) { ng = 5; for (int cand : {5, 4, 3}) if (n_local % (4 * cand) == 0) { ng = cand; break; } }
+            switch (ng) { case 1: SRPS_LMW(1); break; case 2: SRPS_LMW(2); break; case 3: SRPS_LMW(3); break; case 4: SRPS_LMW(4); break; default: SRPS_LMW(5); }
 #undef SRPS_LMW
             SRPS_LAUNCH_CHECK();
             return SRPS_OK;

@@ -181,7 +181,7 @@ struct srps_ctx {
     int light_bytes = 1;             // the tiled lighting sweep reads the 8-bit image store when the context holds one (round 4)
     bool I_in_ws_images = false;
     int light_run = 3;               // the energy + lighting sweep (float images, three channels): 3 = the contraction A'I on the matrix pipe (v_mfma_f32_4x4x1), a block's
-                                     // waves decoupled, each with a quarter of the pixels and all the images (k_light_fused_mfw; up to 20 images, more: 2); 2 = matrix pipe,
+                                     // waves decoupled, each with a quarter of the pixels and all the images (k_light_fused_mfw; more than 20 images: rounds); 2 = matrix pipe,
                                      // waves share a tile (k_light_fused_mfma); 1 = vector form, a wave reads ONE image plane's four 1 KiB pieces back to back, channel by
                                      // channel (k_light_fused_tile; byte images, tile-major copies and one channel always); 0 = round 4's form.  Same box, 2048^2 x 20:
                                      // 0: 0.29, 1: 0.247 - 0.264, 2: 0.240 - 0.253, 3: 0.216 - 0.247 ms (profiles/r05_ab_lighting_mfma.txt)

@@ -545,7 +545,7 @@ def test_lighting_sweep_on_the_matrix_pipe_equals_the_vector_form(pkg, h, w, sf,
     sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img + 2, n_ch=3, mask_kind=kind)
     dh = pkg.DataHandler.from_scene(sc)
     out = {}
-    for run in (1, 2, 3):                                                  # 3: the same with the block's waves decoupled (k_light_fused_mfw; at most 20 images, else = 2)
+    for run in (1, 2, 3):                                                  # 3: the same with the block's waves decoupled (k_light_fused_mfw; 23 and 45 images: rounds)
         ctx = pkg.Context(device_id=0)
         ctx.set_option("light_run", run)
         assert ctx.get_option("light_run") == run
