@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
     light_tile_finish(e_acc, ea, sme, blk);
 }
 
-// Round 5, option "light_run" = 2 (not the default -- see the measurement below): the sweep's contraction A'I (dc.cu:408-444: for every
+// Round 5, option "light_run" = 2 (the default is 3, k_light_fused_mfw below, which shares everything said here): the sweep's contraction A'I (dc.cu:408-444: for every
 // image i and channel c the four sums over the pixels of rho_c N_k I_ic) on the MATRIX pipe, the one use north_star reserves it for.
 // v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 outer products D_b += A_b B_b' (tools/mfma4x4_probe.hip: lane 4 b + q supplies A_b[q]
 // and B_b[q]; lane 4 b + j receives D_b[.][j] in its four accumulator registers), exact f32, one rounding per product like the fmaf chain it
@@ -822,8 +822,9 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 // tile's 4 KiB of those planes; the lane's product rho_c N_q comes from LDS (N_0..2 and a plane of ones, 64 bytes apart more than a plane so
 // that the sixteen lanes of a read hit sixteen different bank groups) and costs one multiplication, the four multiply-adds per sample of the
 // vector form become one matrix instruction per sample, and -- what the change is about -- a wave keeps FOUR accumulator registers per
-// (channel, four images) instead of the vector form's 64 registers of products and 60 of sums, which leaves room for SRPS_LIGHT_MF_DEPTH loads
-// in flight.  The work of a tile is its 3 x ceil(n / 4) units (channel, group of four images) of sixteen loads; wave g takes units g, g + 4, ...
+// (channel, four images) instead of the vector form's 64 registers of products and 60 of sums, which leaves room for the loads in flight
+// (SRPS_LIGHT_MF_DEPTH) and, in k_light_fused_mfw, for ALL the images' sums in one wave (f32 MFMA runs at the vector rate and in the vector
+// pipe's place: the gain is registers, not arithmetic -- without the matrix instructions the sweep takes the same time).  The work of a tile is its 3 x ceil(n / 4) units (channel, group of four images) of sixteen loads; wave g takes units g, g + 4, ...
 // (15 units at 20 images: 4 + 4 + 4 + 3).  The Gram matrices are one more matrix instruction (A = B = the products) in the units of the first
 // group.  The energy's residual stays on the vector pipe, per lane for ITS image: the expression of the other sweeps, other summation order.
 #ifndef SRPS_LIGHT_MF_DEPTH
