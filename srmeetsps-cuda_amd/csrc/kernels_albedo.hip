@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
 // right-hand side q (k_depth_from_sums, the same expressions in the same order: the same bits as the unfused closed form) follow
 // without num, den and the nine sum planes ever being stored -- 250 MB less written, 250 MB less read, two kernels fewer per pass.
 #ifndef SRPS_ALBEDO_UNROLL
-#define SRPS_ALBEDO_UNROLL 4      // image loads in flight per thread (round 5 swept 4 / 5 / 8 / 10: profiles/r05_ab_albedo_sweep.jsonl)
+#define SRPS_ALBEDO_UNROLL 4      // image loads in flight per thread (round 5 swept 1 .. 10: flat between 2 and 4, slower outside; profiles/r05_ab_albedo_sweep.jsonl)
 #endif
 template <int V, bool U8, bool TM = false>
 __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ s, const float* __restrict__ N, const float* __restrict__ I,
