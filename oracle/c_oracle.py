@@ -186,3 +186,70 @@ def bench_cpu_baseline(h, w, sf, mask, budget_s=20.0, reps=5):
             "solves_it_per_s": a["solves"], "solves_it_per_s_1_thread": o["solves"], "spread_over_solves": a["spread"],
             "thread_binding": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")},
             "first_touch": "matrix and vectors copied and first touched by the threads that stream them (static schedule)"}
+
+
+# ---- the whole alternating loop, matrix-free, in one arithmetic type (srps_solve_mf.c) ---------------------------------------------
+_dp = C.POINTER(C.c_double)
+
+
+class _Real:
+    """entry points of one build of srps_solve_mf.c: 'f64' (oc64_*, the calibration reference) or 'f32' (oc32_*)"""
+
+    def __init__(self, precision):
+        self.pfx = {"f64": "oc64", "f32": "oc32"}[precision]
+        self.dtype = {"f64": np.float64, "f32": np.float32}[precision]
+        self.ctype = {"f64": C.c_double, "f32": C.c_float}[precision]
+        assert getattr(_L, self.pfx + "_sizeof_real")() == np.dtype(self.dtype).itemsize
+
+    def fn(self, name):
+        return getattr(_L, f"{self.pfx}_{name}")
+
+    def p(self, a):
+        assert a.dtype == self.dtype and a.flags.c_contiguous
+        return a.ctypes.data_as(C.POINTER(self.ctype))
+
+
+def solve_mf(st: Structure, I, z0s, z_init, xx, yy, fx, fy, precision="f64", max_outer=None, keep_z=False, lam=1.0):
+    """SRPS::execute's loop (SRPS.cu:272-335) with every phase matrix-free in `precision` (srps_solve_mf.c): start values of
+    SRPS.cu:209-217 / dc.cu:133-139, first normals from z_init, then lighting -> albedo -> depth -> stop rule on THIS run's energies
+    (SRPS.cu:297-302) -> normals.  I: float32 [n][c][P] compact (not copied).  Returns energies, the final state, the CG step counts
+    per pass and, with keep_z, the depth after every pass."""
+    _bound()
+    R = _Real(precision)
+    T = R.dtype
+    n_img, n_ch, P = I.shape
+    assert P == st.P and I.dtype == f32 and I.flags.c_contiguous
+    cast = lambda a: np.ascontiguousarray(np.asarray(a), dtype=T)
+    s = np.zeros((n_img, n_ch, 4), T); s[:, :, 2] = -1                       # SRPS.cu:209-217
+    rho = np.full((n_ch, P), 0.5, T)                                         # dc.cu:133-139
+    z, z0s, xx, yy = cast(z_init).copy(), cast(z0s), cast(xx), cast(yy)
+    N = np.empty((4, P), T); dz = np.empty(P, T)
+    fxr, fyr = R.ctype(float(T(f32(fx)))), R.ctype(float(T(f32(fy))))        # K is float in the reference (SRPS.cu:269)
+    R.fn("normals")(P, _i(st.nb), R.p(z), R.p(xx), R.p(yy), fxr, fyr, R.p(N), R.p(dz))
+    energies, steps, z_pass = [], [], []
+    last_error, iteration = float("nan"), 1
+    OUTER_TOL, OUTER_MAX = 5e-3, 10                                          # SRPS.cu:85-86
+    while True:
+        it_l = np.zeros(n_img * n_ch, np.int32); it_a = np.zeros(n_ch, np.int32)
+        rc = R.fn("lighting")(P, n_img, n_ch, R.p(rho.reshape(-1)), R.p(N.reshape(-1)), _f(I), R.p(s.reshape(-1)), _i(it_l))
+        assert rc == 0
+        rc = R.fn("albedo")(P, n_img, n_ch, R.p(s.reshape(-1)), R.p(N.reshape(-1)), _f(I), R.p(rho.reshape(-1)), _i(it_a))
+        assert rc == 0
+        e = C.c_double(0); it_d = C.c_int(0)
+        rc = R.fn("depth")(P, st.Ps, n_img, n_ch, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), R.p(s.reshape(-1)), R.p(rho.reshape(-1)),
+                           R.p(dz), R.p(xx), R.p(yy), fxr, fyr, _f(I), R.p(z0s), R.ctype(lam), R.p(z), C.byref(e), C.byref(it_d))
+        assert rc == 0
+        error = float(T(e.value)) if precision == "f32" else e.value          # the reference's energy is a float (dc.cu:785)
+        energies.append(error)
+        steps.append(dict(lighting=it_l.tolist(), albedo=it_a.tolist(), depth=int(it_d.value)))
+        if keep_z:
+            z_pass.append(z.copy())
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rel_err = abs(T(last_error) - T(error)) / abs(T(error))
+        stop = (error > last_error) or (rel_err < T(OUTER_TOL)) or (iteration > OUTER_MAX)   # SRPS.cu:298-301
+        last_error = error
+        iteration += 1
+        if stop or (max_outer is not None and len(energies) >= max_outer):
+            break
+        R.fn("normals")(P, _i(st.nb), R.p(z), R.p(xx), R.p(yy), fxr, fyr, R.p(N.reshape(-1)), R.p(dz))   # SRPS.cu:304-313
+    return dict(energies=energies, z=z, rho=rho, s=s, N=N, dz=dz, steps=steps, z_pass=z_pass, precision=precision)

@@ -12,9 +12,23 @@ dc.cu:395-406 + 513-548), the C oracle's depth step in the reference's assembled
 
 The difference between the two library runs is printed, so the departures' compound effect is a number in the test's output.
 
-Tolerances: depth RMSE < 1e-4 (north_star), every pass's energy 1e-3 (first pass: the per-size value of the one-pass tests), the
-pass count equal (one apart only inside assert_same_stop's window), albedo bounded through the depth's deviation (DESIGN.md section
-6: the normals multiply depth differences by the focal length), lighting through the shading it predicts.
+Tolerances: depth RMSE < 1e-4 (north_star), the pass count equal (one apart only inside assert_same_stop's window), albedo bounded
+through the depth's deviation (the normals multiply depth differences by the focal length), lighting through the
+shading it predicts.
+
+**The energies are judged against fp64, not against a fixed 1e-3 (round 6).**  Round 5's gate was `|E_hip - E_oracle| < 1e-3 E` per pass,
+and at 2048 x 2048 the two moved apart pass by pass (5e-5 ... 7.8e-4 over seven passes) without anybody knowing whose rounding it was.
+Every run of this test now also solves the same loop in fp64 (oracle/srps_solve_mf.c, `oc64_*`: the reference's recurrences, caps and
+stop rule with every value and sum in double; pinned in tests/test_oracle_fp64.py), a second time with another summation order (its
+own uncertainty), and in fp32 matrix-free on the CPU (`oc32_*`: the library's formulation, another order of sums).  Per pass it prints
+the deviation FROM fp64 of the assembled fp32 oracle, the CPU fp32 matrix-free run and both library runs, in energy and in depth, and
+asserts (constants below, with the measurements they come from):
+
+  * the fp64 run moves with its summation order by less than FP64_SELF of depth RMSE: it is a reference at this size;
+  * the library is not further from fp64 than K_CAL x the worse of the two CPU fp32 runs, per pass, in energy and in depth -- its
+    rounding is of the class any fp32 evaluation of these recurrences has;
+  * |E_hip - E_oracle32| <= K_CAL x (dev_oracle32 + dev_mf32) per pass: the old 1e-3 replaced by what the two fp32 CPU runs
+    themselves leave against fp64 on this box, this scene, this pass.
 """
 import numpy as np
 import pytest
@@ -25,6 +39,12 @@ from test_gpu_parity import assert_same_stop
 pytestmark = pytest.mark.gpu
 f32 = np.float32
 
+# Calibration constants (round 6; measured tables in DESIGN.md section 6 and profiles/r06_drift_calibration.txt)
+FP64_SELF = 2e-6      # depth RMSE between two fp64 runs that differ in the order of their dot products (measured: 1e-8 ... 4e-7)
+K_CAL = 3.0           # the library against the worse fp32 CPU run, per pass (two CPU orderings of one formulation differ by up to 2.1 x)
+E_FLOOR = 2e-5        # below this relative energy deviation two fp32 runs are not told apart (fp64's own uncertainty is ~1e-6 ... 5e-6)
+Z_FLOOR = 5e-6        # the same for the depth RMSE
+
 
 @pytest.fixture(scope="module")
 def coracle():
@@ -32,7 +52,7 @@ def coracle():
     return c_oracle
 
 
-def _oracle_execute(sc, oracle, coracle, max_outer=None):
+def _oracle_execute(sc, oracle, coracle, max_outer=None, keep_z=True):
     """SRPS.cu:272-335 with the oracle's phases; returns the state after every pass's depth step is NOT kept (1 GB of images is
     enough) -- energies, pass count and the final z, rho, s, N"""
     st, o = _oracle_start(sc, oracle, coracle)
@@ -40,7 +60,7 @@ def _oracle_execute(sc, oracle, coracle, max_outer=None):
     s = np.zeros((n_img, n_ch, 4), f32); s[:, :, 2] = -1                      # SRPS.cu:244-249
     rho = np.full((n_ch, P), 0.5, f32)                                        # dc.cu:112-126
     z, N, dz = o["z"].copy(), o["N"], o["dz"]
-    energies, alb_its = [], []
+    energies, alb_its, z_pass = [], [], []
     last_error = float("nan")
     iteration = 1
     import time
@@ -62,6 +82,8 @@ def _oracle_execute(sc, oracle, coracle, max_outer=None):
         t4 = time.perf_counter()
         tm["lighting"] += t1 - t0; tm["albedo"] += t2 - t1; tm["depth"] += t3 - t2; tm["normals"] += t4 - t3
         energies.append(float(e))
+        if keep_z:
+            z_pass.append(z.copy())
         with np.errstate(invalid="ignore", divide="ignore"):
             rel = abs(f32(last_error) - f32(e)) / abs(f32(e))
         stop = (e > last_error) or (rel < oracle.OUTER_TOLERANCE) or (iteration > oracle.OUTER_MAX_ITERATIONS)   # SRPS.cu:298-301
@@ -70,7 +92,7 @@ def _oracle_execute(sc, oracle, coracle, max_outer=None):
         if stop or (max_outer is not None and len(energies) >= max_outer):
             break
     print(f"oracle solve {sc.h}x{sc.w} x {n_img}: {len(energies)} passes, seconds per phase", {k: round(v, 1) for k, v in tm.items()})
-    return dict(energies=energies, z=z, rho=rho, s=s, N=N, dz=dz, albedo_iterations=alb_its, fx=o["fx"], st=st)
+    return dict(energies=energies, z=z, rho=rho, s=s, N=N, dz=dz, albedo_iterations=alb_its, fx=o["fx"], st=st, z_pass=z_pass, start=o)
 
 
 def _library_execute(pkg, sc, options, max_outer=0):
@@ -110,8 +132,72 @@ def _compare(name, got, ref, first_pass_tol):
     assert got["depth_steps"] == 101 and got["fallbacks"] == 0
     assert_same_stop(en, en_ref)
     assert rel[0] < first_pass_tol, rel
-    assert max(rel) < 1e-3, rel
-    return dict(depth_rmse=d_z, depth_max=z_max, albedo_max=d_rho_max, albedo_rmse=d_rho, shading=sh, same_count=len(en) == len(en_ref))
+    # every later pass: _calibrate's bound (what the fp32 CPU runs leave against fp64), no fixed number
+    return dict(rel=rel, depth_rmse=d_z, depth_max=z_max, albedo_max=d_rho_max, albedo_rmse=d_rho, shading=sh, same_count=len(en) == len(en_ref))
+
+
+def _library_depths(pkg, sc, options, n):
+    """the library's depth after pass k, k = 1..n: `srps_execute` capped at k passes on a fresh context each time (the passes of one
+    run are not observable from outside without changing how the run is sequenced)"""
+    dh = pkg.DataHandler.from_scene(sc)
+    out = []
+    for k in range(1, n + 1):
+        ctx = pkg.Context(device_id=0)
+        for key, v in options.items():
+            ctx.set_option(key, v)
+        ctx.setup(dh)
+        en = ctx.execute(k)
+        out.append((ctx.get("z"), [float(e) for e in en]))
+        ctx.close()
+    return out
+
+
+def _calibrate(pkg, coracle, sc, ref, runs):
+    """every fp32 run measured FROM the fp64 solve of the same loop, pass by pass (module docstring)"""
+    import time
+    o, st = ref["start"], ref["st"]
+    args = (st, o["I"], o["z0s"], o["z"], o["xx"], o["yy"], o["fx"], o["fy"])
+    t0 = time.perf_counter()
+    r64 = coracle.solve_mf(*args, precision="f64", keep_z=True)
+    n = len(r64["energies"])
+    t1 = time.perf_counter()
+    try:
+        coracle._L.oc64_set_dot_block(1000)
+        r64b = coracle.solve_mf(*args, precision="f64", keep_z=True, max_outer=n)
+    finally:
+        coracle._L.oc64_set_dot_block(256)
+    r32 = coracle.solve_mf(*args, precision="f32", keep_z=True, max_outer=n)
+    print(f"fp64 solve: {n} passes in {t1 - t0:.1f} s (the assembled fp32 oracle stopped after {len(ref['energies'])}); + a second fp64 and an fp32 matrix-free solve: {time.perf_counter() - t1:.1f} s")
+    e64, z64 = r64["energies"], r64["z_pass"]
+    dE = lambda es: [abs(a - b) / abs(b) for a, b in zip(es, e64)]
+    dZ = lambda zs: [rmse(a, b) for a, b in zip(zs, z64)]
+    rows = {"fp64, other summation order": (dE(r64b["energies"]), dZ(r64b["z_pass"])),
+            "fp32 matrix-free, CPU": (dE(r32["energies"]), dZ(r32["z_pass"])),
+            "fp32 assembled CSR, CPU (the oracle)": (dE(ref["energies"]), dZ(ref["z_pass"]))}
+    lib = {}
+    for name, (options, run) in runs.items():
+        per_pass = _library_depths(pkg, sc, options, min(n, len(run["energies"])))
+        for k, (_, en) in enumerate(per_pass):                                # a capped run IS the first k passes of the full run
+            assert en == run["energies"][:k + 1], (name, k)
+        lib[name] = rows[name] = (dE(run["energies"]), dZ([z for z, _ in per_pass]))
+    fmt = lambda v: " ".join("%8.1e" % x for x in v)
+    print(f"--- deviation from the fp64 solve, per pass: {sc.h}x{sc.w}, sf {sc.sf}, {sc.n_img} images; fp64 energies {['%.6g' % e for e in e64]}")
+    for name, (de, dz) in rows.items():
+        print(f"  {name:44s} energy {fmt(de)}")
+        print(f"  {'':44s} depth  {fmt(dz)}")
+    # 1. the reference run pins itself
+    assert max(rows["fp64, other summation order"][1]) < FP64_SELF, rows["fp64, other summation order"]
+    # 2. the library's rounding is of the class the fp32 CPU runs have
+    de_mf, dz_mf = rows["fp32 matrix-free, CPU"]
+    de_as, dz_as = rows["fp32 assembled CSR, CPU (the oracle)"]
+    for name, (de, dz) in lib.items():
+        for k in range(len(de)):
+            worst_e = max(de_mf[k], de_as[k] if k < len(de_as) else 0.0, E_FLOOR)
+            worst_z = max(dz_mf[k], dz_as[k] if k < len(dz_as) else 0.0, Z_FLOOR)
+            assert de[k] <= K_CAL * worst_e, (name, "energy", k, de[k], worst_e)
+            assert dz[k] <= K_CAL * worst_z, (name, "depth", k, dz[k], worst_z)
+        assert max(dz) < 1e-4, (name, dz)                                      # north_star's bound, against exact arithmetic
+    return dict(de_mf=de_mf, de_as=de_as, dz_mf=dz_mf, dz_as=dz_as, lib=lib, n=n)
 
 
 def _whole_solve(pkg, oracle, coracle, sc, first_pass_tol, expect_resident=True):
@@ -147,6 +233,13 @@ def _whole_solve(pkg, oracle, coracle, sc, first_pass_tol, expect_resident=True)
         assert r["shading"] < 2e-3, r
     if both:
         assert rmse(default["z"], faithful["z"]) < 2e-5
+    cal = _calibrate(pkg, coracle, sc, ref, {"HIP library, default options": ({}, default),
+                                             "HIP library, albedo_mode=0 cg_one_sync=0": ({"albedo_mode": 0, "cg_one_sync": 0}, faithful)})
+    # 3. the library against the assembled oracle, pass by pass: bounded by what the two fp32 CPU runs leave against fp64
+    for r in (r_d, r_f):
+        for k, v in enumerate(r["rel"][:cal["n"]]):
+            bound = K_CAL * (max(cal["de_as"][k] if k < len(cal["de_as"]) else 0.0, E_FLOOR) + max(cal["de_mf"][k], E_FLOOR))
+            assert v <= bound, (k, v, bound)
     return r_d, r_f
 
 

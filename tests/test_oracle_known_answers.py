@@ -207,3 +207,214 @@ def test_cpu_budget_and_the_baseline_entry_point():
     x1 = np.zeros(st.P, np.float32); x2 = np.zeros(st.P, np.float32)
     CO.cg_csr(rp, ci, v, x1, b.copy(), fixed_iters=5); CO.cg_csr(rp, ci, v, x2, b.copy(), fixed_iters=5)
     np.testing.assert_array_equal(x1, x2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: lighting (devicecalls.cu:408-444) and albedo (devicecalls.cu:447-548) by LITERAL transcription -- flat arrays, the
+# reference's own index expressions, plain loops, fp64; no code shared with the oracle.  Small integers (and image values that are
+# multiples of 1/8), so that every Gram entry, right-hand side and expansion value is exact in fp32 as well; two channels, so that the
+# channel strides of `d_s + i*4*nchannels + j*4` (:417), `d_s + c*4` with stride `4*nchannels` (:503, :520) and
+# `d_I + c*npix + i*npix*nchannels` (:526) are exercised.
+# ---------------------------------------------------------------------------------------------------------------------------------
+NPIX, NIMG, NCH = 16, 2, 2
+
+
+def _tiny_photometric_inputs():
+    ii, jj = np.arange(NPIX) % 4, np.arange(NPIX) // 4
+    N = np.stack([ii - 1, jj - 2, -1 - (ii + jj) % 2, np.ones(NPIX)]).astype(f32)            # d_N[h*npix + i]: not unit vectors -- the operator does not ask
+    rho = np.stack([1 + (ii + 2 * jj) % 2, 1 + (ii * jj) % 3]).astype(f32)                    # d_rho[c*npix + i]
+    I = np.stack([[((3 * ii + jj + 2 * c + i) % 8) / 8 for c in range(NCH)] for i in range(NIMG)]).astype(f32)     # d_I[i][c][p]
+    s = np.array([[[1, 0, -1, 0], [0, 1, -1, 1]], [[-1, 1, 0, 1], [1, 1, -1, 0]]], f32)       # d_s[i][c][4]
+    return N, rho, I, s
+
+
+def _literal_cg(row_ptr, col, val, n, x, b):
+    """cuda_based_conjugate_gradient, devicecalls.cu:229-279, on CSR arrays, statement by statement (fp64)"""
+    tol, max_iter = float(f32(1e-9)), 100
+    spmv = lambda v: np.array([sum(val[t] * v[col[t]] for t in range(row_ptr[r], row_ptr[r + 1])) for r in range(n)])
+    k, r0 = 0, 0.0
+    r1 = float(b @ b)                                                                          # :251
+    p = np.zeros(n)
+    while r1 > tol * tol and k <= max_iter:                                                    # :252
+        k += 1
+        if k == 1:
+            p = b.copy()                                                                       # :258
+        else:
+            beta = r1 / r0                                                                     # :262
+            p = beta * p                                                                       # :263
+            p = p + b                                                                          # :264
+        omega = spmv(p)                                                                        # :267
+        alpha = r1 / float(p @ omega)                                                          # :268-269
+        x += alpha * p                                                                         # :270
+        b -= alpha * omega                                                                     # :272
+        r0 = r1
+        r1 = float(b @ b)                                                                      # :274
+    return k
+
+
+def _literal_lighting():
+    """devicecalls.cu:376-383 (A_for_lightning_estimation) and :408-444.  Returns the updated s, and per (image, channel) the Gram
+    matrix and the residual right-hand side the CG was started with."""
+    N, rho, I, s = _tiny_photometric_inputs()
+    d_N, d_rho, d_I, d_s = N.reshape(-1).astype(np.float64), rho.reshape(-1).astype(np.float64), I.reshape(-1).astype(np.float64), s.reshape(-1).astype(np.float64)
+    npix, nimages, nchannels = NPIX, NIMG, NCH
+    d_A = np.zeros(npix * 4 * nchannels)
+    for c in range(nchannels):
+        for h in range(4):
+            for i in range(npix):
+                d_A[c * npix * 4 + h * npix + i] = d_rho[c * npix + i] * d_N[h * npix + i]     # :381
+    grams, rhss = {}, {}
+    for i in range(nimages):                                                                   # :410
+        for j in range(nchannels):                                                             # :411
+            A_ij = j * npix * 4                                                                # :412  (column-major npix x 4, lda = npix)
+            b_ij = i * npix * nchannels + j * npix                                             # :413
+            x_ij = i * 4 * nchannels + j * 4                                                   # :414
+            ATA = np.zeros(16)                                                                 # column-major 4 x 4, ld 4
+            for r in range(4):
+                for cc in range(4):                                                            # sgemm(T, N, 4, 4, npix) :422
+                    ATA[r + 4 * cc] = sum(d_A[A_ij + r * npix + p] * d_A[A_ij + cc * npix + p] for p in range(npix))
+            ATb = np.array([sum(d_A[A_ij + r * npix + p] * d_I[b_ij + p] for p in range(npix)) for r in range(4)])   # sgemv(T) :423
+            for r in range(4):                                                                 # sgemv(N, alpha = -1, beta = 1) :424
+                ATb[r] = -sum(ATA[r + 4 * cc] * d_s[x_ij + cc] for cc in range(4)) + ATb[r]
+            row_idx = [m // 4 for m in range(16)]; col_idx = [m % 4 for m in range(16)]        # :430-431
+            val = [ATA[row_idx[m] + 4 * col_idx[m]] for m in range(16)]                        # :432
+            row_ptr = [0, 4, 8, 12, 16]                                                        # coo2csr of row_idx :436
+            grams[(i, j)] = np.array(val).reshape(4, 4); rhss[(i, j)] = ATb.copy()
+            x = d_s[x_ij:x_ij + 4].copy()
+            _literal_cg(row_ptr, col_idx, val, 4, x, ATb)                                      # :437
+            d_s[x_ij:x_ij + 4] = x
+    return d_s.reshape(NIMG, NCH, 4), grams, rhss
+
+
+def _literal_albedo():
+    """devicecalls.cu:447-463 (fill_A_expansion, fill_AT_expansion), :497-511 (A_for_albedo), :395-406 (MA_Mb), :513-548.
+    Returns the updated rho and per channel the diagonal of A'A and the residual right-hand side."""
+    N, rho, I, s = _tiny_photometric_inputs()
+    d_N, d_rho, d_I, d_s = N.reshape(-1).astype(np.float64), rho.reshape(-1).astype(np.float64), I.reshape(-1).astype(np.float64), s.reshape(-1).astype(np.float64)
+    npix, nimages, nchannels = NPIX, NIMG, NCH
+    diags, rhss = {}, {}
+    for c in range(nchannels):                                                                 # :518
+        s_base = c * 4                                                                         # d_s + c * 4 :520
+        d_s_buff = np.zeros(4 * nimages)
+        for i in range(nimages):                                                               # :502-504
+            d_s_buff[i * 4:i * 4 + 4] = d_s[s_base + i * 4 * nchannels: s_base + i * 4 * nchannels + 4]
+        d_A = np.zeros(npix * nimages)                                                         # sgemm(N, N, npix, nimages, 4): column-major npix x nimages :507
+        for i in range(nimages):
+            for p in range(npix):
+                d_A[p + i * npix] = sum(d_N[p + k * npix] * d_s_buff[k + i * 4] for k in range(4))
+        n_e = npix * nimages
+        A_row = [t for t in range(n_e)]; A_col = [t % npix for t in range(n_e)]; A_val = [d_A[t] for t in range(n_e)]      # fill_A_expansion :447-454
+        AT_col = [t // nimages + (t % nimages) * npix for t in range(n_e)]                     # fill_AT_expansion :459
+        AT_row = [t // nimages for t in range(n_e)]                                            # :460
+        AT_val = [d_A[AT_col[t]] for t in range(n_e)]                                          # :461
+        d_b = np.zeros(n_e)
+        for i in range(nimages):                                                               # :525-527
+            d_b[npix * i: npix * i + npix] = d_I[c * npix + i * npix * nchannels: c * npix + i * npix * nchannels + npix]
+        # cuda_based_MA_Mb :395-406 with M = AT (npix x n_e), A (n_e x npix): MA = M A (csrgemm), Mb = M b - MA x
+        MA = np.zeros((npix, npix))
+        for t in range(n_e):                                                                   # entry (AT_row, AT_col) of M times row AT_col of A
+            k = AT_col[t]
+            assert A_row[k] == k
+            MA[AT_row[t], A_col[k]] += AT_val[t] * A_val[k]
+        Mb = np.zeros(npix)
+        for t in range(n_e):
+            Mb[AT_row[t]] += AT_val[t] * d_b[AT_col[t]]                                        # csrmv :404
+        x = d_rho[npix * c: npix * c + npix].copy()
+        Mb = -(MA @ x) + Mb                                                                    # csrmv(alpha = -1, beta = 1) :405
+        assert np.count_nonzero(MA - np.diag(np.diag(MA))) == 0                                # the normal equations are diagonal
+        diags[c] = np.diag(MA).copy(); rhss[c] = Mb.copy()
+        nz = [(r, cc) for r in range(npix) for cc in range(npix) if MA[r, cc] != 0]
+        row_ptr = [0] * (npix + 1)
+        for r, _ in nz:
+            row_ptr[r + 1] += 1
+        row_ptr = list(np.cumsum(row_ptr))
+        _literal_cg(row_ptr, [cc for _, cc in nz], [MA[r, cc] for r, cc in nz], npix, x, Mb)   # :540
+        d_rho[npix * c: npix * c + npix] = x
+    return d_rho.reshape(NCH, NPIX), diags, rhss
+
+
+def test_lighting_by_hand_one_gram_entry_and_one_right_hand_side():
+    """image 1, channel 0: A = rho_0 (.) [N0..N3].  Gram entry (3, 3) = sum rho_0^2 = sum over the 16 pixels of (1 + (i + 2j) % 2)^2
+    = sum (1 + i % 2)^2 = 8 * 1 + 8 * 4 = 40; entry (0, 3) = sum rho_0^2 (i - 1) = sum_j [ (1)(-1) + (4)(0) + (1)(1) + (4)(2) ] = 4 * 8 = 32."""
+    _, grams, _ = _literal_lighting()
+    assert grams[(1, 0)][3, 3] == 40.0 and grams[(1, 0)][0, 3] == 32.0 and grams[(0, 0)][3, 3] == 40.0
+    for g in grams.values():
+        assert np.array_equal(g, g.T) and np.all(np.linalg.eigvalsh(g) > 0)
+
+
+def test_oracles_reproduce_the_literal_lighting(oracle, CO):
+    N, rho, I, s = _tiny_photometric_inputs()
+    s_lit, grams, rhss = _literal_lighting()
+    # the 4 x 4 systems have converged (r.r <= 1e-18) long before the cap: the literal result IS the least-squares solution
+    for (i, j), g in grams.items():
+        A = (rho[j] * N).astype(np.float64)
+        assert np.array_equal(g, A @ A.T)
+        assert np.array_equal(rhss[(i, j)], A @ I[i, j].astype(np.float64) - g @ s[i, j].astype(np.float64))
+        np.testing.assert_allclose(s_lit[i, j], np.linalg.solve(g, A @ I[i, j].astype(np.float64)), rtol=0, atol=1e-9)
+    s_np = s.copy()
+    oracle.lighting_estimation(s_np, rho.copy(), N, I)
+    np.testing.assert_allclose(s_np, s_lit, rtol=0, atol=2e-5)
+    for prec, tol in (("f64", 1e-9), ("f32", 2e-5)):
+        R = CO._Real(prec)
+        sv = s.astype(R.dtype).copy()
+        rc = R.fn("lighting")(NPIX, NIMG, NCH, R.p(rho.astype(R.dtype).reshape(-1)), R.p(N.astype(R.dtype).reshape(-1)), CO._f(np.ascontiguousarray(I)),
+                              R.p(sv.reshape(-1)), None)
+        assert rc == 0
+        np.testing.assert_allclose(sv, s_lit, rtol=0, atol=tol)
+
+
+def test_albedo_by_hand_one_diagonal_entry():
+    """channel 1, pixel p = 5 = (i, j) = (1, 1): N = (0, -1, -1, 1); s_01 = (0, 1, -1, 1) -> a = -1 + 1 + 1 = 1; s_11 = (1, 1, -1, 0) ->
+    a = -1 + 1 = 0: (A'A)[5, 5] = 1; (A'b)[5] = 1 * I[0][1][5] = ((3 + 1 + 2) % 8) / 8 = 0.75; rho_1[5] = 1 + 1 % 3 = 2: residual -1.25."""
+    _, diags, rhss = _literal_albedo()
+    assert diags[1][5] == 1.0 and rhss[1][5] == -1.25
+
+
+def test_oracles_reproduce_the_literal_albedo(oracle, CO):
+    N, rho, I, s = _tiny_photometric_inputs()
+    rho_lit, diags, rhss = _literal_albedo()
+    for c in range(NCH):
+        sh = s[:, c, :].astype(np.float64) @ N.astype(np.float64)                              # [image][p]
+        assert np.array_equal(diags[c], (sh * sh).sum(0))
+        assert np.array_equal(rhss[c], (sh * I[:, c, :]).sum(0) - diags[c] * rho[c])
+        ok = diags[c] > 0
+        np.testing.assert_allclose(rho_lit[c][ok], ((sh * I[:, c, :]).sum(0) / np.where(ok, diags[c], 1))[ok], rtol=0, atol=1e-9)
+        assert np.array_equal(rho_lit[c][~ok], rho[c][~ok].astype(np.float64))                 # a zero row: the CG never moves that pixel
+    assert any((diags[c] == 0).any() for c in range(NCH)), "the case is meant to contain a pixel no image lights"
+    rho_np = rho.copy()
+    oracle.albedo_estimation(s, rho_np, N, I)
+    np.testing.assert_allclose(rho_np, rho_lit, rtol=0, atol=2e-5)
+    num, den = oracle.albedo_numden(s, N, I)
+    rho_nd = rho.copy()
+    oracle.albedo_solve_numden(rho_nd, num, den)
+    np.testing.assert_allclose(rho_nd, rho_lit, rtol=0, atol=2e-5)
+    for prec, tol in (("f64", 1e-9), ("f32", 2e-5)):
+        R = CO._Real(prec)
+        rv = rho.astype(R.dtype).copy()
+        rc = R.fn("albedo")(NPIX, NIMG, NCH, R.p(s.astype(R.dtype).reshape(-1)), R.p(N.astype(R.dtype).reshape(-1)), CO._f(np.ascontiguousarray(I)),
+                            R.p(rv.reshape(-1)), None)
+        assert rc == 0
+        np.testing.assert_allclose(rv, rho_lit, rtol=0, atol=tol)
+
+
+@pytest.mark.gpu
+def test_hip_library_on_the_literal_lighting_and_albedo(pkg):
+    """the operator-level HIP entries (srps_lightning_estimation, srps_albedo_estimation: the counterparts of devicecalls.cuh:34-35) on
+    the same case against the literal transcriptions -- pins of the product that do not pass through the oracle; both albedo modes"""
+    import torch
+    N, rho, I, s = _tiny_photometric_inputs()
+    s_lit, _, _ = _literal_lighting()
+    rho_lit, diags, _ = _literal_albedo()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).pin_memory().cuda().contiguous()
+    ctx = pkg.Context(device_id=0)
+    d_s = t(s)
+    ctx.lightning_estimation(d_s, t(rho), t(N), t(I), NPIX, NIMG, NCH)
+    ctx.synchronize()
+    np.testing.assert_allclose(d_s.cpu().numpy(), s_lit, rtol=0, atol=2e-5)
+    for mode in (0, 3):
+        ctx.set_option("albedo_mode", mode)
+        d_rho = t(rho)
+        ctx.albedo_estimation(t(s), d_rho, t(N), t(I), NPIX, NIMG, NCH)
+        ctx.synchronize()
+        np.testing.assert_allclose(d_rho.cpu().numpy(), rho_lit, rtol=0, atol=2e-5)
+    ctx.close()
