@@ -604,38 +604,62 @@ def main():
             # The headline workload with the reference's albedo CG in the pipeline (albedo_mode = SRPS_ALBEDO_CG; the default since round 4
             # is the CG's fixed point formed inside the albedo sweep, SRPS_ALBEDO_AUTO -- include/srps.h has the measurements behind that):
             # num / den / image-sum planes, the persistent albedo CG, the depth assembly from the sums.
-            cf = pkg.Context(device_id=local_rank)
-            cf.set_stream(stream.cuda_stream)
-            cf.set_option("exclusive_device", 1)
-            cf.set_option("albedo_mode", 0)
-            cf.setup(dh)
-            for _ in range(max(args.warmup, 1)):
-                pkg.alternating_loop(cf, None, max_outer=1)
-            torch.cuda.synchronize()
-            tf = time.perf_counter()
-            for _ in range(args.steps):
-                pkg.alternating_loop(cf, None, max_outer=1)
-            torch.cuda.synchronize()
-            df = time.perf_counter() - tf
-            itf = cf.last_cg_iterations()
-            assert itf["depth"] == 101 and cf.get_option("persistent_fallbacks") == 0
-            legs["albedo_reference_cg"] = {"cg_iterations_per_sec": itf["depth"] * args.steps / df, "ms_per_step": 1e3 * df / args.steps, "albedo_cg_steps": list(itf["albedo"][:3]),
-                                           "workload": "the headline workload with albedo_mode = SRPS_ALBEDO_CG (the reference's CG on the diagonal albedo system in the pipeline; not the default)"}
-            cf.close()
+            def timed_passes(options):
+                cf = pkg.Context(device_id=local_rank)
+                cf.set_stream(stream.cuda_stream)
+                cf.set_option("exclusive_device", 1)
+                for name, val in options.items():
+                    cf.set_option(name, val)
+                cf.setup(dh)
+                for _ in range(max(args.warmup, 1)):
+                    pkg.alternating_loop(cf, None, max_outer=1)
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
+                for _ in range(args.steps):
+                    pkg.alternating_loop(cf, None, max_outer=1)
+                torch.cuda.synchronize()
+                df = time.perf_counter() - tf
+                itf = cf.last_cg_iterations()
+                assert itf["depth"] == 101 and cf.get_option("persistent_fallbacks") == 0
+                cgb = cf.bench_cg(solves=5, iters=101)
+                res = {"cg_iterations_per_sec": itf["depth"] * args.steps / df, "ms_per_step": 1e3 * df / args.steps, "albedo_cg_steps": list(itf["albedo"][:3]),
+                       "cg_only_us_per_iteration": 1e6 * cgb["seconds"] / cgb["iterations"]}
+                cf.setup(dh)
+                torch.cuda.synchronize()
+                ts = time.perf_counter(); en_f = pkg.alternating_loop(cf, None); torch.cuda.synchronize()
+                res["total_solve_s"] = time.perf_counter() - ts
+                res["total_solve_outer_iterations"] = len(en_f)
+                cf.close()
+                return res
+            legs["albedo_reference_cg"] = dict(timed_passes({"albedo_mode": 0}),
+                                               workload="the headline workload with albedo_mode = SRPS_ALBEDO_CG (the reference's CG on the diagonal albedo system in the pipeline; not the default)")
+            # The price of the reference's exact arithmetic: BOTH documented departures switched off -- the albedo by the reference's CG
+            # (dc.cu:513-548) instead of its fixed point formed in the sweep, and r.r summed directly in every CG step (dc.cu:274)
+            # instead of predicted from the step's three sums (a second grid-wide wait per step).  Same workload, same timing.
+            legs["reference_arithmetic"] = dict(timed_passes({"albedo_mode": 0, "cg_one_sync": 0}),
+                                                workload="the headline workload with albedo_mode = SRPS_ALBEDO_CG AND cg_one_sync = 0: every sum and every solve as devicecalls.cu has them (not the default)",
+                                                headline_ms_per_step=out["ms_per_step"], price_of_exactness=None)
+            legs["reference_arithmetic"]["price_of_exactness"] = legs["reference_arithmetic"]["ms_per_step"] / out["ms_per_step"]
             mitten = os.path.join(ROOT, "tests", "golden", "mitten_full.npz")
-            if os.path.exists(mitten):
+            mitten20 = os.path.join(ROOT, "tests", "golden", "mitten_full_20.npz")
+
+            def mitten_leg(n_images):
                 # BASELINE.json config 2 at its true size: the whole frame of the reference's bundled Mitten data set (960 x 1280,
-                # sf 2, 148 600 masked pixels, the first 8 images; tests/golden/mitten_full.npz holds the masked samples), full
-                # alternating solve to the reference's stop rule -- parity against the oracle: tests/test_mitten_full.py
+                # sf 2, 148 600 masked pixels; tests/golden/mitten_full.npz holds the masked samples of the first 8 images,
+                # mitten_full_20.npz those of the other 12), full alternating solve to the reference's stop rule -- parity against
+                # the oracle: tests/test_mitten_full.py.  20 images is what `srps -t images -d dataset/Images/Mitten` solves
+                # (cv::glob of RGB/, Utilities.cpp:349-352); 8 is BASELINE.json's "~8 images".
                 M = np.load(mitten)
+                X = np.load(mitten20) if n_images == 20 else M
+                bytes_ = M["I_u8"] if n_images == 8 else np.concatenate([M["I_u8"], X["I_u8_9_to_20"]])
                 mh, mw, msf = int(M["h"]), int(M["w"]), int(M["sf"])
                 mmask = np.unpackbits(M["mask_bits"])[: mh * mw].astype(np.float32)
                 mi = np.flatnonzero(mmask == 1)
-                mI = np.zeros((M["I_u8"].shape[0], 3, mh * mw), np.float32); mI[:, :, mi] = M["I_u8"].astype(np.float32) / np.float32(255)
+                mI = np.zeros((n_images, 3, mh * mw), np.float32); mI[:, :, mi] = bytes_.astype(np.float32) / np.float32(255)
                 mzs = np.zeros((mh // msf) * (mw // msf), np.float32); mzs[M["imasks"]] = M["zs_lr_masked"]
                 mzf = np.zeros(mh * mw, np.float32); mzf[mi] = M["z_full_masked"]
-                mdh = pkg.DataHandler(I=mI, mask=mmask, K=M["K"], sf=msf, z0=mzs.reshape(1, -1), I_h=mh, I_w=mw, I_c=3, I_n=mI.shape[0],
-                                      I_n_total=mI.shape[0], zs_lr=mzs, z_full=mzf)
+                mdh = pkg.DataHandler(I=mI, mask=mmask, K=M["K"], sf=msf, z0=mzs.reshape(1, -1), I_h=mh, I_w=mw, I_c=3, I_n=n_images,
+                                      I_n_total=n_images, zs_lr=mzs, z_full=mzf)
                 cm = pkg.Context(device_id=local_rank)
                 cm.set_stream(stream.cuda_stream)
                 cm.set_option("exclusive_device", 1)
@@ -644,11 +668,16 @@ def main():
                 tm0 = time.perf_counter(); cm.setup(mdh); torch.cuda.synchronize()
                 tm1 = time.perf_counter(); men = pkg.alternating_loop(cm, None); torch.cuda.synchronize()
                 tm2 = time.perf_counter()
-                legs["mitten_full_frame"] = {"total_solve_s": tm2 - tm1, "total_solve_with_setup_s": tm2 - tm0, "outer_iterations": len(men),
-                                             "final_energy": men[-1], "oracle_final_energy": float(M["energies"][-1]), "masked_pixels": int(mi.size),
-                                             "images": int(mI.shape[0]), "image_store_bytes_active": cm.get_option("image_store_bytes_active"),
-                                             "workload": "the reference's Mitten data set, whole 960x1280 frame, sf 2, 8 images: full alternating solve to its stop rule"}
+                res = {"total_solve_s": tm2 - tm1, "total_solve_with_setup_s": tm2 - tm0, "outer_iterations": len(men),
+                       "final_energy": men[-1], "oracle_final_energy": float(X["energies"][-1]), "masked_pixels": int(mi.size),
+                       "images": n_images, "image_store_bytes_active": cm.get_option("image_store_bytes_active"),
+                       "workload": f"the reference's Mitten data set, whole 960x1280 frame, sf 2, {n_images} images: full alternating solve to its stop rule"}
                 cm.close()
+                return res
+            if os.path.exists(mitten):
+                legs["mitten_full_frame"] = mitten_leg(8)
+                if os.path.exists(mitten20):
+                    legs["mitten_full_frame_20_images"] = dict(mitten_leg(20), note="all 20 images of the folder: what the reference's CLI solves on its bundled data set (Utilities.cpp:349-352)")
             # what a bare stream of the CG step's shape reaches on THIS box (tools/hbm_ceiling_bench.hip, a child process; the pool's
             # boxes differ by 15 %): the streaming legs' fraction of that, next to their fraction of the 8 TB/s peak
             ceil_bin = os.path.join(ROOT, "tools", "hbm_ceiling_bench.bin")

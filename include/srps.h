@@ -135,6 +135,10 @@ int srps_synchronize(srps_ctx* ctx);
  *  two and three THREADS of one process (tests/test_gpu_strips.py); across devices not yet),
  * "debug_ipc_same_process" (test hook: same-process ranks map each other through the hipIpc handles -- HIP refuses; the ranks must
  *  recognise it together),
+ * "debug_foreign_pid_twin" (test hook, round 6: the rank's handshake record carries a process number of its own.  "Same process" is decided
+ *  by pid AND a random 64-bit number drawn once per process AND a hash of the host's boot id and name -- pids repeat across PID
+ *  namespaces and hosts --, and a same-process peer's address is checked with hipPointerGetAttributes (device memory of the ordinal
+ *  it claims) before a kernel stores through it),
  * "light_run" (0..3, default 3, round 5: the form of the energy + lighting sweep.  1: a wave takes one image plane's four 1 KiB pieces of a
  *  tile back to back -- a 4 KiB run --, channel by channel, the channel's products rho N_k of the four pieces in registers; 0: one piece
  *  of each of the wave's images per step, round 4's form.  2 and 3 (float images in their plane layout, three channels; otherwise 1 is

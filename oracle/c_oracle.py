@@ -153,12 +153,24 @@ def bench_cg_csr(rowptr, col, val, b0, iters, reps, threads):
     return sec
 
 
+def bench_cg_mf(st, M, b0, iters, reps, threads, lam=1.0):
+    """the same for the matrix-free operator (oc_bench_cg_mf)"""
+    _L.oc_bench_cg_mf.restype = C.c_int
+    sec = np.zeros(reps, np.float64)
+    b0 = np.ascontiguousarray(b0, f32); M = np.ascontiguousarray(M, f32)
+    rc = _L.oc_bench_cg_mf(st.P, st.Ps, st.sf, _i(st.nb), _i(st.blk), _i(st.blk_pix), _f(M), C.c_float(lam), _f(b0), int(iters), int(reps), int(threads),
+                           sec.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0, "oc_bench_cg_mf: out of memory"
+    return sec
+
+
 def bench_cpu_baseline(h, w, sf, mask, budget_s=20.0, reps=5):
-    """bench.py cpu_baseline leg: the reference's formulation (assembled CSR + unfused BLAS-1 CG, dc.cu:229-279) on the SAME HR grid.
-    Median of `reps` timed solves after a warm-up, at ONE thread and at all host threads, matrix and vectors first
-    touched by the threads that stream them (oc_bench_cg_csr); the caller binds the threads through the environment
-    (oracle/cpu_baseline_main.py is started with OMP_PROC_BIND=spread OMP_PLACES=cores).  The tensor is synthetic (values do not
-    change the cost of an iteration)."""
+    """bench.py cpu_baseline leg: BOTH CPU variants of BASELINE.md section 3 on the SAME HR grid -- the reference's formulation (assembled
+    CSR + unfused BLAS-1 CG, dc.cu:229-279: `value`) and the matrix-free operator under the same recurrence (`matrix_free`: the stronger
+    baseline, a third of the bytes).  Per variant: median of `reps` timed solves after two warm-up solves, at ONE thread and at all host
+    threads, matrix / tensor and vectors first touched by the threads that stream them; the caller binds the threads through
+    the environment (oracle/cpu_baseline_main.py is started with OMP_PROC_BIND=spread OMP_PLACES=cores).  The tensor is synthetic
+    (values do not change the cost of an iteration)."""
     st = Structure(h, w, sf, mask)
     rng = np.random.default_rng(0)
     M = np.abs(rng.normal(size=(6, st.P))).astype(f32); M[[1, 2, 4]] *= 0.1
@@ -166,26 +178,38 @@ def bench_cpu_baseline(h, w, sf, mask, budget_s=20.0, reps=5):
     rp, ci, v = assemble(st, M)
     b = rng.normal(size=st.P).astype(f32)
     nthr = num_threads()
-    out = {}
-    for label, thr in (("all", nthr), ("one", 1)):
-        t_probe = float(bench_cg_csr(rp, ci, v, b, 3, 1, thr)[0]) / 3                       # seconds per step, after the entry's own warm-up
-        share = budget_s * (0.5 if nthr > 1 else 1.0) / (reps + 1)                           # per solve, warm-up included
-        iters = int(max(3, min(101, share / max(t_probe, 1e-6))))
-        sec = bench_cg_csr(rp, ci, v, b, iters, reps, thr)
-        out[label] = {"it_per_s": iters / float(np.median(sec)), "iters_per_solve": iters, "solves": [iters / float(t) for t in sec],
-                      "spread": float((sec.max() - sec.min()) / np.median(sec)), "threads": thr}
-        if nthr == 1:
-            out["one"] = out["all"]
-            break
-    a, o = out["all"], out["one"]
+    runners = {"assembled_csr": lambda it, rp_, thr: bench_cg_csr(rp, ci, v, b, it, rp_, thr),
+               "matrix_free": lambda it, rp_, thr: bench_cg_mf(st, M, b, it, rp_, thr)}
+    res = {}
+    for kind, run in runners.items():
+        out = {}
+        for label, thr in (("all", nthr), ("one", 1)):
+            t_probe = float(run(3, 1, thr)[0]) / 3                                          # seconds per step, after the entry's own warm-ups
+            share = budget_s * 0.5 * (0.5 if nthr > 1 else 1.0) / (reps + 2)                 # per solve, warm-ups included; half the budget per variant
+            iters = int(max(3, min(101, share / max(t_probe, 1e-6))))
+            sec = run(iters, reps, thr)
+            out[label] = {"it_per_s": iters / float(np.median(sec)), "iters_per_solve": iters, "solves": [iters / float(t) for t in sec],
+                          "spread": float((sec.max() - sec.min()) / np.median(sec)), "threads": thr}
+            if nthr == 1:
+                out["one"] = out["all"]
+                break
+        res[kind] = out
+    a, o = res["assembled_csr"]["all"], res["assembled_csr"]["one"]
+    ma, mo = res["matrix_free"]["all"], res["matrix_free"]["one"]
     return {"value": a["it_per_s"], "unit": "cg_iterations/s", "cores": nthr, "kind": "port",
             "value_1_thread": o["it_per_s"],
-            "sample": f"median of {reps} solves of {a['iters_per_solve']} CG steps each (after a warm-up solve) of the assembled-CSR {h}x{w} system "
+            "sample": f"median of {reps} solves of {a['iters_per_solve']} CG steps each (after two warm-up solves) of the assembled-CSR {h}x{w} system "
                       f"({v.size / st.P:.1f} nnz/row), C/OpenMP restatement of devicecalls.cu:229-279 on {nthr} threads; "
                       f"1 thread: {reps} solves of {o['iters_per_solve']} steps",
             "solves_it_per_s": a["solves"], "solves_it_per_s_1_thread": o["solves"], "spread_over_solves": a["spread"],
+            "matrix_free": {"value": ma["it_per_s"], "unit": "cg_iterations/s", "cores": nthr, "value_1_thread": mo["it_per_s"],
+                            "sample": f"median of {reps} solves of {ma['iters_per_solve']} CG steps each (after two warm-up solves) of the SAME system applied matrix-free "
+                                      f"(oc_mf_apply: 6 tensor planes, 4 neighbour indices and the block index per unknown), same recurrence, {nthr} threads; "
+                                      f"1 thread: {reps} solves of {mo['iters_per_solve']} steps",
+                            "solves_it_per_s": ma["solves"], "spread_over_solves": ma["spread"],
+                            "note": "BASELINE.md section 3's second CPU variant: the formulation the GPU path uses, on the host cores"},
             "thread_binding": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")},
-            "first_touch": "matrix and vectors copied and first touched by the threads that stream them (static schedule)"}
+            "first_touch": "matrix / tensor and vectors copied and first touched by the threads that stream them (static schedule)"}
 
 
 # ---- the whole alternating loop, matrix-free, in one arithmetic type (srps_solve_mf.c) ---------------------------------------------

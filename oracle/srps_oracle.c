@@ -376,7 +376,7 @@ int oc_bench_cg_csr(int n, const int* rowptr, const int* col, const float* val, 
     }
     oc_op A; memset(&A, 0, sizeof(A));
     A.mode = 0; A.n = n; A.rowptr = rp; A.col = ci; A.val = va;
-    for (int k = -1; k < reps; ++k) {                                 /* k = -1: the warm-up */
+    for (int k = -2; k < reps; ++k) {                                 /* k < 0: two warm-up solves (round 5's first timed solve still ran at 0.6 x) */
 #pragma omp parallel for schedule(static)
         for (int r = 0; r < n; ++r) { x[r] = 0.f; b[r] = b0[r]; }
 #ifdef _OPENMP
@@ -390,6 +390,60 @@ int oc_bench_cg_csr(int n, const int* rowptr, const int* col, const float* val, 
 #endif
     }
     free(rp); free(ci); free(va); free(x); free(b); free(p); free(om);
+#ifdef _OPENMP
+    omp_set_num_threads(before);
+#endif
+    return 0;
+}
+
+/* The same for the MATRIX-FREE form of the system (oc_mf_apply: 6 tensor planes + 4 neighbour indices + the block index per unknown
+ * instead of 17.9 non-zeros with their column indices): BASELINE.md section 3's second CPU variant, the stronger baseline -- it moves
+ * about a third of the bytes.  Same recurrence (cg_run_ws), same first-touch discipline, two warm-up solves. */
+int oc_bench_cg_mf(int P, int Ps, int sf, const int* nb, const int* blk, const int* blk_pix, const float* M, float lambda, const float* b0,
+                   int iters, int reps, int threads, double* seconds) {
+#ifdef _OPENMP
+    const int before = omp_get_max_threads();
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    const long LP = P;
+    const int per = sf * sf;
+    int* nb2 = (int*)malloc((size_t)LP * 4 * sizeof(int));
+    int* blk2 = (int*)malloc((size_t)LP * sizeof(int));
+    int* bp2 = (int*)malloc((size_t)(Ps > 0 ? Ps : 1) * per * sizeof(int));
+    float* M2 = (float*)malloc((size_t)LP * 6 * sizeof(float));
+    float* work = (float*)malloc((3 * (size_t)LP + Ps + 8) * sizeof(float));
+    float *x = (float*)malloc((size_t)LP * sizeof(float)), *b = (float*)malloc((size_t)LP * sizeof(float));
+    float *p = (float*)malloc((size_t)LP * sizeof(float)), *om = (float*)malloc((size_t)LP * sizeof(float));
+    if (!nb2 || !blk2 || !bp2 || !M2 || !work || !x || !b || !p || !om) { free(nb2); free(blk2); free(bp2); free(M2); free(work); free(x); free(b); free(p); free(om); return -1; }
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < LP; ++r) {
+        for (int t = 0; t < 4; ++t) nb2[t * LP + r] = nb[t * LP + r];
+        for (int t = 0; t < 6; ++t) M2[t * LP + r] = M[t * LP + r];
+        blk2[r] = blk[r];
+        work[r] = work[LP + r] = work[2 * LP + r] = 0.f;
+        x[r] = 0.f; b[r] = b0[r]; p[r] = 0.f; om[r] = 0.f;
+    }
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < Ps; ++q) {
+        for (int t = 0; t < per; ++t) bp2[q * per + t] = blk_pix[q * per + t];
+        work[3 * LP + q] = 0.f;
+    }
+    oc_op A; memset(&A, 0, sizeof(A));
+    A.mode = 1; A.n = P; A.Ps = Ps; A.sf = sf; A.nb = nb2; A.blk = blk2; A.blk_pix = bp2; A.M = M2; A.lambda = lambda; A.work = work;
+    for (int k = -2; k < reps; ++k) {
+#pragma omp parallel for schedule(static)
+        for (long r = 0; r < LP; ++r) { x[r] = 0.f; b[r] = b0[r]; }
+#ifdef _OPENMP
+        const double t0 = omp_get_wtime();
+#endif
+        cg_run_ws(&A, x, b, 0.f, 0, iters, p, om);
+#ifdef _OPENMP
+        if (k >= 0) seconds[k] = omp_get_wtime() - t0;
+#else
+        if (k >= 0) seconds[k] = 0.0;
+#endif
+    }
+    free(nb2); free(blk2); free(bp2); free(M2); free(work); free(x); free(b); free(p); free(om);
 #ifdef _OPENMP
     omp_set_num_threads(before);
 #endif

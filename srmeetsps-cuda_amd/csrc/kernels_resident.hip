@@ -24,6 +24,8 @@
 //     arithmetic is sunk to the first use of omega, after the loop, together with everything it reads;
 //   * structure masks are formed by v_bfe_i32 in assembly (the portable forms become and + compare + select).
 #include <unistd.h>
+#include <ctime>
+#include <random>
 
 #include "srps_internal.h"
 #include "device_utils.h"
@@ -1459,6 +1461,10 @@ int resident_exchange_buffer(srps_ctx* ctx, size_t need, bool coarse_ok) {
 //   [80]      the device's ordinal in that process (for hipDeviceEnablePeerAccess between ranks of one process)
 //   [81]      1: the buffer is fine-grained memory
 //   [82]      1: this rank got as far as having a buffer at all
+//   [83, 91)  a random 64-bit number drawn once per PROCESS, [91, 95) a hash of the host's boot id and name: a pid alone says "same
+//             process" only inside one PID namespace -- two ranks in separate containers of one node, or on two hosts under a caller's
+//             transport, can carry the same pid, and a foreign virtual address taken for a local one is a memory fault or a spin to the
+//             deadline (round-5 advisor finding).  Same process = same pid AND same number AND same host.
 constexpr int XG_REC = 96;
 struct XgRecord {
     unsigned char handle[64];
@@ -1466,13 +1472,38 @@ struct XgRecord {
     unsigned pid;
     unsigned char pci[4];
     int ordinal, fine, ok;
+    unsigned long long nonce;
+    unsigned host;
 };
+static unsigned long long process_nonce() {
+    static const unsigned long long n = [] {
+        unsigned long long v = 0;
+        if (FILE* f = fopen("/dev/urandom", "rb")) { if (fread(&v, sizeof(v), 1, f) != 1) v = 0; fclose(f); }
+        if (!v) { std::random_device rd; v = ((unsigned long long)rd() << 32) ^ rd() ^ ((unsigned long long)getpid() << 17) ^ (unsigned long long)time(nullptr); }
+        return v ? v : 1ull;
+    }();
+    return n;
+}
+static unsigned host_hash() {
+    static const unsigned h = [] {
+        char buf[320]; size_t n = 0;
+        memset(buf, 0, sizeof(buf));
+        if (FILE* f = fopen("/proc/sys/kernel/random/boot_id", "rb")) { n = fread(buf, 1, 64, f); fclose(f); }
+        if (gethostname(buf + n, sizeof(buf) - n - 1) != 0) buf[n] = 0;
+        unsigned v = 2166136261u;                          // FNV-1a
+        for (size_t i = 0; i < sizeof(buf) && (i < n || buf[i]); ++i) { v ^= (unsigned char)buf[i]; v *= 16777619u; }
+        return v;
+    }();
+    return h;
+}
 static void xg_pack(const XgRecord& r, float* f) {
     for (int b = 0; b < 64; ++b) f[b] = (float)r.handle[b];
     for (int b = 0; b < 8; ++b) f[64 + b] = (float)((r.addr >> (8 * b)) & 0xffull);
     for (int b = 0; b < 4; ++b) f[72 + b] = (float)((r.pid >> (8 * b)) & 0xffu);
     for (int b = 0; b < 4; ++b) f[76 + b] = (float)r.pci[b];
     f[80] = (float)r.ordinal; f[81] = (float)r.fine; f[82] = (float)r.ok;
+    for (int b = 0; b < 8; ++b) f[83 + b] = (float)((r.nonce >> (8 * b)) & 0xffull);
+    for (int b = 0; b < 4; ++b) f[91 + b] = (float)((r.host >> (8 * b)) & 0xffu);
 }
 static void xg_unpack(const float* f, XgRecord& r) {
     memset(&r, 0, sizeof(r));
@@ -1481,6 +1512,8 @@ static void xg_unpack(const float* f, XgRecord& r) {
     for (int b = 0; b < 4; ++b) r.pid |= (unsigned)(unsigned char)f[72 + b] << (8 * b);
     for (int b = 0; b < 4; ++b) r.pci[b] = (unsigned char)f[76 + b];
     r.ordinal = (int)f[80]; r.fine = (int)f[81]; r.ok = (int)f[82];
+    for (int b = 0; b < 8; ++b) r.nonce |= (unsigned long long)(unsigned char)f[83 + b] << (8 * b);
+    for (int b = 0; b < 4; ++b) r.host |= (unsigned)(unsigned char)f[91 + b] << (8 * b);
 }
 // Collective: every rank of the communicator calls it in the same solve (the grid, and with it `need`, is the same on all).  Whatever
 // goes wrong locally is RECORDED and the rank still takes part in the one exchange (with a record that says so): no return path lies
@@ -1509,6 +1542,8 @@ static int resident_rank_open(srps_ctx* ctx, size_t need) {
         mine.fine = ctx->xg_fine;
     }
     mine.pid = (unsigned)getpid();
+    mine.nonce = ctx->debug_foreign_pid_twin ? process_nonce() ^ (0x9e3779b97f4a7c15ull * (unsigned)(rank + 1)) : process_nonce();
+    mine.host = host_hash();
     {
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) {
@@ -1545,7 +1580,11 @@ static int resident_rank_open(srps_ctx* ctx, size_t need) {
     for (int q = 0; q < world && mapped; ++q) {
         if (q == rank) { ctx->xg_peer[q] = ctx->xg_buf; continue; }
         const XgRecord& r = rec[(size_t)q];
-        const bool same_process = r.pid == mine.pid && !ctx->debug_ipc_same_process;
+        const bool same_process = r.pid == mine.pid && r.nonce == mine.nonce && r.host == mine.host && !ctx->debug_ipc_same_process;
+        if (r.host != mine.host) {                          // neither a pointer nor a hipIpc handle crosses hosts
+            set_error("resident strips: rank %d runs on another host (the exchange buffers are reached through device memory mappings)", q);
+            mapped = false; break;
+        }
         if (same_process) {
             // a rank of this process (another host thread, its own context): its pointer is valid here as it stands; a peer DEVICE must be
             // made accessible from this one
@@ -1559,6 +1598,15 @@ static int resident_rank_open(srps_ctx* ctx, size_t need) {
                 const hipError_t e = hipDeviceEnablePeerAccess(r.ordinal, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("resident strips: hipDeviceEnablePeerAccess(%d): %s", r.ordinal, hipGetErrorString(e)); mapped = false; }
                 (void)hipGetLastError();
+            }
+            // the address must be what the record says it is -- device memory of that ordinal in THIS process -- before a kernel
+            // stores through it
+            hipPointerAttribute_t at;
+            memset(&at, 0, sizeof(at));
+            if (hipPointerGetAttributes(&at, (void*)(uintptr_t)r.addr) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != r.ordinal) {
+                (void)hipGetLastError();
+                set_error("resident strips: rank %d's buffer address is not device memory of device %d in this process", q, r.ordinal);
+                mapped = false; break;
             }
             ctx->xg_peer[q] = (void*)(uintptr_t)r.addr;
             continue;

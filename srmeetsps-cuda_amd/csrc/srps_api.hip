@@ -541,6 +541,8 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->cg_resident_debug = value;
     } else if (!strcmp(name, "shard_range_check")) {
         ctx->shard_range_check = value ? 1 : 0;
+    } else if (!strcmp(name, "debug_foreign_pid_twin")) {
+        ctx->debug_foreign_pid_twin = value ? 1 : 0;       // tests: see resident_rank_open (same pid, another process number: never the pointer route)
     } else if (!strcmp(name, "debug_ipc_same_process")) {
         ctx->debug_ipc_same_process = value ? 1 : 0;       // tests: see resident_rank_open
     } else if (!strcmp(name, "debug_inject_abort")) {

@@ -212,6 +212,7 @@ struct srps_ctx {
     int xg_peer_ipc[8] = {};         // 1: mapped with hipIpcOpenMemHandle (closed on release); 0: the pointer of a rank of this process
     int xg_fine = 0;                 // 1: xg_buf is fine-grained memory (coherent across devices while kernels run)
     int debug_ipc_same_process = 0;  // tests: map a same-process peer through its handle (HIP refuses: the failure must be recognised)
+    int debug_foreign_pid_twin = 0;  // tests: this rank's handshake record carries a process number of its own -- a rank of ANOTHER pid namespace that happens to share the pid
     int xg_world = 0;                // ranks the peers were opened for (0: not open)
     int xg_failed = 0;               // the handshake or a launch failed once: not tried again on this context
     double* d_strip_tot = nullptr;   // [12]: [0..3] this rank's sums of a launch, [4..7] / [8..11] the sums over all ranks of the launches of even / odd

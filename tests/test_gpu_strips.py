@@ -530,13 +530,13 @@ def test_resident_strips_between_ranks_of_one_process(pkg, h, w, sf, kind, world
           f" (attempts: {attempts})")
 
 
-def _ipc_refusal_scenario():
-    """child process of the test below: prints one JSON line"""
+def _ipc_refusal_scenario(option="debug_ipc_same_process"):
+    """child process of the tests below: prints one JSON line"""
     import importlib
     import json
     pkg = importlib.import_module("srmeetsps-cuda_amd")
     sc = pkg.synth.make_scene(1024, 2048, 4, 3, seed=99, mask_kind="full")
-    out, errs, cerrs = _thread_ranks(pkg, sc, 2, 512, options={"debug_ipc_same_process": 1}, passes=1)
+    out, errs, cerrs = _thread_ranks(pkg, sc, 2, 512, options={option: 1}, passes=1)
     ref = _single_reference(pkg, sc, 512, passes=1)
     print("SCENARIO" + json.dumps({"errs": errs, "cerrs": cerrs, "it": [r.get("it") for r in out], "resident": [r.get("resident") for r in out],
                                    "strips": [r.get("strips") for r in out], "rmse": [rmse(r["z0"], ref["z0"]) for r in out],
@@ -544,18 +544,22 @@ def _ipc_refusal_scenario():
 
 
 @pytest.mark.timeout(900)
-def test_in_process_ipc_mapping_failure_is_recognised():
+@pytest.mark.parametrize("option", ["debug_ipc_same_process", "debug_foreign_pid_twin"])
+def test_in_process_ipc_mapping_failure_is_recognised(option):
     """With `debug_ipc_same_process` the ranks of one process map each other's buffers through the hipIpc handles, as round 4 did: HIP
     refuses (a handle is opened by OTHER processes only).  The failure must be recognised by all ranks together -- no hang, no wrong
     result -- and the solve goes on without the resident strips (the streaming strips where the ranks have a neighbour transport, else
     the replicated CG) with the same result to rounding.  Run in a child process: a runtime that has refused a mapping has been seen to
-    crash when the process ends (after every result was delivered), which must not take the test session with it."""
+    crash when the process ends (after every result was delivered), which must not take the test session with it.
+    `debug_foreign_pid_twin` (round 6, advisor finding): every rank's handshake record carries a process number of its own while the pids are
+    equal -- what two ranks in separate PID namespaces look like.  A pid match alone must NOT put a peer's raw address into a kernel: the
+    ranks take the handle route (refused here, because they really are one process), recognise it together and go on as above."""
     import json
     import subprocess
     import sys
-    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_strips as T; T._ipc_refusal_scenario()"
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_strips as T; T._ipc_refusal_scenario(%r)"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
-               os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")))
+               os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), option))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=800)
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("SCENARIO")]
     assert line, (res.returncode, res.stdout[-1500:], res.stderr[-1500:])

@@ -40,8 +40,8 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 # Calibration constants (round 6; measured tables in DESIGN.md section 6 and profiles/r06_drift_calibration.txt)
-FP64_SELF = 2e-6      # depth RMSE between two fp64 runs that differ in the order of their dot products (measured: 1e-8 ... 4e-7)
-K_CAL = 3.0           # the library against the worse fp32 CPU run, per pass (two CPU orderings of one formulation differ by up to 2.1 x)
+FP64_SELF = 5e-6      # depth RMSE between two fp64 runs that differ in the order of their dot products (measured: 1.7e-6 ... 2.2e-6 at 1024^2)
+K_CAL = 1.5           # the library against the worse fp32 CPU run, per pass (measured: 0.5 ... 1.09 x; the library and the CPU fp32 matrix-free run agree to two digits)
 E_FLOOR = 2e-5        # below this relative energy deviation two fp32 runs are not told apart (fp64's own uncertainty is ~1e-6 ... 5e-6)
 Z_FLOOR = 5e-6        # the same for the depth RMSE
 

@@ -2,7 +2,12 @@
 convergence"): the WHOLE frame of the reference's bundled Mitten data set (960 x 1280, 148 600 masked pixels, the first 8 images,
 real 16-bit depth, real mask), committed as tests/golden/mitten_full.npz by tests/golden/make_mitten_full.py -- masked samples
 only, the images as the bytes the PNGs hold.  Expected outputs: the oracle's faithful restatement.  Depth is in the data's
-units (~700), so the north_star tolerance applies to the RELATIVE RMSE."""
+units (~700), so the north_star tolerance applies to the RELATIVE RMSE.
+
+Round 6: parametrised over 8 and ALL 20 images.  `srps -t images -d dataset/Images/Mitten` -- the reference's own CLI on its bundled folder --
+globs the whole RGB/ directory (Utilities.cpp:349-352): 20 images, in cv::glob's lexicographic order (I_1, I_10, ..., I_19, I_2, I_20,
+I_3, ...).  tests/golden/mitten_full_20.npz adds the masked bytes of images 9 - 20 of that order and the oracle's outputs of the
+20-image solve (5 passes)."""
 import os
 import time
 
@@ -11,19 +16,28 @@ import pytest
 
 f32 = np.float32
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mitten_full.npz")
-G = np.load(PATH)
+PATH20 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mitten_full_20.npz")
+G8 = np.load(PATH)
+G20 = np.load(PATH20)
+G = G8
 
 
-def _inputs(oracle):
-    h, w, sf = int(G["h"]), int(G["w"]), int(G["sf"])
-    mask = np.unpackbits(G["mask_bits"])[: h * w].astype(f32)
+def _expected(n):
+    return G8 if n == 8 else G20
+
+
+def _inputs(oracle, n=8):
+    h, w, sf = int(G8["h"]), int(G8["w"]), int(G8["sf"])
+    mask = np.unpackbits(G8["mask_bits"])[: h * w].astype(f32)
     geo = oracle.build_geometry(h, w, sf, mask)
-    I = np.zeros((G["I_u8"].shape[0], 3, h * w), f32)
-    I[:, :, geo.imask] = G["I_u8"].astype(f32) / f32(255)                  # what the image loader produces (Utilities.cpp:343)
-    assert np.array_equal(geo.imasks, G["imasks"])
-    zs = np.zeros((h // sf) * (w // sf), f32); zs[geo.imasks] = G["zs_lr_masked"]
-    zf = np.zeros(h * w, f32); zf[geo.imask] = G["z_full_masked"]
-    return h, w, sf, mask, G["K"], I, zs, zf, geo
+    bytes_ = G8["I_u8"] if n == 8 else np.concatenate([G8["I_u8"], G20["I_u8_9_to_20"]])
+    assert bytes_.shape[0] == n
+    I = np.zeros((n, 3, h * w), f32)
+    I[:, :, geo.imask] = bytes_.astype(f32) / f32(255)                     # what the image loader produces (Utilities.cpp:343)
+    assert np.array_equal(geo.imasks, G8["imasks"])
+    zs = np.zeros((h // sf) * (w // sf), f32); zs[geo.imasks] = G8["zs_lr_masked"]
+    zf = np.zeros(h * w, f32); zf[geo.imask] = G8["z_full_masked"]
+    return h, w, sf, mask, G8["K"], I, zs, zf, geo
 
 
 def rel_rmse(a, b):
@@ -39,17 +53,35 @@ def test_fixture_is_self_consistent(oracle):
     assert G["final_z"].shape == (geo.npix,) and G["final_rho"].shape == (3, geo.npix)
     assert 400 < float(G["z_full_masked"].mean()) < 9870 and int(G["n_outer"]) == len(G["energies"]) == 4
     assert np.all(np.diff(G["energies"]) < 0)                              # the reference's stop rule ended a converging run
+    assert G20["I_u8_9_to_20"].shape == (12, 3, geo.npix) and G20["final_z"].shape == (geo.npix,)
+    assert int(G20["n_outer"]) == len(G20["energies"]) == 5 and np.all(np.diff(G20["energies"]) < 0)
+
+
+def test_c_oracle_agrees_with_the_20_image_fixture(oracle):
+    """the fixture's expected outputs are the numpy oracle's; the C oracle's assembled depth step (written separately) from the same start
+    reproduces the first pass's energy -- a regression pin of the 20-image inputs as much as of either oracle"""
+    import c_oracle as CO
+    h, w, sf, mask, K, I, zs, zf, geo = _inputs(oracle, 20)
+    st = oracle.setup(oracle.Problem(h, w, sf, mask, K, I, zs, zf))
+    oracle.lighting_estimation(st.s, st.rho, st.N, st.I)
+    oracle.albedo_estimation(st.s, st.rho, st.N, st.I)
+    cs = CO.Structure(h, w, sf, mask)
+    z = st.z.copy()
+    e, it = CO.depth_estimation(cs, st.s, st.rho, st.I, st.xx, st.yy, st.dz, st.z0s, z, st.fx, st.fy, True)
+    assert it == 101 and abs(e - float(G20["energies"][0])) <= 1e-3 * float(G20["energies"][0])
 
 
 @pytest.mark.gpu
-def test_hip_full_mitten_solve_to_convergence(pkg, oracle):
-    h, w, sf, mask, K, I, zs, zf, geo = _inputs(oracle)
-    dh = pkg.DataHandler(I=I, mask=mask, K=K, sf=sf, z0=zs.reshape(1, -1), I_h=h, I_w=w, I_c=3, I_n=8, I_n_total=8, zs_lr=zs, z_full=zf)
+@pytest.mark.parametrize("n_images", [8, 20])
+def test_hip_full_mitten_solve_to_convergence(pkg, oracle, n_images):
+    G = _expected(n_images)
+    h, w, sf, mask, K, I, zs, zf, geo = _inputs(oracle, n_images)
+    dh = pkg.DataHandler(I=I, mask=mask, K=K, sf=sf, z0=zs.reshape(1, -1), I_h=h, I_w=w, I_c=3, I_n=n_images, I_n_total=n_images, zs_lr=zs, z_full=zf)
     ctx = pkg.Context(device_id=0)
     srps = pkg.SRPS(dh, ctx=ctx)
     en = srps.execute()                                                    # includes the set-up (upload of the images)
     t0 = time.perf_counter(); en = srps.execute(); dt = time.perf_counter() - t0
-    print(f"Mitten, full frame, 8 images: {len(en)} passes, {1e3 * dt:.1f} ms with set-up; resident CG {ctx.get_option('cg_resident_active')}, "
+    print(f"Mitten, full frame, {n_images} images: {len(en)} passes, {1e3 * dt:.1f} ms with set-up; resident CG {ctx.get_option('cg_resident_active')}, "
           f"bytes {ctx.get_option('image_store_bytes_active')}")
     assert ctx.get_option("cg_resident_active") == 1
     occ, tot = ctx.get_option("cg_resident_tiles_occupied_16"), ctx.get_option("cg_resident_tiles_16")
