@@ -91,8 +91,8 @@ int srps_synchronize(srps_ctx* ctx);
  *  srps_normals then launches nothing; same bits as the normals kernel),
  * "albedo_persistent" (0|1: albedo CG in registers, one cooperative launch, when the mask fits),
  * "cg_resident" (0|1: depth CG as one persistent launch with its state in registers and LDS, when the grid fits one
- * 256 x 64 tile per CU; otherwise, and with 0, one operator + one update kernel per step), "light_grouped" (0|1), "light_channel_inner" (0|1),
- * "light_blocks" (0 = automatic), "coop_launch" (0 plain | 1 hipLaunchCooperativeKernel | 2 cooperative only when the process has several contexts on the device),
+ * 256 x 64 tile per CU; otherwise, and with 0, one operator + one update kernel per step), "light_grouped" (0|1),
+ * "coop_launch" (0 plain | 1 hipLaunchCooperativeKernel | 2 cooperative only when the process has several contexts on the device),
  * "assemble_from_sums" (0|1: depth right-hand side from image sums left by the albedo sweep; no second pass over I),
  * "albedo_one_sync" (0|1: persistent albedo CG with one grid-wide wait per step),
  * "albedo_channels_together" (0|1: persistent albedo CG of 3 channels on masks up to 1 M pixels: the channels share the grid-wide waits),
@@ -139,12 +139,14 @@ int srps_synchronize(srps_ctx* ctx);
  *  by pid AND a random 64-bit number drawn once per process AND a hash of the host's boot id and name -- pids repeat across PID
  *  namespaces and hosts --, and a same-process peer's address is checked with hipPointerGetAttributes (device memory of the ordinal
  *  it claims) before a kernel stores through it),
- * "light_run" (0..3, default 3, round 5: the form of the energy + lighting sweep.  1: a wave takes one image plane's four 1 KiB pieces of a
- *  tile back to back -- a 4 KiB run --, channel by channel, the channel's products rho N_k of the four pieces in registers; 0: one piece
- *  of each of the wave's images per step, round 4's form.  2 and 3 (float images in their plane layout, three channels; otherwise 1 is
- *  taken): the contraction A'I of dc.cu:408-444 and the Gram matrices as v_mfma_f32_4x4x1 outer products on the matrix pipe -- exact f32 --,
- *  with 3 the four waves of a block decoupled, a quarter of the pixels and all the images (of a round of at most twenty) each.
- *  0.29 / 0.255 / 0.245 / 0.23 ms same box; results agree to rounding),
+ * "light_run" (1|3, default 3: the form of the tiled energy + lighting sweep on three channels.  3: the contraction A'I of dc.cu:408-444 and
+ *  the Gram matrices as v_mfma_f32_4x4x1 outer products on the matrix pipe -- exact f32 --, the four waves of a block decoupled, a quarter of
+ *  the pixels and all the images (of a round of at most twenty) each; 1: the vector form, a wave takes one image plane's four 1 KiB pieces
+ *  of a tile back to back, channel by channel (what one-channel images always run).  0.255 / 0.23 ms same box; results agree to rounding.
+ *  Round 6 removed the forms that were neither a default on some input class nor a tested fall-back: docs/HISTORY.md),
+ * "light_tiled" (0|1, default 1: 0 runs the generic sweep -- any channel count, four blocks per pixel range -- on 1 and 3 channels too),
+ * "march_snake" (0|1|2, default 2: 1 odd strips of the streaming CG step march right to left; 2 the directions also alternate from step to
+ *  step, so that a step starts where the one before it ended -- in the Infinity Cache),
  * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader
  *  produces, Utilities.cpp:343 -- the context also keeps the images as bytes and the two image sweeps of a pass read those:
  *  the same floats, the same results bit for bit, a quarter of the traffic; other images are read as floats) */

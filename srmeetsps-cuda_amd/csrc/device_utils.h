@@ -722,13 +722,9 @@ __device__ __forceinline__ Vec<V> ldv_stream(const float* __restrict__ p) {
     if constexpr (V == 4 && SRPS_NT_IMAGES) return ldv4_nt(p);
     else return ldv<V>(p);
 }
-// TM: I is the TILE-major copy It[tile][row][1024 pixels] of `rows` rows (srps_internal.h), q any multiple of V inside a tile
-template <int V, bool U8, bool TM = false>
+template <int V, bool U8>
 __device__ __forceinline__ Vec<V> ld_img(const float* __restrict__ I, const unsigned char* __restrict__ I8, size_t row, int P, int q, int rows = 0) {
-    if constexpr (TM) {
-        static_assert(V == 4 && !U8, "the tile-major copy holds floats, read four pixels at a time");
-        return ldv_stream<V>(I + ((size_t)(q >> 10) * rows + row) * 1024 + (q & 1023));
-    } else if constexpr (U8) {
+    if constexpr (U8) {
         static_assert(V == 4, "the 8-bit image store is read four pixels at a time");
         if constexpr (SRPS_NT_IMAGES) {
             const unsigned w = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(I8 + row * (size_t)P + q));

@@ -26,7 +26,7 @@ __device__ __forceinline__ float shading(float n0, float n1, float n2, float n3,
 // SHARD (a context that holds images [s_img_offset, s_img_offset + n_local) of n_total): den = sum_i sh_i^2 does not involve the
 // images -- it is formed over ALL images here, in the single-GPU order (the same bits on every rank and as on one GPU), and only
 // num travels through the all-reduce (C P floats instead of 2 C P).
-template <int V, bool SUMS, bool U8 = false, bool SHARD = false, bool TM = false>
+template <int V, bool SUMS, bool U8 = false, bool SHARD = false>
 __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__ s, const float* __restrict__ N,
                                                        const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_local, int C,
                                                        int s_img_offset, float* __restrict__ num, float* __restrict__ den,
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
             const float* sv = s + ((size_t)(s_img_offset + i) * C + c) * 4;      // uniform -> scalar loads
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
             const float fs0 = fx * s0, fs1 = fy * s1;
-            const Vec<V> iv = ld_img<V, U8, TM>(I, I8, (size_t)i * C + c, P, q, n_local * C);
+            const Vec<V> iv = ld_img<V, U8>(I, I8, (size_t)i * C + c, P, q, n_local * C);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float sh = shading(nk[0].v[e], nk[1].v[e], nk[2].v[e], nk[3].v[e], s0, s1, s2, s3);
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_albedo_numden(const float* __restrict__
 #ifndef SRPS_ALBEDO_UNROLL
 #define SRPS_ALBEDO_UNROLL 4      // image loads in flight per thread (round 5 swept 1 .. 10: flat between 2 and 4, slower outside; profiles/r05_ab_albedo_sweep.jsonl)
 #endif
-template <int V, bool U8, bool TM = false>
+template <int V, bool U8>
 __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ s, const float* __restrict__ N, const float* __restrict__ I,
                                                       const unsigned char* __restrict__ I8, int P, int n_img, int C, float* __restrict__ rho,
                                                       const float* __restrict__ qc, const float* __restrict__ xx, const float* __restrict__ yy,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ 
             const float* sv = s + ((size_t)i * C + c) * 4;
             const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
             const float fs0 = fx * s0, fs1 = fy * s1;
-            const Vec<V> iv = ld_img<V, U8, TM>(I, I8, (size_t)i * C + c, P, q, n_img * C);
+            const Vec<V> iv = ld_img<V, U8>(I, I8, (size_t)i * C + c, P, q, n_img * C);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float sh = shading(nk[0].v[e], nk[1].v[e], nk[2].v[e], nk[3].v[e], s0, s1, s2, s3);
@@ -160,14 +160,11 @@ int albedo_fused(srps_ctx* ctx, const float* d_s, const float* d_N, const float*
     Grid& G = ctx->grid;
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_rho | (uintptr_t)d_xx | (uintptr_t)d_yy | (uintptr_t)d_dz) % 16 == 0);
     const unsigned char* d_I8 = vec ? image_store_bytes(ctx, d_I) : nullptr;
-    // float images: from the tile-major copy when the context keeps one (one contiguous run of N C x 4 KiB per block)
-    const float* d_It = (vec && !d_I8) ? image_store_tiles(ctx, d_I) : nullptr;
-#define SRPS_AF(VV, UU, TT, IMG) hipLaunchKernelGGL((k_albedo_fused<VV, UU, TT>), dim3(cdiv(P, 256 * VV)), dim3(256), 0, ctx->stream, d_s, d_N, IMG, d_I8, P, n_img, C, d_rho, d_qc, \
+#define SRPS_AF(VV, UU, IMG) hipLaunchKernelGGL((k_albedo_fused<VV, UU>), dim3(cdiv(P, 256 * VV)), dim3(256), 0, ctx->stream, d_s, d_N, IMG, d_I8, P, n_img, C, d_rho, d_qc, \
                                            d_xx, d_yy, d_dz, fx, fy, G.d_gofp, G.plane, G.d_q, G.d_G)
-    if (vec && d_I8) SRPS_AF(4, true, false, d_I);
-    else if (vec && d_It) SRPS_AF(4, false, true, d_It);
-    else if (vec) SRPS_AF(4, false, false, d_I);
-    else SRPS_AF(1, false, false, d_I);
+    if (vec && d_I8) SRPS_AF(4, true, d_I);
+    else if (vec) SRPS_AF(4, false, d_I);
+    else SRPS_AF(1, false, d_I);
 #undef SRPS_AF
     SRPS_LAUNCH_CHECK();
     for (int c = 0; c < C; ++c) ctx->last_albedo_iters[c] = 0;
@@ -187,19 +184,16 @@ int albedo_numden(srps_ctx* ctx, const float* d_s, const float* d_N, const float
     const bool part = q1 > 0;
     auto blocks = [&](int per) { return part ? cdiv(std::min(q1, P) - q0, per) : cdiv(P, per); };
     auto first = [&](int per) { return part ? q0 / per : 0; };
-    const float* d_It = (vec && !d_I8) ? image_store_tiles(ctx, d_I) : nullptr;      // the tile-major copy of float images, when the context keeps one
-#define SRPS_NUMDEN(VV, SS, UU, HH, TT, IMG) hipLaunchKernelGGL((k_albedo_numden<VV, SS, UU, HH, TT>), dim3(blocks(256 * VV)), dim3(256), 0, ctx->stream, d_s, d_N, IMG, d_I8, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum, n_total, first(256 * VV))
-#define SRPS_NUMDEN_S(VV, UU, HH, TT, IMG) do { if (d_ssum) SRPS_NUMDEN(VV, true, UU, HH, TT, IMG); else SRPS_NUMDEN(VV, false, UU, HH, TT, IMG); } while (0)
+#define SRPS_NUMDEN(VV, SS, UU, HH, IMG) hipLaunchKernelGGL((k_albedo_numden<VV, SS, UU, HH>), dim3(blocks(256 * VV)), dim3(256), 0, ctx->stream, d_s, d_N, IMG, d_I8, P, n_local, C, s_img_offset, num, den, fx, fy, d_ssum, n_total, first(256 * VV))
+#define SRPS_NUMDEN_S(VV, UU, HH, IMG) do { if (d_ssum) SRPS_NUMDEN(VV, true, UU, HH, IMG); else SRPS_NUMDEN(VV, false, UU, HH, IMG); } while (0)
     if (shard) {
-        if (vec && d_I8) SRPS_NUMDEN_S(4, true, true, false, d_I);
-        else if (vec && d_It) SRPS_NUMDEN_S(4, false, true, true, d_It);
-        else if (vec) SRPS_NUMDEN_S(4, false, true, false, d_I);
-        else SRPS_NUMDEN_S(1, false, true, false, d_I);
+        if (vec && d_I8) SRPS_NUMDEN_S(4, true, true, d_I);
+        else if (vec) SRPS_NUMDEN_S(4, false, true, d_I);
+        else SRPS_NUMDEN_S(1, false, true, d_I);
     } else {
-        if (vec && d_I8) SRPS_NUMDEN_S(4, true, false, false, d_I);
-        else if (vec && d_It) SRPS_NUMDEN_S(4, false, false, true, d_It);
-        else if (vec) SRPS_NUMDEN_S(4, false, false, false, d_I);
-        else SRPS_NUMDEN_S(1, false, false, false, d_I);
+        if (vec && d_I8) SRPS_NUMDEN_S(4, true, false, d_I);
+        else if (vec) SRPS_NUMDEN_S(4, false, false, d_I);
+        else SRPS_NUMDEN_S(1, false, false, d_I);
     }
 #undef SRPS_NUMDEN_S
 #undef SRPS_NUMDEN

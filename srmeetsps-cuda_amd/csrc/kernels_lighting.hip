@@ -286,145 +286,7 @@ __global__ __launch_bounds__(256) void k_light_grouped(const float* __restrict__
     }
 }
 
-// The fused energy + lighting sweep with the channels in the INNER loop (NCH = C known at compile time): the six geometry
-// planes are loaded and the normal is formed once per pixel and image group instead of once per channel (k_light_grouped:
-// 12 reads of the geometry per pixel, about a third of them from HBM).  Same arithmetic, same sums, same bits as
-// k_light_grouped<V, IBW, true>; the Gram matrix of channel c is accumulated by image group c.
-template <int V, int IBW, int NCH>
-__global__ __launch_bounds__(256) void k_light_fused_ci(const float* __restrict__ rho, const float* __restrict__ I, int P, int n_img,
-                                                          int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
-                                                          EnergyArgs ea) {
-    constexpr int C = NCH;
-    __shared__ float sme[16];
-    __shared__ float smr[4][NCH * IBW * 4 + 10];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7, t8 = blockIdx.x >> 3;
-    const int grp = t8 & 3;
-    const int blk = (t8 >> 2) * 8 + xcd;                    // pixel range
-    if (blk * chunk >= P) { if (tid == 0) ea.part_e[blockIdx.x] = 0.f; return; }
-    const int p0 = blk * chunk;
-    const int p1 = min(P, p0 + chunk);
-    float e_acc = 0.f;
-    for (int b0 = 0; b0 < n_img; b0 += 4 * IBW) {
-        const int ib = b0 + grp * IBW;                     // first image of this block (may be past the end: nothing stored)
-        const int gram_c = (b0 == 0 && grp < NCH) ? grp : -1;      // the channel whose Gram matrix this block accumulates
-        // a group none of whose images exists in this round (64 images: three of the four groups in the last round) has nothing
-        // to add; block-uniform, so the barriers below stay matched
-        if (ib >= n_img && gram_c < 0) continue;
-        float acc[NCH][IBW][4];
-        float g[10];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int ii = 0; ii < IBW; ++ii)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[c][ii][k] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 10; ++t) g[t] = 0.f;
-        for (int q = p0 + tid * V; q < p1; q += 256 * V) {
-            Vec<V> nk[3], T[3];
-            const Vec<V> vdz = ldv<V>(ea.dz + q);
-            {
-                const Vec<V> vxx = ldv<V>(ea.xx + q), vyy = ldv<V>(ea.yy + q);
-                const Vec<V> vz = ldv<V>(ea.z + q), vzx = ldv<V>(ea.zx + q), vzy = ldv<V>(ea.zy + q);
-                Vec<V> vnrm;
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    float nrm;
-                    perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], nk[0].v[e], nk[1].v[e], nk[2].v[e], nrm);
-                    vnrm.v[e] = nrm;
-                    T[0].v[e] = ea.fx * vzx.v[e];
-                    T[1].v[e] = ea.fy * vzy.v[e];
-                    T[2].v[e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
-                }
-                if (ea.N_out && grp == 0 && b0 == 0) {                       // block-uniform: one of the four image groups, its first round
-                    stv_stream<V, SRPS_NT_NORMALS>(ea.N_out + q, nk[0]); stv_stream<V, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, nk[1]); stv_stream<V, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, nk[2]);
-                    stv_stream<V, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const Vec<V> r = ldv<V>(rho + (size_t)c * P + q);
-                float a[4][V];
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    a[0][e] = r.v[e] * nk[0].v[e]; a[1][e] = r.v[e] * nk[1].v[e]; a[2][e] = r.v[e] * nk[2].v[e];       // dc.cu:381
-                    a[3][e] = r.v[e] * 1.f;
-                }
-                Vec<V> iv[IBW];                                      // images past the end re-read the last one
-#pragma unroll
-                for (int ii = 0; ii < IBW; ++ii) iv[ii] = ldv_stream<V>(I + ((size_t)min(ib + ii, n_img - 1) * C + c) * P + q);
-#pragma unroll
-                for (int ii = 0; ii < IBW; ++ii)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int e = 0; e < V; ++e) acc[c][ii][k] = fmaf(a[k][e], iv[ii].v[e], acc[c][ii][k]);
-                float E[3][V];
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float vg = r.v[e] / vdz.v[e];
-                    E[0][e] = vg * T[0].v[e];
-                    E[1][e] = vg * T[1].v[e];
-                    E[2][e] = -vg * T[2].v[e];
-                }
-#pragma unroll
-                for (int ii = 0; ii < IBW; ++ii) {
-                    if (ib + ii < n_img) {                                   // wave-uniform
-                        const float* sv = ea.s + ((size_t)(ea.img_offset + ib + ii) * C + c) * 4;
-                        const float s0 = sv[0], s1 = sv[1], s2 = sv[2], s3 = sv[3];
-#pragma unroll
-                        for (int e = 0; e < V; ++e) {
-                            const float res = fmaf(E[0][e], s0, fmaf(E[1][e], s1, fmaf(E[2][e], s2, fmaf(r.v[e], s3, -iv[ii].v[e]))));
-                            e_acc = fmaf(res, res, e_acc);
-                        }
-                    }
-                }
-                if (c == gram_c) {                                           // wave-uniform
-                    int t = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int l = k; l < 4; ++l) {
-#pragma unroll
-                            for (int e = 0; e < V; ++e) g[t] = fmaf(a[k][e], a[l][e], g[t]);
-                            ++t;
-                        }
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int ii = 0; ii < IBW; ++ii)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float v = wave_sum(acc[c][ii][k]);
-                    if (lane == 0) smr[wv][(c * IBW + ii) * 4 + k] = v;
-                }
-        if (gram_c >= 0) {
-#pragma unroll
-            for (int t = 0; t < 10; ++t) {
-                const float v = wave_sum(g[t]);
-                if (lane == 0) smr[wv][NCH * IBW * 4 + t] = v;
-            }
-        }
-        __syncthreads();
-        if (tid < NCH * IBW * 4) {
-            const int c = tid / (IBW * 4), ii = (tid / 4) % IBW, k = tid & 3;
-            if (ib + ii < n_img)
-                part_atb[(((size_t)blk * n_img + ib + ii) * C + c) * 4 + k] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
-        } else if (gram_c >= 0 && tid < NCH * IBW * 4 + 10) {
-            part_g[((size_t)blk * C + gram_c) * 10 + (tid - NCH * IBW * 4)] = smr[0][tid] + smr[1][tid] + smr[2][tid] + smr[3][tid];
-        }
-        __syncthreads();
-    }
-    const float t = block_sum(e_acc, sme);
-    if (tid == 0) ea.part_e[blockIdx.x] = t;
-}
-
-// The end of the tiled sweeps (k_light_fused_tile, k_light_fused_mfma): the block's energy partial sum and -- in the last block to arrive --
+// The end of the tiled sweeps (k_light_fused_tile, k_light_fused_mfw): the block's energy partial sum and -- in the last block to arrive --
 // the pass's report record.
 __device__ __forceinline__ void light_tile_finish(float e_acc, const EnergyArgs& ea, float* sme, int blk) {
     const int tid = threadIdx.x;
@@ -470,37 +332,21 @@ __device__ __forceinline__ void light_tile_finish(float e_acc, const EnergyArgs&
     }
 }
 
-// Round 4: the same sweep with the geometry read ONCE per pixel.  The four image groups of a pixel range are the four WAVES of one
-// block instead of four blocks: per tile of 1024 pixels the block's 256 threads load the six geometry planes and the albedo (16 B per
-// lane), form the normal of the new depth once per pixel (perspective_normal: k_normals' instruction sequence), the channel-
-// independent factors of the residual and rho_c / dz, and leave them in LDS (6 + 2 NCH planes of 4 KiB); then wave g walks the
-// tile's four 256-pixel pieces for ITS images: 12 ds_read_b128 and NCH * IBW image loads of 16 B per lane and piece.  HBM traffic =
-// the algorithmic bytes (k_light_fused_ci fetched the geometry once per image group: 1.41 x the algorithmic bytes by the round-1
-// counters, and formed every normal four times).  Same expressions per pixel as k_light_fused_ci; the sums run over other
-// pixel subsets per lane, so results agree to rounding, not to the bit.
-#ifndef SRPS_LIGHT_SV_REGS
-#define SRPS_LIGHT_SV_REGS 1
-#endif
-#ifndef SRPS_LIGHT_PREFETCH
-#define SRPS_LIGHT_PREFETCH 1
-#endif
+// The vector form of the tiled energy + lighting sweep (one channel; three channels with option "light_run" = 1 or when the sample
+// offsets of the matrix form would not fit 32 bits).  The four image groups of a pixel range are the four WAVES of one block: per tile of
+// 1024 pixels the block's 256 threads load the six geometry planes and the albedo (16 B per lane), form the normal of the new depth once
+// per pixel (perspective_normal: k_normals' instruction sequence), the channel-independent factors of the residual and rho_c / dz, and
+// leave them in LDS (3 + 4 NCH planes of 4 KiB).  Then wave g goes CHANNEL by channel for ITS images: the channel's products rho_c N_k of
+// the tile's four 256-pixel pieces are formed once and kept in registers (64; the lighting vectors are read from LDS, which is what makes
+// the room), then its IBW planes of that channel follow, each as ONE 4 KiB run (four 1 KiB loads back to back -- the albedo sweep's access
+// shape), the next plane's run requested before this one's arithmetic; per (plane, piece) only the residual's three factors are re-read
+// from LDS.  HBM traffic = the algorithmic bytes.  (History of the forms that preceded it -- one block per image group, one piece of each
+// image per step, tile-major image copies -- and their measurements: docs/HISTORY.md.)
+// U8: the images from the context's 8-bit store (bytes, k / 255.f formed in registers: device_utils.h unit_from_byte -- the same floats).
 #ifndef SRPS_LIGHT_RUN_DEPTH
 #define SRPS_LIGHT_RUN_DEPTH 2
 #endif
-#ifndef SRPS_LIGHT_XTILE
-#define SRPS_LIGHT_XTILE 0
-#endif
-// TM: I is the tile-major copy It[tile][image * C + channel][1024] (srps_internal.h): a tile's N C x 4 KiB are one run.
-// U8: the images from the context's 8-bit store (bytes, k / 255.f formed in registers: device_utils.h unit_from_byte -- the same floats);
-// the sweep's vector pipes are a third busy, the bytes are a quarter of the floats.
-// RUN (round 5, option "light_run", the default): a wave takes the tile's four 1 KiB pieces of ONE (image, channel) plane back to back -- a
-// 4 KiB run, the albedo sweep's access shape -- instead of one piece of each of its IBW images.  It goes channel by channel: the
-// channel's products rho_c N_k of the four pieces are formed once and kept in registers (64; the lighting vectors are read from LDS,
-// which is what makes the room), then its IBW planes of that channel follow, the next plane's run requested before this one's
-// arithmetic; per (plane, piece) only the residual's three factors are re-read from LDS.  Same-box A/B at 2048^2 x 20 float images:
-// 0.287 - 0.298 -> 0.244 - 0.265 ms.  (A first form that held nothing per piece -- seven LDS planes re-read and the products re-formed for
-// every (plane, piece) -- was 4 % SLOWER than the non-RUN form: profiles/r05_ab_lighting_sweep.jsonl.)
-template <int IBW, int NCH, bool TAIL, bool TM = false, bool U8 = false, bool RUN = false>
+template <int IBW, int NCH, bool U8 = false>
 __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img,
                                                             int chunk, float* __restrict__ part_atb, float* __restrict__ part_g,
                                                             EnergyArgs ea) {
@@ -535,32 +381,6 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                 for (int k = 0; k < 4; ++k) acc[c][ii][k] = 0.f;
 #pragma unroll
         for (int t = 0; t < 10; ++t) g[t] = 0.f;
-#if SRPS_LIGHT_SV_REGS
-        float4 svr[NCH][IBW];                              // ... and kept in registers for the round: an LDS read per use cost a wait each
-        bool sv_loaded = false;
-#endif
-        // The image loads run as ONE software pipeline over all tiles of the block's range (SRPS_LIGHT_XTILE, round 5): the loads of a
-        // tile's first step(s) go out BEFORE the previous tile's last arithmetic and before the geometry phase between the barriers --
-        // until round 4 every wave's memory pipe ran dry there (nothing depends on the geometry in a load of image samples).
-        constexpr int NS = 4 * NCH;
-        constexpr int PF = SRPS_LIGHT_PREFETCH;                  // steps of look-ahead (PF + 1 sets of IBW float4 rotate)
-        static_assert(!SRPS_LIGHT_XTILE || NS % (PF + 1) == 0, "the buffer rotation continues across tiles");
-        Vec<4> ivb[PF + 1][IBW];
-        auto pieces_of = [&](int t0) { return __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8)); };      // wave-uniform: the range's last tile may be short
-        auto issue = [&](int k, Vec<4> (&buf)[IBW], int t0) {
-            const int sub = k / NCH, c = k - sub * NCH;
-            const int q = t0 + (sub * 64 + lane) * 4;
-            const int ql = q < p1 ? q : p1 - 4;
-#pragma unroll
-            for (int ii = 0; ii < IBW; ++ii) {
-                buf[ii] = ld_img<4, U8, TM>(I, I8, (size_t)min(ib + ii, n_img - 1) * C + c, P, ql, n_img * C);      // images past the end re-read the last one
-            }
-        };
-        if (!RUN && SRPS_LIGHT_XTILE && active && p0 < p1) {
-#pragma unroll
-            for (int k = 0; k < PF; ++k)
-                if (k < NS && k / NCH < pieces_of(p0)) issue(k, ivb[k % (PF + 1)], p0);
-        }
         for (int t0 = p0; t0 < p1; t0 += TP) {
             __syncthreads();                               // the previous tile has been read by every wave
             {
@@ -605,28 +425,8 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
             }
             __syncthreads();
             if (!active) continue;
-#if SRPS_LIGHT_SV_REGS
-            if (!sv_loaded) {                                      // once per round, behind the tile loop's first barrier pair
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int ii = 0; ii < IBW; ++ii) svr[c][ii] = svs[grp][c * IBW + ii];
-                sv_loaded = true;
-            }
-#endif
-            // The tile's 4 pieces x NCH channels as one sequence of steps, software-pipelined: the image loads of step k + 1 are issued
-            // before the arithmetic of step k (PF + 1 sets of IBW float4 rotate).  With one set the sweep ran at 4.9 TB/s, which is
-            // what 8 waves per CU with 5 KiB in flight each can draw from a memory ~2 us away; with two, twice that is in flight.
-            // (Round-4 timing experiments on one box, 2048^2 x 20 images: the sweep 0.271 ms; WITHOUT its image loads 0.149 ms -- the
-            // floor of its arithmetic, LDS traffic and barriers --; with the loads and one add per value instead of the arithmetic
-            // 0.245 ms: the loads alone run at 5.0 TB/s, the arithmetic hides under them.  A wave reads 1 KiB runs of five image planes;
-            // the albedo sweep, whose block reads 4 KiB runs, draws 6.1 TB/s.)
             const int npieces = __builtin_amdgcn_readfirstlane(min(4, (p1 - t0 + 255) >> 8));      // wave-uniform: the range's last tile may be short
-            if constexpr (RUN) {
-                // Channel by channel: the products rho_c N_k of the tile's four pieces are formed once per channel and kept in registers
-                // (64; the lighting vectors stay in LDS, which is what makes room for them), then the wave's IBW planes of that channel
-                // follow, each as one 4 KiB run (four loads back to back), the next plane's run requested before this one's arithmetic.
-                // Per (plane, piece) only the residual's three factors are re-read from LDS.
+            {
                 constexpr int NSR = NCH * IBW;                           // steps: k = c * IBW + ii
                 constexpr int RD = SRPS_LIGHT_RUN_DEPTH;                 // planes in flight ahead of the one being consumed, + 1
                 Vec<4> ivr[RD][4];
@@ -636,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 #pragma unroll
                     for (int sub = 0; sub < 4; ++sub) {
                         const int q = t0 + (sub * 64 + lane) * 4;
-                        buf[sub] = ld_img<4, U8, TM>(I, I8, row, P, q < p1 ? q : p1 - 4, n_img * C);
+                        buf[sub] = ld_img<4, U8>(I, I8, row, P, q < p1 ? q : p1 - 4, n_img * C);
                     }
                 };
 #pragma unroll
@@ -694,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                             for (int e = 0; e < 4; ++e)
 #pragma unroll
                                 for (int kk = 0; kk < 4; ++kk) acc[c][ii][kk] = fmaf(a[sub][kk][e], iv[sub].v[e], acc[c][ii][kk]);
-                            if (!TAIL || ib + ii < n_img) {               // wave-uniform
+                            if (ib + ii < n_img) {                        // wave-uniform
                                 float4 Eq[3];
 #pragma unroll
                                 for (int kk = 0; kk < 3; ++kk) Eq[kk] = geo[3 + NCH + 3 * c + kk][li];
@@ -707,88 +507,6 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
                             }
                         }
                     }
-                }
-                continue;
-            }
-            const bool more = t0 + TP < p1;                             // block-uniform: another tile follows
-            const int npieces_next = more ? pieces_of(t0 + TP) : 0;
-            if (!SRPS_LIGHT_XTILE) {
-#pragma unroll
-                for (int k = 0; k < PF; ++k)
-                    if (k < NS && k / NCH < npieces) issue(k, ivb[k % (PF + 1)], t0);
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int sub = k / NCH, c = k % NCH;
-                // the look-ahead step: of this tile, or -- behind its last steps -- of the next one
-                if (k + PF < NS) { if ((k + PF) / NCH < npieces) issue(k + PF, ivb[(k + PF) % (PF + 1)], t0); }
-                else if (SRPS_LIGHT_XTILE && (k + PF - NS) / NCH < npieces_next) issue(k + PF - NS, ivb[(k + PF) % (PF + 1)], t0 + TP);
-                if (sub < npieces) {                                   // wave-uniform (no break: the loop must unroll completely, k is an array index)
-                // pinned: the compiler otherwise clusters the loads of two steps, consumes both sets and only then issues the next two --
-                // the memory pipe ran dry every second step (s_waitcnt vmcnt(0) in the middle of the sequence)
-                __builtin_amdgcn_sched_barrier(0);
-                Vec<4> (&ivc)[IBW] = ivb[k % (PF + 1)];
-                const int li = sub * 64 + lane;
-                const int q = t0 + li * 4;
-                const bool valid = q < p1;
-                const bool ragged = __builtin_amdgcn_readfirstlane(t0 + sub * 256 + 256) > p1;      // wave-uniform: the range's last, partial piece
-                float4 nkq[3];
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) nkq[kk] = geo[kk][li];
-                const float (*nk)[4] = reinterpret_cast<const float (*)[4]>(nkq);
-                {
-                    const float4 rq = geo[3 + c][li];
-                    const float r[4] = {rq.x, rq.y, rq.z, rq.w};
-                    float a[4][4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a[0][e] = r[e] * nk[0][e]; a[1][e] = r[e] * nk[1][e]; a[2][e] = r[e] * nk[2][e];       // dc.cu:381
-                        a[3][e] = r[e] * 1.f;
-                    }
-                    if (ragged) {                                      // lanes past the range: rho, E and I are all zero there
-#pragma unroll
-                        for (int ii = 0; ii < IBW; ++ii)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) ivc[ii].v[e] = valid ? ivc[ii].v[e] : 0.f;
-                    }
-#pragma unroll
-                    for (int ii = 0; ii < IBW; ++ii)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) acc[c][ii][kk] = fmaf(a[kk][e], ivc[ii].v[e], acc[c][ii][kk]);
-                    float4 Eq[3];
-#pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) Eq[kk] = geo[3 + NCH + 3 * c + kk][li];
-                    const float (*E)[4] = reinterpret_cast<const float (*)[4]>(Eq);
-#pragma unroll
-                    for (int ii = 0; ii < IBW; ++ii) {
-                        if (!TAIL || ib + ii < n_img) {                          // wave-uniform; without TAIL every wave's images exist
-#if SRPS_LIGHT_SV_REGS
-                            const float4 sv = svr[c][ii];
-#else
-                            const float4 sv = svs[grp][c * IBW + ii];
-#endif
-                            const float s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float res = fmaf(E[0][e], s0, fmaf(E[1][e], s1, fmaf(E[2][e], s2, fmaf(r[e], s3, -ivc[ii].v[e]))));
-                                e_acc = fmaf(res, res, e_acc);
-                            }
-                        }
-                    }
-                    if (c == gram_c) {                                           // wave-uniform
-                        int t = 0;
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                            for (int l = kk; l < 4; ++l) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) g[t] = fmaf(a[kk][e], a[l][e], g[t]);
-                                ++t;
-                            }
-                    }
-                }
                 }
             }
         }
@@ -813,8 +531,8 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
     light_tile_finish(e_acc, ea, sme, blk);
 }
 
-// Round 5, option "light_run" = 2 (the default is 3, k_light_fused_mfw below, which shares everything said here): the sweep's contraction A'I (dc.cu:408-444: for every
-// image i and channel c the four sums over the pixels of rho_c N_k I_ic) on the MATRIX pipe, the one use north_star reserves it for.
+// The energy + lighting sweep of the pipeline (three channels; option "light_run" = 3, the default): the sweep's contraction A'I (dc.cu:408-444:
+// for every image i and channel c the four sums over the pixels of rho_c N_k I_ic) on the MATRIX pipe, the one use north_star reserves it for.
 // v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 outer products D_b += A_b B_b' (tools/mfma4x4_probe.hip: lane 4 b + q supplies A_b[q]
 // and B_b[q]; lane 4 b + j receives D_b[.][j] in its four accumulator registers), exact f32, one rounding per product like the fmaf chain it
 // replaces.  Block b = a slot of pixels, A = the four products rho_c N_k of a pixel, B = that pixel in FOUR images: lane 4 b + q loads pixels
@@ -823,21 +541,25 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_tile(const float* __rest
 // that the sixteen lanes of a read hit sixteen different bank groups) and costs one multiplication, the four multiply-adds per sample of the
 // vector form become one matrix instruction per sample, and -- what the change is about -- a wave keeps FOUR accumulator registers per
 // (channel, four images) instead of the vector form's 64 registers of products and 60 of sums, which leaves room for the loads in flight
-// (SRPS_LIGHT_MF_DEPTH) and, in k_light_fused_mfw, for ALL the images' sums in one wave (f32 MFMA runs at the vector rate and in the vector
-// pipe's place: the gain is registers, not arithmetic -- without the matrix instructions the sweep takes the same time).  The work of a tile is its 3 x ceil(n / 4) units (channel, group of four images) of sixteen loads; wave g takes units g, g + 4, ...
-// (15 units at 20 images: 4 + 4 + 4 + 3).  The Gram matrices are one more matrix instruction (A = B = the products) in the units of the first
-// group.  The energy's residual stays on the vector pipe, per lane for ITS image: the expression of the other sweeps, other summation order.
+// (SRPS_LIGHT_MF_DEPTH) and for ALL the images' sums in one wave (f32 MFMA runs at the vector rate and in the vector pipe's place: the gain is
+// registers, not arithmetic -- without the matrix instructions the sweep takes the same time).  The Gram matrices are one more matrix
+// instruction (A = B = the products) in the units of the first group.  The energy's residual stays on the vector pipe, per lane for ITS image:
+// the expression of the other sweeps, other summation order.
+// The four waves of a block are DECOUPLED: a wave owns 256 of the block's 1024 pixels per round and ALL 3 x NG units (channel, group of four
+// images) of them -- 4 NU accumulator registers, which only the matrix form can afford -- in a tile of LDS of its own, so no wave ever waits for
+// another: no block barrier inside the sweep (the form with a tile shared by the block's waves, round 5's light_run = 2, spent a tenth of its
+// time around its two barriers per tile: docs/HISTORY.md, profiles/r05_ab_lighting_mfma.txt).  The sums of the four waves meet once, at the end
+// of a round of 4 NG images.  NG = groups of four images per round (1..5); more than twenty images: rounds (the host picks NG = 5, 4 or 3 so
+// that the rounds are full when it can).
+// No branch inside the pipeline of loads: with wave-uniform branches around its steps hipcc 7.2 loses count of the loads in flight (s_waitcnt
+// vmcnt(0) in front of every load) and copies the accumulators at every join: 0.40 ms against the vector form's 0.255.  A unit that does not
+// exist is run on the round's last image again and dropped; lanes whose image does not exist only feed their own accumulator column, which is
+// never stored.
 #ifndef SRPS_LIGHT_MF_DEPTH
 #define SRPS_LIGHT_MF_DEPTH 3
 #endif
-#ifndef SRPS_LIGHT_MF_TP
-#define SRPS_LIGHT_MF_TP 1024     // pixels per tile: 1024 (66 KB of LDS, two blocks per CU) or 512 (33 KB, four)
-#endif
 #ifndef SRPS_LIGHT_MF_BPC
 #define SRPS_LIGHT_MF_BPC 2
-#endif
-#ifndef SRPS_LIGHT_MF_GEOPF
-#define SRPS_LIGHT_MF_GEOPF 0
 #endif
 typedef float srps_f32x4 __attribute__((ext_vector_type(4)));
 // what a load of the pipeline leaves in flight: four floats, or the dword of four bytes (converted where it is used)
@@ -846,195 +568,6 @@ template <> struct ImgBuf<true> { unsigned w; __device__ __forceinline__ Vec<4> 
 #ifndef SRPS_LIGHT_MF_DEPTH_U8
 #define SRPS_LIGHT_MF_DEPTH_U8 8      // bytes: a load carries a quarter of the bytes, and a register instead of four
 #endif
-// (No branch inside the pipeline of loads: with wave-uniform branches around its steps hipcc 7.2 loses count of the loads in flight -- s_waitcnt
-// vmcnt(0) in front of every load -- and copies the accumulators at every join: 0.40 ms against the vector form's 0.255.  A wave whose last
-// unit does not exist -- 15 units on 4 waves -- runs it all the same on the planes of its first unit (L2 hits, no HBM traffic) and drops the
-// sums; lanes whose image does not exist only feed their own accumulator column, which is never stored.)
-template <bool U8>      // U8: the images from the context's 8-bit store (k / 255.f formed in registers: the same floats)
-__global__ __launch_bounds__(256, SRPS_LIGHT_MF_BPC) void k_light_fused_mfma(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img, int chunk,
-                                                            float* __restrict__ part_atb, float* __restrict__ part_g, EnergyArgs ea) {
-    constexpr int C = 3, TP = SRPS_LIGHT_MF_TP, NE = 4 * C;              // LDS planes: rho_c | E0_c E1_c E2_c
-    constexpr int NKS = TP / 4 + 4;                          // float4 between the planes N_0, N_1, N_2, ones: a plane + 64 bytes
-    constexpr int RI = 20, UPW = 4;                          // images per round; units per wave and round (3 * 5 units on 4 waves)
-    constexpr int SPU = TP / 64;                             // loads of a unit and tile: four planes x 256 bytes each
-    constexpr int D = U8 ? SRPS_LIGHT_MF_DEPTH_U8 : SRPS_LIGHT_MF_DEPTH, NSTEP = UPW * SPU;
-    __shared__ float4 nkp[4][NKS];
-    __shared__ float4 geo[NE][TP / 4];
-    __shared__ float sme[16];
-    const int tid = threadIdx.x, lane = tid & 63, b = lane >> 2, j = lane & 3;
-    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int blk = blockIdx.x;
-    const int p0 = blk * chunk;
-    const int p1 = min(P, p0 + chunk);
-    float e_acc = 0.f;
-    if (tid < TP / 4) nkp[3][tid] = make_float4(1.f, 1.f, 1.f, 1.f);           // N_3 == 1 (dc.cu:175); visible behind the tile loop's first barrier
-    for (int b0 = 0; b0 < n_img; b0 += RI) {
-        const int nunits = C * ((min(RI, n_img - b0) + 3) >> 2);
-        size_t ip[UPW];                                      // the lane's image plane of every unit of its wave (its first sample's index)
-        float4 sv[UPW];                                      // its lighting vector
-        bool img_ok[UPW];
-        int cofs[UPW];                                       // the unit's channel as a byte offset between LDS planes (wave-uniform)
-        float e_u[UPW];                                      // the energy of the unit's samples: added at the end where the lane's image exists
-        srps_f32x4 acc[UPW], gram = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int us = 0; us < UPW; ++us) {
-            const int u0 = grp + 4 * us;
-            const int u = u0 < nunits ? u0 : grp;            // a unit that does not exist: the wave's first one again
-            const int G = u / C, c = u - G * C;
-            const int img = b0 + 4 * G + j;
-            img_ok[us] = u0 < nunits && img < n_img;
-            const int imgc = min(img, n_img - 1);            // images past the end re-read the last one; nothing of them is kept
-            ip[us] = ((size_t)imgc * C + c) * (size_t)P;
-            sv[us] = *reinterpret_cast<const float4*>(ea.s + ((size_t)(ea.img_offset + imgc) * C + c) * 4);
-            cofs[us] = __builtin_amdgcn_readfirstlane(c * (TP * 4));
-            acc[us] = srps_f32x4{0.f, 0.f, 0.f, 0.f};
-            e_u[us] = 0.f;
-        }
-        const bool do_gram = b0 == 0 && grp < C;             // wave-uniform: unit 0 of waves 0..2 is (group 0, channel g)
-        // the geometry of a tile is requested while the tile before it is being swept (SRPS_LIGHT_MF_GEOPF): nine loads per lane that
-        // otherwise stand, with their whole latency, between the two barriers of every tile
-        Vec<4> gq[6], gr[C];
-        auto load_geo = [&](int t0n) {
-            const int qn = t0n + tid * 4, qc = qn < p1 ? qn : p1 - 4;      // lanes past the end re-read the last pixels; nothing of them is used
-            gq[0] = ldv<4>(ea.dz + qc); gq[1] = ldv<4>(ea.xx + qc); gq[2] = ldv<4>(ea.yy + qc);
-            gq[3] = ldv<4>(ea.z + qc); gq[4] = ldv<4>(ea.zx + qc); gq[5] = ldv<4>(ea.zy + qc);
-#pragma unroll
-            for (int c = 0; c < C; ++c) gr[c] = ldv<4>(rho + (size_t)c * P + qc);
-        };
-        if (SRPS_LIGHT_MF_GEOPF && p0 < p1) load_geo(p0);
-        for (int t0 = p0; t0 < p1; t0 += TP) {
-            __syncthreads();                                 // the previous tile has been read by every wave
-            if (!SRPS_LIGHT_MF_GEOPF) load_geo(t0);
-            if (tid < TP / 4) {
-                const int q = t0 + tid * 4;
-                if (q < p1) {
-                    const Vec<4> vdz = gq[0], vxx = gq[1], vyy = gq[2];
-                    const Vec<4> vz = gq[3], vzx = gq[4], vzy = gq[5];
-                    Vec<4> vnrm, n0, n1, n2;
-                    float T[3][4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float nrm;
-                        perspective_normal(ea.fx, ea.fy, vz.v[e], vzx.v[e], vzy.v[e], vxx.v[e], vyy.v[e], n0.v[e], n1.v[e], n2.v[e], nrm);
-                        vnrm.v[e] = nrm;
-                        T[0][e] = ea.fx * vzx.v[e];
-                        T[1][e] = ea.fy * vzy.v[e];
-                        T[2][e] = fmaf(vyy.v[e], vzy.v[e], fmaf(vxx.v[e], vzx.v[e], vz.v[e]));
-                    }
-                    nkp[0][tid] = make_float4(n0.v[0], n0.v[1], n0.v[2], n0.v[3]);
-                    nkp[1][tid] = make_float4(n1.v[0], n1.v[1], n1.v[2], n1.v[3]);
-                    nkp[2][tid] = make_float4(n2.v[0], n2.v[1], n2.v[2], n2.v[3]);
-                    if (ea.N_out && b0 == 0) {               // block-uniform: the first round of images
-                        stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + q, n0); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + (size_t)P + q, n1); stv_stream<4, SRPS_NT_NORMALS>(ea.N_out + 2 * (size_t)P + q, n2);
-                        stv_stream<4, SRPS_NT_NORMALS>(ea.dz_out + q, vnrm);
-                    }
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const Vec<4> r = gr[c];
-                        float4 E0, E1, E2;
-                        float* e0 = &E0.x; float* e1 = &E1.x; float* e2 = &E2.x;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float vg = r.v[e] / vdz.v[e];
-                            e0[e] = vg * T[0][e];
-                            e1[e] = vg * T[1][e];
-                            e2[e] = -vg * T[2][e];
-                        }
-                        geo[c][tid] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
-                        geo[C + c][tid] = E0; geo[2 * C + c][tid] = E1; geo[3 * C + c][tid] = E2;      // plane = kind * C + channel: a channel is one offset
-                    }
-                } else {
-                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    nkp[0][tid] = z4; nkp[1][tid] = z4; nkp[2][tid] = z4;
-#pragma unroll
-                    for (int k = 0; k < NE; ++k) geo[k][tid] = z4;
-                }
-            }
-            __syncthreads();
-            if (SRPS_LIGHT_MF_GEOPF && t0 + TP < p1) load_geo(t0 + TP);      // block-uniform
-            // one software pipeline over the wave's UPW x 16 loads of the tile: D - 1 of them in flight ahead of the one being consumed; written
-            // once, instantiated for whole tiles and for the range's last, short one (whose lanes past the end hold zeros instead of samples)
-            auto run_tile = [&](auto ragged_c) __attribute__((always_inline)) {
-                constexpr bool RAGGED = decltype(ragged_c)::value;
-                ImgBuf<U8> buf[D];
-                auto issue = [&](int k, ImgBuf<U8>& dst) {
-                    const int us = k / SPU, t = k % SPU;
-                    const int q = t0 + 4 * (16 * t + b);
-                    const size_t at = ip[us] + (size_t)(RAGGED ? (q < p1 ? q : p1 - 4) : q);
-                    if constexpr (U8) dst.w = ld_bytes4_stream(I8 + at);
-                    else dst.f = ldv_stream<4>(I + at);
-                };
-#pragma unroll
-                for (int k = 0; k < D - 1; ++k) issue(k, buf[k % D]);
-#pragma unroll
-                for (int k = 0; k < NSTEP; ++k) {
-                    if (k + D - 1 < NSTEP) issue(k + D - 1, buf[(k + D - 1) % D]);
-                    __builtin_amdgcn_sched_barrier(0);       // the look-ahead load goes out before this step's arithmetic
-                    const int us = k / SPU, t = k % SPU;
-                    const int li = 16 * t + b;
-                    Vec<4> iv = buf[k % D].get();
-                    if (RAGGED) {
-                        const bool valid = t0 + 4 * li < p1;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) iv.v[e] = valid ? iv.v[e] : 0.f;
-                    }
-                    const char* gb = reinterpret_cast<const char*>(&geo[0][li]) + cofs[us];
-                    const float4 nq4 = nkp[j][li], rq4 = *reinterpret_cast<const float4*>(gb);
-                    const float4 E04 = *reinterpret_cast<const float4*>(gb + C * TP * 4), E14 = *reinterpret_cast<const float4*>(gb + 2 * C * TP * 4),
-                                 E24 = *reinterpret_cast<const float4*>(gb + 3 * C * TP * 4);
-                    const float nq[4] = {nq4.x, nq4.y, nq4.z, nq4.w}, rq[4] = {rq4.x, rq4.y, rq4.z, rq4.w};
-                    const float E0[4] = {E04.x, E04.y, E04.z, E04.w}, E1[4] = {E14.x, E14.y, E14.z, E14.w}, E2[4] = {E24.x, E24.y, E24.z, E24.w};
-                    const float4 s4 = sv[us];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = rq[e] * nq[e];                                          // dc.cu:381 (lane q: rho_c N_q)
-                        acc[us] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, iv.v[e], acc[us], 0, 0, 0);
-                        if (us == 0) gram = __builtin_amdgcn_mfma_f32_4x4x1f32(a, a, gram, 0, 0, 0);      // every wave, every round (no branch: see above); kept where do_gram
-                        const float res = fmaf(E0[e], s4.x, fmaf(E1[e], s4.y, fmaf(E2[e], s4.z, fmaf(rq[e] * 1.f, s4.w, -iv.v[e]))));
-                        e_u[us] = fmaf(res, res, e_u[us]);
-                    }
-                    asm volatile("" : "+v"(e_u[us]));      // pinned: the compiler otherwise sinks the residuals (and the LDS values they read) below the loop
-                }
-            };
-            if (__builtin_amdgcn_readfirstlane(t0 + TP) > p1) run_tile(std::true_type{});      // block-uniform: the range's last tile may be short
-            else run_tile(std::false_type{});
-        }
-        // the sixteen pixel slots of every sum: lanes 4 b + j, b = 0..15, added in one fixed order; lanes 0..3 hold image j's four sums
-#pragma unroll
-        for (int us = 0; us < UPW; ++us) {
-            const int u = grp + 4 * us, G = u / C, c = u - G * C;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[us][r];
-#pragma unroll
-                for (int o = 4; o < 64; o <<= 1) v[r] += __shfl_xor(v[r], o, 64);
-            }
-            const int img = b0 + 4 * G + j;
-            if (u < nunits && lane < 4 && img < n_img)
-                *reinterpret_cast<float4*>(part_atb + (((size_t)blk * n_img + img) * C + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            e_acc += img_ok[us] ? e_u[us] : 0.f;
-        }
-        if (do_gram) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = gram[r];
-#pragma unroll
-                for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-                // register r of lane j = entry (r, j); the upper triangle in the order of the other sweeps: (0,0) (0,1) .. (0,3) (1,1) ..
-                if (lane < 4 && r <= j) part_g[((size_t)blk * C + grp) * 10 + (r * 4 - (r * (r - 1)) / 2 + (j - r))] = v;
-            }
-        }
-    }
-    light_tile_finish(e_acc, ea, sme, blk);
-}
-
-// The same contraction with the four waves of a block DECOUPLED (option "light_run" = 3): a wave owns 256 of the
-// block's 1024 pixels per round and ALL 3 x NG units of them -- 4 NU accumulator registers, which only the matrix form can afford -- in a
-// tile of LDS of its own, so no wave ever waits for another: no block barrier inside the sweep (k_light_fused_mfma spends a tenth of its
-// time around the two of every tile: timing experiments in profiles/r05_ab_lighting_mfma.txt).  The sums of the four waves meet once, at
-// the end of a round of 4 NG images.  NG = groups of four images per round (1..5); more than twenty images: rounds (the host picks NG = 5, 4
-// or 3 so that the rounds are full when it can).
 template <int NG, bool U8>
 __global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restrict__ rho, const float* __restrict__ I, const unsigned char* __restrict__ I8, int P, int n_img, int chunk,
                                                            float* __restrict__ part_atb, float* __restrict__ part_g, EnergyArgs ea) {
@@ -1170,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void k_light_fused_mfw(const float* __restr
                         const float res = fmaf(E0[e], s4.x, fmaf(E1[e], s4.y, fmaf(E2[e], s4.z, fmaf(rq[e] * 1.f, s4.w, -iv.v[e]))));
                         e_g[G] = fmaf(res, res, e_g[G]);
                     }
-                    asm volatile("" : "+v"(e_g[G]));         // pinned: see k_light_fused_mfma
+                    asm volatile("" : "+v"(e_g[G]));         // pinned: the compiler otherwise sinks the residual's arithmetic behind the loop, with everything it reads
                 }
             };
             if (__builtin_amdgcn_readfirstlane(t0 + WP) > p1) run_tile(std::true_type{});      // wave-uniform: the range's last tile may be short
@@ -1296,24 +829,8 @@ struct LightPlan {
     float *part_atb, *part_g;
     int* d_it;
 };
-// resident blocks per CU of the channel-inner fused sweep (register-bound), asked from the runtime once per variant
-static int fused_ci_blocks_per_cu(int ibw, int C) {
-    static int cache[6][4] = {};
-    int& v = cache[ibw][C];
-    if (v == 0) {
-        const void* fn = nullptr;
-#define SRPS_LCI_PTR(BB, CC) fn = (const void*)k_light_fused_ci<4, BB, CC>
-        if (C == 3) { switch (ibw) { case 1: SRPS_LCI_PTR(1, 3); break; case 2: SRPS_LCI_PTR(2, 3); break; case 3: SRPS_LCI_PTR(3, 3); break; case 4: SRPS_LCI_PTR(4, 3); break; default: SRPS_LCI_PTR(5, 3); } }
-        else { switch (ibw) { case 1: SRPS_LCI_PTR(1, 1); break; case 2: SRPS_LCI_PTR(2, 1); break; case 3: SRPS_LCI_PTR(3, 1); break; case 4: SRPS_LCI_PTR(4, 1); break; default: SRPS_LCI_PTR(5, 1); } }
-#undef SRPS_LCI_PTR
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) nb = 2;
-        v = std::min(nb, 8);
-    }
-    return v;
-}
 // images per wave of the tiled sweep: at most 5 (register budget); a count that divides the images into whole rounds of four waves
-// is preferred (no wave then ever holds an image that does not exist: the kernel without the per-image guards)
+// is preferred
 static int tile_images_per_wave(int n_local) {
     const int n = std::max(n_local, 1);
     if (n <= 20) return std::min(5, cdiv(n, 4));
@@ -1325,7 +842,7 @@ static int fused_tile_blocks_per_cu(int ibw, int C) {
     int& v = cache[ibw][C];
     if (v == 0) {
         const void* fn = nullptr;
-#define SRPS_LT_PTR(BB, CC) fn = (const void*)k_light_fused_tile<BB, CC, true>
+#define SRPS_LT_PTR(BB, CC) fn = (const void*)k_light_fused_tile<BB, CC>
         if (C == 3) { switch (ibw) { case 1: SRPS_LT_PTR(1, 3); break; case 2: SRPS_LT_PTR(2, 3); break; case 3: SRPS_LT_PTR(3, 3); break; case 4: SRPS_LT_PTR(4, 3); break; default: SRPS_LT_PTR(5, 3); } }
         else { switch (ibw) { case 1: SRPS_LT_PTR(1, 1); break; case 2: SRPS_LT_PTR(2, 1); break; case 3: SRPS_LT_PTR(3, 1); break; case 4: SRPS_LT_PTR(4, 1); break; default: SRPS_LT_PTR(5, 1); } }
 #undef SRPS_LT_PTR
@@ -1342,22 +859,19 @@ static int light_plan(srps_ctx* ctx, bool vec, int P, int n_local, int C, LightP
     // the fused sweep holds 7 more planes per pixel: 2 pixels per thread keep it at 2 waves per SIMD
     // (334 us against 504 us at 2048^2, 20 images); alone the lighting sweep is faster with 4 (250 / 268 us)
     L.V = vec ? ((fused && !ctx->light_grouped) ? 2 : 4) : 1;
-    L.tiled = fused && vec && ctx->light_grouped && ctx->light_channel_inner && ctx->light_tiled && (C == 1 || C == 3);
+    L.tiled = fused && vec && ctx->light_grouped && ctx->light_tiled && (C == 1 || C == 3);
     if (L.tiled) {
-        // one round of blocks, each a range of whole 1024-pixel tiles (k_light_fused_tile); one energy partial per block
-        const int per_cu = (ctx->light_run >= 2 && C == 3) ? SRPS_LIGHT_MF_BPC : fused_tile_blocks_per_cu(tile_images_per_wave(n_local), C);      // k_light_fused_mfma: its launch bound
-        const int target = std::max(1, std::min(ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * per_cu, 2048));
+        // one round of blocks, each a range of whole 1024-pixel tiles (k_light_fused_mfw / k_light_fused_tile); one energy partial per block
+        const int per_cu = (ctx->light_run == 3 && C == 3) ? SRPS_LIGHT_MF_BPC : fused_tile_blocks_per_cu(tile_images_per_wave(n_local), C);      // k_light_fused_mfw: its launch bound
+        const int target = std::max(1, std::min(ctx->num_cus * per_cu, 2048));
         L.chunk = std::max(1024, cdiv(cdiv(P, target), 1024) * 1024);
     } else if (ctx->light_grouped && L.V == 4) {
         // one round of blocks: the sweep keeps 3 (fused, 135 registers) or 5 (96 registers) blocks per CU resident; with
         // 1024 blocks the last third of the kernel ran at a third of the occupancy
-        // (the channel-inner fused kernel needs ~250 registers: 2 blocks per CU; 768 blocks were 1.5 rounds, the last half of
-        // the kernel at half the occupancy: 60 us of a 2 ms pass)
-        int per_cu = fused ? 3 : 5;
-        if (fused && ctx->light_channel_inner && (C == 1 || C == 3)) per_cu = fused_ci_blocks_per_cu(std::min(5, cdiv(n_local, 4)), C);
+        const int per_cu = fused ? 3 : 5;
         // pixel ranges; at most 504 of them: the fused sweep leaves cdiv(ranges, 8) * 32 energy partials in the first 2048 floats
         // of d_misc_part (the partials of the depth term start there)
-        const int target = std::max(1, std::min((ctx->light_blocks > 0 ? ctx->light_blocks : ctx->num_cus * per_cu) / 4, 504));
+        const int target = std::max(1, std::min(ctx->num_cus * per_cu / 4, 504));
         const int gran = 256 * L.V;                        // a block covers 256 V pixels per iteration
         L.chunk = std::max(gran, cdiv(cdiv(P, target), gran) * gran);
     } else {
@@ -1379,11 +893,8 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
                                 int P, int n_local, int C, const EnergyArgs& ea) {
     if (ENERGY && L.tiled) {
         const int ibw = tile_images_per_wave(n_local);
-        // (TAIL = false, the kernel without the per-image guards, is not used: hipcc 7.2 then hoists every load and LDS read of a piece
-        // to its top and spills 330 bytes; the guards are wave-uniform branches on a scalar compare)
-        const float* d_It = image_store_tiles(ctx, d_I);       // the tile-major copy of the context's images, when it keeps one
         const unsigned char* d_I8 = ctx->light_bytes ? image_store_bytes(ctx, d_I) : nullptr;      // byte images: the sweep reads the bytes (option "light_bytes")
-        if (ctx->light_run == 3 && C == 3 && !d_It && (size_t)n_local * C * (size_t)P < ((size_t)1 << 32)) {      // ... with the block's four waves decoupled (32-bit sample offsets)
+        if (ctx->light_run == 3 && C == 3 && (size_t)n_local * C * (size_t)P < ((size_t)1 << 32)) {      // the matrix form (32-bit sample offsets)
 #define SRPS_LMW(NGV) do { if (d_I8) hipLaunchKernelGGL((k_light_fused_mfw<NGV, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
                            else hipLaunchKernelGGL((k_light_fused_mfw<NGV, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea); } while (0)
             // groups of four images per round: all of them in one round up to twenty images; beyond, rounds of 20, 16 or 12 -- full ones if the count allows
@@ -1394,19 +905,10 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
             SRPS_LAUNCH_CHECK();
             return SRPS_OK;
         }
-        if (ctx->light_run >= 2 && C == 3 && !d_It) {      // the contraction on the matrix pipe (images in their plane layout, floats or bytes)
-            if (d_I8) hipLaunchKernelGGL(k_light_fused_mfma<true>, dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea);
-            else hipLaunchKernelGGL(k_light_fused_mfma<false>, dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea);
-            SRPS_LAUNCH_CHECK();
-            return SRPS_OK;
-        }
+        // the vector form: one channel; three channels with "light_run" = 1 or sample offsets beyond 32 bits
 #define SRPS_LT_ARGS dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_I, d_I8, P, n_local, L.chunk, L.part_atb, L.part_g, ea
-#define SRPS_LT(BB, CC) do { if (d_I8 && ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true, true>), SRPS_LT_ARGS); \
-                             else if (d_I8) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, true>), SRPS_LT_ARGS); \
-                             else if (d_It && ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true, false, true>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
-                             else if (d_It) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, true, false>), dim3(L.nblk), dim3(256), 0, ctx->stream, d_rho, d_It, (const unsigned char*)nullptr, P, n_local, L.chunk, L.part_atb, L.part_g, ea); \
-                             else if (ctx->light_run) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false, true>), SRPS_LT_ARGS); \
-                             else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true, false, false>), SRPS_LT_ARGS); } while (0)
+#define SRPS_LT(BB, CC) do { if (d_I8) hipLaunchKernelGGL((k_light_fused_tile<BB, CC, true>), SRPS_LT_ARGS); \
+                             else hipLaunchKernelGGL((k_light_fused_tile<BB, CC, false>), SRPS_LT_ARGS); } while (0)
         if (C == 3) { switch (ibw) { case 1: SRPS_LT(1, 3); break; case 2: SRPS_LT(2, 3); break; case 3: SRPS_LT(3, 3); break; case 4: SRPS_LT(4, 3); break; default: SRPS_LT(5, 3); } }
         else { switch (ibw) { case 1: SRPS_LT(1, 1); break; case 2: SRPS_LT(2, 1); break; case 3: SRPS_LT(3, 1); break; case 4: SRPS_LT(4, 1); break; default: SRPS_LT(5, 1); } }
 #undef SRPS_LT
@@ -1417,14 +919,6 @@ static int light_partial_launch(srps_ctx* ctx, const LightPlan& L, const float* 
     if (ctx->light_grouped && L.V == 4) {
         const int ibw = std::min(5, cdiv(n_local, 4));
         const int nb4 = cdiv(L.nblk, 8) * 8 * 4;            // four image groups per pixel range, ranges in sets of 8 (one per XCD)
-        if (ENERGY && ctx->light_channel_inner && (C == 1 || C == 3)) {
-#define SRPS_LCI(BB, CC) hipLaunchKernelGGL((k_light_fused_ci<4, BB, CC>), dim3(nb4), dim3(256), 0, ctx->stream, d_rho, d_I, P, n_local, L.chunk, L.part_atb, L.part_g, ea)
-            if (C == 3) { switch (ibw) { case 1: SRPS_LCI(1, 3); break; case 2: SRPS_LCI(2, 3); break; case 3: SRPS_LCI(3, 3); break; case 4: SRPS_LCI(4, 3); break; default: SRPS_LCI(5, 3); } }
-            else { switch (ibw) { case 1: SRPS_LCI(1, 1); break; case 2: SRPS_LCI(2, 1); break; case 3: SRPS_LCI(3, 1); break; case 4: SRPS_LCI(4, 1); break; default: SRPS_LCI(5, 1); } }
-#undef SRPS_LCI
-            SRPS_LAUNCH_CHECK();
-            return SRPS_OK;
-        }
 #define SRPS_LGR(BB) hipLaunchKernelGGL((k_light_grouped<4, BB, ENERGY>), dim3(nb4), dim3(256), 0, ctx->stream, d_rho, d_N, d_I, P, n_local, C, L.chunk, L.part_atb, L.part_g, ea)
         switch (ibw) { case 1: SRPS_LGR(1); break; case 2: SRPS_LGR(2); break; case 3: SRPS_LGR(3); break; case 4: SRPS_LGR(4); break; default: SRPS_LGR(5); }
 #undef SRPS_LGR
@@ -1481,9 +975,8 @@ int energy_light_fused(srps_ctx* ctx, const float* d_s, const float* d_rho, cons
     EnergyArgs ea{d_s, d_xx, d_yy, d_dz, d_z, d_zx, d_zy, fx, fy, img_offset, G.d_misc_part, nullptr, nullptr, ReportFinish{}};
     const bool finish_in_sweep = fin && fin->ticket && L.tiled && n_local > 0;      // the tiled sweep's last block adds the energy terms itself
     if (finish_in_sweep) ea.fin = *fin;
-    // the channel-inner sweep (the one the pipeline runs for 1 and 3 channels) can leave the normals and dz of the new depth
-    const bool ci = ctx->light_grouped && L.V == 4 && ctx->light_channel_inner && (C == 1 || C == 3);
-    const bool write_normals = ci && ctx->fuse_normals && !ctx->nd_ptr_out && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && ctx->Nrm2 != nullptr && n_local > 0;
+    // the tiled sweeps (the ones the pipeline runs for 1 and 3 channels) leave the normals and dz of the new depth
+    const bool write_normals = L.tiled && ctx->fuse_normals && !ctx->nd_ptr_out && ctx->have_state && d_z == ctx->z && d_dz == ctx->dz && ctx->dz2 != nullptr && ctx->Nrm2 != nullptr && n_local > 0;
     if (write_normals) { ea.N_out = ctx->Nrm2; ea.dz_out = ctx->dz2; }
     SRPS_TRY(light_partial_launch<true>(ctx, L, d_rho, nullptr, d_I, P, n_local, C, ea));
     if (finish_in_sweep) { if (fin_armed) *fin_armed = true; }

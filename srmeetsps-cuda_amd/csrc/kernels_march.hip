@@ -94,30 +94,16 @@ __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballo
 struct F4 {
     float e[4];
 };
-// NTP: non-temporal loads and stores (`nt`) -- for grids whose CG vectors exceed the 256 MiB Infinity Cache (4096 x 4096: 560 MB per
-// step): every byte of a step is touched once per step and evicted before the next one, so keeping the lines in the caches only
-// costs; tools/hbm_ceiling_bench.hip: a float4 stream reads 5.3 - 6.4 TB/s with the default policy and 6.5 - 7.15 non-temporally.
-// At 2048 x 2048 (140 MB: inside the cache) the default policy stays.
-template <bool NTP = false>
+// (Non-temporal forms of these loads and stores were measured and removed: the one-launch step re-reads what it wrote a step earlier, and
+// its strips re-read their halo columns -- 15 - 35 % slower at 2304^2 ... 4096^2 with every stream non-temporal, 4 - 15 % with the stores only,
+// run-to-run noise with the g planes only.  What does pay is order: march_snake = 2 below.  docs/HISTORY.md, profiles/r04_march_nt_sweep.txt)
 __device__ __forceinline__ F4 ld4(const float* __restrict__ p) {
     F4 r;
-    if constexpr (NTP) {
-        const srps_vf4 t = __builtin_nontemporal_load(reinterpret_cast<const srps_vf4*>(p));
-        r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
-    } else {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
-    }
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
     return r;
 }
-template <bool NTP = false>
-__device__ __forceinline__ void st4(float* __restrict__ p, const F4& a) {
-    if constexpr (NTP) {
-        srps_vf4 t; t.x = a.e[0]; t.y = a.e[1]; t.z = a.e[2]; t.w = a.e[3];
-        __builtin_nontemporal_store(t, reinterpret_cast<srps_vf4*>(p));
-    } else
-        *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]);
-}
+__device__ __forceinline__ void st4(float* __restrict__ p, const F4& a) { *reinterpret_cast<float4*>(p) = make_float4(a.e[0], a.e[1], a.e[2], a.e[3]); }
 __device__ __forceinline__ F4 zero4() { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0.f; return r; }
 
 // MODE 0: out = A_ xin.  MODE 1: r -= A_ xin, partial r.r (residual, dc.cu:758).  MODE 2: p = beta p + r, out = A_ p, partial
@@ -131,7 +117,7 @@ __device__ __forceinline__ F4 zero4() { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] 
 // this launch and is what the next launch uses for alpha_k and as the denominator of beta_{k+1}: every predicted value is
 // anchored on a direct sum one step old, the prediction error does not accumulate.  45 B per unknown instead of 37 + 12, one
 // launch per step instead of two.
-template <int SF, int MODE, int NC, int NTP = 0>      // NTP 0: default cache policy; 1: non-temporal loads and stores; 2: non-temporal stores only
+template <int SF, int MODE, int NC>
 __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
     const int TJ = a.tj;                      // strip width: even, multiple of SF (runtime, the loop is unrolled by two)
     constexpr int NT = (NC > 0) ? NC : 6;     // planes streamed for the tensor: NC (recompute) or 6 (stored M)
@@ -220,15 +206,15 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
         };
         auto issue = [&](Raw& w, int c) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w.T[t] = ld4<NTP == 1>(tens + (size_t)t * pl + (size_t)(c + D) * Hs + rowL);
+            for (int t = 0; t < NT; ++t) w.T[t] = ld4(tens + (size_t)t * pl + (size_t)(c + D) * Hs + rowL);
             w.fl = *reinterpret_cast<const unsigned*>(a.flags + (size_t)(c + D) * Hs + rowL);
             const size_t off = (size_t)(c + D * L) * Hs + rowL;
-            if (MODE < 2) { w.r = ld4<NTP == 1>(a.xin + off); }
+            if (MODE < 2) { w.r = ld4(a.xin + off); }
             else {
-                w.r = ld4<NTP == 1>(a.r + off); w.p = ld4<NTP == 1>(a.p_in + off);
+                w.r = ld4(a.r + off); w.p = ld4(a.p_in + off);
                 const size_t oo = (size_t)c * Hs + rowL;               // the column step c outputs
-                w.xo = ld4<NTP == 1>(a.x + oo); w.po = ld4<NTP == 1>(a.p_in + oo);
-                if (MODE == 3) w.wp = (a.k != 1) ? ld4<NTP == 1>(a.w_prev + off) : zero4();      // step 1 has no update pending (uniform)
+                w.xo = ld4(a.x + oo); w.po = ld4(a.p_in + oo);
+                if (MODE == 3) w.wp = (a.k != 1) ? ld4(a.w_prev + off) : zero4();      // step 1 has no update pending (uniform)
             }
         };
         auto convert = [&](const Raw& w, F4& rnew) -> F4 {     // x of the loaded column (CG: p_new = beta p + r)
@@ -243,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
         };
         auto load_x = [&](int col, F4& rnew) -> F4 {           // prologue only (waited immediately)
             const size_t off = (size_t)col * Hs + rowL;
-            if (MODE < 2) return ld4<NTP == 1>(a.xin + off);
-            const F4 rv = ld4<NTP == 1>(a.r + off);
-            const F4 pv = ld4<NTP == 1>(a.p_in + off);
-            const F4 wv = (MODE == 3 && a.k != 1) ? ld4<NTP == 1>(a.w_prev + off) : zero4();
+            if (MODE < 2) return ld4(a.xin + off);
+            const F4 rv = ld4(a.r + off);
+            const F4 pv = ld4(a.p_in + off);
+            const F4 wv = (MODE == 3 && a.k != 1) ? ld4(a.w_prev + off) : zero4();
             F4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -427,17 +413,17 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
                 if (owned && (unsigned)(c - PAD) < (unsigned)a.Wg) {
                     const size_t off = (size_t)c * Hs + row0;
                     if (MODE == 0) {
-                        st4<NTP != 0>(a.out + off, acc);
+                        st4(a.out + off, acc);
                     } else if (MODE == 1) {
-                        F4 rv = ld4<NTP == 1>(a.r + off);
+                        F4 rv = ld4(a.r + off);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { rv.e[e] -= acc.e[e]; red = fmaf(rv.e[e], rv.e[e], red); }
-                        st4<NTP != 0>(a.r + off, rv);
+                        st4(a.r + off, rv);
                     } else {
-                        st4<NTP != 0>(a.p_out + off, X[1]);
-                        st4<NTP != 0>(a.out + off, acc);
+                        st4(a.p_out + off, X[1]);
+                        st4(a.out + off, acc);
                         if (MODE == 3) {
-                            st4<NTP != 0>(a.r_out + off, R[0]);
+                            st4(a.r_out + off, R[0]);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float rv = R[0].e[e];
@@ -448,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
                             F4 xn;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) xn.e[e] = fmaf(alpha_prev, cur.po.e[e], cur.xo.e[e]);   // Saxpy dc.cu:270
-                            st4<NTP != 0>(a.x + off, xn);
+                            st4(a.x + off, xn);
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) red = fmaf(X[1].e[e], acc.e[e], red);
@@ -471,7 +457,10 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
         }
     };
     if (item < a.n_items) {
-        if (a.snake && (strip & 1)) body(std::integral_constant<int, -1>{});
+        // snake = 2: the direction also alternates from STEP to step -- what a wave touched last in step k (the far end of its strip, still in
+        // the Infinity Cache: a step's planes are three times its size) is what it touches first in step k + 1
+        const int flip = (a.snake == 2 && MODE == 3) ? (a.k & 1) : 0;
+        if (a.snake && ((strip ^ flip) & 1)) body(std::integral_constant<int, -1>{});
         else body(std::integral_constant<int, 1>{});
     }
     if (MODE == 3) {
@@ -543,11 +532,7 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
     const int nb = cdiv(a.n_items, 4);
 #define SRPS_MARCH_NC(SF, NCV)                                                                                \
     do {                                                                                                      \
-        if constexpr (MODE == 3) {                                                                            \
-            if (nt == 1) { hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV, 1>), dim3(nb), dim3(256), 0, ctx->stream, a); break; } \
-            if (nt == 2) { hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV, 2>), dim3(nb), dim3(256), 0, ctx->stream, a); break; } \
-        }                                                                                                     \
-        hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV, 0>), dim3(nb), dim3(256), 0, ctx->stream, a);       \
+        hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV>), dim3(nb), dim3(256), 0, ctx->stream, a);          \
     } while (0)
 #define SRPS_MARCH_TJ(SF)                                                                                     \
     switch (nc) {                                                                                             \
@@ -557,11 +542,6 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
         default: set_error("march kernel: unsupported channel count %d for tensor recompute", nc); return SRPS_ERR_UNSUPPORTED; \
     }
     const int nc = march_recompute_channels(ctx);
-    // non-temporal streams for the one-launch step when its vectors do not fit the Infinity Cache (option "march_nt": 0 never,
-    // 1 always, 2 = automatic: the step's planes -- g [nc or 6], x, r [2], p [2], omega [2] -- above 200 MB)
-    const size_t step_bytes = (size_t)((nc > 0 ? nc : 6) + 7) * G.used * sizeof(float);
-    const int nt = ctx->march_nt == 3 ? 2 : (ctx->march_nt == 1 || (ctx->march_nt == 2 && step_bytes > ((size_t)200 << 20))) ? 1 : 0;      // option 3: stores only
-    (void)nt;
     a.tj = G.strip_cols;
     a.snake = ctx->march_snake;
     switch (G.sf) {

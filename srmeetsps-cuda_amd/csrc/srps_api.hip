@@ -111,7 +111,6 @@ static void grid_free(Grid& G) {
 
 static void state_release(srps_ctx* c) {
     c->i8_state = 0;                       // I8 (its own allocation, made when the images turn out to be bytes) is kept for the next set-up
-    c->it_state = 0;                       // likewise the tile-major copy
     c->s = c->rho = c->z = c->Nrm = c->Nrm2 = c->dz = c->dz2 = c->zx = c->zy = c->xx = c->yy = c->z0s = c->I = c->albedo_ex = c->q_ex = nullptr;      // carved out of state_arena
     c->normals_pending = false;
     c->nd_ptr_out = false;                 // every pointer handed out is void with the arrays
@@ -444,7 +443,6 @@ int srps_destroy(srps_ctx* ctx) {
     state_release(ctx);
     grid_free(ctx->grid);
     dfree(ctx->I8);
-    dfree(ctx->It);
     resident_rank_release(ctx);
     dfree(ctx->d_strip_tot);
     if (ctx->state_arena.p) (void)hipFree(ctx->state_arena.p);
@@ -497,7 +495,7 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->tensor_recompute = value ? 1 : 0;
         ctx->depth_assembled = false;        // a depth system the albedo sweep left (SRPS_ALBEDO_FUSED / AUTO) is in the other form
     } else if (!strcmp(name, "march_snake")) {
-        ctx->march_snake = value ? 1 : 0;
+        ctx->march_snake = value == 2 ? 2 : (value ? 1 : 0);
     } else if (!strcmp(name, "fuse_energy_lighting")) {
         ctx->fuse_energy_lighting = value ? 1 : 0;
         ctx->light_cache_valid = false;
@@ -524,10 +522,6 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         ctx->image_store = value ? 1 : 0;
         if (ctx->i8_state == 2 && value) ctx->i8_state = 0;      // look (again) at the next sweep
         ctx->light_cache_valid = false;
-    } else if (!strcmp(name, "image_tiles")) {
-        ctx->image_tiles = value ? 1 : 0;
-        if (ctx->it_state == 2 && value) ctx->it_state = 0;
-        ctx->light_cache_valid = false;
     } else if (!strcmp(name, "phase_timing")) {
         ctx->phase_timing = value ? 1 : 0;
         ctx->ev_mask = 0;
@@ -549,21 +543,12 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
         // test hook: the next look at the abort flags finds these bits (1 depth, 2 albedo) as if ANOTHER rank had reported them
         SRPS_REQUIRE(value >= 0 && value <= 3, SRPS_ERR_INVALID, "debug_inject_abort: 0..3, got %d", value);
         ctx->debug_inject_abort = value;
-    } else if (!strcmp(name, "light_blocks")) {
-        SRPS_REQUIRE(value >= 0 && value <= 2016, SRPS_ERR_INVALID, "light_blocks: 0 (automatic) .. 2016, got %d", value);
-        ctx->light_blocks = value;
-        ctx->light_cache_valid = false;
-    } else if (!strcmp(name, "light_channel_inner")) {
-        ctx->light_channel_inner = value ? 1 : 0;
-        ctx->light_cache_valid = false;
-    } else if (!strcmp(name, "march_nt")) {
-        SRPS_REQUIRE(value >= 0 && value <= 3, SRPS_ERR_INVALID, "march_nt: 0 (never), 1 (always), 2 (automatic) or 3 (stores only), got %d", value);
-        ctx->march_nt = value;
     } else if (!strcmp(name, "light_bytes")) {
         ctx->light_bytes = value ? 1 : 0;
         ctx->light_cache_valid = false;
     } else if (!strcmp(name, "light_run")) {
-        ctx->light_run = (value == 2 || value == 3) ? value : (value ? 1 : 0);
+        SRPS_REQUIRE(value == 1 || value == 3, SRPS_ERR_INVALID, "light_run: 1 (vector form) or 3 (matrix pipe, the default), got %d", value);
+        ctx->light_run = value;
     } else if (!strcmp(name, "light_tiled")) {
         ctx->light_tiled = value ? 1 : 0;
         ctx->light_cache_valid = false;
@@ -627,7 +612,6 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "keep_stored_tensor")) *value = ctx->keep_stored_tensor;
     else if (!strcmp(name, "fuse_energy_lighting")) *value = ctx->fuse_energy_lighting;
     else if (!strcmp(name, "fuse_normals")) *value = ctx->fuse_normals;
-    else if (!strcmp(name, "march_nt")) *value = ctx->march_nt;
     else if (!strcmp(name, "light_tiled")) *value = ctx->light_tiled;
     else if (!strcmp(name, "light_run")) *value = ctx->light_run;
     else if (!strcmp(name, "exchange_buffer_fine")) *value = (ctx->xg_buf && ctx->xg_fine) ? 1 : 0;      // the resident strips' exchange buffer is fine-grained memory
@@ -638,8 +622,6 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "phase_timing")) *value = ctx->phase_timing;
     else if (!strcmp(name, "pin_uploads")) *value = ctx->pin_uploads;
     else if (!strcmp(name, "image_store")) *value = ctx->image_store;
-    else if (!strcmp(name, "image_tiles")) *value = ctx->image_tiles;
-    else if (!strcmp(name, "image_tiles_active")) *value = (ctx->image_tiles && ctx->have_state && ctx->it_state == 1) ? 1 : 0;
     else if (!strcmp(name, "image_store_bytes_active")) *value = (ctx->image_store && ctx->have_state && ctx->i8_state == 1) ? 1 : 0;
     else if (!strcmp(name, "roctx")) *value = ctx->roctx;
     else if (!strcmp(name, "cg_one_sync")) *value = ctx->cg_one_sync;
@@ -838,32 +820,8 @@ static int image_store_prepare(srps_ctx* ctx) {
     ctx->i8_state = 1;
     return SRPS_OK;
 }
-// planar I[row][P] -> It[tile][row][1024] (srps_internal.h "TILE-major copy"); pixels past P are zero
-__global__ __launch_bounds__(256) void k_tile_images(const float* __restrict__ I, int rows, int P, float* __restrict__ It) {
-    const int tile = blockIdx.x, row = blockIdx.y;
-    const int q = tile * 1024 + threadIdx.x * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < P) v = *reinterpret_cast<const float4*>(I + (size_t)row * P + q);
-    *reinterpret_cast<float4*>(It + ((size_t)tile * rows + row) * 1024 + threadIdx.x * 4) = v;
-}
 extern "C++" {
 namespace srps {
-// the tile-major copy of d_I when d_I is the context's image array; built here when the images changed since it was made
-const float* image_store_tiles(srps_ctx* ctx, const float* d_I) {
-    const int P = ctx->grid.P, rows = ctx->N_local * ctx->C;
-    if (!ctx->image_tiles || !ctx->have_state || d_I != ctx->I || ctx->it_state == 2 || P % 4 != 0 || rows <= 0 || rows > 65535) return nullptr;
-    if (ctx->it_state == 1) return ctx->It;
-    const size_t n = (size_t)cdiv(P, 1024) * rows * 1024;
-    if (ctx->It == nullptr || ctx->It_cap < n) {
-        if (ctx->It) { (void)hipFree(ctx->It); ctx->It = nullptr; ctx->It_cap = 0; }
-        if (hipMalloc((void**)&ctx->It, n * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); ctx->It = nullptr; ctx->it_state = 2; return nullptr; }
-        ctx->It_cap = n;
-    }
-    hipLaunchKernelGGL(k_tile_images, dim3(cdiv(P, 1024), rows), dim3(256), 0, ctx->stream, ctx->I, rows, P, ctx->It);
-    if (hipGetLastError() != hipSuccess) { ctx->it_state = 2; return nullptr; }
-    ctx->it_state = 1;
-    return ctx->It;
-}
 // the byte copy of d_I when d_I is the context's image array and the copy is current, else null (the caller reads the floats)
 const unsigned char* image_store_bytes(srps_ctx* ctx, const float* d_I) {
     if (!ctx->image_store || !ctx->have_state || d_I != ctx->I) return nullptr;
@@ -1097,13 +1055,11 @@ static int upload_image_impl(srps_ctx* ctx, int li, const void* host_image, bool
     float* out = ctx->I + (size_t)li * ctx->C * G.P;
     if (!bytes_in) {
         ctx->i8_state = 0;                   // looked at again at the next sweep
-        if (ctx->it_state == 1) ctx->it_state = 0;
         return launch_gather_images(ctx->stream, (const float*)ctx->ws_stage.p, G.d_imask, G.P, ctx->C, hw, 1, out);
     }
     // bytes: the byte store stays current when it is in use (every other image is a byte image already)
     unsigned char* out8 = (ctx->i8_state == 1 && ctx->I8) ? ctx->I8 + (size_t)li * ctx->C * G.P : nullptr;
     if (!out8) ctx->i8_state = 0;
-    if (ctx->it_state == 1) ctx->it_state = 0;
     return launch_gather_images_u8(ctx->stream, (const unsigned char*)ctx->ws_stage.p, G.d_imask, G.P, ctx->C, hw, 1, out, out8);
 }
 int srps_upload_image(srps_ctx* ctx, int li, const float* host_image) {
@@ -1641,7 +1597,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     ctx->grad_current = false;
     ctx->depth_assembled = false;
     ctx->normals_pending = false;
-    if (p == ctx->I) { ctx->i8_state = 0; if (ctx->it_state == 1) ctx->it_state = 0; }
+    if (p == ctx->I) ctx->i8_state = 0;
     SRPS_TRY(host_upload(ctx, p, host, len * sizeof(float), ctx->stream));
     return SRPS_OK;
 }
@@ -1661,7 +1617,6 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
         // the caller may write the images through the pointer at any later time: the byte copy cannot follow that
         ctx->i8_state = 2;
     }
-    if (p == ctx->I) ctx->it_state = 2;                // likewise the tile-major copy
     // "N" / "dz": with fuse_normals the energy sweep stores the next normals into a SECOND set of arrays and srps_normals swaps the
     // sets -- a pointer handed out would point at the non-current set from the next pass on (round-3 advisor finding).  From here on
     // this context keeps ONE set (the normals kernel writes it in place, as before round 3) until the next srps_setup.

@@ -125,7 +125,7 @@ struct srps_ctx {
     int apply_mode = SRPS_APPLY_AUTO;
     int march_tj = 0;                // strip width of the marching operator (multiple of 4); 0 = chosen by march_plan
     int keep_stored_tensor = 0;      // also write the 6-plane tensor when the recompute form is active (tests)
-    int march_snake = 1;             // odd strips march right-to-left (halo columns shared through L2)
+    int march_snake = 2;             // 1: odd strips march right-to-left (halo columns shared through L2); 2 (default, round 6): the directions also alternate from CG step to CG step -- the far end of every strip is still in the Infinity Cache when the next step starts there (4096^2: 171 - 174 -> 154 - 160 us per step, 3584^2: 129 -> 105)
     int tensor_recompute = 1;        // rebuild M in the operator kernel from (rho_c/dz)^2 instead of streaming 6 planes
     int cg_max_iter = 100;           // dc.cu:231
     float cg_tol = 1e-9f;            // dc.cu:230
@@ -175,17 +175,13 @@ struct srps_ctx {
     bool depth_assembled = false;    // SRPS_ALBEDO_FUSED: this pass's albedo sweep has left g and q on the grid (srps_depth_partial has nothing to do)
     // energy(k) + lighting(k+1) fusion: ws_light holds the lighting partial sums of the current rho, z, I
     int fuse_energy_lighting = 1;
-    int light_blocks = 0;            // blocks of the lighting sweep (0: one resident round)
-    int light_channel_inner = 1;     // fused energy + lighting sweep with the channels in the inner loop (C in {1, 3})
-    int march_nt = 0;                // streaming CG step with non-temporal loads / stores: 0 never (default: measured 15 - 35 % SLOWER at 2304^2 ... 4096^2, tools/march_nt_sweep.sh -- the strips re-read their halo columns, which then miss the L2; stores only, 3: 59.5 -> 65.0 us at 2560^2, 153 -> 165 - 176 at 4096^2 sf 4), 1 always, 2 when its vectors exceed the Infinity Cache, 3 stores only
     int light_bytes = 1;             // the tiled lighting sweep reads the 8-bit image store when the context holds one (round 4)
     bool I_in_ws_images = false;
-    int light_run = 3;               // the energy + lighting sweep (float images, three channels): 3 = the contraction A'I on the matrix pipe (v_mfma_f32_4x4x1), a block's
-                                     // waves decoupled, each with a quarter of the pixels and all the images (k_light_fused_mfw; more than 20 images: rounds); 2 = matrix pipe,
-                                     // waves share a tile (k_light_fused_mfma); 1 = vector form, a wave reads ONE image plane's four 1 KiB pieces back to back, channel by
-                                     // channel (k_light_fused_tile; byte images, tile-major copies and one channel always); 0 = round 4's form.  Same box, 2048^2 x 20:
-                                     // 0: 0.29, 1: 0.247 - 0.264, 2: 0.240 - 0.253, 3: 0.216 - 0.247 ms (profiles/r05_ab_lighting_mfma.txt)
-    int light_tiled = 1;             // ... with the four image groups as the waves of one block and the geometry shared through LDS (k_light_fused_tile)
+    int light_run = 3;               // the tiled energy + lighting sweep, three channels: 3 = the contraction A'I on the matrix pipe (v_mfma_f32_4x4x1), a block's
+                                     // waves decoupled, each with a quarter of the pixels and all the images (k_light_fused_mfw; more than 20 images: rounds); 1 = vector
+                                     // form, a wave reads ONE image plane's four 1 KiB pieces back to back, channel by channel (k_light_fused_tile; one channel always).
+                                     // Same box, 2048^2 x 20: 1: 0.247 - 0.264, 3: 0.216 - 0.247 ms (profiles/r05_ab_lighting_mfma.txt; earlier forms: docs/HISTORY.md)
+    int light_tiled = 1;             // the fused sweep as a tiled kernel (1 or 3 channels): geometry and normals once per pixel through LDS; 0: the sweep any other channel count takes (k_light_grouped)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue
                                      // per device: two such kernels of this process cannot interleave their blocks and wait for each
@@ -255,15 +251,6 @@ struct srps_ctx {
     int image_store = 1;                  // option "image_store": 0 floats only, 1 bytes whenever the samples allow it
     unsigned char* I8 = nullptr;          // [N_local][C][P] bytes
     size_t I8_cap = 0;                    // bytes allocated behind I8 (kept across set-ups)
-    // The TILE-major copy of the context's float images (round 4, option "image_tiles"): It[tile][image * C + channel][1024 pixels].
-    // The image sweeps give a block 1024 consecutive pixels of every (image, channel) row; in the reference's layout I[n][c][P] those are
-    // N C pieces of 4 KiB, P * 4 bytes apart -- in this one a single run of N C * 4 KiB.  tools/hbm_ceiling_bench.hip (sweep_*): the same
-    // 1.0 GB read at 5.9 TB/s from the planes and at 7.1 TB/s from the tiles (non-temporal loads both).
-    float* It = nullptr;
-    size_t It_cap = 0;                    // floats allocated behind It (kept across set-ups)
-    int it_state = 0;                     // 0: stale (rebuilt at the next sweep), 1: current, 2: not to be used (the caller holds a pointer to I)
-    int image_tiles = 0;                  // option; off: measured in the sweeps themselves (gpurun_out/r04e, 2048 x 2048 x 20 images) the copy did not pay --
-                                          // albedo sweep 0.251 ms from the tiles against 0.226 from the planes, lighting sweep 0.261 / 0.261
     bool I8_cap_ok(size_t n) const { return I8 != nullptr && I8_cap >= n; }
     std::vector<hipEvent_t> ev_copied, ev_gathered;      // upload pipeline of srps_setup: per staging slot
     int i8_state = 0;                     // 0: not looked at since I last changed, 1: I8 holds I, 2: I is not representable
@@ -326,7 +313,6 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 int launch_fill(hipStream_t st, float* d, size_t n, float v);
 int launch_pack_bytes(hipStream_t st, const float* d_I, size_t n, unsigned char* d_out, int* d_inexact);
 const unsigned char* image_store_bytes(srps_ctx* ctx, const float* d_I);
-const float* image_store_tiles(srps_ctx* ctx, const float* d_I);      // null: read the planar array
 int launch_gather_image(hipStream_t st, const float* d_full, const int* d_imask, int P, int C, size_t hw, float* d_out);
 int launch_meshgrid_compact(hipStream_t st, const int* d_imask, int P, int h, float cx, float cy, float* xx, float* yy);
 int launch_meshgrid_full(hipStream_t st, int w, int h, float K02, float K12, float* xx, float* yy);

@@ -502,16 +502,17 @@ def test_normals_stored_by_the_energy_sweep_equal_the_normals_kernel(pkg, h, w, 
 
 
 # ------------------------------------------------------------------------------------------------
-# round 4: the tiled energy + lighting sweep (k_light_fused_tile) against round 3's four blocks per pixel range (k_light_fused_ci)
+# the tiled energy + lighting sweeps (k_light_fused_mfw, k_light_fused_tile) against the sweep any channel count other than 1 and 3 takes (k_light_grouped)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("h,w,sf,n_img,n_ch,kind,bytes_in", [(96, 80, 2, 5, 3, "ragged", False), (512, 384, 4, 23, 3, "ellipse", False), (300, 200, 1, 2, 1, "ragged", False),
                                                              (1024, 1024, 4, 20, 3, "full", False), (256, 128, 4, 20, 3, "full", True), (320, 240, 2, 45, 3, "ellipse", False),
                                                              (192, 128, 4, 24, 3, "full", True)])
 def test_tiled_lighting_sweep_equals_the_sweep_of_four_blocks_per_range(pkg, h, w, sf, n_img, n_ch, kind, bytes_in):
-    """option light_tiled: the four image groups of a pixel range as the four waves of one block, geometry and normals once per pixel
-    through LDS, image loads prefetched (and, with byte images, from the 8-bit store: light_bytes) -- the same expressions per pixel as
-    k_light_fused_ci, other pixel subsets per lane: energies, lighting, albedo and depth agree to rounding over three passes; masks whose
-    pixel count is no multiple of the 1 024-pixel tile, image counts with partial rounds (23, 45) and one channel included"""
+    """option light_tiled: 1 (default) the fused energy + lighting sweep as a tiled kernel -- geometry and normals once per pixel through
+    LDS (and, with byte images, the samples from the 8-bit store: light_bytes); 0 the generic sweep, four blocks per pixel range
+    (k_light_grouped: what a channel count other than 1 and 3 runs) -- the same expressions per pixel, other pixel subsets per lane:
+    energies, lighting, albedo and depth agree to rounding over three passes; masks whose pixel count is no multiple of the 1 024-pixel
+    tile, image counts with partial rounds (23, 45) and one channel (the vector form k_light_fused_tile) included"""
     sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img + 1, n_ch=n_ch, mask_kind=kind)
     if bytes_in:
         sc.I = (np.rint(np.clip(sc.I, 0, 1) * 255).astype(f32) / f32(255)).astype(f32)
@@ -538,14 +539,14 @@ def test_tiled_lighting_sweep_equals_the_sweep_of_four_blocks_per_range(pkg, h, 
 @pytest.mark.parametrize("h,w,sf,n_img,kind", [(96, 80, 2, 5, "ragged"), (512, 384, 4, 23, "ellipse"), (1024, 1024, 4, 20, "full"), (320, 240, 2, 45, "ellipse"),
                                                 (256, 256, 4, 4, "full"), (300, 260, 2, 13, "ellipse"), (128, 96, 2, 10, "ellipse"), (72, 56, 2, 2, "full"), (64, 48, 2, 3, "ellipse")])
 def test_lighting_sweep_on_the_matrix_pipe_equals_the_vector_form(pkg, h, w, sf, n_img, kind):
-    """option light_run = 2 (k_light_fused_mfma): the contraction A'I of dc.cu:408-444 and the Gram matrices as v_mfma_f32_4x4x1 outer
-    products -- exact f32, one rounding per product like the fmaf chains of the vector form (light_run = 1), summed over other pixel
-    subsets per lane: energies, lighting, albedo and depth agree to rounding over three passes; image counts that are no multiple of
-    four (5, 23, 45: lanes whose image does not exist), more than one round of twenty, ragged tiles"""
+    """option light_run = 3 (k_light_fused_mfw, the default): the contraction A'I of dc.cu:408-444 and the Gram matrices as v_mfma_f32_4x4x1
+    outer products -- exact f32, one rounding per product like the fmaf chains of the vector form (light_run = 1, k_light_fused_tile), summed
+    over other pixel subsets per lane: energies, lighting, albedo and depth agree to rounding over three passes; image counts that are no
+    multiple of four (5, 23, 45: lanes whose image does not exist), more than one round of twenty, ragged tiles"""
     sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + w + n_img + 2, n_ch=3, mask_kind=kind)
     dh = pkg.DataHandler.from_scene(sc)
     out = {}
-    for run in (1, 2, 3):                                                  # 3: the same with the block's waves decoupled (k_light_fused_mfw; 23 and 45 images: rounds)
+    for run in (1, 3):
         ctx = pkg.Context(device_id=0)
         ctx.set_option("light_run", run)
         assert ctx.get_option("light_run") == run
@@ -554,7 +555,7 @@ def test_lighting_sweep_on_the_matrix_pipe_equals_the_vector_form(pkg, h, w, sf,
         out[run] = (np.array(en, f32), srps.z(), srps.rho(), ctx.get("s"), ctx.get("N"))
         ctx.close()
     a = out[1]
-    for run in (2, 3):
+    for run in (3,):
         b = out[run]
         print(f"{h}x{w} sf {sf} x {n_img}, light_run {run}: energies {a[0]} / {b[0]}; depth rmse {rmse(b[1], a[1]):.2e}, albedo rmse {rmse(b[2], a[2]):.2e}, lighting max {np.abs(b[3] - a[3]).max():.2e}")
         np.testing.assert_allclose(b[0], a[0], rtol=1e-3)

@@ -168,6 +168,47 @@ __global__ __launch_bounds__(256) void k_sweep(const float* __restrict__ I, size
     if (s == 1.2345f) out[0] = s;
 }
 
+// ---- round 6: what separates k_sweep (6.85 TB/s from the tiles) from the library's sweeps (5.4 - 5.5 TB/s, tiles or planes alike)?
+// The same loop with (a) the OCCUPANCY of the library's kernels (blocks per CU capped by a dynamic LDS allocation: a block of 256 threads is
+// one wave per SIMD), (b) U loads in flight per lane, (c) the albedo sweep's SIDE streams: 8 planes read before the images (normals, dz,
+// xx, yy, the grid map), per channel a plane read and written (rho) and a plane stored (g), three planes stored at the end (q).
+// SIDE bits: 1 side reads, 2 side writes, 4 the writes non-temporal, 8 the side reads non-temporal
+template <bool NT, bool TILED, int U, int SIDE>
+__global__ __launch_bounds__(256) void k_sweep_occ(const float* __restrict__ I, size_t P, int NP, const float* __restrict__ side_in, float* __restrict__ side_out, float* __restrict__ out) {
+    extern __shared__ float lds_cap[];
+    constexpr bool RD = SIDE & 1, WR = SIDE & 2, WNT = SIDE & 4, RNT = SIDE & 8;
+    const size_t q = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q >= P) return;
+    float s = 0.f;
+    if (RD) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const F4 v = ld4<RNT>(side_in + (size_t)k * P + q); s += v.e[0] * v.e[3]; }
+    }
+    const int C = 3, NI = NP / C;
+    for (int c = 0; c < C; ++c) {
+        float a = 0.f;
+#pragma unroll U
+        for (int i = 0; i < NI; ++i) {
+            const int pl = TILED ? c * NI + i : i * C + c;                       // tile-major rows are channel-major; the planes are image-major
+            const float* src = TILED ? I + ((size_t)blockIdx.x * NP + pl) * 1024 + threadIdx.x * 4 : I + (size_t)pl * P + q;
+            const F4 v = ld4<NT>(src);
+            a = fmaf(v.e[0], v.e[1], a) + v.e[2] * v.e[3];
+        }
+        s += a;
+        F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] = a;
+        if (RD) r = ld4<RNT>(side_in + (size_t)(8 + c) * P + q);
+        if (WR) {
+            r.e[0] += a; st4<WNT>(side_out + (size_t)c * P + q, r);              // rho: read, written
+            r.e[1] += a; st4<WNT>(side_out + (size_t)(3 + c) * P + q, r);        // g_c
+        } else s += r.e[2];
+    }
+    if (WR) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] = s + t; st4<WNT>(side_out + (size_t)(6 + t) * P + q, r); }
+    }
+    if (s == 1.2345f) out[0] = s + lds_cap[0];
+}
+
 int main(int argc, char** argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 4096, cols = argc > 2 ? atoi(argv[2]) : 4096, reps = argc > 3 ? atoi(argv[3]) : 20;
     const int Hs = rows + 32;
@@ -251,6 +292,31 @@ int main(int argc, char** argv) {
             timeit("sweep_60planes_nt", 4.0 * Pp * NP, [&] { hipLaunchKernelGGL((k_sweep<true, false>), dim3(nbs), dim3(256), 0, 0, img, Pp, NP, chk); });
             timeit("sweep_tilemajor", 4.0 * Pp * NP, [&] { hipLaunchKernelGGL((k_sweep<false, true>), dim3(nbs), dim3(256), 0, 0, img, Pp, NP, chk); });
             timeit("sweep_tilemajor_nt", 4.0 * Pp * NP, [&] { hipLaunchKernelGGL((k_sweep<true, true>), dim3(nbs), dim3(256), 0, 0, img, Pp, NP, chk); });
+            // round 6: occupancy x loads in flight x side streams (see k_sweep_occ)
+            float *sin, *sout; CHECK(hipMalloc(&sin, Pp * 11 * 4)); CHECK(hipMalloc(&sout, Pp * 9 * 4)); CHECK(hipMemset(sin, 0, Pp * 11 * 4));
+#define OCC_CASE(NTV, TIL, UU, SD, nm_) do {                                                                                            \
+                CHECK(hipFuncSetAttribute((const void*)k_sweep_occ<NTV, TIL, UU, SD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
+                for (int occ : {8, 4}) {                                                                                                   \
+                    char nm[96]; snprintf(nm, sizeof nm, "%s_u%d_%dwaves", nm_, UU, occ);                                               \
+                    const int lds = occ >= 8 ? 0 : (160 * 1024 / occ) - 1024;                                                          \
+                    const double sb = 4.0 * Pp * (((SD) & 1 ? 11 : 0) + ((SD) & 2 ? 9 : 0));                                           \
+                    timeit(nm, 4.0 * Pp * NP + sb, [&] { hipLaunchKernelGGL((k_sweep_occ<NTV, TIL, UU, SD>), dim3(nbs), dim3(256), lds, 0, img, Pp, NP, sin, sout, chk); }); \
+                } } while (0)
+            OCC_CASE(true, true, 4, 0, "occ_tiles_nt");
+            OCC_CASE(true, false, 4, 0, "occ_planes_nt");
+            OCC_CASE(true, false, 8, 0, "occ_planes_nt");
+            OCC_CASE(true, true, 4, 1, "occ_tiles_nt_sideR");
+            OCC_CASE(true, true, 4, 9, "occ_tiles_nt_sideRnt");
+            OCC_CASE(true, true, 4, 2, "occ_tiles_nt_sideW");
+            OCC_CASE(true, true, 4, 6, "occ_tiles_nt_sideWnt");
+            OCC_CASE(true, true, 4, 3, "occ_tiles_nt_sideRW");
+            OCC_CASE(true, true, 4, 7, "occ_tiles_nt_sideRWnt");
+            OCC_CASE(true, true, 4, 15, "occ_tiles_nt_sideRntWnt");
+            OCC_CASE(true, false, 4, 3, "occ_planes_nt_sideRW");
+            OCC_CASE(true, false, 4, 7, "occ_planes_nt_sideRWnt");
+            OCC_CASE(true, false, 4, 15, "occ_planes_nt_sideRntWnt");
+#undef OCC_CASE
+            CHECK(hipFree(sin)); CHECK(hipFree(sout));
             CHECK(hipFree(img));
         }
         timeit("hipMemcpyDtoD_600MB", 16.0 * big4, [&] { CHECK(hipMemcpyAsync(big + big4 / 2, big, big4 / 2 * 16, hipMemcpyDeviceToDevice, 0)); });

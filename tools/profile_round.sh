@@ -34,7 +34,6 @@ python3 "$R/bench.py" > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.e
 # the occupied-tiles curve and the cache-policy sweep of the streaming step (round 4; kernels unchanged since): only when asked for
 if [ "${SRPS_PROFILE_LONG:-0}" = 1 ]; then
 python3 "$R/tools/cliff_curve.py" 2>/dev/null | grep "^{" > "$OUT/cliff_curve.jsonl"
-bash "$R/tools/march_nt_sweep.sh" > "$OUT/march_nt_sweep.txt" 2>&1
 fi
 find "$OUT" -name "*.db" -delete; find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
 ls "$OUT"
