@@ -281,6 +281,35 @@ def select_workload(args):
     return args
 
 
+def describe_parallelism(world, partition, comm_requested, comm_kind, resident_strips_active, strips_active, shared_gpu):
+    """What ran, and what it fell back from (no GPU call: tests/test_bench_launcher.py runs it on CPU).  The chain of a multi-GPU job, every
+    link decided by ALL ranks together inside the same run (nothing is exec'ed, no rank goes its own way):
+        communicator of the library (RCCL)  --fails-->  torch.distributed collectives on the library's exchange buffers
+        depth CG as the resident kernel on strips (cg_partition = 2)  --handshake fails / grid does not fit-->  streaming strips (4-double
+        all-reduce + edge exchange per step)  --no transport / refused-->  replicated CG (every rank runs the 101 steps)
+    Returns (text, degraded): `degraded` lists the links that were asked for and not taken."""
+    if world == 1:
+        return "1 GPU", []
+    degraded = []
+    if comm_requested == "library" and comm_kind == "torch":
+        degraded.append("library communicator (RCCL inside libsrps_hip.so) -> torch.distributed collectives")
+    if partition == "strips":
+        if comm_kind == "torch":
+            degraded.append("--partition strips needs the library's communicator -> replicated CG")
+        elif not resident_strips_active:
+            degraded.append("resident kernel on strips (cg_partition = 2) -> " + ("streaming strips" if strips_active else "replicated CG"))
+    if resident_strips_active:
+        cg = "depth CG as the resident kernel on strips of tile columns (sums and border edges through hipIpc-mapped buffers, no collective between the steps)"
+    elif strips_active:
+        cg = "depth CG partitioned into column strips (4-double all-reduce + edge-column exchange per step)"
+    else:
+        cg = "replicated CG"
+    how = {"library": "RCCL all-reduce of partial sums", "hosted": "all-reduce of partial sums by host collectives under the library's loop",
+           "torch": "torch.distributed all-reduce of partial sums"}.get(comm_kind, "all-reduce of partial sums")
+    text = f"images sharded over {world} ranks, {how}, {cg}" + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")
+    return text, degraded
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,12 +448,18 @@ def main():
     fallbacks = ctx.get_option("persistent_fallbacks")
     assert depth_steps == 101, f"the depth CG ran {depth_steps} steps, not the 101 of devicecalls.cu:252"
     cg_iters = depth_steps * args.steps
+    par_text, par_degraded = describe_parallelism(world, args.partition, args.comm, comm_kind, bool(ctx.get_option("cg_partition_resident_active")),
+                                                  bool(ctx.get_option("cg_partition_active")), shared_gpu)
+    for d in par_degraded:
+        if rank == 0:
+            print(f"bench.py: fell back: {d}", file=sys.stderr)
     out = {
         "metric": "cg_iterations_per_sec", "value": cg_iters / dt, "unit": "cg_iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload,
-                   "hr_grid": [H, W], "sf": args.sf, "images_per_gpu": args.images, "images_total": n_total,
+                   "hr_grid": [H, W], "sf": args.sf, "images_per_gpu": args.images if args.images is not None else max(pkg.shard_range(n_total, world, r)[1] - pkg.shard_range(n_total, world, r)[0] for r in range(world)),
+                   "images_total": n_total,
                    "unknowns": dims["npix"], "cg_steps_per_solve": depth_steps, "persistent_fallbacks": fallbacks,
                    "albedo_mode": {0: "SRPS_ALBEDO_CG", 1: "SRPS_ALBEDO_CLOSED_FORM", 2: "SRPS_ALBEDO_FUSED", 3: "SRPS_ALBEDO_AUTO (pipeline: the albedo CG's fixed point formed inside the sweep)"}[ctx.get_option("albedo_mode")],
                    "exclusive_device": ctx.get_option("exclusive_device"),       # 1: plain launches of the persistent kernels (the library's default is the cooperative launch: ~26 us per pass more)
@@ -437,10 +472,8 @@ def main():
                    "partition": args.partition if world > 1 else "none",
                    "images_per_rank": [pkg.shard_range(n_total, world, r)[1] - pkg.shard_range(n_total, world, r)[0] for r in range(world)],
                    "launched_by": "bench.py itself (child torch.distributed.run)" if os.environ.get("SRPS_BENCH_SELF_LAUNCHED") == "1" else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"),
-                   "parallelism": "1 GPU" if world == 1 else f"images sharded over {world} ranks, RCCL all-reduce of partial sums, "
-                                   + ("depth CG as the resident kernel on strips of tile columns (sums and border edges through hipIpc-mapped buffers, no collective between the steps)" if ctx.get_option("cg_partition_resident_active")
-                                      else "depth CG partitioned into column strips (4-double all-reduce + edge-column exchange per step)" if ctx.get_option("cg_partition_active") else "replicated CG")
-                                   + (" [dry run: ranks share one GPU, gloo]" if shared_gpu else "")},
+                   "parallelism": par_text, "degraded": par_degraded,
+                   "forced_failures": os.environ.get("SRPS_FORCE_FAIL") or None},
         "energies": energies,
     }
     if not args.no_total_solve:

@@ -1117,9 +1117,12 @@ int SRPS_RES_NAME(resident_cg)(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     // launch numbers run out; otherwise this launch's tags lie above every tag in them (gen_base) and nothing is zeroed: a tag is
     // compared for EQUALITY with the generation a block waits for, and a launch uses fewer than 1024 generations (pass 0 + 101 steps +
     // the direct sums of the one-wait form; two waits per step: 2 x 102).
-    if (ctx->res_tags_ptr != ctx->ws_resident.p || ctx->res_tags_bytes < need || ctx->res_launch_seq + (unsigned)((2 * ((long long)max_steps + 2) + 16 + 1023) >> 10) >= (1u << 21)) {
+    // ... and when the LAYOUT of the arrays changes (another grid or tile shape in the same buffer: ent | ent3 | edge granules move with
+    // `tiles`, TC and HALO_N, and a word that held a value -- float bits -- could then lie where this layout reads a tag; round-5 advisor finding)
+    const unsigned long long layout = ((unsigned long long)tiles << 32) | ((unsigned long long)TC << 16) | (unsigned long long)NT;
+    if (ctx->res_tags_ptr != ctx->ws_resident.p || ctx->res_tags_bytes < need || ctx->res_tags_layout != layout || ctx->res_launch_seq + (unsigned)((2 * ((long long)max_steps + 2) + 16 + 1023) >> 10) >= (1u << 21)) {
         SRPS_HIP(hipMemsetAsync(ctx->ws_resident.p, 0, ctx->ws_resident.bytes, ctx->stream));
-        ctx->res_tags_ptr = ctx->ws_resident.p; ctx->res_tags_bytes = ctx->ws_resident.bytes; ctx->res_launch_seq = 0;
+        ctx->res_tags_ptr = ctx->ws_resident.p; ctx->res_tags_bytes = ctx->ws_resident.bytes; ctx->res_launch_seq = 0; ctx->res_tags_layout = layout;
     }
     const unsigned gen_base = ctx->res_launch_seq << 10;
     ctx->res_launch_seq += (unsigned)((2 * ((long long)max_steps + 2) + 16 + 1023) >> 10);      // the tags this launch may use, in units of 1024 (option "cg_max_iter" can ask for many steps)
@@ -1639,7 +1642,8 @@ int resident_cg_rank(srps_ctx* ctx, int max_steps, bool fixed_steps) {
     const size_t need = U.bytes(pl.tiles);
     const int orc = resident_rank_open(ctx, need);
     if (orc != SRPS_OK && orc != SRPS_ERR_UNSUPPORTED) return orc;      // the exchange itself failed: no rank can go on
-    bool opened = orc == SRPS_OK;
+    bool opened = orc == SRPS_OK && !forced_failure("resident_strips");      // (forced: as a rank whose mapping failed -- the flag below tells the others)
+    if (orc == SRPS_OK && !opened) set_error("resident strips: refused on purpose (SRPS_FORCE_FAIL=resident_strips)");
     if (opened && hipMemsetAsync(ctx->xg_buf, 0, need, ctx->stream) != hipSuccess) { (void)hipGetLastError(); opened = false; }
     // One float through the all-reduce: the barrier (every rank's buffer is zeroed before any rank's kernel publishes into it) AND the
     // decision -- a rank whose mapping failed says so, and ALL ranks leave this path together (a rank that went its own way would meet

@@ -75,6 +75,20 @@ int rccl_fail(ncclResult_t r, const char* what) {
 
 bool comm_bound(const srps_ctx* ctx) { return ctx->comm != nullptr || ctx->host_allreduce != nullptr; }
 
+bool forced_failure(const char* stage) {
+    const char* e = getenv("SRPS_FORCE_FAIL");
+    if (!e || !*e) return false;
+    const size_t n = strlen(stage);
+    for (const char* p = e; *p;) {                           // comma-separated, whole words
+        const char* q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len == n && !strncmp(p, stage, n)) return true;
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+
 // the caller's collectives (srps_set_host_collectives) instead of RCCL: host functions on device pointers, called with the
 // stream(s) that produced the data drained
 static int hosted_all_reduce(srps_ctx* ctx, hipStream_t st, void* d_buf, size_t n, int f64) {
@@ -185,6 +199,7 @@ int srps_comm_unique_id(void* id) {
 int srps_comm_init_rank(srps_ctx* ctx, const void* id, int rank, int world) {
     SRPS_REQUIRE(ctx != nullptr && id != nullptr, SRPS_ERR_INVALID, "comm_init_rank: null argument");
     SRPS_REQUIRE(world >= 1 && rank >= 0 && rank < world, SRPS_ERR_INVALID, "comm_init_rank: rank %d of %d", rank, world);
+    SRPS_REQUIRE(!forced_failure("comm"), SRPS_ERR_UNSUPPORTED, "comm_init_rank: refused on purpose (SRPS_FORCE_FAIL=comm)");
     SRPS_TRY(rccl_need());
     SRPS_HIP(hipSetDevice(ctx->device));
     comm_release(ctx);
@@ -205,6 +220,7 @@ int srps_comm_init_all(srps_ctx* const* ctxs, int n) {
         for (int k = 0; k < i; ++k)
             SRPS_REQUIRE(dev[k] != dev[i], SRPS_ERR_INVALID, "comm_init_all: contexts %d and %d are both on device %d (RCCL takes one rank per device)", k, i, dev[i]);
     }
+    SRPS_REQUIRE(!forced_failure("comm"), SRPS_ERR_UNSUPPORTED, "comm_init_all: refused on purpose (SRPS_FORCE_FAIL=comm)");
     SRPS_TRY(rccl_need());
     std::vector<ncclComm_t> comms(n, nullptr);
     SRPS_RCCL(g_rccl.CommInitAll(comms.data(), n, dev.data()));

@@ -235,6 +235,7 @@ struct srps_ctx {
     srps::DevBuf ws_resident;
     const void* res_tags_ptr = nullptr;      // the granule arrays the single resident launch last used (see resident_cg: launch-numbered generation tags)
     size_t res_tags_bytes = 0;
+    unsigned long long res_tags_layout = 0;      // (tiles, tile columns, threads) of that launch: another layout in the same buffer is zeroed first
     unsigned res_launch_seq = 0;
     int cg_resident_debug = 0;       // timing experiments (kernels_resident.hip)
     int shard_range_check = 1;       // srps_execute_sharded verifies (one small all-reduce per call) that the ranks' image ranges tile the image set
@@ -440,6 +441,12 @@ int comm_exchange(srps_ctx* ctx, int nbuf, const float* const* send_left, float*
 int comm_all_gather_pieces(srps_ctx* ctx, float* d_buf, const size_t* offset, const size_t* count);
 
 // ---- strip-partitioned depth CG (srps_strips.hip) --------------------------------------------
+// First contact with a multi-GPU node (round 6): SRPS_FORCE_FAIL=comm,resident_strips,strips in the environment makes the named stage fail
+// on EVERY rank (all read the same environment) exactly where a real failure would be noticed, so that the fall-back behind it can be run
+// on purpose: "comm" -- srps_comm_init_rank / _init_all refuse (the caller falls back to its own collectives); "resident_strips" -- the
+// handshake of cg_partition = 2 reports a local failure (all ranks leave for the streaming strips together); "strips" -- the streaming
+// strips are not taken (the replicated CG runs).  tools/multi_gpu_first_contact.sh, tests/test_gpu_distributed.py.
+bool forced_failure(const char* stage);
 bool strips_active(const srps_ctx* ctx);                       // option "cg_partition" = 1, a communicator of more than one rank, a grid the streaming step handles
 int strips_bind_view(srps_ctx* ctx, int rank, int world);      // this rank's columns of the bound grid
 void strips_clear_view(srps_ctx* ctx);

@@ -186,7 +186,7 @@ int ensure_strip_buffers(srps_ctx* ctx) {
 
 bool strips_active(const srps_ctx* ctx) {
     const bool transport = (ctx->comm != nullptr && ctx->comm_world > 1) || (ctx->strip_allreduce != nullptr && ctx->strip_world > 1);
-    return ctx->cg_strips && transport && ctx->grid.bound && cg_fused_step(ctx);
+    return ctx->cg_strips && transport && ctx->grid.bound && cg_fused_step(ctx) && !forced_failure("strips");
 }
 
 void strips_clear_view(srps_ctx* ctx) {

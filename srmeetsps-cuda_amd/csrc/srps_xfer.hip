@@ -67,10 +67,21 @@ int pool_acquire(size_t bytes, PoolBuf* out, bool wc = false) {
     *out = PoolBuf{(char*)p, bytes, wc};
     return SRPS_OK;
 }
+// Back into the pool -- up to kPoolKeep idle buffers and kPoolKeepBytes of pinned memory are kept for the next transfers; what exceeds
+// that is given back to the system (round-5 advisor finding: `srps --gpus 8` with its image uploader threads pinned about a gigabyte for
+// the life of the process).  Freed outside the lock.
+constexpr size_t kPoolKeep = 4, kPoolKeepBytes = (size_t)320 << 20;
 void pool_release(const PoolBuf& b) {
     if (!b.p) return;
-    std::lock_guard<std::mutex> lk(g_pool.m);
-    g_pool.free_.push_back(b);
+    bool keep = true;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        size_t held = 0;
+        for (const PoolBuf& f : g_pool.free_) held += f.bytes;
+        keep = g_pool.free_.size() < kPoolKeep && held + b.bytes <= kPoolKeepBytes;
+        if (keep) g_pool.free_.push_back(b);
+    }
+    if (!keep) (void)hipHostFree(b.p);
 }
 struct Lease {                                 // a transfer's buffer, back in the pool when the transfer ends (its copies have been waited for by then)
     PoolBuf buf{nullptr, 0, false};
@@ -103,7 +114,7 @@ int env_int(const char* name, int dflt) {
 }
 // bytes per DMA of a large transfer (SRPS_XFER_CHUNK_MB: development, tools/setup_time.py): a multiple of the piece
 size_t big_chunk() {
-    static const size_t c = (size_t)std::max(1, std::min(env_int("SRPS_XFER_CHUNK_MB", (int)(kBig >> 20)), 256)) << 20;
+    static const size_t c = (size_t)std::max(1, std::min(env_int("SRPS_XFER_CHUNK_MB", (int)(kBig >> 20)), 64)) << 20;      // (development knob; 64 MB x 4 slots = the largest buffer the pool keeps)
     return c;
 }
 // streams a large transfer's DMAs alternate between (SRPS_XFER_STREAMS; 1: all on the caller's stream): consecutive copies of ONE stream
@@ -231,6 +242,7 @@ int upload_big(char* base, void* d_dst, const void* h_src, size_t bytes, hipStre
     size_t issued = 0, done = 0;
     auto pieces_of = [&](size_t c) { return (int)std::min<size_t>((size_t)ppc, npieces - c * (size_t)ppc); };
     for (int s = 0; s < kBigSlots && rc == SRPS_OK; ++s) rc = se.make(s);
+    int idle = 0;
     while (rc == SRPS_OK && done < nch) {
         bool progressed = false;
         if (issued < nch) {
@@ -257,7 +269,11 @@ int upload_big(char* base, void* d_dst, const void* h_src, size_t bytes, hipStre
             } else if (q != hipErrorNotReady) { rc = SRPS_ERR_HIP; break; }
             else (void)hipGetLastError();
         }
-        if (!progressed) __builtin_ia32_pause();
+        // idle: a pause, and after a run of idle rounds the thread gives its time slice away -- the filling threads work under the same CPU
+        // quota this loop would otherwise burn (round-5 advisor finding)
+        if (progressed) idle = 0;
+        else if (++idle < 64) __builtin_ia32_pause();
+        else { std::this_thread::yield(); idle = 0; }
     }
     stop.store(1);
     if (rc != SRPS_OK) next.store(npieces);    // nothing more to claim

@@ -68,3 +68,28 @@ def test_which_workload_a_command_line_means():
     assert "(7, 7, 6 per rank)" in a.workload and a.scaling == "strong"
     a = pick(1, config=3)
     assert (a.size, a.sf, a.images_total) == (1024, 4, 20) and "configs[2]" in a.workload
+
+
+def test_the_degrade_chain_of_a_multi_gpu_run_is_reported():
+    """bench.py: describe_parallelism -- what `config.parallelism` and `config.degraded` say for every way a multi-GPU run can fall back
+    inside the SAME run (round-5 review, next #5b).  The failures themselves are forced on a GPU box with SRPS_FORCE_FAIL
+    (tests/test_gpu_distributed.py, tools/multi_gpu_first_contact.sh); this is the reporting logic, which needs no GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    d = bench.describe_parallelism
+    assert d(1, "images", "library", "none", False, False, False) == ("1 GPU", [])
+    t, g = d(8, "images", "library", "library", False, False, False)
+    assert "RCCL all-reduce" in t and "replicated CG" in t and g == []
+    t, g = d(8, "images", "library", "torch", False, False, False)                       # the library's communicator failed on some rank
+    assert "torch.distributed all-reduce" in t and len(g) == 1 and "library communicator" in g[0]
+    t, g = d(8, "strips", "library", "library", True, False, False)                      # everything asked for ran
+    assert "resident kernel on strips" in t and g == []
+    t, g = d(8, "strips", "library", "library", False, True, False)                      # handshake failed / grid did not fit: streaming strips
+    assert "column strips" in t and g == ["resident kernel on strips (cg_partition = 2) -> streaming strips"]
+    t, g = d(8, "strips", "library", "library", False, False, False)                     # ... and those were not available either
+    assert "replicated CG" in t and g == ["resident kernel on strips (cg_partition = 2) -> replicated CG"]
+    t, g = d(8, "strips", "library", "torch", False, False, False)                       # no library communicator: no partitioned CG at all
+    assert "replicated CG" in t and len(g) == 2 and "needs the library's communicator" in g[1]
+    t, g = d(2, "strips", "library", "hosted", True, False, True)
+    assert "[dry run" in t and "host collectives" in t and g == []

@@ -188,6 +188,32 @@ def test_bench_dry_run_with_the_resident_kernel_on_strips():
     np.testing.assert_allclose(two["energies"], ref["energies"], rtol=1e-4)
 
 
+@pytest.mark.parametrize("forced,expect", [("resident_strips", "replicated CG"), ("resident_strips,strips", "replicated CG")])
+def test_bench_dry_run_degrades_inside_the_same_run(forced, expect):
+    """SRPS_FORCE_FAIL (round 6): the handshake of the resident strips is made to fail on every rank exactly where a real failure would
+    be noticed -- the ranks leave that path TOGETHER, the run goes on in the same processes (no exec, no restart) with the next form of
+    the depth CG, finishes its 101 steps with the one-GPU job's energies, and the line names what it fell back from.  (The gloo dry run
+    has no neighbour transport for the streaming strips, so the next form here is the replicated CG; on RCCL it is the streaming strips.)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SRPS_FORCE_FAIL=forced)
+    common = ["--steps", "2", "--warmup", "1", "--size", "1024", "--sf", "4", "--no-cpu-baseline", "--no-legs", "--option", "cg_resident_tile=512"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "3", "--partition", "strips"] + common, env=env,
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = two["config"]
+    assert expect in cfg["parallelism"] and "resident kernel on strips" not in cfg["parallelism"], cfg["parallelism"]
+    assert cfg["forced_failures"] == forced and len(cfg["degraded"]) == 1 and cfg["degraded"][0].startswith("resident kernel on strips"), cfg["degraded"]
+    assert cfg["cg_steps_per_solve"] == 101 and "fell back" in out.stderr
+    env.pop("SRPS_FORCE_FAIL")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--images", "6"] + common, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    np.testing.assert_allclose(two["energies"], ref["energies"], rtol=1e-4)
+
+
 @pytest.mark.parametrize("bytes_store", [False, True])
 def test_a_shard_forms_the_complete_albedo_denominator_itself(pkg, bytes_store):
     """srps_albedo_partial on a context that holds a shard of the images: den = sum_i (N . s_i)^2 does not involve the images, so it

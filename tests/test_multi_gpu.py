@@ -134,9 +134,24 @@ def test_command_line_program_on_two_gpus(pkg, tmp_path, partition):
     assert two.returncode == 0, two.stderr
     assert "Images sharded over 2 GPUs" in two.stdout and two.stdout.count("Iteration") == one.stdout.count("Iteration") and "Done!" in two.stdout
     if partition == "strips":
-        # the ranks are threads of one process: the handshake must take the peer-pointer route (hipIpc handles open in OTHER processes only)
-        # and the solve must end on the resident kernel, not on a fall-back (256 x 192, sf 2: 12 tiles of 256 x 16 over two ranks)
-        assert "Depth CG: the resident kernel on strips" in two.stdout, two.stdout[-1500:]
+        # the ranks are threads of one process: the handshake takes the peer-pointer route (hipIpc handles open in OTHER processes only).
+        # Whether the solve then ends on the resident kernel depends on the node: it needs peer access between the two devices and
+        # fine-grained device memory for the exchange buffers -- a node without either falls back (streaming strips / replicated CG), which
+        # is correct behaviour and is REPORTED here, not failed (round-5 advisor finding: this route has never run on two real devices; the
+        # rmse checks below are what catch a coherence bug).  Where both are available the resident path is required.
+        line = [ln for ln in two.stdout.splitlines() if ln.startswith("Depth CG:")]
+        assert line, two.stdout[-1500:]
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        can01, can10 = C.c_int(0), C.c_int(0)
+        hip.hipDeviceCanAccessPeer(C.byref(can01), 0, 1); hip.hipDeviceCanAccessPeer(C.byref(can10), 1, 0)
+        fine = C.c_void_p()
+        fine_ok = hip.hipExtMallocWithFlags(C.byref(fine), C.c_size_t(1 << 20), C.c_uint(0x1)) == 0      # hipDeviceMallocFinegrained
+        if fine_ok:
+            hip.hipFree(fine)
+        print(f"srps --gpus 2 --partition strips: {line[-1]} (peer access 0->1 {can01.value}, 1->0 {can10.value}, fine-grained memory {'yes' if fine_ok else 'no'})")
+        if can01.value and can10.value and fine_ok:
+            assert "the resident kernel on strips" in line[-1], two.stdout[-1500:]
     za = scipy.io.loadmat(str(tmp_path / "a" / "z.mat"))["x"][:, 0]; zb = scipy.io.loadmat(str(tmp_path / "b" / "z.mat"))["x"][:, 0]
     assert rmse(za, zb) < 3e-5
     ra = scipy.io.loadmat(str(tmp_path / "a" / "rho.mat"))["x"][:, 0]; rb = scipy.io.loadmat(str(tmp_path / "b" / "rho.mat"))["x"][:, 0]
