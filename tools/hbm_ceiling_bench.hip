@@ -269,7 +269,8 @@ int main(int argc, char** argv) {
     }
     // the guide's recipe swept: blocks x loads in flight x cache policy x block-contiguous chunks; read of 1.2 GB (guide :351) and
     // copy of 2 x 0.6 GB; also what the runtime's own device-to-device copy and memset reach
-    if (argc > 4 && atoi(argv[4]) != 0) {
+    const int mode = argc > 4 ? atoi(argv[4]) : 0;      // 1: everything; 2: the image sweeps' shapes only (what tools/tcc_sweeps.sh profiles)
+    if (mode != 0) {
         const size_t big4 = ((size_t)1200 << 20) / 16;
         float4* big; CHECK(hipMalloc(&big, big4 * 16));
         CHECK(hipMemset(big, 0, big4 * 16));
@@ -281,8 +282,10 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "guide_copy_u%d%s%s_%dblk", U, NT ? "_nt" : "", CONTIG ? "_contig" : "", nb);                  \
             timeit(nm, 16.0 * big4, [&] { hipLaunchKernelGGL((k_stream<U, NT, CONTIG, true>), dim3(nb), dim3(256), 0, 0, (const float4*)big, big + big4 / 2, big4 / 2, chk); });  \
         }
+        if (mode == 1) {
         SWEEP(1, false, false) SWEEP(4, false, false) SWEEP(8, false, false) SWEEP(4, true, false) SWEEP(8, true, false)
         SWEEP(4, false, true) SWEEP(8, true, true)
+        }
 #undef SWEEP
         {
             const size_t Pp = (size_t)2048 * 2048; const int NP = 60;          // 1.0066 GB: the images of the metric's configuration
@@ -319,8 +322,8 @@ int main(int argc, char** argv) {
             CHECK(hipFree(sin)); CHECK(hipFree(sout));
             CHECK(hipFree(img));
         }
-        timeit("hipMemcpyDtoD_600MB", 16.0 * big4, [&] { CHECK(hipMemcpyAsync(big + big4 / 2, big, big4 / 2 * 16, hipMemcpyDeviceToDevice, 0)); });
-        timeit("hipMemset_1200MB", 16.0 * big4, [&] { CHECK(hipMemsetAsync(big, 0, big4 * 16, 0)); });
+        if (mode == 1) timeit("hipMemcpyDtoD_600MB", 16.0 * big4, [&] { CHECK(hipMemcpyAsync(big + big4 / 2, big, big4 / 2 * 16, hipMemcpyDeviceToDevice, 0)); });
+        if (mode == 1) timeit("hipMemset_1200MB", 16.0 * big4, [&] { CHECK(hipMemsetAsync(big, 0, big4 * 16, 0)); });
         CHECK(hipFree(big));
     }
     CHECK(hipFree(arena));
