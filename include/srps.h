@@ -85,7 +85,7 @@ int srps_transfer_buffers(int* n);
 int srps_set_stream(srps_ctx* ctx, void* hip_stream);      /* NULL = the context's own stream */
 int srps_synchronize(srps_ctx* ctx);
 /* options: "albedo_mode" (SRPS_ALBEDO_*), "apply_mode" (SRPS_APPLY_*), "cg_max_iter", "march_strip" (0 = automatic,
- * or a multiple of 4 in [4,512]), "march_snake" (0|1), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1),
+ * or a multiple of 4 in [4,512]), "march_snake" (0|1|2, below), "tensor_recompute" (0|1), "keep_stored_tensor" (0|1),
  * "fuse_energy_lighting" (0|1: the energy sweep over I also leaves the lighting sums of the next pass),
  * "fuse_normals" (0|1, default 1: that sweep also stores the normals and dz of the depth just solved, which it forms in registers anyway --
  *  srps_normals then launches nothing; same bits as the normals kernel),
@@ -145,6 +145,9 @@ int srps_synchronize(srps_ctx* ctx);
  *  of a tile back to back, channel by channel (what one-channel images always run).  0.255 / 0.23 ms same box; results agree to rounding.
  *  Round 6 removed the forms that were neither a default on some input class nor a tested fall-back: docs/HISTORY.md),
  * "light_tiled" (0|1, default 1: 0 runs the generic sweep -- any channel count, four blocks per pixel range -- on 1 and 3 channels too),
+ * "march_x2" (0|1|2, default 2: the one-launch streaming CG step reads and writes x every SECOND launch only and applies both pending
+ *  updates there in their order -- the same bits, 43 B per unknown and step instead of 45; 2 = where the step's planes exceed the Infinity
+ *  Cache; "march_x2_active" tells),
  * "march_snake" (0|1|2, default 2: 1 odd strips of the streaming CG step march right to left; 2 the directions also alternate from step to
  *  step, so that a step starts where the one before it ended -- in the Infinity Cache),
  * "image_store" (0|1, default 1: when every image sample is k / 255.f for a byte k -- what the reference's image loader

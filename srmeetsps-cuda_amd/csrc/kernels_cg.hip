@@ -438,8 +438,10 @@ __global__ __launch_bounds__(256) void k_cg_flush_x(float* __restrict__ x, const
 
 // the x update still pending after the last executed step K of the one-launch protocol: alpha_K = r_{K-1}.r_{K-1} / p_K.omega_K from
 // the sums launch K left (dc.cu:269-270)
+// x2: the steps ran with the x update every second launch (option "march_x2"): after an EVEN last step K two updates are pending --
+// alpha_{K-1} p_{K-1} (alpha_{K-1}: left by launch K in alpha_hist[(K - 1) & 1]) and alpha_K p_K, applied in that order
 __global__ __launch_bounds__(256) void k_cg_flush_x2(float* __restrict__ x, const float* __restrict__ p0, const float* __restrict__ p1,
-                                                     size_t n4, const float* __restrict__ part4, int n_part, int n_live, CgScalars* __restrict__ scal, const double* __restrict__ totals4) {
+                                                     size_t n4, const float* __restrict__ part4, int n_part, int n_live, CgScalars* __restrict__ scal, const double* __restrict__ totals4, int x2) {
     __shared__ double smd4[4][4];
     const int it = scal->iters;
     if (it < 1) return;
@@ -448,16 +450,23 @@ __global__ __launch_bounds__(256) void k_cg_flush_x2(float* __restrict__ x, cons
     else sum_partials4(part4 + (size_t)(it & 1) * 4 * n_part, n_live, n_part, s4, smd4);
     const float alpha = (float)s4[3] / (float)s4[0];
     const float4* p4 = reinterpret_cast<const float4*>((it & 1) ? p1 : p0);
+    const bool two = x2 && it >= 2 && (it & 1) == 0;
+    const float alpha_before = two ? scal->alpha_hist[(it - 1) & 1] : 0.f;
+    const float4* q4 = reinterpret_cast<const float4*>((it & 1) ? p0 : p1);      // p_{K-1}
     float4* x4 = reinterpret_cast<float4*>(x);
     for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < n4; t += (size_t)gridDim.x * 256) {
         const float4 pv = p4[t];
         float4 xv = x4[t];
+        if (two) {
+            const float4 qv = q4[t];
+            xv.x = fmaf(alpha_before, qv.x, xv.x); xv.y = fmaf(alpha_before, qv.y, xv.y); xv.z = fmaf(alpha_before, qv.z, xv.z); xv.w = fmaf(alpha_before, qv.w, xv.w);
+        }
         xv.x = fmaf(alpha, pv.x, xv.x); xv.y = fmaf(alpha, pv.y, xv.y); xv.z = fmaf(alpha, pv.z, xv.z); xv.w = fmaf(alpha, pv.w, xv.w);
         x4[t] = xv;
     }
 }
 __global__ void k_cg_reset2(CgScalars* scal) {
-    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = 0.f; scal->iters = 0; scal->active = 1; scal->alpha = 0.f; }
+    if (threadIdx.x == 0) { scal->r0 = 0.f; scal->r1_last = 0.f; scal->iters = 0; scal->active = 1; scal->alpha = 0.f; scal->alpha_hist[0] = 0.f; scal->alpha_hist[1] = 0.f; }
 }
 
 __global__ void k_cg_reset(CgScalars* scal, float* rr0, int n_rr, const float* first) {
@@ -604,7 +613,7 @@ int cg_flush_x(srps_ctx* ctx) {
         // a rank of the strip-partitioned CG moves its own columns only (the others arrive with the all-gather of x)
         const size_t off = G.view_w > 0 ? (size_t)(G.view_c0 + PAD) * G.Hs : 0, n4 = G.view_w > 0 ? (size_t)G.view_w * G.Hs / 4 : G.used / 4;
         hipLaunchKernelGGL(k_cg_flush_x2, dim3(G.nb_update), dim3(256), 0, ctx->stream, G.d_x + off, G.d_p + off, G.d_p + G.plane + off, n4, G.d_part4, G.n_part4,
-                           march_blocks(G), G.d_scal, (const double*)G.d_totals4);
+                           march_blocks(G), G.d_scal, (const double*)G.d_totals4, march_x2_on(ctx) ? 1 : 0);
         SRPS_LAUNCH_CHECK();
         return SRPS_OK;
     }

@@ -117,7 +117,12 @@ __device__ __forceinline__ F4 zero4() { F4 r; r.e[0] = r.e[1] = r.e[2] = r.e[3] 
 // this launch and is what the next launch uses for alpha_k and as the denominator of beta_{k+1}: every predicted value is
 // anchored on a direct sum one step old, the prediction error does not accumulate.  45 B per unknown instead of 37 + 12, one
 // launch per step instead of two.
-template <int SF, int MODE, int NC>
+// XU (MODE 3): what this launch does with x.  1: x += alpha_{k-1} p_{k-1}, every launch (k > 1).  The two-step form (option "march_x2"):
+// 0: nothing -- an even launch leaves its update pending --, 2: an odd launch k >= 3 applies BOTH pending updates, x += alpha_{k-2} p_{k-2}
+// then += alpha_{k-1} p_{k-1}: the same two fused multiply-adds a launch apart would have done, so the same bits; p_{k-2} is what the
+// plane p_out still holds when this launch reaches the column (the lane that overwrites it with p_k reads it first).  x is then
+// read and written every second step and p_{k-2} read once: 43 B per unknown and step instead of 45.
+template <int SF, int MODE, int NC, int XU = 1>
 __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
     const int TJ = a.tj;                      // strip width: even, multiple of SF (runtime, the loop is unrolled by two)
     constexpr int NT = (NC > 0) ? NC : 6;     // planes streamed for the tensor: NC (recompute) or 6 (stored M)
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
     __shared__ float sm4[4 + 4 * 4];
     float beta = 0.f;
     float alpha_prev3 = 0.f;
+    float alpha_pp = 0.f;                     // XU == 2: alpha_{k-2}
     if (MODE == 3) {
         if (!a.scal->active) return;                                   // an earlier launch found r.r <= tol^2 (dc.cu:252)
         double s4[4];
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
             if (blockIdx.x == 0 && threadIdx.x == 0) a.scal->active = 0;
             return;
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal->iters = a.k; a.scal->r0 = r1_direct; a.scal->r1_last = r1; a.scal->alpha = alpha_prev3; }
+        if (XU == 2) alpha_pp = a.scal->alpha_hist[a.k & 1];           // left by launch k - 1 in slot (k - 2) & 1; this launch writes the OTHER slot
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal->iters = a.k; a.scal->r0 = r1_direct; a.scal->r1_last = r1; a.scal->alpha = alpha_prev3; a.scal->alpha_hist[(a.k - 1) & 1] = alpha_prev3; }
     }
     if (MODE == 2) {
         const float r1 = (float)sum_partials(a.rr_part, a.n_rr, smd);
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
             unsigned fl;
             F4 r, p;
             F4 xo, po;         // MODE 2, 3: x and the previous p of the column this step outputs
+            F4 po2;            // XU == 2: p of two steps ago at that column (still in the plane this launch overwrites)
             F4 wp;             // MODE 3: omega of the previous step (column c + D*L)
         };
         auto issue = [&](Raw& w, int c) {
@@ -213,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
             else {
                 w.r = ld4(a.r + off); w.p = ld4(a.p_in + off);
                 const size_t oo = (size_t)c * Hs + rowL;               // the column step c outputs
-                w.xo = ld4(a.x + oo); w.po = ld4(a.p_in + oo);
+                if (MODE != 3 || XU != 0) { w.xo = ld4(a.x + oo); w.po = ld4(a.p_in + oo); }
+                if (MODE == 3 && XU == 2) w.po2 = ld4(a.p_out + oo);
                 if (MODE == 3) w.wp = (a.k != 1) ? ld4(a.w_prev + off) : zero4();      // step 1 has no update pending (uniform)
             }
         };
@@ -430,7 +439,12 @@ __global__ __launch_bounds__(256, 2) void k_apply_march(MarchArgs a) {
                                 red_rw = fmaf(rv, acc.e[e], red_rw); red_ww = fmaf(acc.e[e], acc.e[e], red_ww); red_rr = fmaf(rv, rv, red_rr);
                             }
                         }
-                        if (a.k != 1) {                                   // uniform
+                        if (MODE == 3 && XU == 2) {
+                            F4 xn;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xn.e[e] = fmaf(alpha_prev, cur.po.e[e], fmaf(alpha_pp, cur.po2.e[e], cur.xo.e[e]));   // two Saxpy of dc.cu:270, in their order
+                            st4(a.x + off, xn);
+                        } else if ((MODE != 3 || XU == 1) && a.k != 1) {      // uniform
                             F4 xn;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) xn.e[e] = fmaf(alpha_prev, cur.po.e[e], cur.xo.e[e]);   // Saxpy dc.cu:270
@@ -532,7 +546,11 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
     const int nb = cdiv(a.n_items, 4);
 #define SRPS_MARCH_NC(SF, NCV)                                                                                \
     do {                                                                                                      \
-        hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV>), dim3(nb), dim3(256), 0, ctx->stream, a);          \
+        if constexpr (MODE == 3) {                                                                            \
+            if (xu == 0) { hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV, 0>), dim3(nb), dim3(256), 0, ctx->stream, a); break; } \
+            if (xu == 2) { hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV, 2>), dim3(nb), dim3(256), 0, ctx->stream, a); break; } \
+        }                                                                                                     \
+        hipLaunchKernelGGL((k_apply_march<SF, MODE, NCV, 1>), dim3(nb), dim3(256), 0, ctx->stream, a);       \
     } while (0)
 #define SRPS_MARCH_TJ(SF)                                                                                     \
     switch (nc) {                                                                                             \
@@ -542,6 +560,10 @@ static int launch_march(srps_ctx* ctx, MarchArgs& a) {
         default: set_error("march kernel: unsupported channel count %d for tensor recompute", nc); return SRPS_ERR_UNSUPPORTED; \
     }
     const int nc = march_recompute_channels(ctx);
+    // the two-step x update of the one-launch step: launch 1 has nothing pending (the one-step form's k == 1 case), even launches leave
+    // theirs pending, odd launches from 3 on apply two
+    const int xu = (MODE == 3 && a.k > 1 && march_x2_on(ctx)) ? ((a.k & 1) ? 2 : 0) : 1;
+    (void)xu;
     a.tj = G.strip_cols;
     a.snake = ctx->march_snake;
     switch (G.sf) {
@@ -569,6 +591,16 @@ static MarchArgs march_base(srps_ctx* ctx) {
 }
 
 int march_blocks(const Grid& G) { return cdiv(G.n_seg * G.n_strip, 4); }
+
+// The two-step x update pays where the step is HBM-bound: 4096^2 158.3 -> 152.5 us same box; at 2048^2, where the step's 201 MB sit in the
+// Infinity Cache, the alternation of two kernel bodies costs more than the 4 % of bytes it saves (34.6 -> 38.3 us).  Automatic (2): on when
+// the step's planes -- g [nc or 6], x, r [2], p [2], omega [2] -- exceed 240 MB.
+bool march_x2_on(const srps_ctx* ctx) {
+    if (!cg_fused_step(ctx) || ctx->march_x2 == 0) return false;
+    if (ctx->march_x2 == 1) return true;
+    const int nc = march_recompute_channels(ctx);
+    return (size_t)((nc > 0 ? nc : 6) + 7) * ctx->grid.used * sizeof(float) > ((size_t)240 << 20);
+}
 
 int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane) {
     MarchArgs a = march_base(ctx);

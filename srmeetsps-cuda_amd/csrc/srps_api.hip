@@ -494,6 +494,9 @@ int srps_set_option(srps_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "tensor_recompute")) {
         ctx->tensor_recompute = value ? 1 : 0;
         ctx->depth_assembled = false;        // a depth system the albedo sweep left (SRPS_ALBEDO_FUSED / AUTO) is in the other form
+    } else if (!strcmp(name, "march_x2")) {
+        SRPS_REQUIRE(value >= 0 && value <= 2, SRPS_ERR_INVALID, "march_x2: 0 (never), 1 (always) or 2 (when the step's planes exceed the Infinity Cache), got %d", value);
+        ctx->march_x2 = value;
     } else if (!strcmp(name, "march_snake")) {
         ctx->march_snake = value == 2 ? 2 : (value ? 1 : 0);
     } else if (!strcmp(name, "fuse_energy_lighting")) {
@@ -608,6 +611,8 @@ int srps_get_option(srps_ctx* ctx, const char* name, int* value) {
     else if (!strcmp(name, "apply_mode")) *value = ctx->apply_mode;
     else if (!strcmp(name, "tensor_recompute")) *value = ctx->tensor_recompute;
     else if (!strcmp(name, "march_snake")) *value = ctx->march_snake;
+    else if (!strcmp(name, "march_x2")) *value = ctx->march_x2;
+    else if (!strcmp(name, "march_x2_active")) *value = (ctx->grid.bound && march_x2_on(ctx)) ? 1 : 0;
     else if (!strcmp(name, "march_strip")) *value = ctx->grid.bound ? ctx->grid.strip_cols : ctx->march_tj;
     else if (!strcmp(name, "keep_stored_tensor")) *value = ctx->keep_stored_tensor;
     else if (!strcmp(name, "fuse_energy_lighting")) *value = ctx->fuse_energy_lighting;
@@ -1672,7 +1677,9 @@ int srps_cg_bytes(srps_ctx* ctx, double* apply_bytes, double* update_bytes) {
     const bool fused = use_march(ctx);
     // one-launch step: the operator launch also reads omega of the previous step and reads + writes r (+8), no update kernel
     const bool one = cg_fused_step(ctx);
-    if (apply_bytes) *apply_bytes = ((nc > 0 ? 17.0 + 4.0 * nc : 41.0) + (fused ? 8.0 : 0.0) + (one ? 8.0 : 0.0)) * P;
+    // ... and with the two-step x update (march_x2_on) x is read and written every second launch only and p of two steps ago read once: -2 on average
+    const double x2 = march_x2_on(ctx) ? -2.0 : 0.0;
+    if (apply_bytes) *apply_bytes = ((nc > 0 ? 17.0 + 4.0 * nc : 41.0) + (fused ? 8.0 : 0.0) + (one ? 8.0 : 0.0) + x2) * P;
     if (update_bytes) *update_bytes = one ? 0.0 : (fused ? 12.0 : 24.0) * P;
     return SRPS_OK;
 }

@@ -36,6 +36,7 @@ struct CgScalars {
     int abort_flags;    // bit 0: depth CG (k_cg_resident), bit 1: albedo CG (k_dcg_persistent*); 0 = every wait completed
     int abort_arrived;  // blocks whose granule had arrived at the first wait that gave up
     int abort_gen;      // generation (wait number) of that wait: 1 = not all blocks became resident
+    float alpha_hist[2];   // one-launch streaming step with the x update every SECOND launch (march_x2): launch k leaves alpha_{k-1} in slot (k - 1) & 1
 };
 enum { ABORT_DEPTH = 1, ABORT_ALBEDO = 2 };
 // class of a tile of the resident CG (kernels_resident.hip: resident_body<.., RECT>), per tile shape, set by build_grid
@@ -125,6 +126,7 @@ struct srps_ctx {
     int apply_mode = SRPS_APPLY_AUTO;
     int march_tj = 0;                // strip width of the marching operator (multiple of 4); 0 = chosen by march_plan
     int keep_stored_tensor = 0;      // also write the 6-plane tensor when the recompute form is active (tests)
+    int march_x2 = 2;                // 0 never, 1 always, 2 (default) when the step's planes exceed the Infinity Cache (march_x2_on).  One-launch streaming step: x is read and written by every SECOND launch only, which applies the two pending updates (x += alpha_{k-2} p_{k-2}, then alpha_{k-1} p_{k-1}: the same two fmas, the same bits) -- p_{k-2} is what the launch finds in the plane it is about to overwrite with p_k; 43 B per unknown and step instead of 45
     int march_snake = 2;             // 1: odd strips march right-to-left (halo columns shared through L2); 2 (default, round 6): the directions also alternate from CG step to CG step -- the far end of every strip is still in the Infinity Cache when the next step starts there (4096^2: 171 - 174 -> 154 - 160 us per step, 3584^2: 129 -> 105)
     int tensor_recompute = 1;        // rebuild M in the operator kernel from (rho_c/dz)^2 instead of streaming 6 planes
     int cg_max_iter = 100;           // dc.cu:231
@@ -415,6 +417,7 @@ int march_apply_plain(srps_ctx* ctx, const float* d_in_plane, float* d_out_plane
 int march_residual(srps_ctx* ctx);
 int march_cg_apply(srps_ctx* ctx, int k);
 int march_cg_step(srps_ctx* ctx, int k);
+bool march_x2_on(const srps_ctx* ctx);      // the two-step x update is in use on the bound grid (option "march_x2")
 bool cg_fused_step(const srps_ctx* ctx);      // the streaming CG runs one launch per step
 int cg_flush_x(srps_ctx* ctx);
 int march_recompute_channels(const srps_ctx* ctx);

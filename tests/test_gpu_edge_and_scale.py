@@ -669,3 +669,49 @@ def test_transfers_of_two_contexts_do_not_wait_for_each_other(pkg):
     assert uploads[0] >= 3 and n.value >= 2
     assert med < 0.5 * one_upload                          # behind one lock the median read waited for most of an upload
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("h,w,sf,n_img,kind", [(512, 384, 4, 3, "ellipse"), (300, 260, 2, 2, "ragged"), (1024, 1024, 4, 2, "full"), (64, 48, 1, 2, "full")])
+def test_streaming_cg_with_the_x_update_every_second_launch_gives_the_same_bits(pkg, h, w, sf, n_img, kind):
+    """option march_x2 (round 6, default on): the one-launch streaming CG step reads and writes x in every SECOND launch only and applies the
+    two pending updates there -- x += alpha_{k-2} p_{k-2}, then += alpha_{k-1} p_{k-1}, the same two fused multiply-adds the one-step form
+    performs a launch apart; p_{k-2} is read from the plane the launch is about to overwrite with p_k.  Depth, energy and step count of
+    three passes are the one-step form's bit for bit: 101-step solves (odd last step: one update left for the flush) and, with the cap
+    lowered to 49 (`cg_max_iter`: 50 steps, an EVEN last step), two updates left for the flush."""
+    sc = pkg.synth.make_scene(h, w, sf, n_img, seed=h + 7 * n_img, mask_kind=kind)
+    dh = pkg.DataHandler.from_scene(sc)
+    for cap in (100, 49):
+        out = []
+        for x2 in (1, 0):
+            ctx = pkg.Context(device_id=0)
+            ctx.set_option("cg_resident", 0); ctx.set_option("march_x2", x2); ctx.set_option("cg_max_iter", cap)
+            srps = pkg.SRPS(dh, ctx=ctx)
+            en = srps.execute(max_outer=3)
+            assert ctx.get_option("cg_resident_active") == 0
+            out.append((np.array(en, f32), srps.z().copy(), ctx.last_cg_iterations()["depth"]))
+            ctx.close()
+        (e1, z1, it1), (e0, z0, it0) = out
+        assert it1 == it0 == cap + 1
+        assert np.array_equal(e1.view(np.uint32), e0.view(np.uint32)), (cap, e1, e0)
+        assert np.array_equal(z1.view(np.uint32), z0.view(np.uint32)), cap
+
+
+def test_streaming_cg_two_step_x_update_when_the_solve_converges_early(pkg):
+    """the same on a system that converges (r.r <= tol^2) long before the cap -- the hand-built 4 x 4 depth system of
+    tests/test_oracle_known_answers.py through the operator-level entry: the launches behind the converged one return at once, and
+    the flush applies what the last executed step left pending, one update or two"""
+    import torch
+    from test_oracle_known_answers import _tiny_inputs, H, W, SF, FX, FY
+    s, rho, dz, xx, yy, I, z0s, z0 = _tiny_inputs()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).pin_memory().cuda().contiguous()
+    res = []
+    for x2 in (1, 0):
+        ctx = pkg.Context(device_id=0)
+        ctx.set_option("cg_resident", 0); ctx.set_option("march_x2", x2)
+        ctx.bind_grid(H, W, SF, np.ones(H * W, f32))
+        z = t(z0)
+        ctx.depth_estimation(t(s), t(rho), t(np.zeros((4, 16), f32)), t(I), t(xx), t(yy), t(dz), t(z0s), z, FX, FY, 16, 2, 1)
+        res.append((z.cpu().numpy().copy(), ctx.last_cg_iterations()["depth"]))
+        ctx.close()
+    assert res[0][1] == res[1][1] < 101
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
