@@ -139,7 +139,57 @@ def _newest_profile(suffix):
     return None, None
 
 
-def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
+def live_traffic(H, sf, resident, timeout_s=150):
+    """HBM-side bytes per launch of the dominant CG kernel, MEASURED BY THIS RUN: two child processes under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE, then WRITE_SIZE: separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; never another trace domain beside
+    them) run tools/cg_prof.py -- a few solves of the same grid with the same kernel -- and the counters of that kernel's launches are
+    summed as the guide says for gfx950: 2 x FETCH_SIZE + WRITE_SIZE, in KB.  The children are started by this process and waited for
+    (nothing is exec'ed); the profiler's command line has the program itself behind `--`.  Returns None when the profiler is not there
+    or a pass fails: the line then replays the committed measurement and says so."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    kernel = "k_cg_resident" if resident else "k_apply_march"
+    vals, durs = {}, []
+    tmp = tempfile.mkdtemp(prefix="srps_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "cg_prof.py"), str(H), str(sf), "1", "0", "101", "1" if resident else "0"]
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            # (the profiled child may die in its exit handlers AFTER the profiler has written its tables -- seen as rc -11 on these boxes;
+            # what counts is that the table is there and holds the kernel's launches)
+            if not files:
+                print(f"bench.py: live traffic: the {counter} pass left no counter table (rc {res.returncode}): {res.stderr[-300:]}", file=sys.stderr)
+                return None
+            v = []
+            for r in csv.DictReader(open(files[0])):
+                if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    v.append(float(r["Counter_Value"]))
+                    if counter == "FETCH_SIZE":
+                        durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            if not v:
+                return None
+            vals[counter] = statistics.median(v)
+        return {"bytes_per_launch": 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024, "fetch_KB": vals["FETCH_SIZE"], "write_KB": vals["WRITE_SIZE"],
+                "median_us_under_pmc": statistics.median(durs), "launches": len(durs), "kernel": kernel}
+    except Exception as exc:
+        print(f"bench.py: live traffic: {exc}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10, live=False):
     """isolated inner loop (srps_bench_cg: HIP events on the launch stream) and the roofline of its dominant kernel"""
     out = {}
     b = ctx.bench_cg(solves=solves, iters=101)
@@ -157,6 +207,12 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
     traffic_source = (f"replayed from profiles/{tj_name}: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes) of tools/cg_prof.py on another "
                       "run and box, 2 x FETCH_SIZE + WRITE_SIZE per launch, median; not measured by this process") if tj else None
     key = f"{H}x{W}_sf{sf}"
+    # the headline leg measures its traffic itself (two profiler passes as child processes, ~10 s each); the side legs replay
+    lt = live_traffic(H, sf, resident) if (live and H == W) else None
+    live_value = lt["bytes_per_launch"] if lt else None
+    if lt:
+        traffic_source = (f"measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, child processes) of tools/cg_prof.py {H} {sf}, "
+                          f"median over {lt['launches']} launches of {lt['kernel']}: 2 x {lt['fetch_KB']:.0f} KB + {lt['write_KB']:.0f} KB; {lt['median_us_under_pmc']:.1f} us per launch under the counters")
     if resident:
         # ONE launch runs the residual pass and all 101 steps with the CG state in registers + LDS (kernels_resident.hip).
         # HBM is not what bounds it (the state never leaves the chip): the binding resource is the vector ALU.  `achieved` =
@@ -179,7 +235,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         out["roofline"] = {"bound": "valu", "kernel": "k_cg_resident (" + ("mask-free body: every tile lies inside the mask" if rect else "general body") +
                                                       "): residual pass + the whole truncated CG (101 steps) in one persistent launch",
                            "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
-                           "traffic": (tj.get(key) or {}).get("resident"), "traffic_source": traffic_source, "avg_launch_us": launch_us, "steps_per_launch": 101,
+                           "traffic": live_value if live_value is not None else (tj.get(key) or {}).get("resident"), "traffic_source": traffic_source, "avg_launch_us": launch_us, "steps_per_launch": 101,
                            "flops_per_launch": flops, "flops_per_unknown_and_step": FLOPS_PER_UNKNOWN_STEP, "issue": issue,
                            "minimal_flop_count": {"flops_per_unknown_and_step": FLOPS_PER_UNKNOWN_STEP_MINIMAL,
                                                   "frac": float(P) * (101 * FLOPS_PER_UNKNOWN_STEP_MINIMAL + FLOPS_PER_UNKNOWN_RESIDUAL_PASS_MINIMAL) / (launch_us * 1e6) / FP32_VALU_PEAK_TFLOPS,
@@ -203,7 +259,7 @@ def cg_legs(pkg, ctx, H, W, sf, resident_expected, solves=10):
         out["roofline"] = {"bound": "infinity_cache" if in_mall else "hbm",
                            "kernel": "k_apply_march: depth operator (p = beta p + r, omega = A_ p, partial dot products, deferred x / r updates)",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": (tj.get(key) or {}).get("apply"), "traffic_source": traffic_source, "avg_launch_us": apply_us,
+                           "traffic": live_value if live_value is not None else (tj.get(key) or {}).get("apply"), "traffic_source": traffic_source, "avg_launch_us": apply_us,
                            "algorithmic_bytes_per_launch": b["apply_bytes"]}
         if in_mall:
             out["roofline"]["note"] = (f"the step's {ws_bytes / 2**20:.0f} MiB fit the 256 MiB Infinity Cache: `frac` is against the 8 TB/s HBM peak by the contract of this "
@@ -325,6 +381,7 @@ def main():
                          "1 GPU: the metric's configuration (2048^2 sf 4 x 20 images); N > 1: config 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-total-solve", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (~20 s); replay the committed profile instead")
     ap.add_argument("--no-legs", action="store_true", help="skip the streaming-CG legs (2048^2 streaming, 4096^2 sf 2)")
     ap.add_argument("--apply-mode", type=int, default=0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="srps_set_option before setup (A/B runs)")
@@ -510,7 +567,8 @@ def main():
         # the resident kernel runs where the grid has at most one 256 x 64 tile per CU (2048 x 2048 on 256 CUs); it must then
         # really have run -- a persistent launch that gave up a wait would have switched the context to the streaming kernels
         tiles = -(-dims["grid_h"] // 256) * -(-dims["grid_w"] // 64)
-        legs_cg = cg_legs(pkg, ctx, H, W, args.sf, resident_expected=(tiles <= ctx.get_option("num_cus")) and not cg_collective)
+        legs_cg = cg_legs(pkg, ctx, H, W, args.sf, resident_expected=(tiles <= ctx.get_option("num_cus")) and not cg_collective,
+                          live=(world == 1 and not args.no_live_traffic))
         if rank == 0:
             out.update(legs_cg)
     if rank == 0:

@@ -95,7 +95,7 @@ def test_bench_two_ranks_on_one_gpu():
     import json
     import subprocess
     env = dict(os.environ, SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "2", "--warmup", "1", "--size", "256", "--sf", "2", "--no-cpu-baseline"]
+    common = ["--steps", "2", "--warmup", "1", "--size", "256", "--sf", "2", "--no-cpu-baseline", "--no-live-traffic"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "3"] + common
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
@@ -125,7 +125,7 @@ def test_bench_starts_its_own_ranks():
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "2", "--warmup", "1", "--size", "256", "--sf", "2", "--no-cpu-baseline", "--images", "3"]
+    common = ["--steps", "2", "--warmup", "1", "--size", "256", "--sf", "2", "--no-cpu-baseline", "--no-live-traffic", "--images", "3"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True,
                          timeout=800, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -175,7 +175,7 @@ def test_bench_dry_run_with_the_resident_kernel_on_strips():
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--steps", "2", "--warmup", "1", "--size", "1024", "--sf", "4", "--no-cpu-baseline", "--no-legs", "--option", "cg_resident_tile=512"]
+    common = ["--steps", "2", "--warmup", "1", "--size", "1024", "--sf", "4", "--no-cpu-baseline", "--no-legs", "--no-live-traffic", "--option", "cg_resident_tile=512"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "3", "--partition", "strips"] + common, env=env,
                          capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -198,7 +198,7 @@ def test_bench_dry_run_degrades_inside_the_same_run(forced, expect):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SRPS_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SRPS_FORCE_FAIL=forced)
-    common = ["--steps", "2", "--warmup", "1", "--size", "1024", "--sf", "4", "--no-cpu-baseline", "--no-legs", "--option", "cg_resident_tile=512"]
+    common = ["--steps", "2", "--warmup", "1", "--size", "1024", "--sf", "4", "--no-cpu-baseline", "--no-legs", "--no-live-traffic", "--option", "cg_resident_tile=512"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "3", "--partition", "strips"] + common, env=env,
                          capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]

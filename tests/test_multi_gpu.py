@@ -169,7 +169,7 @@ def test_bench_on_two_gpus_started_bare_and_by_the_launcher():
     line = json.loads([ln for ln in bare.stdout.splitlines() if ln.startswith("{")][0])
     cfg = line["config"]
     assert line["n_gpus"] == 2 and cfg["ncclCommCount"] == 2 and cfg["images_per_rank"] == [20, 20] and cfg["comm"].startswith("ncclAllReduce inside libsrps_hip.so")
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--images", "40", "--no-legs", "--no-total-solve"] + common, env=env,
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--images", "40", "--no-legs", "--no-total-solve", "--no-live-traffic"] + common, env=env,
                          capture_output=True, text=True, timeout=1000, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -- python3 "$R/bench.py" --steps 5 --no-cpu-baseline --no-total-solve > "$OUT/bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -- python3 "$R/bench.py" --steps 5 --no-cpu-baseline --no-total-solve --no-live-traffic > "$OUT/bench.json" 2> "$OUT/bench.err"
 for cfg in "2048 4 1 0 101 1 resident_2048" "2048 4 1 0 101 0 streaming_2048" "4096 2 1 0 101 0 streaming_4096"; do
     set -- $cfg
     for pmc in FETCH_SIZE WRITE_SIZE; do
