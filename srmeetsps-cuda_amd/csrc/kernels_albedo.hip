@@ -102,12 +102,18 @@ __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ 
                                                       const unsigned char* __restrict__ I8, int P, int n_img, int C, float* __restrict__ rho,
                                                       const float* __restrict__ qc, const float* __restrict__ xx, const float* __restrict__ yy,
                                                       const float* __restrict__ dz, float fx, float fy, const int* __restrict__ gofp, size_t plane,
-                                                      float* __restrict__ Q, float* __restrict__ Gp) {
+                                                      float* __restrict__ Q, float* __restrict__ Gp, int n3_one) {
     const int q = (blockIdx.x * 256 + threadIdx.x) * V;
     if (q >= P) return;
     Vec<V> nk[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+    for (int k = 0; k < 3; ++k) nk[k] = ldv<V>(N + (size_t)k * P + q);
+    // N3 == 1 (dc.cu:175): the pipeline's own normals hold a plane of ones there, which is then not read (kernel-uniform; 1.f * s3 is exact:
+    // the same bits) -- 16.8 MB less per sweep at 2048^2.  A caller's array (srps_set / a pointer handed out) is read as it is.
+    if (n3_one) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) nk[3].v[e] = 1.f;
+    } else nk[3] = ldv<V>(N + (size_t)3 * P + q);
     const Vec<V> vdz = ldv<V>(dz + q), vxx = ldv<V>(xx + q), vyy = ldv<V>(yy + q);
     const GridIdx<V> gi = grid_idx<V>(gofp, q);
     float qq[3][V];
@@ -133,10 +139,16 @@ __global__ __launch_bounds__(256) void k_albedo_fused(const float* __restrict__ 
                 sb.v[e] = fmaf(s2, iv.v[e], sb.v[e]);
             }
         }
-        Vec<V> vr = ldv<V>(rho + (size_t)c * P + q);
+        // k_albedo_closed: pixels with a zero denominator keep their value -- the old albedo is read only by a thread that has such a pixel
+        // (no image lights it: rare; 50 MB less read per sweep at 2048^2 x 3 channels)
+        bool keep = false;
+#pragma unroll
+        for (int e = 0; e < V; ++e) keep = keep || !(de.v[e] > 0.f);
+        Vec<V> vr;
+        if (keep) vr = ldv<V>(rho + (size_t)c * P + q);
 #pragma unroll
         for (int e = 0; e < V; ++e)
-            if (de.v[e] > 0.f) vr.v[e] = nu.v[e] / de.v[e];                      // k_albedo_closed: pixels with a zero denominator keep their value
+            if (de.v[e] > 0.f) vr.v[e] = nu.v[e] / de.v[e];
         stv<V>(rho + (size_t)c * P + q, vr);
         const float ca = qc[c * 4 + 0], cap = qc[c * 4 + 1], cb = qc[c * 4 + 2];
         float g[V], g2[V];
@@ -161,7 +173,7 @@ int albedo_fused(srps_ctx* ctx, const float* d_s, const float* d_N, const float*
     const bool vec = (P % 4 == 0) && (((uintptr_t)d_N | (uintptr_t)d_I | (uintptr_t)d_rho | (uintptr_t)d_xx | (uintptr_t)d_yy | (uintptr_t)d_dz) % 16 == 0);
     const unsigned char* d_I8 = vec ? image_store_bytes(ctx, d_I) : nullptr;
 #define SRPS_AF(VV, UU, IMG) hipLaunchKernelGGL((k_albedo_fused<VV, UU>), dim3(cdiv(P, 256 * VV)), dim3(256), 0, ctx->stream, d_s, d_N, IMG, d_I8, P, n_img, C, d_rho, d_qc, \
-                                           d_xx, d_yy, d_dz, fx, fy, G.d_gofp, G.plane, G.d_q, G.d_G)
+                                           d_xx, d_yy, d_dz, fx, fy, G.d_gofp, G.plane, G.d_q, G.d_G, (ctx->n3_one && d_N == ctx->Nrm) ? 1 : 0)
     if (vec && d_I8) SRPS_AF(4, true, d_I);
     else if (vec) SRPS_AF(4, false, d_I);
     else SRPS_AF(1, false, d_I);

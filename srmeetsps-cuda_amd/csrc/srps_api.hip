@@ -981,6 +981,7 @@ static int setup_impl(srps_ctx* ctx, const srps_problem* pr) {
     SRPS_LAUNCH_CHECK();
     SRPS_TRY(launch_fill(ax, ctx->rho, (size_t)C * P, 0.5f));                               // SRPS.cu:220
     SRPS_TRY(launch_fill(ax, ctx->Nrm2 + 3 * (size_t)P, (size_t)P, 1.f));                   // N3 == 1 (dc.cu:175) in the second set of normals too
+    ctx->n3_one = true;                                                                     // ... and in the first: the set-up's normals kernel writes it
     // masked LR depth and initial HR depth (copy_if SRPS.cu:237-246): uploaded whole into the scratch the mask came through,
     // compacted with the index lists
     {
@@ -1603,6 +1604,7 @@ int srps_set(srps_ctx* ctx, const char* name, const float* host, size_t n) {
     ctx->depth_assembled = false;
     ctx->normals_pending = false;
     if (p == ctx->I) ctx->i8_state = 0;
+    if (p == ctx->Nrm) ctx->n3_one = false;             // the caller's N3 is taken as it is from here on
     SRPS_TRY(host_upload(ctx, p, host, len * sizeof(float), ctx->stream));
     return SRPS_OK;
 }
@@ -1626,6 +1628,7 @@ int srps_get_device_ptr(srps_ctx* ctx, const char* name, void** d_ptr, size_t* n
     // sets -- a pointer handed out would point at the non-current set from the next pass on (round-3 advisor finding).  From here on
     // this context keeps ONE set (the normals kernel writes it in place, as before round 3) until the next srps_setup.
     if (p == ctx->Nrm || p == ctx->dz) ctx->nd_ptr_out = true;
+    if (p == ctx->Nrm) ctx->n3_one = false;
     ctx->light_cache_valid = false;      // the caller may write through the pointer
     ctx->depth_assembled = false;
     ctx->normals_pending = false;

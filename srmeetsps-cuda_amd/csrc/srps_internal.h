@@ -183,6 +183,7 @@ struct srps_ctx {
                                      // waves decoupled, each with a quarter of the pixels and all the images (k_light_fused_mfw; more than 20 images: rounds); 1 = vector
                                      // form, a wave reads ONE image plane's four 1 KiB pieces back to back, channel by channel (k_light_fused_tile; one channel always).
                                      // Same box, 2048^2 x 20: 1: 0.247 - 0.264, 3: 0.216 - 0.247 ms (profiles/r05_ab_lighting_mfma.txt; earlier forms: docs/HISTORY.md)
+    bool n3_one = false;             // the context's N[3] plane holds ones (set-up and every normals kernel write it so; false once the caller may have written N)
     int light_tiled = 1;             // the fused sweep as a tiled kernel (1 or 3 channels): geometry and normals once per pixel through LDS; 0: the sweep any other channel count takes (k_light_grouped)
     int light_grouped = 1;           // lighting sweep with the images of a batch dealt to four blocks per pixel range
     int coop_launch = 1;             // launch of the persistent kernels: 1 = hipLaunchCooperativeKernel (default; one cooperative queue

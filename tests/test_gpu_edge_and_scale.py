@@ -715,3 +715,37 @@ def test_streaming_cg_two_step_x_update_when_the_solve_converges_early(pkg):
         ctx.close()
     assert res[0][1] == res[1][1] < 101
     assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+
+
+def test_albedo_sweep_keeps_unlit_pixels_and_takes_a_callers_n3_as_it_is(pkg, oracle):
+    """two branches of the pipeline's albedo sweep (k_albedo_fused) that whole solves never take.  (1) A pixel no image lights (every
+    shading N . s_ic is zero: the diagonal system's row is empty) keeps its albedo -- the reference's CG never moves it (dc.cu:540); the
+    sweep reads the old albedo only in threads that have such a pixel (round 6).  (2) The sweep does not read the plane N3 of the
+    context's own normals (it holds ones, dc.cu:175) -- but normals the CALLER set are taken as they are, N3 included."""
+    sc = pkg.synth.make_scene(64, 48, 2, 4, seed=9, mask_kind="ellipse")      # snapped to 2 x 2 blocks: the pixel count is a multiple of 4
+    ctx = pkg.Context(device_id=0)
+    ctx.setup(pkg.DataHandler.from_scene(sc))
+    P = ctx.dims()["npix"]
+    assert P % 4 == 0 and P < 64 * 48
+    rho0 = ctx.get("rho").copy()
+    ctx.set("s", np.zeros(4 * 3 * 4, f32))                                   # nothing lights anything
+    ctx.albedo()
+    assert np.array_equal(ctx.get("rho"), rho0)
+    # (2): a lighting that makes N3 matter, and normals with N3 = 2 set by the caller
+    ctx.lighting()
+    s = ctx.get("s").reshape(4, 3, 4).copy(); s[:, :, 3] = 0.3
+    ctx.set("s", s.reshape(-1))
+    N = ctx.get("N").reshape(4, P).copy()
+    ctx.albedo()
+    rho_ones = ctx.get("rho").reshape(3, P).copy()
+    I = ctx.get("I").reshape(4, 3, P)
+    want = oracle.albedo_closed_form(s, np.full((3, P), 0.5, f32), N, I)
+    np.testing.assert_allclose(rho_ones, want, rtol=2e-5, atol=2e-6)
+    N2 = N.copy(); N2[3] = 2.0
+    ctx.set("N", N2.reshape(-1))
+    ctx.albedo()
+    rho_two = ctx.get("rho").reshape(3, P)
+    want2 = oracle.albedo_closed_form(s, np.full((3, P), 0.5, f32), N2, I)
+    np.testing.assert_allclose(rho_two, want2, rtol=2e-5, atol=2e-6)
+    assert np.abs(rho_two - rho_ones).max() > 1e-3                           # N3 did matter
+    ctx.close()

@@ -30,7 +30,7 @@ def main():
            "k_light_fused_mfw": img + 4.0 * P * (6 + C) + 4.0 * P * 4,                 # the same sweep on the matrix pipe (round 5)
            "k_light_fused_mfma": img + 4.0 * P * (6 + C) + 4.0 * P * 4,
            "k_albedo_numden": img + 4.0 * P * 4 + 4.0 * P * (2 * C + 3 * C),          # I; N (4); num, den [C] + the three image sums [C][3]
-           "k_albedo_fused": img + 4.0 * P * (4 + 3 + C + 1) + 4.0 * P * (C + C + 3),  # I; N (4), dz xx yy, rho [C] (zero-denominator pixels keep it), gofp; rho [C], g [C], q [3] out
+           "k_albedo_fused": img + 4.0 * P * (3 + 3 + 1) + 4.0 * P * (C + C + 3),       # I; N0..2 (N3 == 1 is not read since round 6), dz xx yy, gofp (the old rho only where a denominator is zero); rho [C], g [C], q [3] out
            "k_depth_from_sums": 4.0 * P * (3 * C + C + 1 + 2) + 4.0 * P * (3 + 3)}
     res = {}
     for name, d in sorted(out.items()):
