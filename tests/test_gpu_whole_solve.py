@@ -200,15 +200,16 @@ def _calibrate(pkg, coracle, sc, ref, runs):
     return dict(de_mf=de_mf, de_as=de_as, dz_mf=dz_mf, dz_as=dz_as, lib=lib, n=n)
 
 
-def _whole_solve(pkg, oracle, coracle, sc, first_pass_tol, expect_resident=True):
+def _whole_solve(pkg, oracle, coracle, sc, first_pass_tol, expect_resident=True, base_options=None):
     import time
+    base = dict(base_options or {})
     t0 = time.perf_counter()
     ref = _oracle_execute(sc, oracle, coracle)
     print(f"oracle solve: {time.perf_counter() - t0:.1f} s in all")
-    default = _library_execute(pkg, sc, {})
+    default = _library_execute(pkg, sc, base)
     assert default["albedo_mode"] == 3 and default["one_sync"] == 1, "this test is about the library's DEFAULT options"
     assert default["resident"] == (1 if expect_resident else 0)
-    faithful = _library_execute(pkg, sc, {"albedo_mode": 0, "cg_one_sync": 0})
+    faithful = _library_execute(pkg, sc, dict(base, albedo_mode=0, cg_one_sync=0))
     if len(default["energies"]) != len(ref["energies"]):                       # inside assert_same_stop's window: compare at the same pass count
         ref_d = _oracle_execute(sc, oracle, coracle, max_outer=len(default["energies"]))
     else:
@@ -233,8 +234,8 @@ def _whole_solve(pkg, oracle, coracle, sc, first_pass_tol, expect_resident=True)
         assert r["shading"] < 2e-3, r
     if both:
         assert rmse(default["z"], faithful["z"]) < 2e-5
-    cal = _calibrate(pkg, coracle, sc, ref, {"HIP library, default options": ({}, default),
-                                             "HIP library, albedo_mode=0 cg_one_sync=0": ({"albedo_mode": 0, "cg_one_sync": 0}, faithful)})
+    cal = _calibrate(pkg, coracle, sc, ref, {"HIP library, default options": (base, default),
+                                             "HIP library, albedo_mode=0 cg_one_sync=0": (dict(base, albedo_mode=0, cg_one_sync=0), faithful)})
     # 3. the library against the assembled oracle, pass by pass: bounded by what the two fp32 CPU runs leave against fp64
     for r in (r_d, r_f):
         for k, v in enumerate(r["rel"][:cal["n"]]):
@@ -262,3 +263,13 @@ def test_ellipse_whole_solve_against_the_oracle(pkg, oracle, coracle):
     the resident kernel's GENERAL body -- the one every real mask runs (SRPS.cu:29-47: backward differences on the right / lower
     boundary) -- over a whole solve to the stop rule, against the oracle"""
     _whole_solve(pkg, oracle, coracle, pkg.synth.make_scene(2048, 2048, 4, 8, seed=1241, mask_kind="ellipse"), first_pass_tol=6.5e-4)
+
+
+@pytest.mark.timeout(1500)
+def test_streaming_cg_whole_solve_against_the_oracle_and_fp64(pkg, oracle, coracle):
+    """The STREAMING depth CG (what grids beyond one tile per CU run: 4096 x 4096 of configs[4]) over a whole solve, calibrated like the
+    resident kernel above: 1024 x 1024, sf 4, 20 images with `cg_resident = 0`, and the two things round 6 changed in that kernel switched
+    on whatever the grid's size -- the march direction alternating from step to step (`march_snake` = 2, the default) and x read and
+    written every second launch (`march_x2` = 1; the default applies it only above 240 MB of planes)."""
+    _whole_solve(pkg, oracle, coracle, pkg.synth.make_scene(1024, 1024, 4, 20, seed=1236, mask_kind="full"), first_pass_tol=1e-4,
+                 expect_resident=False, base_options={"cg_resident": 0, "march_x2": 1, "march_snake": 2})
