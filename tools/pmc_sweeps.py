@@ -26,9 +26,7 @@ def main():
     img = 4.0 * P * N * C
     # algorithmic bytes of the sweeps: the images once + the per-pixel planes each reads / writes once
     alg = {"k_light_fused_tile": img + 4.0 * P * (6 + C) + 4.0 * P * 4,                # I; dz xx yy z zx zy (6), rho (C); N0 N1 N2 + dz out (4)
-           "k_light_fused_ci": img + 4.0 * P * (6 + C) + 4.0 * P * 4,
            "k_light_fused_mfw": img + 4.0 * P * (6 + C) + 4.0 * P * 4,                 # the same sweep on the matrix pipe (round 5)
-           "k_light_fused_mfma": img + 4.0 * P * (6 + C) + 4.0 * P * 4,
            "k_albedo_numden": img + 4.0 * P * 4 + 4.0 * P * (2 * C + 3 * C),          # I; N (4); num, den [C] + the three image sums [C][3]
            "k_albedo_fused": img + 4.0 * P * (3 + 3 + 1) + 4.0 * P * (C + C + 3),       # I; N0..2 (N3 == 1 is not read since round 6), dz xx yy, gofp (the old rho only where a denominator is zero); rho [C], g [C], q [3] out
            "k_depth_from_sums": 4.0 * P * (3 * C + C + 1 + 2) + 4.0 * P * (3 + 3)}
