@@ -310,7 +310,11 @@ int srps_exchange(srps_ctx* ctx, const char* which /* "s","albedo","depth","ener
  *       distributes its SRPS_COMM_ID_BYTES bytes, every rank joins (ncclCommInitRank on the context's device);
  *   srps_comm_init_all : one process, n contexts on n different devices (ncclCommInitAll); rank = index in the array;
  *   srps_set_comm      : borrow an ncclComm_t the caller made itself (not destroyed with the context); NULL unbinds.
- * The communicators the library creates are destroyed by srps_comm_release / srps_destroy. */
+ * The communicators the library creates are destroyed by srps_comm_release / srps_destroy.
+ * First contact with a multi-GPU node: the environment variable SRPS_FORCE_FAIL (a comma-separated list of "comm", "resident_strips",
+ * "strips") makes the named stage fail on every rank where a real failure would be noticed -- srps_comm_init_rank / _init_all return
+ * SRPS_ERR_UNSUPPORTED; the handshake of "cg_partition" = 2 reports a local failure and all ranks go on with the streaming strips; the
+ * streaming strips are not taken and the replicated CG runs -- so that every fall-back can be run on purpose (tools/multi_gpu_first_contact.sh). */
 #define SRPS_COMM_ID_BYTES 128
 int srps_comm_unique_id(void* id /* [SRPS_COMM_ID_BYTES] */);
 int srps_comm_init_rank(srps_ctx* ctx, const void* id, int rank, int world);
